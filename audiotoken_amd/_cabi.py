@@ -1,0 +1,108 @@
+"""ctypes binding of libaudiotoken_hip.so (C ABI: include/audiotoken_hip.h).
+
+The HIP library IS the product path: if it cannot be loaded this module raises — there is no CPU or
+PyTorch fallback anywhere in ``audiotoken_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libaudiotoken_hip.so"
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    """Mirror of ``at_gemm_desc`` (include/audiotoken_hip.h)."""
+    _fields_ = [
+        ("X", C.c_void_p), ("x_bstride", C.c_int64), ("Tin", C.c_int32), ("Cin", C.c_int32), ("ldx", C.c_int32),
+        ("ktaps", C.c_int32), ("stride", C.c_int32), ("pad_left", C.c_int32), ("pad_mode", C.c_int32),
+        ("W", C.c_void_p), ("bias", C.c_void_p),
+        ("C", C.c_void_p), ("c_bstride", C.c_int64), ("ldc", C.c_int32),
+        ("R", C.c_void_p), ("r_bstride", C.c_int64), ("ldr", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
+        ("pro", C.c_int32), ("epi", C.c_int32), ("alpha", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/audiotoken_hip.h declares
+SIGNATURES = {
+    "at_version": (C.c_int, []),
+    "at_last_error": (C.c_char_p, []),
+    "at_encodec_create": (C.c_void_p, [C.c_int]),
+    "at_encodec_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "at_encodec_finalize": (C.c_int, [C.c_void_p, C.c_int]),
+    "at_encodec_destroy": (None, [C.c_void_p]),
+    "at_encodec_num_codebooks": (C.c_int, [C.c_void_p]),
+    "at_encodec_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "at_encodec_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "at_encodec_decode_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "at_encodec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
+    "at_op_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "at_op_rvq_encode": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("AUDIOTOKEN_HIP_LIB", str(_LIB_PATH)))
+
+
+def load():
+    """Load the shared library once; raise HipLibraryError if it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise HipLibraryError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C audiotoken_amd/csrc`). audiotoken_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as e:  # pragma: no cover - environment specific
+        raise HipLibraryError(f"cannot load {path}: {e}") from e
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{path} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().at_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def ptr(t) -> int:
+    """Device/host address of a torch tensor (or None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream_handle(device) -> int:
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def set_tensor(lib, fn, handle, name: str, arr: np.ndarray):
+    arr = np.ascontiguousarray(arr, dtype=np.float32)
+    shape = (C.c_int64 * arr.ndim)(*arr.shape)
+    check(fn(handle, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim), f"set_tensor({name})")

@@ -1,0 +1,65 @@
+// Shared declarations for the audiotoken HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+namespace at {
+
+// ---- error plumbing (C-ABI returns codes; text via at_last_error) ---------------------------
+void set_error(const std::string& msg);
+#define AT_CHECK_HIP(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            ::at::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return -2;                                                                          \
+        }                                                                                       \
+    } while (0)
+#define AT_REQUIRE(cond, msg)                                                                   \
+    do {                                                                                        \
+        if (!(cond)) {                                                                          \
+            ::at::set_error(std::string("requirement failed: ") + #cond + " — " + (msg));       \
+            return -1;                                                                          \
+        }                                                                                       \
+    } while (0)
+
+// ---- the one dense contraction every layer maps onto ----------------------------------------
+// out[b][m][n] = epi( alpha * ( sum_kk A(b,m,kk) * W[n][kk] + bias[n] ) ) (+ R[b][m][n])
+// where A(b,m,kk) = pro( X[b][ row(m, kk / Cin) ][ kk % Cin ] ),  row(m,tap) = m*stride + tap - pad_left,
+// rows outside [0,Tin) are reflected (pad_mode 1) or read as zero (pad_mode 0).
+// Activations are time-major / channels-last ([B][T][C], C contiguous), so a causal conv1d, a strided
+// conv1d, a transposed conv1d (as s-phase GEMM) and a Linear layer are all this one contraction with a
+// window of K = ktaps*Cin contiguous floats per output row — no im2col buffer ever exists.
+enum Prologue { PRO_NONE = 0, PRO_ELU = 1 };
+enum Epilogue { EPI_NONE = 0, EPI_SWISH = 1, EPI_ELU = 2, EPI_GELU = 3 };
+
+struct GemmArgs {
+    const float* X = nullptr;  // [batch][Tin][Cin]
+    long long x_bstride = 0;   // floats between clips
+    int Tin = 0, Cin = 0;
+    int ldx = 0;               // floats between consecutive input rows (= Cin for a dense [T][Cin] clip)
+    int ktaps = 1, stride = 1, pad_left = 0, pad_mode = 0;
+    const float* W = nullptr;     // [N][K], K = ktaps*Cin, tap-major then channel
+    const float* bias = nullptr;  // [N] or null
+    float* C = nullptr;           // [batch][M][ldc]
+    long long c_bstride = 0;
+    int ldc = 0;
+    const float* R = nullptr;  // residual, same indexing as C (may alias C)
+    long long r_bstride = 0;
+    int ldr = 0;
+    int M = 0, N = 0, K = 0, batch = 1;
+    int pro = PRO_NONE, epi = EPI_NONE;
+    float alpha = 1.0f;
+};
+
+int launch_gemm(const GemmArgs& a, hipStream_t stream);
+int check_gemm_args(const GemmArgs& a);
+
+// ---- small helpers shared by kernels ---------------------------------------------------------
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x / (1.0f + expf(-x)); }
+
+}  // namespace at

@@ -1,0 +1,527 @@
+// Acoustic tokenizer (EnCodec 24 kHz) — host side: weight intake / repacking and the launch sequence.
+// C ABI in include/audiotoken_hip.h. Replaces reference AcousticEncoder / AcousticDecoder
+// (audiotoken/encoder.py:29-57, audiotoken/decoder.py:50-76), whose arithmetic is the PyPI `encodec` model;
+// architecture per SURVEY.md Appendix A.1.
+//
+// Data layout: every activation is time-major / channels-last [clip][t][c] so that conv windows are contiguous
+// (see at_common.h). Weights are repacked once at finalize():
+//   Conv1d  [Cout][Cin][k]      -> [Cout][k*Cin]            (tap-major rows, matches the window order)
+//   ConvTr  [Cin][Cout][k=2s]   -> [s*Cout][2*Cin]          (phase p row block: [W[:, :, p+s] | W[:, :, p]])
+//   LSTM    [4H][H] gate blocks -> rows 4*j + g             (gates of one unit adjacent; see lstm_step_kernel)
+#include <map>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cmath>
+
+#include "../../include/audiotoken_hip.h"
+#include "at_common.h"
+#include "encodec_kernels.h"
+
+namespace at {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+const char* last_error_cstr() { return g_last_error.c_str(); }
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct ConvW {
+    const float* w = nullptr;
+    const float* b = nullptr;
+    int cin = 0, cout = 0, k = 0, stride = 1;
+};
+
+constexpr int kRatiosEnc[4] = {2, 4, 5, 8};
+constexpr int kRatiosDec[4] = {8, 5, 4, 2};
+constexpr int kH = 512;
+constexpr int kDim = 128;
+constexpr int kCodes = 1024;
+constexpr int kSubBatch = 32;  // clips per pass through the 24 kHz..75 Hz conv stack (bounds the workspace)
+
+}  // namespace at
+
+using namespace at;
+
+struct at_encodec {
+    int device = 0;
+    bool finalized = false;
+    bool has_decoder = false;
+    std::map<std::string, HostTensor> staged;
+    float* blob = nullptr;
+    size_t blob_floats = 0;
+    // encoder
+    ConvW conv0, res[4][3], down[4], fin;
+    const float *wih[2] = {}, *whh[2] = {}, *bih[2] = {}, *bhh[2] = {};
+    // quantiser
+    const float* codebooks = nullptr;  // [n_cb][1024][128]
+    const float* e2 = nullptr;         // [n_cb][1024]
+    int n_codebooks = 0;
+    // decoder
+    ConvW dconv0, dup[4], dres[4][3], dlast;
+    const float *dwih[2] = {}, *dwhh[2] = {}, *dbih[2] = {}, *dbhh[2] = {};
+};
+
+namespace {
+
+const HostTensor* find(const at_encodec* h, const std::string& name) {
+    auto it = h->staged.find(name);
+    return it == h->staged.end() ? nullptr : &it->second;
+}
+
+struct Packer {
+    std::vector<float> host;
+    size_t add(const std::vector<float>& v) {
+        size_t off = host.size();
+        host.insert(host.end(), v.begin(), v.end());
+        while (host.size() % 4) host.push_back(0.f);  // keep every tensor 16-byte aligned
+        return off;
+    }
+};
+
+// Conv1d weight [cout][cin][k] -> [cout][k][cin]
+bool pack_conv(const at_encodec* h, const std::string& prefix, int cin, int cout, int k, Packer& p, size_t& w_off,
+               size_t& b_off) {
+    const HostTensor* w = find(h, prefix + ".weight");
+    const HostTensor* b = find(h, prefix + ".bias");
+    if (!w || !b) { set_error("missing tensor " + prefix + ".{weight,bias}"); return false; }
+    if (w->shape != std::vector<int64_t>{cout, cin, k} || b->shape != std::vector<int64_t>{cout}) {
+        set_error("bad shape for " + prefix);
+        return false;
+    }
+    std::vector<float> out((size_t)cout * k * cin);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < k; ++t) out[((size_t)co * k + t) * cin + ci] = w->data[((size_t)co * cin + ci) * k + t];
+    w_off = p.add(out);
+    b_off = p.add(b->data);
+    return true;
+}
+
+// ConvTranspose1d weight [cin][cout][k = 2s] -> rows (p*cout + co), cols [x[t-1] block | x[t] block]
+bool pack_convtr(const at_encodec* h, const std::string& prefix, int cin, int cout, int s, Packer& p, size_t& w_off,
+                 size_t& b_off) {
+    const HostTensor* w = find(h, prefix + ".weight");
+    const HostTensor* b = find(h, prefix + ".bias");
+    if (!w || !b) { set_error("missing tensor " + prefix + ".{weight,bias}"); return false; }
+    const int k = 2 * s;
+    if (w->shape != std::vector<int64_t>{cin, cout, k} || b->shape != std::vector<int64_t>{cout}) {
+        set_error("bad shape for " + prefix);
+        return false;
+    }
+    std::vector<float> out((size_t)s * cout * 2 * cin);
+    for (int ph = 0; ph < s; ++ph)
+        for (int co = 0; co < cout; ++co) {
+            float* row = &out[((size_t)ph * cout + co) * 2 * cin];
+            for (int ci = 0; ci < cin; ++ci) {
+                row[ci] = w->data[((size_t)ci * cout + co) * k + ph + s];  // x[t-1] contributes tap p+s
+                row[cin + ci] = w->data[((size_t)ci * cout + co) * k + ph];  // x[t] contributes tap p
+            }
+        }
+    std::vector<float> bias((size_t)s * cout);
+    for (int ph = 0; ph < s; ++ph)
+        for (int co = 0; co < cout; ++co) bias[(size_t)ph * cout + co] = b->data[co];
+    w_off = p.add(out);
+    b_off = p.add(bias);
+    return true;
+}
+
+bool pack_lstm(const at_encodec* h, const std::string& prefix, Packer& p, size_t off[2][4]) {
+    for (int l = 0; l < 2; ++l) {
+        const char* names[4] = {"weight_ih", "weight_hh", "bias_ih", "bias_hh"};
+        for (int which = 0; which < 4; ++which) {
+            const std::string key = prefix + ".lstm." + names[which] + "_l" + std::to_string(l);
+            const HostTensor* t = find(h, key);
+            if (!t) { set_error("missing tensor " + key); return false; }
+            const bool is_w = which < 2;
+            if ((is_w && t->shape != std::vector<int64_t>{4 * kH, kH}) || (!is_w && t->shape != std::vector<int64_t>{4 * kH})) {
+                set_error("bad shape for " + key);
+                return false;
+            }
+            const size_t cols = is_w ? kH : 1;
+            std::vector<float> out(t->data.size());
+            for (int g = 0; g < 4; ++g)
+                for (int j = 0; j < kH; ++j)
+                    std::memcpy(&out[((size_t)j * 4 + g) * cols], &t->data[((size_t)g * kH + j) * cols], cols * sizeof(float));
+            off[l][which] = p.add(out);
+        }
+    }
+    return true;
+}
+
+void set_conv(ConvW& c, const float* blob, size_t w_off, size_t b_off, int cin, int cout, int k, int stride) {
+    c.w = blob + w_off; c.b = blob + b_off; c.cin = cin; c.cout = cout; c.k = k; c.stride = stride;
+}
+
+int out_len(int L, int stride) { return (L + stride - 1) / stride; }
+
+// One causal conv as a windowed GEMM over `batch` clips.
+int conv_gemm(const ConvW& c, const float* X, long long x_bstride, int Tin, float* C, long long c_bstride, int M, int batch,
+              int pro, const float* R, long long r_bstride, hipStream_t stream, int pad_mode = 1) {
+    GemmArgs a;
+    a.X = X; a.x_bstride = x_bstride; a.Tin = Tin; a.Cin = c.cin; a.ldx = c.cin;
+    a.ktaps = c.k; a.stride = c.stride; a.pad_left = c.k - c.stride; a.pad_mode = pad_mode;
+    a.W = c.w; a.bias = c.b;
+    a.C = C; a.c_bstride = c_bstride; a.ldc = c.cout;
+    a.R = R; a.r_bstride = r_bstride; a.ldr = c.cout;
+    a.M = M; a.N = c.cout; a.K = c.k * c.cin; a.batch = batch;
+    a.pro = pro; a.epi = EPI_NONE; a.alpha = 1.0f;
+    return launch_gemm(a, stream);
+}
+
+// SEANet residual block: out = shortcut(x) + conv1(ELU(conv3(ELU(x)))), three windowed GEMMs.
+int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L, int batch, hipStream_t stream) {
+    const int C = r[2].cout;
+    const long long xs = (long long)L * C, hs = (long long)L * (C / 2);
+    if (int rc = conv_gemm(r[0], x, xs, L, hbuf, hs, L, batch, PRO_ELU, nullptr, 0, stream)) return rc;
+    if (int rc = conv_gemm(r[2], x, xs, L, out, xs, L, batch, PRO_NONE, nullptr, 0, stream)) return rc;
+    return conv_gemm(r[1], hbuf, hs, L, out, xs, L, batch, PRO_ELU, out, xs, stream);
+}
+
+// 2-layer LSTM + skip over [B][T][512]; xg/c/h0 are scratch. y = lstm(x) + x.
+int lstm_skip(const float* const wih[2], const float* const whh[2], const float* const bih[2], const float* const bhh[2],
+              const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream) {
+    for (int layer = 0; layer < 2; ++layer) {
+        const float* in = layer == 0 ? x : h0;
+        float* hout = layer == 0 ? h0 : h1;
+        GemmArgs g;
+        g.X = in; g.x_bstride = 0; g.Tin = B * T; g.Cin = kH; g.ldx = kH;
+        g.W = wih[layer]; g.bias = bih[layer];
+        g.C = xg; g.ldc = 4 * kH; g.M = B * T; g.N = 4 * kH; g.K = kH; g.batch = 1;
+        if (int rc = launch_gemm(g, stream)) return rc;
+        for (int t = 0; t < T; ++t) {
+            GemmArgs s;
+            s.X = hout + (long long)(t > 0 ? t - 1 : 0) * kH; s.x_bstride = 0; s.Tin = B; s.Cin = kH; s.ldx = T * kH;
+            s.W = whh[layer]; s.M = B; s.N = 4 * kH; s.K = kH; s.batch = 1; s.ldc = 4 * kH;
+            LstmStepArgs ls;
+            ls.xg = xg; ls.b_hh = bhh[layer]; ls.c = c; ls.h_out = hout;
+            ls.y_out = layer == 1 ? y : nullptr; ls.skip = x;
+            ls.T = T; ls.t = t; ls.H = kH; ls.first = t == 0;
+            if (int rc = launch_lstm_step(s, ls, stream)) return rc;
+        }
+    }
+    return 0;
+}
+
+struct EncPlan {
+    int L[5];        // lengths: L[0] = N, L[s+1] = ceil(L[s]/ratio)
+    int G;           // sub-batch
+    size_t off_x[4], off_h[4], off_r[4];  // per-stage sub-batch buffers (floats)
+    size_t off_x4, off_xg, off_h0, off_h1, off_c, off_y, off_emb;
+    size_t total_floats;
+};
+
+EncPlan make_plan(int B, int N) {
+    EncPlan p;
+    p.L[0] = N;
+    for (int s = 0; s < 4; ++s) p.L[s + 1] = out_len(p.L[s], kRatiosEnc[s]);
+    p.G = B < kSubBatch ? B : kSubBatch;
+    size_t cur = 0;
+    auto take = [&](size_t n) { size_t o = cur; cur += (n + 63) / 64 * 64; return o; };
+    for (int s = 0; s < 4; ++s) {
+        const size_t C = 32u << s;
+        p.off_x[s] = take((size_t)p.G * p.L[s] * C);
+        p.off_h[s] = take((size_t)p.G * p.L[s] * (C / 2));
+        p.off_r[s] = take((size_t)p.G * p.L[s] * C);
+    }
+    const size_t T = p.L[4];
+    p.off_x4 = take((size_t)B * T * kH);
+    p.off_xg = take((size_t)B * T * 4 * kH);
+    p.off_h0 = take((size_t)B * T * kH);
+    p.off_h1 = take((size_t)B * T * kH);
+    p.off_c = take((size_t)B * kH);
+    p.off_y = take((size_t)B * T * kH);
+    p.off_emb = take((size_t)B * T * kDim);
+    p.total_floats = cur;
+    return p;
+}
+
+struct DecPlan {
+    int L[5];  // L[0] = T, L[s+1] = L[s]*ratio
+    int G;
+    size_t off_z, off_x0, off_xg, off_h0, off_h1, off_c, off_y;
+    size_t off_u[4], off_h[4], off_r[4];
+    size_t total_floats;
+};
+
+DecPlan make_dec_plan(int B, int T) {
+    DecPlan p;
+    p.L[0] = T;
+    for (int s = 0; s < 4; ++s) p.L[s + 1] = p.L[s] * kRatiosDec[s];
+    p.G = B < kSubBatch ? B : kSubBatch;
+    size_t cur = 0;
+    auto take = [&](size_t n) { size_t o = cur; cur += (n + 63) / 64 * 64; return o; };
+    p.off_z = take((size_t)B * T * kDim);
+    p.off_x0 = take((size_t)B * T * kH);
+    p.off_xg = take((size_t)B * T * 4 * kH);
+    p.off_h0 = take((size_t)B * T * kH);
+    p.off_h1 = take((size_t)B * T * kH);
+    p.off_c = take((size_t)B * kH);
+    p.off_y = take((size_t)B * T * kH);
+    int C = kH;
+    for (int s = 0; s < 4; ++s) {
+        C /= 2;
+        p.off_u[s] = take((size_t)p.G * p.L[s + 1] * C);
+        p.off_h[s] = take((size_t)p.G * p.L[s + 1] * (C / 2));
+        p.off_r[s] = take((size_t)p.G * p.L[s + 1] * C);
+    }
+    p.total_floats = cur;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int at_version(void) { return 1; }
+const char* at_last_error(void) { return at::last_error_cstr(); }
+
+at_encodec_t* at_encodec_create(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) {
+        set_error("at_encodec_create: no such HIP device " + std::to_string(device_id));
+        return nullptr;
+    }
+    at_encodec* h = new at_encodec();
+    h->device = device_id;
+    return h;
+}
+
+int at_encodec_set_tensor(at_encodec_t* h, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+    AT_REQUIRE(h && name && host_data && shape && ndim >= 1 && ndim <= 4, "bad arguments");
+    AT_REQUIRE(!h->finalized, "model already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(host_data, host_data + n);
+    h->staged[name] = std::move(t);
+    return 0;
+}
+
+int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
+    AT_REQUIRE(h && !h->finalized, "bad handle");
+    AT_CHECK_HIP(hipSetDevice(h->device));
+    Packer p;
+    struct Off { size_t w, b; };
+    Off o_conv0, o_res[4][3], o_down[4], o_fin;
+    size_t o_lstm[2][4];
+    // conv0 keeps [32][7] (Cin = 1): tap-major == torch layout
+    if (!pack_conv(h, "encoder.model.0.conv.conv", 1, 32, 7, p, o_conv0.w, o_conv0.b)) return -1;
+    int C = 32, idx = 1;
+    for (int s = 0; s < 4; ++s) {
+        const std::string base = "encoder.model." + std::to_string(idx);
+        if (!pack_conv(h, base + ".block.1.conv.conv", C, C / 2, 3, p, o_res[s][0].w, o_res[s][0].b)) return -1;
+        if (!pack_conv(h, base + ".block.3.conv.conv", C / 2, C, 1, p, o_res[s][1].w, o_res[s][1].b)) return -1;
+        if (!pack_conv(h, base + ".shortcut.conv.conv", C, C, 1, p, o_res[s][2].w, o_res[s][2].b)) return -1;
+        if (!pack_conv(h, "encoder.model." + std::to_string(idx + 2) + ".conv.conv", C, 2 * C, 2 * kRatiosEnc[s], p,
+                       o_down[s].w, o_down[s].b))
+            return -1;
+        C *= 2;
+        idx += 3;
+    }
+    if (!pack_lstm(h, "encoder.model.13", p, o_lstm)) return -1;
+    if (!pack_conv(h, "encoder.model.15.conv.conv", kH, kDim, 7, p, o_fin.w, o_fin.b)) return -1;
+
+    // codebooks: consecutive layers 0..n-1
+    int ncb = 0;
+    while (find(h, "quantizer.vq.layers." + std::to_string(ncb) + "._codebook.embed")) ++ncb;
+    AT_REQUIRE(ncb >= 1, "no codebooks (quantizer.vq.layers.0._codebook.embed) supplied");
+    std::vector<float> cbs((size_t)ncb * kCodes * kDim), e2s((size_t)ncb * kCodes);
+    for (int q = 0; q < ncb; ++q) {
+        const std::string key = "quantizer.vq.layers." + std::to_string(q) + "._codebook.embed";
+        const HostTensor* t = find(h, key);
+        AT_REQUIRE(t->shape == (std::vector<int64_t>{kCodes, kDim}), "bad codebook shape");
+        std::memcpy(&cbs[(size_t)q * kCodes * kDim], t->data.data(), (size_t)kCodes * kDim * sizeof(float));
+        const HostTensor* e = find(h, key.substr(0, key.size() - 5) + "e2");
+        if (e) {
+            AT_REQUIRE(e->shape == (std::vector<int64_t>{kCodes}), "bad e2 shape");
+            std::memcpy(&e2s[(size_t)q * kCodes], e->data.data(), kCodes * sizeof(float));
+        } else {
+            for (int n = 0; n < kCodes; ++n) {
+                float acc = 0.f;
+                for (int k = 0; k < kDim; ++k) { const float v = t->data[(size_t)n * kDim + k]; acc += v * v; }
+                e2s[(size_t)q * kCodes + n] = acc;
+            }
+        }
+    }
+    const size_t o_cb = p.add(cbs), o_e2 = p.add(e2s);
+
+    // decoder
+    Off d_conv0 = {}, d_up[4] = {}, d_res[4][3] = {}, d_last = {};
+    size_t d_lstm[2][4] = {};
+    if (with_decoder) {
+        if (!pack_conv(h, "decoder.model.0.conv.conv", kDim, kH, 7, p, d_conv0.w, d_conv0.b)) return -1;
+        if (!pack_lstm(h, "decoder.model.1", p, d_lstm)) return -1;
+        int Cd = kH, di = 3;
+        for (int s = 0; s < 4; ++s) {
+            if (!pack_convtr(h, "decoder.model." + std::to_string(di) + ".convtr.convtr", Cd, Cd / 2, kRatiosDec[s], p,
+                             d_up[s].w, d_up[s].b))
+                return -1;
+            Cd /= 2;
+            const std::string base = "decoder.model." + std::to_string(di + 1);
+            if (!pack_conv(h, base + ".block.1.conv.conv", Cd, Cd / 2, 3, p, d_res[s][0].w, d_res[s][0].b)) return -1;
+            if (!pack_conv(h, base + ".block.3.conv.conv", Cd / 2, Cd, 1, p, d_res[s][1].w, d_res[s][1].b)) return -1;
+            if (!pack_conv(h, base + ".shortcut.conv.conv", Cd, Cd, 1, p, d_res[s][2].w, d_res[s][2].b)) return -1;
+            di += 3;
+        }
+        if (!pack_conv(h, "decoder.model.15.conv.conv", 32, 1, 7, p, d_last.w, d_last.b)) return -1;
+    }
+
+    h->blob_floats = p.host.size();
+    AT_CHECK_HIP(hipMalloc((void**)&h->blob, h->blob_floats * sizeof(float)));
+    AT_CHECK_HIP(hipMemcpy(h->blob, p.host.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice));
+    const float* bl = h->blob;
+    set_conv(h->conv0, bl, o_conv0.w, o_conv0.b, 1, 32, 7, 1);
+    C = 32;
+    for (int s = 0; s < 4; ++s) {
+        set_conv(h->res[s][0], bl, o_res[s][0].w, o_res[s][0].b, C, C / 2, 3, 1);
+        set_conv(h->res[s][1], bl, o_res[s][1].w, o_res[s][1].b, C / 2, C, 1, 1);
+        set_conv(h->res[s][2], bl, o_res[s][2].w, o_res[s][2].b, C, C, 1, 1);
+        set_conv(h->down[s], bl, o_down[s].w, o_down[s].b, C, 2 * C, 2 * kRatiosEnc[s], kRatiosEnc[s]);
+        C *= 2;
+    }
+    set_conv(h->fin, bl, o_fin.w, o_fin.b, kH, kDim, 7, 1);
+    for (int l = 0; l < 2; ++l) {
+        h->wih[l] = bl + o_lstm[l][0]; h->whh[l] = bl + o_lstm[l][1]; h->bih[l] = bl + o_lstm[l][2]; h->bhh[l] = bl + o_lstm[l][3];
+    }
+    h->codebooks = bl + o_cb;
+    h->e2 = bl + o_e2;
+    h->n_codebooks = ncb;
+    if (with_decoder) {
+        set_conv(h->dconv0, bl, d_conv0.w, d_conv0.b, kDim, kH, 7, 1);
+        int Cd = kH;
+        for (int s = 0; s < 4; ++s) {
+            // transposed conv as a k=2, stride-1, zero-left-pad GEMM with N = s*Cout
+            set_conv(h->dup[s], bl, d_up[s].w, d_up[s].b, Cd, kRatiosDec[s] * (Cd / 2), 2, 1);
+            Cd /= 2;
+            set_conv(h->dres[s][0], bl, d_res[s][0].w, d_res[s][0].b, Cd, Cd / 2, 3, 1);
+            set_conv(h->dres[s][1], bl, d_res[s][1].w, d_res[s][1].b, Cd / 2, Cd, 1, 1);
+            set_conv(h->dres[s][2], bl, d_res[s][2].w, d_res[s][2].b, Cd, Cd, 1, 1);
+        }
+        set_conv(h->dlast, bl, d_last.w, d_last.b, 32, 1, 7, 1);
+        for (int l = 0; l < 2; ++l) {
+            h->dwih[l] = bl + d_lstm[l][0]; h->dwhh[l] = bl + d_lstm[l][1]; h->dbih[l] = bl + d_lstm[l][2]; h->dbhh[l] = bl + d_lstm[l][3];
+        }
+    }
+    h->has_decoder = with_decoder != 0;
+    h->staged.clear();
+    h->finalized = true;
+    return 0;
+}
+
+void at_encodec_destroy(at_encodec_t* h) {
+    if (!h) return;
+    if (h->blob) { (void)hipSetDevice(h->device); (void)hipFree(h->blob); }
+    delete h;
+}
+
+int at_encodec_num_codebooks(const at_encodec_t* h) { return h ? h->n_codebooks : 0; }
+
+size_t at_encodec_workspace_bytes(const at_encodec_t* h, int B, int N) {
+    (void)h;
+    if (B <= 0 || N <= 0) return 0;
+    return make_plan(B, N).total_floats * sizeof(float);
+}
+
+int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes, int* T_out,
+                      float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream_) {
+    (void)mask;  // the reference's AcousticEncoder.forward ignores attention_mask (audiotoken/encoder.py:44-52)
+    AT_REQUIRE(h && h->finalized, "model not finalized");
+    AT_REQUIRE(wav && codes && workspace, "null pointer");
+    AT_REQUIRE(B >= 1 && N >= 10, "need B >= 1 and N >= 10 samples");
+    AT_REQUIRE(n_q >= 1 && n_q <= h->n_codebooks, "n_q out of range for the loaded codebooks");
+    hipStream_t stream = (hipStream_t)stream_;
+    const EncPlan p = make_plan(B, N);
+    AT_REQUIRE(workspace_bytes >= p.total_floats * sizeof(float), "workspace too small");
+    AT_REQUIRE(p.L[3] > 8, "clip too short for the strided convs");
+    float* ws = (float*)workspace;
+    const int T = p.L[4];
+    if (T_out) *T_out = T;
+
+    float* x4 = ws + p.off_x4;
+    for (int b0 = 0; b0 < B; b0 += p.G) {
+        const int g = (B - b0) < p.G ? (B - b0) : p.G;
+        if (int rc = launch_conv0(wav + (long long)b0 * N, h->conv0.w, h->conv0.b, ws + p.off_x[0], g, N, stream)) return rc;
+        for (int s = 0; s < 4; ++s) {
+            const int C = 32 << s, L = p.L[s], Lo = p.L[s + 1];
+            float* x = ws + p.off_x[s];
+            float* r = ws + p.off_r[s];
+            if (int rc = resblock(h->res[s], x, ws + p.off_h[s], r, L, g, stream)) return rc;
+            float* out = s < 3 ? ws + p.off_x[s + 1] : x4 + (long long)b0 * T * kH;
+            if (int rc = conv_gemm(h->down[s], r, (long long)L * C, L, out, (long long)Lo * 2 * C, Lo, g, PRO_ELU, nullptr, 0, stream))
+                return rc;
+        }
+    }
+    float* y = ws + p.off_y;
+    if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream))
+        return rc;
+    float* emb = emb_out ? emb_out : ws + p.off_emb;
+    if (int rc = conv_gemm(h->fin, y, (long long)T * kH, T, emb, (long long)T * kDim, T, B, PRO_ELU, nullptr, 0, stream)) return rc;
+    return launch_rvq_encode(emb, (long long)B * T, T, h->codebooks, h->e2, n_q, codes, stream);
+}
+
+size_t at_encodec_decode_workspace_bytes(const at_encodec_t* h, int B, int T) {
+    (void)h;
+    if (B <= 0 || T <= 0) return 0;
+    return make_dec_plan(B, T).total_floats * sizeof(float);
+}
+
+int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T, float* wav, void* workspace,
+                      size_t workspace_bytes, at_stream_t stream_) {
+    AT_REQUIRE(h && h->finalized && h->has_decoder, "model not finalized with a decoder");
+    AT_REQUIRE(codes && wav && workspace, "null pointer");
+    AT_REQUIRE(B >= 1 && T >= 7 && K >= 1 && K <= h->n_codebooks, "bad B/T/K");
+    hipStream_t stream = (hipStream_t)stream_;
+    const DecPlan p = make_dec_plan(B, T);
+    AT_REQUIRE(workspace_bytes >= p.total_floats * sizeof(float), "workspace too small");
+    float* ws = (float*)workspace;
+    float* z = ws + p.off_z;
+    if (int rc = launch_rvq_decode(codes, B, K, T, h->codebooks, z, stream)) return rc;
+    float* x0 = ws + p.off_x0;
+    if (int rc = conv_gemm(h->dconv0, z, (long long)T * kDim, T, x0, (long long)T * kH, T, B, PRO_NONE, nullptr, 0, stream)) return rc;
+    float* y = ws + p.off_y;
+    if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream))
+        return rc;
+    const int Lout = p.L[4];
+    for (int b0 = 0; b0 < B; b0 += p.G) {
+        const int g = (B - b0) < p.G ? (B - b0) : p.G;
+        const float* in = y + (long long)b0 * T * kH;
+        int Cin = kH;
+        for (int s = 0; s < 4; ++s) {
+            const int Li = p.L[s], Lo = p.L[s + 1], Co = Cin / 2;
+            float* u = ws + p.off_u[s];
+            // ELU -> ConvTranspose1d(k = 2r, stride r) trimmed right by r, as one GEMM with N = r*Cout:
+            // out[t][p*Cout + co] = x[t-1].W[:, co, p+r] + x[t].W[:, co, p]; [Li][r*Cout] is [Lo][Cout] in memory.
+            if (int rc = conv_gemm(h->dup[s], in, (long long)Li * Cin, Li, u, (long long)Lo * Co, Li, g, PRO_ELU, nullptr, 0, stream, 0))
+                return rc;
+            float* r = ws + p.off_r[s];
+            if (int rc = resblock(h->dres[s], u, ws + p.off_h[s], r, Lo, g, stream)) return rc;
+            in = r;
+            Cin = Co;
+        }
+        if (int rc = launch_conv_last(in, h->dlast.w, h->dlast.b, wav + (long long)b0 * Lout, g, Lout, stream)) return rc;
+    }
+    return 0;
+}
+
+int at_op_gemm(const at_gemm_desc* d, at_stream_t stream) {
+    AT_REQUIRE(d != nullptr, "null descriptor");
+    GemmArgs a;
+    a.X = d->X; a.x_bstride = d->x_bstride; a.Tin = d->Tin; a.Cin = d->Cin; a.ldx = d->ldx;
+    a.ktaps = d->ktaps; a.stride = d->stride; a.pad_left = d->pad_left; a.pad_mode = d->pad_mode;
+    a.W = d->W; a.bias = d->bias; a.C = d->C; a.c_bstride = d->c_bstride; a.ldc = d->ldc;
+    a.R = d->R; a.r_bstride = d->r_bstride; a.ldr = d->ldr;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.batch = d->batch; a.pro = d->pro; a.epi = d->epi; a.alpha = d->alpha;
+    return launch_gemm(a, (hipStream_t)stream);
+}
+
+int at_op_rvq_encode(const float* x, int64_t rows, int T, const float* codebooks, const float* e2, int n_q, int16_t* codes,
+                     at_stream_t stream) {
+    AT_REQUIRE(x && codebooks && e2 && codes && T >= 1 && n_q >= 1, "bad arguments");
+    return launch_rvq_encode(x, rows, T, codebooks, e2, n_q, codes, (hipStream_t)stream);
+}
+
+}  // extern "C"

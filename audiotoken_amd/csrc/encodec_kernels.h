@@ -1,0 +1,24 @@
+// Launchers of the EnCodec-specific kernels (encodec_kernels.hip).
+#pragma once
+#include "at_common.h"
+
+namespace at {
+
+struct LstmStepArgs {
+    const float* xg;    // [B][T][4H], gate-interleaved columns (4*j + g), includes b_ih
+    const float* b_hh;  // [4H], gate-interleaved
+    float* c;           // [B][H] cell state (in/out)
+    float* h_out;       // [B][T][H]
+    float* y_out;       // optional [B][T][H]: h + skip
+    const float* skip;  // [B][T][H] (LSTM stack input) when y_out != null
+    int T, t, H, first;
+};
+
+int launch_conv0(const float* wav, const float* w, const float* bias, float* out, int B, int N, hipStream_t stream);
+int launch_lstm_step(const GemmArgs& a, const LstmStepArgs& s, hipStream_t stream);
+int launch_rvq_encode(const float* x, long long rows, int T, const float* codebooks, const float* e2, int n_q,
+                      int16_t* codes, hipStream_t stream);
+int launch_rvq_decode(const int64_t* codes, int B, int K, int T, const float* codebooks, float* z, hipStream_t stream);
+int launch_conv_last(const float* x, const float* w, const float* bias, float* out, int B, int L, hipStream_t stream);
+
+}  // namespace at

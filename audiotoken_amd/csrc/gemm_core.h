@@ -1,0 +1,120 @@
+// Core of the fp32 windowed GEMM (see gemm_f32.hip for the design notes): computes the BM x BN accumulator
+// tile of one workgroup and leaves it in registers so that callers can attach their own epilogue.
+#pragma once
+#include "at_common.h"
+
+namespace at {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int BK = 32;
+
+// Accumulator ownership after gemm_tile(): lane (r16 = lane&15, q = lane>>4) of wave (wm, wn) holds
+//   acc[i][j] = out[m = m0 + wm*TM*16 + i*16 + r16][n = n0 + wn*TN*16 + j*16 + q*4 .. +3]
+template <int BM, int BN, int WM, int WN>
+struct GemmTile {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static constexpr int TM = BM / WM / 16;
+    static constexpr int TN = BN / WN / 16;
+    static constexpr int XCH = BM / 32;                   // float4 chunks per thread, activation tile
+    static constexpr int WCH = (BN >= 32) ? BN / 32 : 1;  // float4 chunks per thread, weight tile
+    static constexpr size_t LDS_BYTES = (size_t)(BM + BN) * BK * 2 * sizeof(float);
+
+    __device__ static __forceinline__ void run(const GemmArgs& a, float* smem, int m0, int n0, int b, f4 (&acc)[TM][TN]) {
+        float* Xs = smem;                // [2][BM*32]
+        float* Ws = smem + 2 * BM * BK;  // [2][BN*32]
+        const int tid = threadIdx.x;
+        const int lane = tid & 63;
+        const int wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int r16 = lane & 15, q = lane >> 4;
+        const float* Xb = a.X + (long long)b * a.x_bstride;
+        const int lrow = tid >> 3;  // 0..31
+        const int kc = tid & 7;     // 16-byte chunk within the 32-float K slice
+
+        f4 xreg[XCH], wreg[WCH];
+        const int nk = (a.K + BK - 1) / BK;
+
+        auto load_tile = [&](int kt) {
+            const int kk = kt * BK + kc * 4;
+            const bool kvalid = kk < a.K;
+            const int tap = kvalid ? kk / a.Cin : 0;
+            const int ci = kk - tap * a.Cin;
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const int m = m0 + lrow + j * 32;
+                f4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kvalid && m < a.M) {
+                    int r = m * a.stride + tap - a.pad_left;
+                    bool ok = true;
+                    if (r < 0) {
+                        if (a.pad_mode) r = -r; else ok = false;
+                    } else if (r >= a.Tin) {
+                        if (a.pad_mode) r = 2 * (a.Tin - 1) - r; else ok = false;
+                    }
+                    if (ok) {
+                        v = *reinterpret_cast<const f4*>(Xb + (long long)r * a.ldx + ci);
+                        if (a.pro == PRO_ELU) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+                    }
+                }
+                xreg[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < WCH; ++j) {
+                const int n = n0 + lrow + j * 32;
+                f4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kvalid && n < a.N && (BN >= 32 || lrow < BN)) v = *reinterpret_cast<const f4*>(a.W + (long long)n * a.K + kk);
+                wreg[j] = v;
+            }
+        };
+        auto store_tile = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const int row = lrow + j * 32;
+                *reinterpret_cast<f4*>(Xs + buf * BM * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) = xreg[j];
+            }
+#pragma unroll
+            for (int j = 0; j < WCH; ++j) {
+                const int row = lrow + j * 32;
+                if (BN >= 32 || row < BN)
+                    *reinterpret_cast<f4*>(Ws + buf * BN * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) = wreg[j];
+            }
+        };
+
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        if (nk == 0) return;
+
+        const int sw = (r16 >> 1) & 7;
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tile(kt + 1);
+            const float* xs = Xs + buf * BM * BK + (wm * TM * 16 + r16) * BK;
+            const float* ws = Ws + buf * BN * BK + (wn * TN * 16 + r16) * BK;
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                const int ch = (((kg << 2) + q) ^ sw) << 2;
+                f4 xa[TM], wb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const f4*>(xs + i * 16 * BK + ch);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wb[j] = *reinterpret_cast<const f4*>(ws + j * 16 * BK + ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j][e], xa[i][e], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+};
+
+}  // namespace at

@@ -1,0 +1,97 @@
+// fp32 windowed GEMM on the CDNA4 f32 matrix cores (v_mfma_f32_16x16x4_f32): the dense contraction behind
+// every conv1d / transposed conv1d / Linear of the tokenizers (see GemmArgs in at_common.h).
+//
+// Why fp32 MFMA: token ids must equal the reference's fp32 CPU result; the f32-input MFMA is an exact
+// k-ordered fmaf chain (MI355X guide §3 "FP32-input MFMA") at the fp32 vector peak (157 TFLOP/s) and leaves
+// the VALU free for the ELU prologue / epilogues.
+//
+// Tiling (wave64, 4 waves per workgroup): block tile BM x BN, K step 32. Both operand tiles are staged
+// global -> registers -> LDS (register staging because the A tile needs the ELU prologue and reflected rows),
+// double-buffered so tile k+1's global loads fly during tile k's MFMAs, one barrier per K step.
+// LDS image: [row][32 floats], 16-byte chunk index XOR ((row>>1)&7) — conflict-free for the ds_read_b128
+// fragment reads (16 rows x same chunk) and for the ds_write_b128 staging writes (8 chunks of one row).
+// Fragment trick: one ds_read_b128 gives a lane 4 consecutive k; MFMA step j uses element j, so the four
+// lane-quads cover 16 distinct k per four MFMAs — any k permutation is legal as long as A and B agree.
+// The MFMA is issued "swapped" (weights as the A operand, activations as B) so each lane ends up with 4
+// consecutive output channels of one output row: the epilogue is one float4 load (bias / residual) and one
+// float4 store per 16x16 tile.
+#include "gemm_core.h"
+
+namespace at {
+
+__device__ __forceinline__ f4 apply_act4(f4 v, int epi) {
+    if (epi == EPI_SWISH) {
+        v.x = swishf_(v.x); v.y = swishf_(v.y); v.z = swishf_(v.z); v.w = swishf_(v.w);
+    } else if (epi == EPI_ELU) {
+        v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
+    } else if (epi == EPI_GELU) {
+        v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752440f));
+        v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752440f));
+        v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752440f));
+        v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f));
+    }
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+    using Tile = GemmTile<BM, BN, WM, WN>;
+    constexpr int TM = Tile::TM, TN = Tile::TN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+    f4 acc[TM][TN];
+    Tile::run(a, smem, m0, n0, b, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, q = lane >> 4;
+    float* Cb = a.C + (long long)b * a.c_bstride;
+    const float* Rb = a.R ? a.R + (long long)b * a.r_bstride : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * TM * 16 + i * 16 + r16;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 16 + j * 16 + q * 4;
+            if (n >= a.N) continue;
+            f4 v = acc[i][j];
+            if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
+            v = apply_act4(v, a.epi);
+            v *= a.alpha;
+            if (Rb) v += *reinterpret_cast<const f4*>(Rb + (long long)m * a.ldr + n);
+            *reinterpret_cast<f4*>(Cb + (long long)m * a.ldc + n) = v;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+    using Tile = GemmTile<BM, BN, WM, WN>;
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN>), grid, dim3(256), Tile::LDS_BYTES, stream, a);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int check_gemm_args(const GemmArgs& a) {
+    AT_REQUIRE(a.K == a.ktaps * a.Cin, "K must equal ktaps*Cin");
+    AT_REQUIRE(a.Cin % 4 == 0 && a.N % 4 == 0, "Cin and N must be multiples of 4");
+    AT_REQUIRE(a.ldx % 4 == 0 && a.ldx >= 4, "ldx must be a positive multiple of 4");
+    AT_REQUIRE(a.ldc % 4 == 0 && (a.R == nullptr || a.ldr % 4 == 0), "ldc/ldr must be multiples of 4");
+    AT_REQUIRE(a.batch >= 1 && a.batch <= 65535, "batch out of range");
+    AT_REQUIRE(a.pad_mode == 0 || a.Tin > a.pad_left, "reflect padding needs Tin > pad");
+    return 0;
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+    if (int rc = check_gemm_args(a)) return rc;
+    if (a.M <= 0 || a.N <= 0) return 0;
+    if (a.N <= 16) return launch_cfg<128, 16, 4, 1>(a, stream);
+    if (a.N <= 32) return launch_cfg<128, 32, 4, 1>(a, stream);
+    if (a.N <= 64) return launch_cfg<128, 64, 4, 1>(a, stream);
+    if ((long long)a.M * a.batch <= 1024) return launch_cfg<64, 64, 2, 2>(a, stream);
+    return launch_cfg<128, 128, 2, 2>(a, stream);
+}
+
+}  // namespace at

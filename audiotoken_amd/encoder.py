@@ -1,0 +1,137 @@
+"""Encoder callables with the reference's protocol: ``encoder(input_batch, attention_mask) -> int16 [B, K, T]``
+(reference audiotoken/encoder.py:29-186), backed by libaudiotoken_hip.so through the C ABI.
+
+PyTorch is used for device tensors, the caching allocator (workspace) and the current stream only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Union
+
+import numpy as np
+import torch
+
+from . import _cabi
+from . import weights as W
+from .configs import AcousticEncoderConfig
+from .logger import get_logger
+
+logger = get_logger(__name__)
+
+
+def _device_index(device: Union[str, torch.device]) -> int:
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError(
+            f"audiotoken_amd runs on MI355X only (device 'cuda[:i]' under PyTorch-ROCm); got {device!r}. "
+            "There is no CPU path in this package.")
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+def encodec_bandwidth_to_nq(bandwidth: float) -> int:
+    """``n_q = max(1, floor(bw*1000 / (log2(1024)*75)))`` — encodec ResidualVectorQuantizer
+    (call site reference audiotoken/encoder.py:50-52)."""
+    return int(max(1, math.floor(bandwidth * 1000 / (10 * 75))))
+
+
+def fold_encodec_weights(w: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """encodec checkpoint dict (weight_g / weight_v pairs) -> folded ``.weight`` tensors for the C ABI."""
+    out: Dict[str, np.ndarray] = {}
+    for k, v in w.items():
+        if k.endswith(".weight_g"):
+            base = k[: -len(".weight_g")]
+            out[base + ".weight"] = W.fold_weight_norm(v, w[base + ".weight_v"])
+        elif k.endswith(".weight_v"):
+            continue
+        elif k.endswith("._codebook.embed"):
+            out[k] = np.ascontiguousarray(v, dtype=np.float32)
+            e = torch.from_numpy(out[k])
+            # |e|^2 exactly as the reference forms it: embed.t().pow(2).sum(0, keepdim=True)
+            out[k[: -len("embed")] + "e2"] = e.t().pow(2).sum(0).numpy()
+        elif k.startswith(("encoder.", "decoder.", "quantizer.")) and not k.endswith(("inited", "cluster_size", "embed_avg")):
+            out[k] = np.ascontiguousarray(v, dtype=np.float32)
+    return out
+
+
+def load_encodec_checkpoint(path: str) -> Dict[str, np.ndarray]:
+    """Read an ``encodec_24khz-*.th`` state dict (torch.save format) into numpy arrays."""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    return {k: v.float().numpy() for k, v in sd.items() if torch.is_tensor(v)}
+
+
+class _EncodecHandle:
+    """Owns one ``at_encodec_t`` (device weights live inside the library)."""
+
+    def __init__(self, device: Union[str, torch.device], weights: Optional[Union[str, Dict[str, np.ndarray]]],
+                 with_decoder: bool):
+        self.lib = _cabi.load()
+        self.device_index = _device_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        if weights is None:
+            logger.warning("No EnCodec checkpoint given (weights=/AUDIOTOKEN_ENCODEC_WEIGHTS): using synthetic weights, seed 0")
+            weights = W.synth_encodec_weights(seed=0, with_decoder=with_decoder)
+        elif isinstance(weights, (str, bytes)):
+            weights = load_encodec_checkpoint(weights)
+        folded = fold_encodec_weights(weights)
+        self.handle = self.lib.at_encodec_create(self.device_index)
+        if not self.handle:
+            raise _cabi.HipLibraryError(f"at_encodec_create failed: {_cabi.last_error()}")
+        for name, arr in folded.items():
+            if not with_decoder and name.startswith("decoder."):
+                continue
+            _cabi.set_tensor(self.lib, self.lib.at_encodec_set_tensor, self.handle, name, arr)
+        _cabi.check(self.lib.at_encodec_finalize(self.handle, 1 if with_decoder else 0), "at_encodec_finalize")
+        self.n_codebooks = self.lib.at_encodec_num_codebooks(self.handle)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.at_encodec_destroy(h)
+
+
+class AcousticEncoder(torch.nn.Module):
+    """Drop-in for reference ``AcousticEncoder`` (audiotoken/encoder.py:29-57)."""
+
+    def __init__(self, config: AcousticEncoderConfig = None, device: str = "cuda:0",
+                 weights: Optional[Union[str, Dict[str, np.ndarray]]] = None):
+        super().__init__()
+        config = config or AcousticEncoderConfig()
+        self.config = config
+        self._h = _EncodecHandle(device, weights if weights is not None else config.weights, with_decoder=False)
+        self.device = self._h.device
+        self.n_q = encodec_bandwidth_to_nq(config.bandwidth)
+        if self.n_q > self._h.n_codebooks:
+            raise ValueError(f"bandwidth {config.bandwidth} needs {self.n_q} codebooks, checkpoint has {self._h.n_codebooks}")
+        self._ws: Optional[torch.Tensor] = None
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    @torch.no_grad()
+    def forward(self, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                return_embeddings: bool = False):
+        """``float32 [B, N]`` on the device (+ ignored mask) -> ``int16 [B, n_q, ceil(N/320)]`` on the device."""
+        assert input_batch.dim() == 2, "input_batch must be [B, N]"
+        x = input_batch.to(device=self.device, dtype=torch.float32).contiguous()
+        B, N = x.shape
+        T = -(-N // W.ENCODEC_HOP)
+        lib = self._h.lib
+        codes = torch.empty((B, self.n_q, T), dtype=torch.int16, device=self.device)
+        emb = torch.empty((B, T, W.ENCODEC_DIM), dtype=torch.float32, device=self.device) if return_embeddings else None
+        nbytes = lib.at_encodec_workspace_bytes(self._h.handle, B, N)
+        ws = self._workspace(nbytes)
+        t_out = C.c_int(0)
+        with torch.cuda.device(self.device):
+            stream = _cabi.current_stream_handle(self.device)
+            rc = lib.at_encodec_encode(self._h.handle, x.data_ptr(), 0, B, N, self.n_q, codes.data_ptr(), C.byref(t_out),
+                                       _cabi.ptr(emb), ws.data_ptr(), nbytes, stream)
+        _cabi.check(rc, "at_encodec_encode")
+        assert t_out.value == T
+        logger.info(f'Codes shape: {codes.shape}')
+        if return_embeddings:
+            return codes, emb
+        return codes

@@ -1,0 +1,103 @@
+/*
+ * audiotoken_hip.h — C ABI of libaudiotoken_hip.so: the MI355X (gfx950) hot path of cmeraki/audiotoken.
+ *
+ * The reference has no FFI: its seam is the Python callable protocol
+ *     self.encoder(input_batch: float32[B,N] on device, attention_mask: float32[B,N]) -> int16[B,K,T]
+ * (reference audiotoken/core.py:194 and :276; encoder classes audiotoken/encoder.py:29-186) and
+ *     self.decoder(tokens: int64[B,K,T]) -> float32[1, B*320*T]
+ * (reference audiotoken/core.py:355-359; audiotoken/decoder.py:66-76).
+ * Each entry point below names the reference interface it replaces. All pointers marked "device" are HIP
+ * device pointers on the handle's device; everything is row-major and contiguous. Calls are stream-ordered and
+ * never synchronise or allocate; scratch comes from a caller-provided workspace so the caller's allocator
+ * (PyTorch's caching allocator in the Python binding) stays the only allocator. Functions return 0 on success,
+ * a negative code on failure; at_last_error() returns the thread-local message. Nothing aborts.
+ *
+ * Threading: a handle is bound to one device; calls on one handle must be serialised by the caller; different
+ * handles are independent (one process per GPU in the multi-GPU harness).
+ */
+#ifndef AUDIOTOKEN_HIP_H
+#define AUDIOTOKEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* at_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------------------------------ */
+int at_version(void);
+const char* at_last_error(void);
+
+/* ---- acoustic tokenizer: EnCodec 24 kHz SEANet encoder + residual VQ, and the decoder ------------------
+ * Replaces reference AcousticEncoder (audiotoken/encoder.py:29-57: ctor builds
+ * EncodecModel.encodec_model_24khz(), forward = model.encoder -> model.quantizer.encode -> transpose ->
+ * int16) and AcousticDecoder (audiotoken/decoder.py:50-76). */
+typedef struct at_encodec at_encodec_t;
+
+/* Create an empty model bound to `device_id` (replaces encoder.py:38-39 `EncodecModel...to(device)`). */
+at_encodec_t* at_encodec_create(int device_id);
+
+/* Hand one named host tensor (float32) to the model. Names are the `encodec` checkpoint keys with the
+ * weight-norm pair already folded to a plain `.weight` (W = g*v/||v||, the tensor the reference convolves
+ * with): "encoder.model.0.conv.conv.weight" [32,1,7] / ".bias", "encoder.model.{1,4,7,10}.block.{1,3}.conv.conv.*",
+ * "encoder.model.{1,4,7,10}.shortcut.conv.conv.*", "encoder.model.{3,6,9,12}.conv.conv.*",
+ * "encoder.model.13.lstm.{weight_ih,weight_hh,bias_ih,bias_hh}_l{0,1}", "encoder.model.15.conv.conv.*",
+ * "quantizer.vq.layers.{k}._codebook.embed" [1024,128] (optional ".e2" [1024] = row-wise sum of squares),
+ * and for decode "decoder.model.*" ("…convtr.convtr.weight" is [in,out,k]). */
+int at_encodec_set_tensor(at_encodec_t* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
+
+/* Repack to kernel layouts, upload, free host staging. with_decoder != 0 also requires the decoder tensors. */
+int at_encodec_finalize(at_encodec_t* h, int with_decoder);
+void at_encodec_destroy(at_encodec_t* h);
+int at_encodec_num_codebooks(const at_encodec_t* h);
+
+/* Workspace size for at_encodec_encode on B clips of N samples. */
+size_t at_encodec_workspace_bytes(const at_encodec_t* h, int B, int N);
+
+/* Replaces AcousticEncoder.forward (audiotoken/encoder.py:44-57).
+ *   wav   device float32 [B][N]           (24 kHz mono, any N >= 1 with N > 9 so reflect padding is defined)
+ *   mask  device float32 [B][N] or NULL   — ignored, exactly as the reference ignores attention_mask
+ *   n_q   number of codebooks in {1..loaded}; the reference derives it from the bandwidth (encoder.py:50-52)
+ *   codes device int16   [B][n_q][T], T = ceil(N/320) returned through *T_out (may be NULL)
+ *   emb_out optional device float32 [B][T][128]: the pre-quantiser embedding (parity taps; NULL in production) */
+int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes,
+                      int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream);
+
+size_t at_encodec_decode_workspace_bytes(const at_encodec_t* h, int B, int T);
+
+/* Replaces AcousticDecoder.forward (audiotoken/decoder.py:66-76): codes device int64 [B][K][T] ->
+ * wav device float32 [B*320*T] (the reference's [1, B*320*T] row). */
+int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T, float* wav, void* workspace,
+                      size_t workspace_bytes, at_stream_t stream);
+
+/* ---- operator-level entry points (the kernels behind the models; used by the parity tests) ------------- */
+
+/* Windowed fp32 GEMM: out[b][m][n] = act(alpha*(sum_kk A(b,m,kk)*W[n][kk] + bias[n])) (+ R[b][m][n]) with
+ * A(b,m,kk) = pro(X[b][m*stride + kk/Cin - pad_left][kk%Cin]); rows outside [0,Tin) reflect (pad_mode=1) or are
+ * zero (pad_mode=0). Covers conv1d (ref: encodec SConv1d), Linear and ConvTranspose1d-as-phases. */
+typedef struct at_gemm_desc {
+    const float* X; int64_t x_bstride; int32_t Tin, Cin, ldx;
+    int32_t ktaps, stride, pad_left, pad_mode;
+    const float* W; const float* bias;
+    float* C; int64_t c_bstride; int32_t ldc;
+    const float* R; int64_t r_bstride; int32_t ldr;
+    int32_t M, N, K, batch;
+    int32_t pro; /* 0 none, 1 ELU */
+    int32_t epi; /* 0 none, 1 swish, 2 ELU, 3 GELU(erf) */
+    float alpha;
+} at_gemm_desc;
+int at_op_gemm(const at_gemm_desc* d, at_stream_t stream);
+
+/* Residual VQ search (ref: encodec ResidualVectorQuantizer.encode; formula SURVEY.md Appendix A.1):
+ * x device float32 [rows][128]; codebooks device [n_q][1024][128]; e2 device [n_q][1024];
+ * codes int16 written at codes[(row / T)*n_q*T + q*T + row % T]. */
+int at_op_rvq_encode(const float* x, int64_t rows, int T, const float* codebooks, const float* e2, int n_q,
+                     int16_t* codes, at_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOTOKEN_HIP_H */
