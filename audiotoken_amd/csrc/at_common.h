@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <vector>
 
 namespace at {
 
@@ -56,6 +57,23 @@ struct GemmArgs {
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int check_gemm_args(const GemmArgs& a);
+
+// ---- optional per-group timing with HIP events on the launch stream (bench.py roofline) -------
+struct Profiler {
+    bool enabled = false;
+    struct Span { int group; int launches; hipEvent_t a, b; };
+    std::vector<std::string> names;
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    int open_ = -1;
+    hipEvent_t get_event();
+    void begin(const char* group, int launches, hipStream_t s);
+    void end(hipStream_t s);
+    void reset();
+    // sums elapsed ms per group; synchronises on the recorded events
+    int read(std::vector<float>& ms, std::vector<int>& launches);
+    ~Profiler();
+};
 
 // ---- small helpers shared by kernels ---------------------------------------------------------
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }

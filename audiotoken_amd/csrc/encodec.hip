@@ -24,6 +24,50 @@ static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 const char* last_error_cstr() { return g_last_error.c_str(); }
 
+hipEvent_t Profiler::get_event() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void Profiler::begin(const char* group, int launches, hipStream_t s) {
+    if (!enabled) return;
+    int g = -1;
+    for (size_t i = 0; i < names.size(); ++i) if (names[i] == group) { g = (int)i; break; }
+    if (g < 0) { names.push_back(group); g = (int)names.size() - 1; }
+    Span sp{g, launches, get_event(), get_event()};
+    (void)hipEventRecord(sp.a, s);
+    spans.push_back(sp);
+    open_ = (int)spans.size() - 1;
+}
+void Profiler::end(hipStream_t s) {
+    if (!enabled || open_ < 0) return;
+    (void)hipEventRecord(spans[open_].b, s);
+    open_ = -1;
+}
+void Profiler::reset() {
+    for (auto& sp : spans) { pool.push_back(sp.a); pool.push_back(sp.b); }
+    spans.clear();
+    names.clear();
+    open_ = -1;
+}
+int Profiler::read(std::vector<float>& ms, std::vector<int>& launches) {
+    ms.assign(names.size(), 0.f);
+    launches.assign(names.size(), 0);
+    for (auto& sp : spans) {
+        if (hipEventSynchronize(sp.b) != hipSuccess) return -2;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, sp.a, sp.b) != hipSuccess) return -2;
+        ms[sp.group] += t;
+        launches[sp.group] += sp.launches;
+    }
+    return 0;
+}
+Profiler::~Profiler() {
+    reset();
+    for (auto e : pool) (void)hipEventDestroy(e);
+}
+
 struct HostTensor {
     std::vector<int64_t> shape;
     std::vector<float> data;
@@ -63,6 +107,7 @@ struct at_encodec {
     // decoder
     ConvW dconv0, dup[4], dres[4][3], dlast;
     const float *dwih[2] = {}, *dwhh[2] = {}, *dbih[2] = {}, *dbhh[2] = {};
+    Profiler prof;
 };
 
 namespace {
@@ -183,7 +228,8 @@ int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L
 
 // 2-layer LSTM + skip over [B][T][512]; xg/c/h0 are scratch. y = lstm(x) + x.
 int lstm_skip(const float* const wih[2], const float* const whh[2], const float* const bih[2], const float* const bhh[2],
-              const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream) {
+              const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream,
+              Profiler& prof) {
     for (int layer = 0; layer < 2; ++layer) {
         const float* in = layer == 0 ? x : h0;
         float* hout = layer == 0 ? h0 : h1;
@@ -191,7 +237,10 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
         g.X = in; g.x_bstride = 0; g.Tin = B * T; g.Cin = kH; g.ldx = kH;
         g.W = wih[layer]; g.bias = bih[layer];
         g.C = xg; g.ldc = 4 * kH; g.M = B * T; g.N = 4 * kH; g.K = kH; g.batch = 1;
+        prof.begin("lstm_ih", 1, stream);
         if (int rc = launch_gemm(g, stream)) return rc;
+        prof.end(stream);
+        prof.begin("lstm_rec", T, stream);
         for (int t = 0; t < T; ++t) {
             GemmArgs s;
             s.X = hout + (long long)(t > 0 ? t - 1 : 0) * kH; s.x_bstride = 0; s.Tin = B; s.Cin = kH; s.ldx = T * kH;
@@ -202,6 +251,7 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
             ls.T = T; ls.t = t; ls.H = kH; ls.first = t == 0;
             if (int rc = launch_lstm_step(s, ls, stream)) return rc;
         }
+        prof.end(stream);
     }
     return 0;
 }
@@ -444,23 +494,63 @@ int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int 
     float* x4 = ws + p.off_x4;
     for (int b0 = 0; b0 < B; b0 += p.G) {
         const int g = (B - b0) < p.G ? (B - b0) : p.G;
+        static const char* kRes[4] = {"res0", "res1", "res2", "res3"};
+        static const char* kDown[4] = {"down0", "down1", "down2", "down3"};
+        Profiler& prof = h->prof;
+        prof.begin("conv0", 1, stream);
         if (int rc = launch_conv0(wav + (long long)b0 * N, h->conv0.w, h->conv0.b, ws + p.off_x[0], g, N, stream)) return rc;
+        prof.end(stream);
         for (int s = 0; s < 4; ++s) {
             const int C = 32 << s, L = p.L[s], Lo = p.L[s + 1];
             float* x = ws + p.off_x[s];
             float* r = ws + p.off_r[s];
+            prof.begin(kRes[s], 3, stream);
             if (int rc = resblock(h->res[s], x, ws + p.off_h[s], r, L, g, stream)) return rc;
+            prof.end(stream);
             float* out = s < 3 ? ws + p.off_x[s + 1] : x4 + (long long)b0 * T * kH;
+            prof.begin(kDown[s], 1, stream);
             if (int rc = conv_gemm(h->down[s], r, (long long)L * C, L, out, (long long)Lo * 2 * C, Lo, g, PRO_ELU, nullptr, 0, stream))
                 return rc;
+            prof.end(stream);
         }
     }
+    Profiler& prof = h->prof;
     float* y = ws + p.off_y;
-    if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream))
+    if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof))
         return rc;
     float* emb = emb_out ? emb_out : ws + p.off_emb;
+    prof.begin("final_conv", 1, stream);
     if (int rc = conv_gemm(h->fin, y, (long long)T * kH, T, emb, (long long)T * kDim, T, B, PRO_ELU, nullptr, 0, stream)) return rc;
-    return launch_rvq_encode(emb, (long long)B * T, T, h->codebooks, h->e2, n_q, codes, stream);
+    prof.end(stream);
+    prof.begin("rvq", 1, stream);
+    int rc = launch_rvq_encode(emb, (long long)B * T, T, h->codebooks, h->e2, n_q, codes, stream);
+    prof.end(stream);
+    return rc;
+}
+
+int at_encodec_profile(at_encodec_t* h, int enable) {
+    AT_REQUIRE(h != nullptr, "null handle");
+    h->prof.reset();
+    h->prof.enabled = enable != 0;
+    return 0;
+}
+
+int at_encodec_profile_read(at_encodec_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups) {
+    AT_REQUIRE(h && names && total_ms && launches, "null pointer");
+    std::vector<float> ms;
+    std::vector<int> ln;
+    if (h->prof.read(ms, ln) != 0) { set_error("profile read: event query failed"); return -2; }
+    std::string joined;
+    int n = 0;
+    for (size_t i = 0; i < h->prof.names.size() && n < max_groups; ++i, ++n) {
+        joined += h->prof.names[i];
+        joined += '\n';
+        total_ms[n] = ms[i];
+        launches[n] = ln[i];
+    }
+    AT_REQUIRE(joined.size() + 1 <= names_cap, "names buffer too small");
+    std::memcpy(names, joined.c_str(), joined.size() + 1);
+    return n;
 }
 
 size_t at_encodec_decode_workspace_bytes(const at_encodec_t* h, int B, int T) {
@@ -483,7 +573,8 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
     float* x0 = ws + p.off_x0;
     if (int rc = conv_gemm(h->dconv0, z, (long long)T * kDim, T, x0, (long long)T * kH, T, B, PRO_NONE, nullptr, 0, stream)) return rc;
     float* y = ws + p.off_y;
-    if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream))
+    Profiler noprof;
+    if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof))
         return rc;
     const int Lout = p.L[4];
     for (int b0 = 0; b0 < B; b0 += p.G) {

@@ -1,0 +1,56 @@
+"""Clip-level data parallelism: one process per GPU, weights broadcast once over RCCL/xGMI, no steady-state
+collective. The reference is single-device (audiotoken/core.py:66); this module is what lets
+``encode_batch_files``-style work shard across the 8 GPUs of a node."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Items (clips / files) owned by ``rank``: contiguous blocks, sizes differing by at most one.
+    All chunks of one file stay on one rank so the per-file append order of the reference
+    (audiotoken/utils.py:214-217) is preserved."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return list(range(start, start + base + (1 if rank < rem else 0)))
+
+
+def broadcast_weights(weights: Optional[Dict[str, np.ndarray]], device: torch.device, dist=None, src: int = 0):
+    """Rank ``src`` holds the weight dict; every rank returns an identical dict.
+
+    One metadata broadcast (names/shapes) + ONE flat float32 tensor broadcast (backend "nccl" = RCCL on ROCm,
+    ring/tree over xGMI; "gloo" on CPU in the tests)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return weights
+    rank = dist.get_rank()
+    meta = [[(k, tuple(v.shape)) for k, v in weights.items()]] if rank == src else [None]
+    dist.broadcast_object_list(meta, src=src)
+    layout = meta[0]
+    total = int(sum(int(np.prod(s)) for _, s in layout))
+    if rank == src:
+        flat = torch.from_numpy(np.concatenate([np.asarray(weights[k], dtype=np.float32).reshape(-1) for k, _ in layout]))
+        flat = flat.to(device)
+    else:
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+    dist.broadcast(flat, src=src)
+    host = flat.cpu().numpy()
+    out: Dict[str, np.ndarray] = {}
+    off = 0
+    for k, shp in layout:
+        n = int(np.prod(shp))
+        out[k] = host[off:off + n].reshape(shp).copy()
+        off += n
+    return out
+
+
+def gather_scalars(values: Sequence[float], device: torch.device, dist=None) -> List[List[float]]:
+    """All-gather a few per-rank scalars (benchmark reporting only)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [list(values)]
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [o.tolist() for o in outs]

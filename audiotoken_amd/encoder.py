@@ -135,3 +135,17 @@ class AcousticEncoder(torch.nn.Module):
         if return_embeddings:
             return codes, emb
         return codes
+
+    # ---- benchmark taps (HIP events recorded by the library on the launch stream) -----------------
+    def enable_profile(self, on: bool) -> None:
+        _cabi.check(self._h.lib.at_encodec_profile(self._h.handle, 1 if on else 0), "at_encodec_profile")
+
+    def read_profile(self) -> Dict[str, tuple]:
+        names = C.create_string_buffer(4096)
+        ms = (C.c_float * 64)()
+        ln = (C.c_int * 64)()
+        n = self._h.lib.at_encodec_profile_read(self._h.handle, names, 4096, ms, ln, 64)
+        if n < 0:
+            raise _cabi.HipLibraryError(f"at_encodec_profile_read failed: {_cabi.last_error()}")
+        keys = names.value.decode().split("\n")[:n]
+        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(keys)}

@@ -66,6 +66,13 @@ size_t at_encodec_workspace_bytes(const at_encodec_t* h, int B, int N);
 int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes,
                       int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream);
 
+/* Optional timing taps for the benchmark: when enabled, encode brackets each kernel group (conv0, res0..3,
+ * down0..3, lstm_ih, lstm_rec, final_conv, rvq) with HIP events recorded on the launch stream.
+ * at_encodec_profile(h, enable) resets the accumulated spans. at_encodec_profile_read synchronises on the
+ * recorded events and returns the number of groups (names '\n'-separated), or a negative error code. */
+int at_encodec_profile(at_encodec_t* h, int enable);
+int at_encodec_profile_read(at_encodec_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups);
+
 size_t at_encodec_decode_workspace_bytes(const at_encodec_t* h, int B, int T);
 
 /* Replaces AcousticDecoder.forward (audiotoken/decoder.py:66-76): codes device int64 [B][K][T] ->
