@@ -140,3 +140,61 @@ def synth_waveform(n_clips: int, n_samples: int, sample_rate: int, seed: int = 1
         noise = prng.irwin_hall("wave.noise", (n_samples,), 1.0, s).astype(np.float64)
         out[i] = np.clip(0.3 * x + 0.05 * noise, -1.0, 1.0).astype(np.float32)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Wav2Vec2-BERT (semantic_m) — HF state-dict keys; architecture constants
+# ----------------------------------------------------------------------------------------------
+W2V_HIDDEN = 1024
+W2V_FFN = 4096
+W2V_HEADS = 16
+W2V_HEAD_DIM = 64
+W2V_FEAT = 160
+W2V_DW_KERNEL = 31
+W2V_REL_BUCKETS = 73          # left 64 + right 8 + 1
+W2V_LAYERS_USED = 19          # hidden_states[19] = output of layer index 18 (reference encoder.py:172-175)
+W2V_CODEBOOK = 2048
+
+
+def synth_w2vbert_weights(n_layers: int = W2V_LAYERS_USED, seed: int = 0, with_vq: bool = True) -> Dict[str, np.ndarray]:
+    """Synthetic Wav2Vec2-BERT weights (first ``n_layers`` conformer layers) + the 2048 x 1024 VQ codebook."""
+    w: Dict[str, np.ndarray] = {}
+    H, Fd = W2V_HIDDEN, W2V_FFN
+
+    def lin(name, out_f, in_f, bias=True, gain=1.0):
+        a = gain * np.sqrt(3.0 / in_f)
+        w[name + ".weight"] = prng.uniform(name + ".weight", (out_f, in_f), -a, a, seed)
+        if bias:
+            w[name + ".bias"] = prng.uniform(name + ".bias", (out_f,), -0.05, 0.05, seed)
+
+    def ln(name, dim):
+        w[name + ".weight"] = prng.uniform(name + ".weight", (dim,), 0.8, 1.2, seed)
+        w[name + ".bias"] = prng.uniform(name + ".bias", (dim,), -0.1, 0.1, seed)
+
+    ln("feature_projection.layer_norm", W2V_FEAT)
+    lin("feature_projection.projection", H, W2V_FEAT)
+    for i in range(n_layers):
+        p = f"encoder.layers.{i}"
+        ln(p + ".ffn1_layer_norm", H)
+        lin(p + ".ffn1.intermediate_dense", Fd, H, gain=1.4)
+        lin(p + ".ffn1.output_dense", H, Fd)
+        ln(p + ".self_attn_layer_norm", H)
+        for nm in ("linear_q", "linear_k", "linear_v", "linear_out"):
+            lin(p + ".self_attn." + nm, H, H, gain=1.6 if nm in ("linear_q", "linear_k") else 1.0)
+        w[p + ".self_attn.distance_embedding.weight"] = prng.uniform(
+            p + ".self_attn.distance_embedding.weight", (W2V_REL_BUCKETS, W2V_HEAD_DIM), -0.5, 0.5, seed)
+        ln(p + ".conv_module.layer_norm", H)
+        a = np.sqrt(3.0 / H)
+        w[p + ".conv_module.pointwise_conv1.weight"] = prng.uniform(p + ".conv_module.pointwise_conv1.weight", (2 * H, H, 1), -1.4 * a, 1.4 * a, seed)
+        ad = np.sqrt(3.0 / W2V_DW_KERNEL)
+        w[p + ".conv_module.depthwise_conv.weight"] = prng.uniform(p + ".conv_module.depthwise_conv.weight", (H, 1, W2V_DW_KERNEL), -ad, ad, seed)
+        ln(p + ".conv_module.depthwise_layer_norm", H)
+        w[p + ".conv_module.pointwise_conv2.weight"] = prng.uniform(p + ".conv_module.pointwise_conv2.weight", (H, H, 1), -a, a, seed)
+        ln(p + ".ffn2_layer_norm", H)
+        lin(p + ".ffn2.intermediate_dense", Fd, H, gain=1.4)
+        lin(p + ".ffn2.output_dense", H, Fd)
+        ln(p + ".final_layer_norm", H)
+    if with_vq:
+        # state-dict key of vector_quantize_pytorch.VectorQuantize (reference audiotoken/utils.py:331-339)
+        w["vq._codebook.embed"] = prng.irwin_hall("vq._codebook.embed", (1, W2V_CODEBOOK, H), 1.0, seed)
+    return w

@@ -60,6 +60,96 @@ def make_encodec():
         print("encodec", tag, emb.shape, toks.shape, wav_out.shape)
 
 
+def make_fbank():
+    """Reference-authored front-end: /root/reference/audiotoken/processors.py via _ref_loader stubs."""
+    from _ref_loader import load_reference_modules
+    mods = load_reference_modules()
+    proc = mods["processors"].Wav2VecBertProcessor(feature_size=80, num_mel_bins=80, sampling_rate=16000, stride=2,
+                                                   padding_value=1)
+    cases = {
+        # tag: (B, N, valid lengths (None = full), pad_to_multiple_of, noise level added on top of the bench waveform)
+        "a": (3, 16000 * 2 + 123, [None, 20000, 9000], 2, 0.0),
+        "b": (2, 16000, [None, 3200], 2, 0.0),
+        "c": (2, 16000 * 3 + 77, [None, 30000], 10, 0.02),
+    }
+    for tag, (B, N, lens, mult, noise) in cases.items():
+        wave = W.synth_waveform(B, N, 16000, seed=77)
+        if noise:
+            from audiotoken_amd import prng
+            wave = np.clip(wave + noise * prng.irwin_hall("fbank.noise", (B, N), 1.0, 5), -1, 1).astype(np.float32)
+        mask = np.ones((B, N), dtype=np.float32)
+        for i, ln in enumerate(lens):
+            if ln is not None:
+                mask[i, ln:] = 0
+                wave[i, ln:] = 0  # datasets.py:102: pad_token = 0
+        with torch.no_grad():
+            out = proc(torch.from_numpy(wave), torch.from_numpy(mask), mult)
+        np.savez_compressed(os.path.join(HERE, f"fbank_{tag}.npz"), wave=wave, mask=mask, pad_to_multiple_of=mult,
+                            input_features=out["input_features"].numpy(), attention_mask=out["attention_mask"].numpy())
+        print("fbank", tag, out["input_features"].shape, out["attention_mask"].sum(1))
+
+
+def _hf_w2vbert(n_layers, w):
+    from transformers import Wav2Vec2BertConfig, Wav2Vec2BertModel
+    from transformers.models.wav2vec2_bert.modeling_wav2vec2_bert import Wav2Vec2BertSelfAttention
+    from _ref_loader import load_reference_modules
+    mods = load_reference_modules()
+    Wav2Vec2BertSelfAttention.forward = mods["modeling_wav2vec2_bert"].forward   # reference encoder.py:14-15
+    model = Wav2Vec2BertModel(Wav2Vec2BertConfig(num_hidden_layers=n_layers)).eval()
+    sd = model.state_dict()
+    for k, v in w.items():
+        if k.startswith("vq."):
+            continue
+        assert k in sd and tuple(sd[k].shape) == tuple(v.shape), k
+        sd[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(sd)
+    return model
+
+
+def make_attention():
+    """The reference's SDPA rel-pos attention (modeling_wav2vec2_bert.py:20-80) bound to HF's attention module."""
+    from audiotoken_amd import prng
+    w = W.synth_w2vbert_weights(n_layers=1, seed=3, with_vq=False)
+    model = _hf_w2vbert(1, w)
+    attn = model.encoder.layers[0].self_attn
+    B, T = 2, 90
+    x = torch.from_numpy(prng.irwin_hall("attn.x", (B, T, 1024), 1.0, 9))
+    mask = torch.ones(B, T)
+    mask[1, 61:] = 0
+    add = (1.0 - mask[:, None, None, :]) * torch.finfo(torch.float32).min
+    add = add.expand(B, 1, T, T)
+    with torch.no_grad():
+        out = attn(x, attention_mask=add.clone())[0]
+    np.savez_compressed(os.path.join(HERE, "attention_a.npz"), weight_seed=3, x_seed=9, B=B, T=T, mask=mask.numpy(),
+                        out=out.numpy())
+    print("attention", out.shape)
+
+
+def make_conformer():
+    """HF Wav2Vec2BertModel (3 layers, synthetic weights) + the reference attention patch: hidden_states."""
+    from _ref_loader import load_reference_modules
+    mods = load_reference_modules()
+    n_layers = 3
+    w = W.synth_w2vbert_weights(n_layers=n_layers, seed=5, with_vq=True)
+    model = _hf_w2vbert(n_layers, w)
+    proc = mods["processors"].Wav2VecBertProcessor(feature_size=80, num_mel_bins=80, sampling_rate=16000, stride=2, padding_value=1)
+    B, N = 2, 16000 + 400
+    wave = W.synth_waveform(B, N, 16000, seed=21)
+    mask = np.ones((B, N), dtype=np.float32)
+    mask[1, 9000:] = 0
+    wave[1, 9000:] = 0
+    with torch.no_grad():
+        po = proc(torch.from_numpy(wave), torch.from_numpy(mask), 2)
+        hs = model(po["input_features"], attention_mask=po["attention_mask"], output_hidden_states=True).hidden_states
+        e = torch.nn.functional.layer_norm(hs[n_layers], (1024,))          # reference encoder.py:138-143,176
+        embed = torch.from_numpy(w["vq._codebook.embed"][0])
+        idx = torch.cdist(e.reshape(-1, 1024), embed).argmin(-1).reshape(B, -1)   # L2-nearest code (cdist cross-check)
+    np.savez_compressed(os.path.join(HERE, "conformer_a.npz"), weight_seed=5, wave_seed=21, n_layers=n_layers, B=B, N=N,
+                        mask=mask, attention_mask=po["attention_mask"].numpy(),
+                        hs0=hs[0].numpy(), hs1=hs[1].numpy(), hs_last=hs[n_layers].numpy(), tokens_cdist=idx.numpy().astype(np.int16))
+    print("conformer", hs[n_layers].shape, idx.shape)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["encodec"]
     torch.manual_seed(0)
