@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("R", C.c_void_p), ("r_bstride", C.c_int64), ("ldr", C.c_int32),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
         ("pro", C.c_int32), ("epi", C.c_int32), ("alpha", C.c_float),
+        ("aux_off", C.c_int32), ("row_mask", C.c_void_p),
     ]
 
 
@@ -49,6 +50,21 @@ SIGNATURES = {
     "at_encodec_decode_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "at_encodec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),
+    "at_w2vbert_create": (C.c_void_p, [C.c_int]),
+    "at_w2vbert_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "at_w2vbert_finalize": (C.c_int, [C.c_void_p]),
+    "at_w2vbert_destroy": (None, [C.c_void_p]),
+    "at_w2vbert_num_layers": (C.c_int, [C.c_void_p]),
+    "at_w2vbert_num_tokens": (C.c_int, [C.c_int, C.c_int]),
+    "at_w2vbert_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "at_w2vbert_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "at_w2vbert_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "at_w2vbert_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
+    "at_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "at_op_relpos_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "at_op_dwconv_ln_swish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "at_op_vq_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "at_op_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "at_op_rvq_encode": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
 }

@@ -33,8 +33,12 @@ void set_error(const std::string& msg);
 // Activations are time-major / channels-last ([B][T][C], C contiguous), so a causal conv1d, a strided
 // conv1d, a transposed conv1d (as s-phase GEMM) and a Linear layer are all this one contraction with a
 // window of K = ktaps*Cin contiguous floats per output row — no im2col buffer ever exists.
-enum Prologue { PRO_NONE = 0, PRO_ELU = 1 };
-enum Epilogue { EPI_NONE = 0, EPI_SWISH = 1, EPI_ELU = 2, EPI_GELU = 3 };
+enum Prologue { PRO_NONE = 0, PRO_ELU = 1, PRO_POWER = 2 };  // POWER: A = X[kk]^2 + X[kk + aux_off]^2 (|DFT|^2)
+enum Epilogue {
+    EPI_NONE = 0, EPI_SWISH = 1, EPI_ELU = 2, EPI_GELU = 3,
+    EPI_LOGFLOOR = 4,  // log(max(v, floor)) with floor = alpha-free constant 1.192092955078125e-07 (mel floor)
+    EPI_GLU = 5        // weight rows interleaved (a_c, b_c): out[m][n/2] = a * sigmoid(b); C has N/2 columns
+};
 
 struct GemmArgs {
     const float* X = nullptr;  // [batch][Tin][Cin]
@@ -53,6 +57,8 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0, batch = 1;
     int pro = PRO_NONE, epi = EPI_NONE;
     float alpha = 1.0f;
+    int aux_off = 0;                  // PRO_POWER: offset (floats) of the imaginary half within an input row
+    const float* row_mask = nullptr;  // optional [batch*M]: output rows whose mask is 0 are written as 0
 };
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);

@@ -606,6 +606,7 @@ int at_op_gemm(const at_gemm_desc* d, at_stream_t stream) {
     a.W = d->W; a.bias = d->bias; a.C = d->C; a.c_bstride = d->c_bstride; a.ldc = d->ldc;
     a.R = d->R; a.r_bstride = d->r_bstride; a.ldr = d->ldr;
     a.M = d->M; a.N = d->N; a.K = d->K; a.batch = d->batch; a.pro = d->pro; a.epi = d->epi; a.alpha = d->alpha;
+    a.aux_off = d->aux_off; a.row_mask = d->row_mask;
     return launch_gemm(a, (hipStream_t)stream);
 }
 

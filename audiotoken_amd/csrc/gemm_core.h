@@ -54,6 +54,10 @@ struct GemmTile {
                     if (ok) {
                         v = *reinterpret_cast<const f4*>(Xb + (long long)r * a.ldx + ci);
                         if (a.pro == PRO_ELU) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+                        else if (a.pro == PRO_POWER) {
+                            const f4 u = *reinterpret_cast<const f4*>(Xb + (long long)r * a.ldx + ci + a.aux_off);
+                            v = v * v + u * u;
+                        }
                     }
                 }
                 xreg[j] = v;

@@ -29,6 +29,9 @@ __device__ __forceinline__ f4 apply_act4(f4 v, int epi) {
         v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752440f));
         v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752440f));
         v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f));
+    } else if (epi == EPI_LOGFLOOR) {
+        const float fl = 1.192092955078125e-07f;
+        v.x = logf(fmaxf(v.x, fl)); v.y = logf(fmaxf(v.y, fl)); v.z = logf(fmaxf(v.z, fl)); v.w = logf(fmaxf(v.w, fl));
     }
     return v;
 }
@@ -57,9 +60,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
             if (n >= a.N) continue;
             f4 v = acc[i][j];
             if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
+            if (a.epi == EPI_GLU) {
+                // interleaved rows: (v.x, v.y) = (a_c, b_c), (v.z, v.w) = (a_{c+1}, b_{c+1})
+                float2 o;
+                o.x = v.x * sigmoidf_(v.y);
+                o.y = v.z * sigmoidf_(v.w);
+                if (a.row_mask && a.row_mask[(long long)b * a.M + m] == 0.f) o = float2{0.f, 0.f};
+                *reinterpret_cast<float2*>(Cb + (long long)m * a.ldc + (n >> 1)) = o;
+                continue;
+            }
             v = apply_act4(v, a.epi);
             v *= a.alpha;
             if (Rb) v += *reinterpret_cast<const f4*>(Rb + (long long)m * a.ldr + n);
+            if (a.row_mask && a.row_mask[(long long)b * a.M + m] == 0.f) v = f4{0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f4*>(Cb + (long long)m * a.ldc + n) = v;
         }
     }
@@ -78,7 +91,8 @@ int check_gemm_args(const GemmArgs& a) {
     AT_REQUIRE(a.K == a.ktaps * a.Cin, "K must equal ktaps*Cin");
     AT_REQUIRE(a.Cin % 4 == 0 && a.N % 4 == 0, "Cin and N must be multiples of 4");
     AT_REQUIRE(a.ldx % 4 == 0 && a.ldx >= 4, "ldx must be a positive multiple of 4");
-    AT_REQUIRE(a.ldc % 4 == 0 && (a.R == nullptr || a.ldr % 4 == 0), "ldc/ldr must be multiples of 4");
+    AT_REQUIRE((a.ldc % 4 == 0 || (a.epi == EPI_GLU && a.ldc % 2 == 0)) && (a.R == nullptr || a.ldr % 4 == 0), "ldc/ldr must be multiples of 4");
+    AT_REQUIRE(a.pro != PRO_POWER || (a.aux_off % 4 == 0 && a.ktaps == 1), "PRO_POWER needs ktaps == 1 and an aligned aux_off");
     AT_REQUIRE(a.batch >= 1 && a.batch <= 65535, "batch out of range");
     AT_REQUIRE(a.pad_mode == 0 || a.Tin > a.pad_left, "reflect padding needs Tin > pad");
     return 0;

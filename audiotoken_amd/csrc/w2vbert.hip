@@ -1,0 +1,449 @@
+// semantic_m tokenizer (log-mel front-end -> Wav2Vec2-BERT conformer -> LayerNorm -> VQ) — host side.
+// C ABI in include/audiotoken_hip.h. Replaces reference Wav2VecBertEncoder (audiotoken/encoder.py:111-186):
+// processor (audiotoken/processors.py), HF Wav2Vec2BertModel with the reference's rel-pos SDPA attention
+// (audiotoken/modeling_wav2vec2_bert.py:20-80), non-affine LayerNorm and VectorQuantize lookup.
+// Arithmetic per SURVEY.md Appendix A.2 / A.3.
+//
+// The conformer is fp32 on the f32 matrix cores: token ids must equal the reference's fp32 CPU result and the
+// bf16 autocast the reference uses on GPU is not reproducible. The front-end's frame
+// arithmetic and DFT run in f64 (see w2vbert_kernels.hip: frame_prep_kernel / dft_f64_kernel for why).
+//
+// Weight repacking at finalize():
+//   DFT            generated here in double: [520][400], rows 0..256 cos, 260..516 -sin (rest zero)
+//   mel            [257][80] (reference layout) -> [80][260]
+//   q,k,v Linear   -> one [3072][1024] matrix (one GEMM, one pass over the LayerNorm output)
+//   pointwise_conv1 [2048][1024][1] -> rows interleaved (a_c, b_c) so GLU is the GEMM epilogue
+//   depthwise_conv [1024][1][31] -> [31][1024]
+//   distance_embedding [73][64] -> [80][64] zero padded (MFMA row tiles)
+#include <map>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cmath>
+
+#include "../../include/audiotoken_hip.h"
+#include "at_common.h"
+#include "w2vbert_kernels.h"
+
+namespace at {
+const char* last_error_cstr();
+}
+using namespace at;
+
+namespace {
+constexpr int kHid = 1024, kFfn = 4096, kFeat = 160, kMel = 80, kFrame = 400, kHop = 160;
+constexpr int kSpecLd = 520, kImOff = 260, kCodes = 2048, kBuckets = 73;
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct LayerW {
+    const float *ln_ffn1_g, *ln_ffn1_b, *w1a, *b1a, *w1b, *b1b;
+    const float *ln_att_g, *ln_att_b, *wqkv, *bqkv, *dist, *wo, *bo;
+    const float *ln_conv_g, *ln_conv_b, *pw1, *dw, *ln_dw_g, *ln_dw_b, *pw2;
+    const float *ln_ffn2_g, *ln_ffn2_b, *w2a, *b2a, *w2b, *b2b;
+    const float *ln_fin_g, *ln_fin_b;
+};
+}  // namespace
+
+struct at_w2vbert {
+    int device = 0;
+    bool finalized = false;
+    std::map<std::string, HostTensor> staged;
+    std::vector<float*> allocs;
+    const float *window = nullptr, *melw = nullptr;
+    double* dft64 = nullptr;  // [520][400] DFT matrix in double (see dft_f64_kernel)
+    const float *fp_ln_g = nullptr, *fp_ln_b = nullptr, *fp_w = nullptr, *fp_b = nullptr;
+    std::vector<LayerW> layers;
+    const float *codebook = nullptr, *e2 = nullptr;
+    Profiler prof;
+};
+
+namespace {
+
+const HostTensor* find(const at_w2vbert* h, const std::string& name) {
+    auto it = h->staged.find(name);
+    return it == h->staged.end() ? nullptr : &it->second;
+}
+
+// upload one packed tensor into its own device allocation (the model is ~1.8 GB: no second full host copy)
+const float* upload(at_w2vbert* h, const std::vector<float>& v) {
+    float* d = nullptr;
+    size_t n = (v.size() + 3) / 4 * 4;
+    if (hipMalloc((void**)&d, n * sizeof(float)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    h->allocs.push_back(d);
+    return d;
+}
+
+const float* take(at_w2vbert* h, const std::string& name, std::vector<int64_t> shape, bool& ok) {
+    const HostTensor* t = find(h, name);
+    if (!t) { set_error("missing tensor " + name); ok = false; return nullptr; }
+    if (t->shape != shape) { set_error("bad shape for " + name); ok = false; return nullptr; }
+    const float* d = upload(h, t->data);
+    if (!d) { set_error("device allocation/copy failed for " + name); ok = false; }
+    return d;
+}
+
+int frames_of(int N) { return N >= kFrame ? 1 + (N - kFrame) / kHop : 0; }
+int tokens_of(int N, int mult) {
+    int t = frames_of(N) / 2;
+    if (mult > 0 && t % mult) t += mult - t % mult;
+    return t;
+}
+
+struct Plan {
+    int F, Tp;
+    size_t off_frames, off_fmask, off_spec, off_logmel, off_stats, off_feats, off_amask, off_x, off_t1, off_big, off_tok;
+    size_t total_floats;
+};
+
+Plan make_plan(int B, int N, int mult) {
+    Plan p;
+    p.F = frames_of(N);
+    p.Tp = tokens_of(N, mult);
+    size_t cur = 0;
+    auto takef = [&](size_t n) { size_t o = cur; cur += (n + 63) / 64 * 64; return o; };
+    const size_t M = (size_t)B * p.Tp, BF = (size_t)B * p.F;
+    p.off_frames = takef(BF * kFrame * 2);  // float64 frames
+    p.off_fmask = takef(BF);
+    p.off_spec = takef(BF * kSpecLd);
+    p.off_logmel = takef(BF * kMel);
+    p.off_stats = takef((size_t)B * 2 * kMel);
+    p.off_feats = takef(M * kFeat);
+    p.off_amask = takef(M);
+    p.off_x = takef(M * kHid);
+    p.off_t1 = takef(M * kHid);
+    p.off_big = takef(M * kFfn);
+    p.off_tok = takef(M);
+    p.total_floats = cur;
+    return p;
+}
+
+int linear(const float* X, int K, const float* W, const float* bias, float* C, int N, long long M, int epi, float alpha,
+           const float* R, const float* row_mask, int ldc, hipStream_t stream) {
+    GemmArgs a;
+    a.X = X; a.x_bstride = 0; a.Tin = (int)M; a.Cin = K; a.ldx = K;
+    a.W = W; a.bias = bias; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc;
+    a.M = (int)M; a.N = N; a.K = K; a.batch = 1; a.epi = epi; a.alpha = alpha; a.row_mask = row_mask;
+    return launch_gemm(a, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+at_w2vbert_t* at_w2vbert_create(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) {
+        set_error("at_w2vbert_create: no such HIP device " + std::to_string(device_id));
+        return nullptr;
+    }
+    at_w2vbert* h = new at_w2vbert();
+    h->device = device_id;
+    return h;
+}
+
+int at_w2vbert_set_tensor(at_w2vbert_t* h, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+    AT_REQUIRE(h && name && host_data && shape && ndim >= 1 && ndim <= 4, "bad arguments");
+    AT_REQUIRE(!h->finalized, "model already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(host_data, host_data + n);
+    h->staged[name] = std::move(t);
+    return 0;
+}
+
+int at_w2vbert_finalize(at_w2vbert_t* h) {
+    AT_REQUIRE(h && !h->finalized, "bad handle");
+    AT_CHECK_HIP(hipSetDevice(h->device));
+    bool ok = true;
+    // ---- front-end tables --------------------------------------------------------------------
+    h->window = take(h, "frontend.window", {kFrame}, ok);
+    if (!ok) return -1;
+    {
+        const HostTensor* mf = find(h, "frontend.mel_filters");
+        AT_REQUIRE(mf && mf->shape == (std::vector<int64_t>{257, kMel}), "frontend.mel_filters [257,80] missing");
+        std::vector<float> m((size_t)kMel * kImOff, 0.f);
+        for (int k = 0; k < 257; ++k)
+            for (int j = 0; j < kMel; ++j) m[(size_t)j * kImOff + k] = mf->data[(size_t)k * kMel + j];
+        h->melw = upload(h, m);
+        std::vector<double> d((size_t)kSpecLd * kFrame, 0.0);
+        const double two_pi = 6.283185307179586476925286766559;
+        for (int k = 0; k < 257; ++k)
+            for (int t = 0; t < kFrame; ++t) {
+                const int ph = (int)(((long long)k * t) % 512);  // exact argument reduction
+                const double ang = two_pi * ph / 512.0;
+                d[(size_t)k * kFrame + t] = std::cos(ang);
+                d[(size_t)(kImOff + k) * kFrame + t] = -std::sin(ang);
+            }
+        AT_CHECK_HIP(hipMalloc((void**)&h->dft64, d.size() * sizeof(double)));
+        AT_CHECK_HIP(hipMemcpy(h->dft64, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice));
+        AT_REQUIRE(h->melw != nullptr, "device allocation failed (front-end tables)");
+    }
+    // ---- feature projection ------------------------------------------------------------------
+    h->fp_ln_g = take(h, "feature_projection.layer_norm.weight", {kFeat}, ok);
+    h->fp_ln_b = take(h, "feature_projection.layer_norm.bias", {kFeat}, ok);
+    h->fp_w = take(h, "feature_projection.projection.weight", {kHid, kFeat}, ok);
+    h->fp_b = take(h, "feature_projection.projection.bias", {kHid}, ok);
+    if (!ok) return -1;
+    // ---- conformer layers ----------------------------------------------------------------------
+    int nl = 0;
+    while (find(h, "encoder.layers." + std::to_string(nl) + ".ffn1_layer_norm.weight")) ++nl;
+    for (int i = 0; i < nl; ++i) {
+        const std::string p = "encoder.layers." + std::to_string(i);
+        LayerW L{};
+        L.ln_ffn1_g = take(h, p + ".ffn1_layer_norm.weight", {kHid}, ok);
+        L.ln_ffn1_b = take(h, p + ".ffn1_layer_norm.bias", {kHid}, ok);
+        L.w1a = take(h, p + ".ffn1.intermediate_dense.weight", {kFfn, kHid}, ok);
+        L.b1a = take(h, p + ".ffn1.intermediate_dense.bias", {kFfn}, ok);
+        L.w1b = take(h, p + ".ffn1.output_dense.weight", {kHid, kFfn}, ok);
+        L.b1b = take(h, p + ".ffn1.output_dense.bias", {kHid}, ok);
+        L.ln_att_g = take(h, p + ".self_attn_layer_norm.weight", {kHid}, ok);
+        L.ln_att_b = take(h, p + ".self_attn_layer_norm.bias", {kHid}, ok);
+        if (!ok) return -1;
+        {
+            std::vector<float> w((size_t)3 * kHid * kHid), b((size_t)3 * kHid);
+            const char* nm[3] = {"linear_q", "linear_k", "linear_v"};
+            for (int j = 0; j < 3; ++j) {
+                const HostTensor* wt = find(h, p + ".self_attn." + nm[j] + ".weight");
+                const HostTensor* bt = find(h, p + ".self_attn." + nm[j] + ".bias");
+                AT_REQUIRE(wt && bt && wt->shape == (std::vector<int64_t>{kHid, kHid}) && bt->shape == (std::vector<int64_t>{kHid}),
+                           "attention projection tensors missing or mis-shaped");
+                std::memcpy(&w[(size_t)j * kHid * kHid], wt->data.data(), (size_t)kHid * kHid * sizeof(float));
+                std::memcpy(&b[(size_t)j * kHid], bt->data.data(), kHid * sizeof(float));
+            }
+            L.wqkv = upload(h, w);
+            L.bqkv = upload(h, b);
+            const HostTensor* de = find(h, p + ".self_attn.distance_embedding.weight");
+            AT_REQUIRE(de && de->shape == (std::vector<int64_t>{kBuckets, 64}), "distance_embedding [73,64] missing");
+            std::vector<float> e((size_t)80 * 64, 0.f);
+            std::memcpy(e.data(), de->data.data(), (size_t)kBuckets * 64 * sizeof(float));
+            L.dist = upload(h, e);
+            AT_REQUIRE(L.wqkv && L.bqkv && L.dist, "device allocation failed");
+        }
+        L.wo = take(h, p + ".self_attn.linear_out.weight", {kHid, kHid}, ok);
+        L.bo = take(h, p + ".self_attn.linear_out.bias", {kHid}, ok);
+        L.ln_conv_g = take(h, p + ".conv_module.layer_norm.weight", {kHid}, ok);
+        L.ln_conv_b = take(h, p + ".conv_module.layer_norm.bias", {kHid}, ok);
+        if (!ok) return -1;
+        {
+            const HostTensor* pw = find(h, p + ".conv_module.pointwise_conv1.weight");
+            AT_REQUIRE(pw && pw->shape == (std::vector<int64_t>{2 * kHid, kHid, 1}), "pointwise_conv1 [2048,1024,1] missing");
+            std::vector<float> w((size_t)2 * kHid * kHid);
+            for (int c = 0; c < kHid; ++c) {
+                std::memcpy(&w[(size_t)(2 * c) * kHid], &pw->data[(size_t)c * kHid], kHid * sizeof(float));
+                std::memcpy(&w[(size_t)(2 * c + 1) * kHid], &pw->data[(size_t)(kHid + c) * kHid], kHid * sizeof(float));
+            }
+            L.pw1 = upload(h, w);
+            const HostTensor* dw = find(h, p + ".conv_module.depthwise_conv.weight");
+            AT_REQUIRE(dw && dw->shape == (std::vector<int64_t>{kHid, 1, 31}), "depthwise_conv [1024,1,31] missing");
+            std::vector<float> d((size_t)31 * kHid);
+            for (int c = 0; c < kHid; ++c)
+                for (int j = 0; j < 31; ++j) d[(size_t)j * kHid + c] = dw->data[(size_t)c * 31 + j];
+            L.dw = upload(h, d);
+            AT_REQUIRE(L.pw1 && L.dw, "device allocation failed");
+        }
+        L.ln_dw_g = take(h, p + ".conv_module.depthwise_layer_norm.weight", {kHid}, ok);
+        L.ln_dw_b = take(h, p + ".conv_module.depthwise_layer_norm.bias", {kHid}, ok);
+        L.pw2 = take(h, p + ".conv_module.pointwise_conv2.weight", {kHid, kHid, 1}, ok);
+        L.ln_ffn2_g = take(h, p + ".ffn2_layer_norm.weight", {kHid}, ok);
+        L.ln_ffn2_b = take(h, p + ".ffn2_layer_norm.bias", {kHid}, ok);
+        L.w2a = take(h, p + ".ffn2.intermediate_dense.weight", {kFfn, kHid}, ok);
+        L.b2a = take(h, p + ".ffn2.intermediate_dense.bias", {kFfn}, ok);
+        L.w2b = take(h, p + ".ffn2.output_dense.weight", {kHid, kFfn}, ok);
+        L.b2b = take(h, p + ".ffn2.output_dense.bias", {kHid}, ok);
+        L.ln_fin_g = take(h, p + ".final_layer_norm.weight", {kHid}, ok);
+        L.ln_fin_b = take(h, p + ".final_layer_norm.bias", {kHid}, ok);
+        if (!ok) return -1;
+        h->layers.push_back(L);
+        // free the staged host copies of this layer early
+        for (auto it = h->staged.begin(); it != h->staged.end();)
+            it = it->first.compare(0, p.size() + 1, p + ".") == 0 ? h->staged.erase(it) : std::next(it);
+    }
+    // ---- VQ codebook (state-dict key _codebook.embed [1, 2048, 1024], reference audiotoken/utils.py:331-339) ---
+    if (const HostTensor* cb = find(h, "vq._codebook.embed")) {
+        AT_REQUIRE((cb->shape == std::vector<int64_t>{1, kCodes, kHid}) || (cb->shape == std::vector<int64_t>{kCodes, kHid}),
+                   "vq._codebook.embed must be [1,2048,1024]");
+        h->codebook = upload(h, cb->data);
+        std::vector<float> e2(kCodes);
+        if (const HostTensor* e = find(h, "vq._codebook.e2")) {
+            AT_REQUIRE(e->data.size() == (size_t)kCodes, "bad e2 shape");
+            e2 = e->data;
+        } else {
+            for (int n2 = 0; n2 < kCodes; ++n2) {
+                float acc = 0.f;
+                for (int k = 0; k < kHid; ++k) { const float v = cb->data[(size_t)n2 * kHid + k]; acc += v * v; }
+                e2[n2] = acc;
+            }
+        }
+        h->e2 = upload(h, e2);
+        AT_REQUIRE(h->codebook && h->e2, "device allocation failed (codebook)");
+    }
+    h->staged.clear();
+    h->finalized = true;
+    return 0;
+}
+
+void at_w2vbert_destroy(at_w2vbert_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (float* p : h->allocs) (void)hipFree(p);
+    if (h->dft64) (void)hipFree(h->dft64);
+    delete h;
+}
+
+int at_w2vbert_num_layers(const at_w2vbert_t* h) { return h ? (int)h->layers.size() : 0; }
+int at_w2vbert_num_tokens(int N, int pad_to_multiple_of) { return tokens_of(N, pad_to_multiple_of); }
+
+size_t at_w2vbert_workspace_bytes(const at_w2vbert_t* h, int B, int N, int pad_to_multiple_of) {
+    (void)h;
+    if (B <= 0 || N < kFrame) return 0;
+    return make_plan(B, N, pad_to_multiple_of).total_floats * sizeof(float);
+}
+
+int at_w2vbert_profile(at_w2vbert_t* h, int enable) {
+    AT_REQUIRE(h != nullptr, "null handle");
+    h->prof.reset();
+    h->prof.enabled = enable != 0;
+    return 0;
+}
+
+int at_w2vbert_profile_read(at_w2vbert_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups) {
+    AT_REQUIRE(h && names && total_ms && launches, "null pointer");
+    std::vector<float> ms;
+    std::vector<int> ln;
+    if (h->prof.read(ms, ln) != 0) { set_error("profile read: event query failed"); return -2; }
+    std::string joined;
+    int n = 0;
+    for (size_t i = 0; i < h->prof.names.size() && n < max_groups; ++i, ++n) {
+        joined += h->prof.names[i];
+        joined += '\n';
+        total_ms[n] = ms[i];
+        launches[n] = ln[i];
+    }
+    AT_REQUIRE(joined.size() + 1 <= names_cap, "names buffer too small");
+    std::memcpy(names, joined.c_str(), joined.size() + 1);
+    return n;
+}
+
+int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int B, int N, int pad_to_multiple_of, int n_layers,
+                      int16_t* tokens, int* T_out, float* features_out, float* attn_mask_out, float* hidden_out, void* workspace,
+                      size_t workspace_bytes, at_stream_t stream_) {
+    AT_REQUIRE(h && h->finalized, "model not finalized");
+    AT_REQUIRE(wav && workspace, "null pointer");
+    AT_REQUIRE(B >= 1 && N >= kFrame + kHop, "need B >= 1 and at least two frames (N >= 560 samples)");
+    AT_REQUIRE(n_layers >= 0 && n_layers <= (int)h->layers.size(), "n_layers exceeds the loaded layers");
+    AT_REQUIRE(tokens == nullptr || h->codebook != nullptr, "tokens requested but no VQ codebook loaded");
+    hipStream_t stream = (hipStream_t)stream_;
+    const Plan p = make_plan(B, N, pad_to_multiple_of);
+    AT_REQUIRE(workspace_bytes >= p.total_floats * sizeof(float), "workspace too small");
+    AT_REQUIRE(p.Tp >= 1, "clip too short");
+    float* ws = (float*)workspace;
+    const int F = p.F, T = p.Tp;
+    const long long M = (long long)B * T, BF = (long long)B * F;
+    if (T_out) *T_out = T;
+    Profiler& prof = h->prof;
+
+    // ---- log-mel front-end (reference processors.py) -------------------------------------------
+    double* frames = reinterpret_cast<double*>(ws + p.off_frames);
+    float* fmask = ws + p.off_fmask;
+    float* spec = ws + p.off_spec;
+    float* logmel = ws + p.off_logmel;
+    float* feats = features_out ? features_out : ws + p.off_feats;
+    float* amask = attn_mask_out ? attn_mask_out : ws + p.off_amask;
+    prof.begin("frontend", 5, stream);
+    if (int rc = launch_frame_prep(wav, mask, h->window, frames, fmask, B, N, F, stream)) return rc;
+    if (int rc = launch_dft_f64(frames, h->dft64, spec, BF, kSpecLd, stream)) return rc;
+    {   // |X|^2 folded into the mel projection's prologue, log(max(., floor)) into its epilogue
+        GemmArgs a;
+        a.X = spec; a.Tin = (int)BF; a.Cin = kImOff; a.ldx = kSpecLd; a.W = h->melw; a.C = logmel; a.ldc = kMel;
+        a.M = (int)BF; a.N = kMel; a.K = kImOff; a.batch = 1; a.pro = PRO_POWER; a.aux_off = kImOff; a.epi = EPI_LOGFLOOR;
+        if (int rc = launch_gemm(a, stream)) return rc;
+    }
+    if (int rc = launch_fbank_normalize(logmel, fmask, ws + p.off_stats, feats, amask, B, F, T, stream)) return rc;
+    prof.end(stream);
+
+    // ---- feature projection; padded rows zeroed (HF encoder entry) ------------------------------
+    float* x = ws + p.off_x;
+    float* t1 = ws + p.off_t1;
+    float* big = ws + p.off_big;
+    prof.begin("feature_projection", 2, stream);
+    if (int rc = launch_layernorm(feats, h->fp_ln_g, h->fp_ln_b, nullptr, t1, M, kFeat, stream)) return rc;
+    if (int rc = linear(t1, kFeat, h->fp_w, h->fp_b, x, kHid, M, EPI_NONE, 1.f, nullptr, amask, kHid, stream)) return rc;
+    prof.end(stream);
+
+    for (int li = 0; li < n_layers; ++li) {
+        const LayerW& L = h->layers[li];
+        prof.begin("ffn", 3, stream);
+        if (int rc = launch_layernorm(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, t1, M, kHid, stream)) return rc;
+        if (int rc = linear(t1, kHid, L.w1a, L.b1a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
+        if (int rc = linear(big, kFfn, L.w1b, L.b1b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
+        prof.end(stream);
+
+        prof.begin("attn_proj", 3, stream);
+        if (int rc = launch_layernorm(x, L.ln_att_g, L.ln_att_b, nullptr, t1, M, kHid, stream)) return rc;
+        if (int rc = linear(t1, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, 1.f, nullptr, nullptr, 3 * kHid, stream)) return rc;
+        prof.end(stream);
+        prof.begin("attention", 1, stream);
+        if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream)) return rc;
+        prof.end(stream);
+        prof.begin("attn_proj", 0, stream);
+        if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) return rc;
+        prof.end(stream);
+
+        prof.begin("conv_module", 4, stream);
+        if (int rc = launch_layernorm(x, L.ln_conv_g, L.ln_conv_b, amask, t1, M, kHid, stream)) return rc;
+        if (int rc = linear(t1, kHid, L.pw1, nullptr, big, 2 * kHid, M, EPI_GLU, 1.f, nullptr, nullptr, kHid, stream)) return rc;
+        if (int rc = launch_dwconv_ln_swish(big, L.dw, L.ln_dw_g, L.ln_dw_b, t1, B, T, stream)) return rc;
+        if (int rc = linear(t1, kHid, L.pw2, nullptr, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) return rc;
+        prof.end(stream);
+
+        prof.begin("ffn", 4, stream);
+        if (int rc = launch_layernorm(x, L.ln_ffn2_g, L.ln_ffn2_b, nullptr, t1, M, kHid, stream)) return rc;
+        if (int rc = linear(t1, kHid, L.w2a, L.b2a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
+        if (int rc = linear(big, kFfn, L.w2b, L.b2b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
+        if (int rc = launch_layernorm(x, L.ln_fin_g, L.ln_fin_b, nullptr, x, M, kHid, stream)) return rc;
+        prof.end(stream);
+    }
+    if (hidden_out) AT_CHECK_HIP(hipMemcpyAsync(hidden_out, x, (size_t)M * kHid * sizeof(float), hipMemcpyDeviceToDevice, stream));
+
+    if (tokens) {
+        // non-affine LayerNorm (reference encoder.py:138-143,176) then nearest code (encoder.py:180-181)
+        prof.begin("vq", 3, stream);
+        if (int rc = launch_layernorm(x, nullptr, nullptr, nullptr, t1, M, kHid, stream)) return rc;
+        if (int rc = linear(t1, kHid, h->codebook, nullptr, big, kCodes, M, EPI_NONE, 1.f, nullptr, nullptr, kCodes, stream)) return rc;
+        if (int rc = launch_vq_argmax(t1, big, h->e2, tokens, M, kHid, kCodes, stream)) return rc;
+        prof.end(stream);
+    }
+    return 0;
+}
+
+/* ---- operator-level entry points for the parity tests ---------------------------------------------------- */
+int at_op_layernorm(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, int64_t rows, int D,
+                    at_stream_t stream) {
+    AT_REQUIRE(x && y, "null pointer");
+    return launch_layernorm(x, gamma, beta, row_mask, y, rows, D, (hipStream_t)stream);
+}
+
+int at_op_relpos_attention(const float* qkv, const float* attn_mask, const float* dist_emb80, float* ctx, int B, int T,
+                           at_stream_t stream) {
+    AT_REQUIRE(qkv && attn_mask && dist_emb80 && ctx && B >= 1 && T >= 1, "bad arguments");
+    return launch_relpos_attention(qkv, attn_mask, dist_emb80, ctx, B, T, (hipStream_t)stream);
+}
+
+int at_op_dwconv_ln_swish(const float* g, const float* w31x1024, const float* gamma, const float* beta, float* out, int B, int T,
+                          at_stream_t stream) {
+    AT_REQUIRE(g && w31x1024 && gamma && beta && out && B >= 1 && T >= 1, "bad arguments");
+    return launch_dwconv_ln_swish(g, w31x1024, gamma, beta, out, B, T, (hipStream_t)stream);
+}
+
+int at_op_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, int64_t rows, int D, int C, at_stream_t stream) {
+    AT_REQUIRE(x && dots && e2 && out && D % 4 == 0 && C % 4 == 0, "bad arguments");
+    return launch_vq_argmax(x, dots, e2, out, rows, D, C, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,21 @@
+// Launchers of the semantic_m-specific kernels (w2vbert_kernels.hip).
+#pragma once
+#include "at_common.h"
+
+namespace at {
+
+int launch_frame_prep(const float* wav, const float* smask, const float* window, double* frames, float* fmask, int B, int N,
+                      int F, hipStream_t stream);
+int launch_dft_f64(const double* frames, const double* dft, float* spec, long long M, int N, hipStream_t stream);
+int launch_fbank_normalize(const float* logmel, const float* fmask, float* stats, float* feats, float* amask, int B, int F, int Tp,
+                           hipStream_t stream);
+int launch_layernorm(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, long long rows, int D,
+                     hipStream_t stream);
+int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
+                            hipStream_t stream);
+int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,
+                           hipStream_t stream);
+int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,
+                     hipStream_t stream);
+
+}  // namespace at

@@ -1,0 +1,641 @@
+// Kernels of the semantic_m tokenizer that are not plain GEMMs: log-mel framing, masked normalisation +
+// frame stacking, LayerNorm, relative-position attention, GLU'd depthwise conv + LayerNorm + swish, VQ argmax.
+// GEMM-shaped work (DFT, mel projection, all Linear layers) goes through gemm_core.h.
+#include "gemm_core.h"
+#include "w2vbert_kernels.h"
+
+namespace at {
+
+// ------------------------------------------------------------------------------------------------------
+// Frame preparation (reference audiotoken/processors.py:155-175, one frame per wave):
+//   x * 2^15 -> subtract the frame mean -> pre-emphasis with the PRE-update neighbour -> Povey window.
+// Evaluated in float64 with the reference's fp32 constants (0.97f, 0.03f, the fp32 window table) and handed to the
+// f64 DFT below. Rationale: after the x 2^15 scaling a sample is ~1e4, so every fp32 rounding of the reference's
+// frame arithmetic is ~1e-3 absolute; in a mel bin that is 40 dB below its neighbours this noise moves the
+// log-mel value by ~1e-3 and depends on the summation order of torch.mean (ISA-dependent), i.e. it cannot be
+// reproduced. Carrying the frame in f64 makes this side exact, so the distance to the reference is the
+// reference's own rounding noise only (measured: <= 5e-4 on the golden vectors).
+// Also emits the frame-validity mask: valid iff all 400 sample-mask values are 1 (avg_pool1d == 1, :102-108).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_prep_kernel(const float* __restrict__ wav, const float* __restrict__ smask,
+                                                         const float* __restrict__ window, double* __restrict__ frames,
+                                                         float* __restrict__ fmask, int N, int F, long long total_frames) {
+    const int lane = threadIdx.x & 63;
+    const long long fid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (fid >= total_frames) return;
+    const long long b = fid / F;
+    const int f = (int)(fid - b * F);
+    const float* x = wav + b * N + (long long)f * 160;
+    double v[7];
+    double sum = 0.0;
+    bool all_valid = true;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int n = lane + 64 * j;
+        v[j] = n < 400 ? (double)x[n] * 32768.0 : 0.0;
+        sum += v[j];
+        if (smask && n < 400) all_valid = all_valid && (smask[b * N + (long long)f * 160 + n] == 1.0f);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    const double mean = sum / 400.0;
+    const unsigned long long ok = __ballot(all_valid);
+    double* out = frames + fid * 400;
+    const double pre = (double)0.97f, first = (double)0.03f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int n = lane + 64 * j;
+        if (n >= 400) continue;
+        const double cur = v[j] - mean;
+        double y;
+        if (n == 0) {
+            y = cur * first;
+        } else {
+            const double prev = (double)x[n - 1] * 32768.0 - mean;
+            y = cur - pre * prev;
+        }
+        out[n] = y * (double)window[n];
+    }
+    if (lane == 0) fmask[fid] = (ok == ~0ull) ? 1.0f : 0.0f;
+}
+
+int launch_frame_prep(const float* wav, const float* smask, const float* window, double* frames, float* fmask, int B, int N,
+                      int F, hipStream_t stream) {
+    const long long total = (long long)B * F;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(frame_prep_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, wav, smask, window, frames,
+                       fmask, N, F, total);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// DFT of the prepared frames in float64 on the f64 matrix cores (v_mfma_f64_16x16x4_f64):
+//   spec[m][n] = (float) sum_t frames[m][t] * dft[n][t],  n < 257: cos, 260 <= n < 517: -sin  (K = 400).
+// Why f64: the reference takes an fp32 FFT, whose rounding noise in weak bins next to strong ones reaches 1e-3 of
+// the log-mel value. Any other fp32 transform adds its own, independent noise on top; an (effectively) exact
+// transform adds none, so the distance to the reference is the reference's own noise and nothing more.
+// The work is tiny (0.4 MFLOP per frame), so the f64 rate is irrelevant.
+// Workgroup 64 frames x 64 bins, 4 waves x (32 x 32), K step 16, operands staged through LDS as doubles.
+// ------------------------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int DFT_K = 400, DFT_BK = 16, DFT_LD = 17;
+
+__global__ __launch_bounds__(256) void dft_f64_kernel(const double* __restrict__ frames, const double* __restrict__ dft,
+                                                      float* __restrict__ spec, long long M, int N) {
+    __shared__ double As[64 * DFT_LD];
+    __shared__ double Bs[64 * DFT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const long long m0 = (long long)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    const int wm = wave >> 1, wn = wave & 1;
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = d4{0., 0., 0., 0.};
+    const int srow = tid >> 2, sk = (tid & 3) * 4;   // staging: 64 rows x 16 k, 4 values per thread
+    for (int k0 = 0; k0 < DFT_K; k0 += DFT_BK) {
+        __syncthreads();
+        {
+            const long long m = m0 + srow;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[srow * DFT_LD + sk + e] = m < M ? frames[m * DFT_K + k0 + sk + e] : 0.0;
+            const int n = n0 + srow;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Bs[srow * DFT_LD + sk + e] = n < N ? dft[(long long)n * DFT_K + k0 + sk + e] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = q * 4 + e;   // MFMA step e covers k in {4*quad + e}
+            double a[2], bb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(wm * 32 + i * 16 + r16) * DFT_LD + k];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = Bs[(wn * 32 + j * 16 + r16) * DFT_LD + k];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // f64 C/D map: col = lane & 15 (bin), row = (lane >> 4) + 4 * reg (frame)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const long long m = m0 + wm * 32 + i * 16 + q + 4 * reg;
+                const int n = n0 + wn * 32 + j * 16 + r16;
+                if (m < M && n < N) spec[m * N + n] = (float)acc[i][j][reg];
+            }
+}
+
+int launch_dft_f64(const double* frames, const double* dft, float* spec, long long M, int N, hipStream_t stream) {
+    if (M <= 0) return 0;
+    dim3 grid((unsigned)((M + 63) / 64), (N + 63) / 64);
+    hipLaunchKernelGGL(dft_f64_kernel, grid, dim3(256), 0, stream, frames, dft, spec, M, N);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Masked per-clip, per-mel-bin mean and POPULATION variance (processors.py:117-135):
+//   mean = sum(x*m)/max(cnt,1);  var = sum(((x*m) - mean)^2 * m)/max(cnt,1)
+// One workgroup (320 threads = 80 bins x 4 frame groups) per clip.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(320) void fbank_stats_kernel(const float* __restrict__ logmel, const float* __restrict__ fmask,
+                                                          float* __restrict__ stats /*[B][2][80]*/, int F) {
+    __shared__ float red[4][80];
+    __shared__ float mean_s[80];
+    __shared__ float cnt_s;
+    const int b = blockIdx.x;
+    const int bin = threadIdx.x % 80, grp = threadIdx.x / 80;
+    const float* x = logmel + (long long)b * F * 80;
+    const float* m = fmask + (long long)b * F;
+    float s = 0.f, c = 0.f;
+    for (int f = grp; f < F; f += 4) {
+        const float mk = m[f];
+        s += x[(long long)f * 80 + bin] * mk;
+        c += mk;
+    }
+    red[grp][bin] = s;
+    __syncthreads();
+    __shared__ float cred[4];  // every bin column sees the same mask: bin 0's four partial counts define cnt
+    if (bin == 0) cred[grp] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt_s = fmaxf(cred[0] + cred[1] + cred[2] + cred[3], 1.0f);
+    __syncthreads();
+    if (grp == 0) mean_s[bin] = (red[0][bin] + red[1][bin] + red[2][bin] + red[3][bin]) / cnt_s;
+    __syncthreads();
+    const float mean = mean_s[bin];
+    float v = 0.f;
+    for (int f = grp; f < F; f += 4) {
+        const float mk = m[f];
+        const float d = x[(long long)f * 80 + bin] * mk - mean;
+        v += d * d * mk;
+    }
+    __syncthreads();
+    red[grp][bin] = v;
+    __syncthreads();
+    if (grp == 0) {
+        stats[((long long)b * 2 + 0) * 80 + bin] = mean;
+        stats[((long long)b * 2 + 1) * 80 + bin] = (red[0][bin] + red[1][bin] + red[2][bin] + red[3][bin]) / cnt_s;
+    }
+}
+
+// normalise, stack 2 frames -> 160 features, fill invalid with 1.0, pad time (processors.py:242-266, 192-207)
+__global__ __launch_bounds__(256) void fbank_stack_kernel(const float* __restrict__ logmel, const float* __restrict__ fmask,
+                                                          const float* __restrict__ stats, float* __restrict__ feats,
+                                                          float* __restrict__ amask, int F, int Tp, long long total) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;  // one thread = one (b, t', 4 features)
+    if (gid >= total) return;
+    const int c4 = (int)(gid % 40);
+    const long long bt = gid / 40;
+    const long long b = bt / Tp;
+    const int t = (int)(bt - b * Tp);
+    const int half = c4 >= 20;
+    const int bin = (c4 - half * 20) * 4;
+    const int f = 2 * t + half;
+    const int Fs = F / 2;  // stacked frames that exist (odd trailing frame dropped)
+    f4 o = {1.f, 1.f, 1.f, 1.f};
+    const bool exists = t < Fs;
+    if (exists && fmask[b * F + f] != 0.f) {
+        const f4 x = *reinterpret_cast<const f4*>(logmel + (b * F + f) * 80 + bin);
+        const f4 mu = *reinterpret_cast<const f4*>(stats + (b * 2 + 0) * 80 + bin);
+        const f4 var = *reinterpret_cast<const f4*>(stats + (b * 2 + 1) * 80 + bin);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (x[k] - mu[k]) / sqrtf(var[k] + 1e-7f);
+    }
+    *reinterpret_cast<f4*>(feats + bt * 160 + c4 * 4) = o;
+    if (c4 == 0) amask[bt] = (exists && fmask[b * F + 2 * t] != 0.f) ? 1.0f : 0.0f;
+}
+
+int launch_fbank_normalize(const float* logmel, const float* fmask, float* stats, float* feats, float* amask, int B, int F, int Tp,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(fbank_stats_kernel, dim3(B), dim3(320), 0, stream, logmel, fmask, stats, F);
+    AT_CHECK_HIP(hipGetLastError());
+    const long long total = (long long)B * Tp * 40;
+    hipLaunchKernelGGL(fbank_stack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, logmel, fmask, stats,
+                       feats, amask, F, Tp, total);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (eps 1e-5), one wave per row, two-pass moments in registers.
+// y = ((x*rstd) + (-rstd*mean)) * gamma + beta  (operation order of torch's CPU LayerNorm kernel);
+// gamma/beta null -> non-affine. Optional row mask: masked rows are written as zeros.
+// D must be a multiple of 4 and <= 1024. In-place (y == x) is safe: a wave reads its whole row first.
+// ------------------------------------------------------------------------------------------------------
+template <int MAXV>  // float4 per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ row_mask,
+                                                        float* __restrict__ y, long long rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = D >> 2;
+    const f4* xr = reinterpret_cast<const f4*>(x + row * D);
+    f4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = c < nv ? xr[c] : f4{0.f, 0.f, 0.f, 0.f};
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+            const f4 d = v[j] - mean;
+            q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+    const float shift = -rstd * mean;
+    const bool zero = row_mask && row_mask[row] == 0.f;
+    f4* yr = reinterpret_cast<f4*>(y + row * D);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c >= nv) continue;
+        f4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = fmaf(v[j][k], rstd, shift);
+        if (gamma) {
+            const f4 g = reinterpret_cast<const f4*>(gamma)[c];
+            const f4 bb = reinterpret_cast<const f4*>(beta)[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaf(o[k], g[k], bb[k]);
+        }
+        if (zero) o = f4{0.f, 0.f, 0.f, 0.f};
+        yr[c] = o;
+    }
+}
+
+int launch_layernorm(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, long long rows, int D,
+                     hipStream_t stream) {
+    AT_REQUIRE(D % 4 == 0 && D <= 1024 && D > 0, "LayerNorm width must be a multiple of 4, <= 1024");
+    if (rows <= 0) return 0;
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (D <= 256)
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, rows, D);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, rows, D);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Relative-position self-attention (reference audiotoken/modeling_wav2vec2_bert.py:46-73), flash style, fp32 MFMA.
+//   scores[l][r] = q_l.k_r / 8 + (q_l . E[clamp(r-l,-64,8)+64]) / 8 + (key r padded ? finfo.min : 0);  softmax;  . v
+// The reference materialises the [B,16,T,T] bias with an einsum; here q.E^T (73 buckets) is formed once per query
+// tile with MFMA into LDS and gathered per score — the T x T tensor never exists.
+// Workgroup = 128 queries of one (clip, head); wave = 32 queries. Key/value tiles of 64 go global -> LDS
+// (K row-major + XOR swizzle; V transposed so a lane's 4 consecutive keys are one ds_read_b128).
+// S^T = K.Q^T is computed with keys on the MFMA rows: a lane then holds, for ONE query, the 4 keys (4*quad+reg) of
+// each 16-key tile — exactly the B-operand fragment of the P.V MFMA, so P never leaves registers.
+// qkv layout: [B*T][3072] = [q | k | v], head h at columns h*64.
+// ------------------------------------------------------------------------------------------------------
+constexpr int ATT_QB = 128, ATT_KB = 64, ATT_D = 64;
+constexpr int ATT_QE_LD = 81;   // 73 buckets padded to an odd stride
+constexpr int ATT_VT_LD = 68;
+constexpr int ATT_LDS_FLOATS = ATT_KB * ATT_D + ATT_D * ATT_VT_LD + ATT_QB * ATT_QE_LD + ATT_KB;
+
+__global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ amask,
+                                                               const float* __restrict__ dist_emb /*[80][64], rows>=73 zero*/,
+                                                               float* __restrict__ ctx, int T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                              // [64 keys][64 d], chunk ^= key&15
+    float* Vt = Ks + ATT_KB * ATT_D;               // [64 dv][68]: Vt[dv][key]
+    float* QE = Vt + ATT_D * ATT_VT_LD;            // [128 queries][81]: 0.125 * q.E[bucket]
+    float* kb = QE + ATT_QB * ATT_QE_LD;           // [64] additive key bias: 0 / finfo.min (padded) / -inf (beyond T)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, qd = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int l0 = blockIdx.x * ATT_QB;
+    const long long rowbase = (long long)b * T;
+    const int LD = 3072;
+    const float* qp = qkv + h * 64;
+    const float* kp = qkv + 1024 + h * 64;
+    const float* vp = qkv + 2048 + h * 64;
+
+    // query fragments (B operand): qf[i][c] = q[l][c*16 + qd*4 .. +3]
+    int lq[2];
+    f4 qf[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        lq[i] = l0 + wave * 32 + i * 16 + r16;
+        const int lc = lq[i] < T ? lq[i] : T - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qf[i][c] = *reinterpret_cast<const f4*>(qp + (rowbase + lc) * LD + c * 16 + qd * 4);
+    }
+    // QE = 0.125 * q . E^T  -> LDS (lane: query r16 of tile i, buckets bt*16 + qd*4 + reg)
+#pragma unroll
+    for (int bt = 0; bt < 5; ++bt) {
+        f4 ef[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ef[c] = *reinterpret_cast<const f4*>(dist_emb + (bt * 16 + r16) * 64 + c * 16 + qd * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[c][e], qf[i][c][e], acc, 0, 0, 0);
+            float* dst = QE + (wave * 32 + i * 16 + r16) * ATT_QE_LD + bt * 16 + qd * 4;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) dst[reg] = 0.125f * acc[reg];
+        }
+    }
+    // far-field constants: bucket 0 (r - l <= -64) and bucket 72 (r - l >= 8); own rows, visible after the first barrier
+    f4 oacc[2][4];
+    float mrun[2], lrun[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        mrun[i] = -INFINITY;
+        lrun[i] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[i][dt] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int wl_min = l0 + wave * 32, wl_max = wl_min + 31;
+    const float FMIN = -3.4028234663852886e38f;
+
+    const int nkt = (T + ATT_KB - 1) / ATT_KB;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int r0 = kt * ATT_KB;
+        __syncthreads();  // previous tile fully consumed (also orders the QE stores before first use)
+        {   // K tile: thread -> key = tid>>2, 4 chunks starting at (tid&3)*4
+            const int key = tid >> 2, cg = (tid & 3) * 4;
+            const int r = r0 + key;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < T) v = *reinterpret_cast<const f4*>(kp + (rowbase + r) * LD + (cg + j) * 4);
+                *reinterpret_cast<f4*>(Ks + key * ATT_D + (((cg + j) ^ (key & 15)) << 2)) = v;
+            }
+            // V tile transposed: thread -> dv = tid&63, 16 keys starting at (tid>>6)*16
+            const int dv = tid & 63, k0 = (tid >> 6) * 16;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rr = r0 + k0 + g * 4 + e;
+                    v[e] = rr < T ? vp[(rowbase + rr) * LD + dv] : 0.f;
+                }
+                *reinterpret_cast<f4*>(Vt + dv * ATT_VT_LD + k0 + g * 4) = v;
+            }
+            if (tid < ATT_KB) {
+                const int rr = r0 + tid;
+                kb[tid] = rr < T ? (amask[rowbase + rr] != 0.f ? 0.f : FMIN) : -INFINITY;
+            }
+        }
+        __syncthreads();
+        // S^T tiles: lane holds s[i][j][reg] = q_l . k_r for l = lq[i], r = r0 + j*16 + qd*4 + reg
+        f4 s[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f4 kf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                kf[j] = *reinterpret_cast<const f4*>(Ks + (j * 16 + r16) * ATT_D + ((((c << 2) + qd) ^ r16) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][e], qf[i][c][e], s[i][j], 0, 0, 0);
+        }
+        // bias + mask, online softmax
+        const bool far_left = (r0 + ATT_KB - 1) - wl_min <= -64;   // every (l, r) of this wave has r - l <= -64
+        const bool far_right = r0 - wl_max >= 8;                   // every (l, r) has r - l >= 8
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* qe = QE + (wave * 32 + i * 16 + r16) * ATT_QE_LD;
+            const float c_far = far_left ? qe[0] : qe[72];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f4 kbv = *reinterpret_cast<const f4*>(kb + j * 16 + qd * 4);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    float bias;
+                    if (far_left || far_right) {
+                        bias = c_far;
+                    } else {
+                        int dd = (r0 + j * 16 + qd * 4 + reg) - lq[i];
+                        dd = dd < -64 ? -64 : (dd > 8 ? 8 : dd);
+                        bias = qe[dd + 64];
+                    }
+                    const float t = bias + kbv[reg];
+                    const float sc = fmaf(0.125f, s[i][j][reg], t);
+                    s[i][j][reg] = sc;
+                    mx = fmaxf(mx, sc);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[i], mx);
+            const float alpha = expf(mrun[i] - mnew);   // exp(-inf) = 0 on the first tile
+            float rs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float p = expf(s[i][j][reg] - mnew);
+                    s[i][j][reg] = p;
+                    rs += p;
+                }
+            rs += __shfl_xor(rs, 16);
+            rs += __shfl_xor(rs, 32);
+            lrun[i] = lrun[i] * alpha + rs;
+            mrun[i] = mnew;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[i][dt] *= alpha;
+        }
+        // O^T += V^T . P^T : A = V^T fragment (dv rows), B = P (lane's own registers)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f4 vf[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) vf[dt] = *reinterpret_cast<const f4*>(Vt + (dt * 16 + r16) * ATT_VT_LD + j * 16 + qd * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        oacc[i][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dt][e], s[i][j][e], oacc[i][dt], 0, 0, 0);
+        }
+    }
+    // lane holds O[l = lq[i]][dv = dt*16 + qd*4 + reg]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (lq[i] >= T) continue;
+        const float inv = 1.0f / lrun[i];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<f4*>(ctx + (rowbase + lq[i]) * 1024 + h * 64 + dt * 16 + qd * 4) = oacc[i][dt] * inv;
+    }
+}
+
+int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
+                            hipStream_t stream) {
+    dim3 grid((T + ATT_QB - 1) / ATT_QB, 16, B);
+    const size_t lds = ATT_LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(relpos_attention_kernel, grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Conformer conv-module middle: causal depthwise conv k=31 (left zero pad 30 within the clip) -> LayerNorm(1024)
+// -> swish (HF modeling_wav2vec2_bert.py:212-222). Input g = GLU output [B*T][1024] (from the EPI_GLU GEMM).
+// Workgroup = 8 consecutive time steps of one clip x all 1024 channels; thread = 4 channels. Each input row is
+// read once per workgroup (38 rows for 8 outputs) instead of 31 times; tap weights [31][1024] stay in registers.
+// ------------------------------------------------------------------------------------------------------
+constexpr int DW_TT = 8, DW_K = 31;
+
+__global__ __launch_bounds__(256) void dwconv_ln_swish_kernel(const float* __restrict__ g, const float* __restrict__ w /*[31][1024]*/,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ out, int T) {
+    __shared__ float red[2][4][DW_TT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * DW_TT;
+    const long long base = (long long)b * T;
+    f4 wt[DW_K];
+#pragma unroll
+    for (int j = 0; j < DW_K; ++j) wt[j] = reinterpret_cast<const f4*>(w + j * 1024)[tid];
+    f4 acc[DW_TT];
+#pragma unroll
+    for (int i = 0; i < DW_TT; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < DW_TT + DW_K - 1; ++r) {   // input row t0 - 30 + r
+        const int t = t0 - (DW_K - 1) + r;
+        f4 x = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < T) x = reinterpret_cast<const f4*>(g + (base + t) * 1024)[tid];
+#pragma unroll
+        for (int i = 0; i < DW_TT; ++i) {
+            const int tap = r - i;   // out[t0+i] uses in[t0+i-30+tap]
+            if (tap >= 0 && tap < DW_K) acc[i] += wt[tap] * x;
+        }
+    }
+    // LayerNorm over 1024 channels for each of the 8 rows
+    float s[DW_TT];
+#pragma unroll
+    for (int i = 0; i < DW_TT; ++i) {
+        s[i] = (acc[i].x + acc[i].y) + (acc[i].z + acc[i].w);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s[i] += __shfl_xor(s[i], off);
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < DW_TT; ++i) red[0][wave][i] = s[i];
+    __syncthreads();
+    float mean[DW_TT], q[DW_TT];
+#pragma unroll
+    for (int i = 0; i < DW_TT; ++i) {
+        mean[i] = ((red[0][0][i] + red[0][1][i]) + (red[0][2][i] + red[0][3][i])) * (1.0f / 1024.0f);
+        const f4 d = acc[i] - mean[i];
+        q[i] = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) q[i] += __shfl_xor(q[i], off);
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < DW_TT; ++i) red[1][wave][i] = q[i];
+    __syncthreads();
+    const f4 gm = reinterpret_cast<const f4*>(gamma)[tid];
+    const f4 bt = reinterpret_cast<const f4*>(beta)[tid];
+#pragma unroll
+    for (int i = 0; i < DW_TT; ++i) {
+        const int t = t0 + i;
+        if (t >= T) continue;
+        const float var = ((red[1][0][i] + red[1][1][i]) + (red[1][2][i] + red[1][3][i])) * (1.0f / 1024.0f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float shift = -rstd * mean[i];
+        f4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = swishf_(fmaf(fmaf(acc[i][k], rstd, shift), gm[k], bt[k]));
+        reinterpret_cast<f4*>(out + (base + t) * 1024)[tid] = o;
+    }
+}
+
+int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,
+                           hipStream_t stream) {
+    dim3 grid((T + DW_TT - 1) / DW_TT, B);
+    hipLaunchKernelGGL(dwconv_ln_swish_kernel, grid, dim3(256), 0, stream, g, w, gamma, beta, out, T);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// VQ assignment from the score GEMM: dots[m][n] = x_m . e_n. vector_quantize_pytorch eval:
+//   idx = argmax_n -sqrt(max((|x|^2 + |e_n|^2) + (-2 dots), 0)), first maximal index. One wave per row.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict__ x, const float* __restrict__ dots,
+                                                        const float* __restrict__ e2, int16_t* __restrict__ out, long long rows,
+                                                        int D, int C) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float x2 = 0.f;
+    for (int c = lane; c < (D >> 2); c += 64) {
+        const f4 v = reinterpret_cast<const f4*>(x + row * D)[c];
+        x2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x2 += __shfl_xor(x2, off);
+    float best = -INFINITY;
+    int bidx = 0;
+    for (int c = lane; c < (C >> 2); c += 64) {   // increasing n per lane: strict > keeps the first index
+        const f4 d = reinterpret_cast<const f4*>(dots + row * C)[c];
+        const f4 y2 = reinterpret_cast<const f4*>(e2)[c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d2 = __fadd_rn(__fadd_rn(x2, y2[k]), -2.0f * d[k]);
+            const float v = -sqrtf(fmaxf(d2, 0.f));
+            if (v > best) { best = v; bidx = c * 4 + k; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bidx, off);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if (lane == 0) out[row] = (int16_t)bidx;
+}
+
+int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,
+                     hipStream_t stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(vq_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, dots, e2, out, rows, D, C);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace at

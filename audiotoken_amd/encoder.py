@@ -149,3 +149,135 @@ class AcousticEncoder(torch.nn.Module):
             raise _cabi.HipLibraryError(f"at_encodec_profile_read failed: {_cabi.last_error()}")
         keys = names.value.decode().split("\n")[:n]
         return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(keys)}
+
+
+# ======================================================================================================
+# semantic_m: Wav2Vec2-BERT + VQ
+# ======================================================================================================
+def frontend_tables() -> Dict[str, np.ndarray]:
+    """Povey window and mel filter bank, built with the reference's formulas so the device uses the very same
+    fp32 tables (reference audiotoken/processors.py:8-26,66-78; audiotoken/utils.py:286-328): triangles built in
+    mel space over 256 bins of width 16000/512 from 20 Hz to 8 kHz (Kaldi mel), plus one zero row."""
+    def hz2mel(f):
+        return 1127.0 * torch.log(1.0 + (f / 700.0))
+
+    filt = torch.linspace(hz2mel(torch.tensor(20.0)), hz2mel(torch.tensor(8000.0)), 80 + 2)
+    fft_freqs = hz2mel((16000 / 512) * torch.arange(256))
+    diff = torch.diff(filt)
+    slopes = filt.unsqueeze(0) - fft_freqs.unsqueeze(1)
+    fb = torch.maximum(torch.zeros(1), torch.minimum(-slopes[:, :-2] / diff[:-1], slopes[:, 2:] / diff[1:]))
+    fb = torch.nn.functional.pad(fb, (0, 0, 0, 1))
+    window = torch.pow(torch.hann_window(400, periodic=False), 0.85)
+    return {"frontend.mel_filters": fb.numpy(), "frontend.window": window.numpy()}
+
+
+def load_w2vbert_checkpoint(model_dir: str, quantizer_path: Optional[str]) -> Dict[str, np.ndarray]:
+    """HF ``model.safetensors`` of the trimmed w2v-bert-2.0 (+ the VQ ``.pkl`` state dict) -> numpy dict
+    (reference audiotoken/encoder.py:132,156-161; audiotoken/configs.py:114-134)."""
+    import os
+    from safetensors.numpy import load_file
+    w = {k: v.astype(np.float32) for k, v in load_file(os.path.join(model_dir, "model.safetensors")).items()}
+    if quantizer_path:
+        sd = torch.load(quantizer_path, map_location="cpu", weights_only=True)
+        w["vq._codebook.embed"] = sd["_codebook.embed"].float().numpy()
+    return w
+
+
+class Wav2VecBertEncoder(torch.nn.Module):
+    """Drop-in for reference ``Wav2VecBertEncoder`` with ``quantize=True`` (audiotoken/encoder.py:111-186)."""
+
+    def __init__(self, config=None, device: str = "cuda:0", quantize: bool = True,
+                 weights: Optional[Union[str, Dict[str, np.ndarray]]] = None):
+        super().__init__()
+        from .configs import Wav2VecBertConfig
+        config = config or Wav2VecBertConfig()
+        self.config = config
+        self.quantize = quantize
+        self.output_layer = config.output_layer
+        self.lib = _cabi.load()
+        self.device_index = _device_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        if weights is None:
+            weights = config.weights
+        if weights is None:
+            logger.warning("No Wav2Vec2-BERT checkpoint given (weights=/AUDIOTOKEN_W2VBERT_WEIGHTS): synthetic weights, seed 0")
+            weights = W.synth_w2vbert_weights(n_layers=self.output_layer, seed=0, with_vq=True)
+        elif isinstance(weights, (str, bytes)):
+            weights = load_w2vbert_checkpoint(weights, config.quantizer_path)
+        self.handle = self.lib.at_w2vbert_create(self.device_index)
+        if not self.handle:
+            raise _cabi.HipLibraryError(f"at_w2vbert_create failed: {_cabi.last_error()}")
+        tensors = dict(frontend_tables())
+        for k, v in weights.items():
+            if k.startswith("encoder.layers."):
+                if int(k.split(".")[2]) >= self.output_layer:   # layers past the consumed hidden state are dead compute
+                    continue
+            elif not k.startswith(("feature_projection.", "vq.")):
+                continue
+            tensors[k] = v
+        if "vq._codebook.embed" in tensors:
+            e = torch.from_numpy(np.ascontiguousarray(tensors["vq._codebook.embed"], dtype=np.float32)).reshape(-1, 1024)
+            tensors["vq._codebook.e2"] = (e ** 2).sum(-1).numpy()   # y2 of vector_quantize_pytorch's cdist
+        for name, arr in tensors.items():
+            _cabi.set_tensor(self.lib, self.lib.at_w2vbert_set_tensor, self.handle, name, arr)
+        _cabi.check(self.lib.at_w2vbert_finalize(self.handle), "at_w2vbert_finalize")
+        self.n_layers = self.lib.at_w2vbert_num_layers(self.handle)
+        if self.n_layers < self.output_layer:
+            raise ValueError(f"checkpoint has {self.n_layers} conformer layers, output_layer={self.output_layer} needs that many")
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        h = self.__dict__.pop("handle", None)
+        if h:
+            self.lib.at_w2vbert_destroy(h)
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    @torch.no_grad()
+    def forward(self, input_batch: torch.Tensor, mask: Optional[torch.Tensor] = None, pad_to_multiple_of: int = 2,
+                n_layers: Optional[int] = None, return_taps: bool = False):
+        """``float32 [B, N]`` @16 kHz + ``float32 [B, N]`` mask -> ``int16 [B, 1, T']`` on the device.
+        With ``quantize=False`` returns the selected hidden state ``[B, T', 1024]`` like the reference."""
+        assert input_batch.dim() == 2, "Input tensor must have shape [batch, time]"
+        x = input_batch.to(device=self.device, dtype=torch.float32).contiguous()
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.float32).contiguous()
+        B, N = x.shape
+        nl = self.output_layer if n_layers is None else n_layers
+        T = self.lib.at_w2vbert_num_tokens(N, pad_to_multiple_of)
+        want_tokens = self.quantize
+        tokens = torch.empty((B, 1, T), dtype=torch.int16, device=self.device) if want_tokens else None
+        feats = amask = hidden = None
+        if return_taps or not want_tokens:
+            hidden = torch.empty((B, T, 1024), dtype=torch.float32, device=self.device)
+        if return_taps:
+            feats = torch.empty((B, T, 160), dtype=torch.float32, device=self.device)
+            amask = torch.empty((B, T), dtype=torch.float32, device=self.device)
+        nbytes = self.lib.at_w2vbert_workspace_bytes(self.handle, B, N, pad_to_multiple_of)
+        ws = self._workspace(nbytes)
+        t_out = C.c_int(0)
+        with torch.cuda.device(self.device):
+            rc = self.lib.at_w2vbert_encode(self.handle, x.data_ptr(), _cabi.ptr(m), B, N, pad_to_multiple_of, nl,
+                                            _cabi.ptr(tokens), C.byref(t_out), _cabi.ptr(feats), _cabi.ptr(amask),
+                                            _cabi.ptr(hidden), ws.data_ptr(), nbytes, _cabi.current_stream_handle(self.device))
+        _cabi.check(rc, "at_w2vbert_encode")
+        assert t_out.value == T
+        if return_taps:
+            return tokens, {"input_features": feats, "attention_mask": amask, "hidden": hidden}
+        return tokens if want_tokens else hidden
+
+    def enable_profile(self, on: bool) -> None:
+        _cabi.check(self.lib.at_w2vbert_profile(self.handle, 1 if on else 0), "at_w2vbert_profile")
+
+    def read_profile(self) -> Dict[str, tuple]:
+        names = C.create_string_buffer(4096)
+        ms = (C.c_float * 64)()
+        ln = (C.c_int * 64)()
+        n = self.lib.at_w2vbert_profile_read(self.handle, names, 4096, ms, ln, 64)
+        if n < 0:
+            raise _cabi.HipLibraryError(f"at_w2vbert_profile_read failed: {_cabi.last_error()}")
+        keys = names.value.decode().split("\n")[:n]
+        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(keys)}

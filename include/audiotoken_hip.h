@@ -80,6 +80,41 @@ size_t at_encodec_decode_workspace_bytes(const at_encodec_t* h, int B, int T);
 int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T, float* wav, void* workspace,
                       size_t workspace_bytes, at_stream_t stream);
 
+/* ---- semantic_m tokenizer: log-mel front-end + Wav2Vec2-BERT conformer + LayerNorm + VQ ------------------
+ * Replaces reference Wav2VecBertEncoder (audiotoken/encoder.py:111-186): ctor = Wav2VecBertProcessor +
+ * Wav2Vec2BertModel.from_pretrained + VectorQuantize(dim=1024, codebook_size=2048) (:112-161); forward =
+ * processor -> model(..., output_hidden_states=True).hidden_states[output_layer] -> LayerNorm(no affine) ->
+ * vq -> int16 [B,1,T'] (:163-184), with the attention of audiotoken/modeling_wav2vec2_bert.py:20-80. */
+typedef struct at_w2vbert at_w2vbert_t;
+
+at_w2vbert_t* at_w2vbert_create(int device_id);
+
+/* Named host tensors (float32): the HF Wav2Vec2BertModel state-dict keys ("feature_projection.*",
+ * "encoder.layers.{i}.*" for consecutive i from 0), "vq._codebook.embed" [1,2048,1024] (the VectorQuantize
+ * state-dict key, reference audiotoken/utils.py:331-339; optional "vq._codebook.e2" [2048]), and the two front-end
+ * tables of reference processors.py:66-78: "frontend.window" [400], "frontend.mel_filters" [257,80]. */
+int at_w2vbert_set_tensor(at_w2vbert_t* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int at_w2vbert_finalize(at_w2vbert_t* h);
+void at_w2vbert_destroy(at_w2vbert_t* h);
+int at_w2vbert_num_layers(const at_w2vbert_t* h);
+
+/* T' = pad_to_multiple(floor((1 + floor((N-400)/160)) / 2)) (reference processors.py:158,246-259). */
+int at_w2vbert_num_tokens(int N, int pad_to_multiple_of);
+size_t at_w2vbert_workspace_bytes(const at_w2vbert_t* h, int B, int N, int pad_to_multiple_of);
+
+/* Replaces Wav2VecBertEncoder.forward (audiotoken/encoder.py:163-184).
+ *   wav device float32 [B][N] (16 kHz); mask device float32 [B][N] (1 = real sample) or NULL (= all ones)
+ *   pad_to_multiple_of: the reference's third argument (default 2)
+ *   n_layers: conformer layers to run = the reference's output_layer (19; hidden_states[n] is the output of layer n-1)
+ *   tokens device int16 [B][1][T'] or NULL (then no VQ); *T_out = T'
+ *   parity taps, all optional (NULL in production): features_out [B][T'][160], attn_mask_out [B][T'],
+ *   hidden_out [B][T'][1024] = hidden_states[n_layers]. */
+int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int B, int N, int pad_to_multiple_of, int n_layers,
+                      int16_t* tokens, int* T_out, float* features_out, float* attn_mask_out, float* hidden_out, void* workspace,
+                      size_t workspace_bytes, at_stream_t stream);
+int at_w2vbert_profile(at_w2vbert_t* h, int enable);
+int at_w2vbert_profile_read(at_w2vbert_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups);
+
 /* ---- operator-level entry points (the kernels behind the models; used by the parity tests) ------------- */
 
 /* Windowed fp32 GEMM: out[b][m][n] = act(alpha*(sum_kk A(b,m,kk)*W[n][kk] + bias[n])) (+ R[b][m][n]) with
@@ -92,9 +127,11 @@ typedef struct at_gemm_desc {
     float* C; int64_t c_bstride; int32_t ldc;
     const float* R; int64_t r_bstride; int32_t ldr;
     int32_t M, N, K, batch;
-    int32_t pro; /* 0 none, 1 ELU */
-    int32_t epi; /* 0 none, 1 swish, 2 ELU, 3 GELU(erf) */
+    int32_t pro; /* 0 none, 1 ELU, 2 power: A = X[kk]^2 + X[kk+aux_off]^2 */
+    int32_t epi; /* 0 none, 1 swish, 2 ELU, 3 GELU(erf), 4 log(max(v, mel_floor)), 5 GLU over interleaved rows */
     float alpha;
+    int32_t aux_off;
+    const float* row_mask; /* optional [batch*M]: rows with mask 0 are written as zeros */
 } at_gemm_desc;
 int at_op_gemm(const at_gemm_desc* d, at_stream_t stream);
 
@@ -103,6 +140,23 @@ int at_op_gemm(const at_gemm_desc* d, at_stream_t stream);
  * codes int16 written at codes[(row / T)*n_q*T + q*T + row % T]. */
 int at_op_rvq_encode(const float* x, int64_t rows, int T, const float* codebooks, const float* e2, int n_q,
                      int16_t* codes, at_stream_t stream);
+
+/* LayerNorm over the last dim (eps 1e-5); gamma/beta NULL = non-affine; rows with row_mask 0 are zeroed. */
+int at_op_layernorm(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, int64_t rows, int D,
+                    at_stream_t stream);
+
+/* Rel-pos attention (ref audiotoken/modeling_wav2vec2_bert.py:46-73): qkv [B*T][3072] = [q|k|v] (16 heads x 64),
+ * attn_mask [B*T] (1 = valid key), dist_emb80 [80][64] (73 rows used, rest zero) -> ctx [B*T][1024]. */
+int at_op_relpos_attention(const float* qkv, const float* attn_mask, const float* dist_emb80, float* ctx, int B, int T,
+                           at_stream_t stream);
+
+/* Conformer conv middle (HF modeling_wav2vec2_bert.py:212-222): causal depthwise k31 -> LayerNorm -> swish;
+ * g [B*T][1024], w [31][1024]. */
+int at_op_dwconv_ln_swish(const float* g, const float* w31x1024, const float* gamma, const float* beta, float* out, int B, int T,
+                          at_stream_t stream);
+
+/* VQ assign from precomputed dots [rows][C]: argmax_n -sqrt(max(|x|^2 + e2[n] - 2 dots, 0)), first index. */
+int at_op_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, int64_t rows, int D, int C, at_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,170 @@
+"""GPU parity of the semantic_m path (C ABI) against the CPU oracle and the reference-generated golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from audiotoken_amd import _cabi, prng
+from audiotoken_amd import weights as W
+from oracle import w2vbert_ref as R
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+FBANK = sorted(glob.glob(os.path.join(G, "fbank_*.npz")))
+
+
+def _stream(dev):
+    return _cabi.current_stream_handle(dev)
+
+
+@pytest.fixture(scope="module")
+def enc3(cuda_device):
+    from audiotoken_amd.configs import Wav2VecBertConfig
+    from audiotoken_amd.encoder import Wav2VecBertEncoder
+    w = W.synth_w2vbert_weights(n_layers=3, seed=5, with_vq=True)
+    cfg = Wav2VecBertConfig(output_layer=3)
+    return Wav2VecBertEncoder(cfg, device="cuda:0", quantize=True, weights=w), w
+
+
+@pytest.mark.parametrize("path", FBANK, ids=[os.path.basename(p) for p in FBANK])
+def test_frontend_matches_reference(path, enc3):
+    enc, _ = enc3
+    g = np.load(path)
+    wave, mask = torch.from_numpy(g["wave"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    _, taps = enc(wave, mask, int(g["pad_to_multiple_of"]), n_layers=0, return_taps=True)
+    torch.cuda.synchronize()
+    got_mask = taps["attention_mask"].cpu().numpy()
+    assert got_mask.shape == g["attention_mask"].shape, (got_mask.shape, g["attention_mask"].shape)
+    assert np.array_equal(got_mask, g["attention_mask"]), np.nonzero(got_mask != g["attention_mask"])
+    d = np.abs(taps["input_features"].cpu().numpy() - g["input_features"])
+    err = d.max()
+    print(f"{os.path.basename(path)}: input_features max abs err {err:.3e} at {np.unravel_index(d.argmax(), d.shape)} mean {d.mean():.2e}")
+    assert err < 1e-3
+
+
+@pytest.mark.parametrize("rows,D,affine,masked", [(1000, 1024, True, False), (333, 160, True, False), (257, 1024, False, True)])
+def test_layernorm(cuda_device, rows, D, affine, masked):
+    lib = _cabi.load()
+    x = torch.from_numpy(prng.irwin_hall("ln.x", (rows, D), 2.0, 1)) + 0.5
+    g = torch.from_numpy(prng.uniform("ln.g", (D,), 0.5, 1.5, 1)) if affine else None
+    b = torch.from_numpy(prng.uniform("ln.b", (D,), -0.5, 0.5, 1)) if affine else None
+    m = (torch.from_numpy(prng.uniform01("ln.m", rows, 1)) > 0.3).float() if masked else None
+    ref = F.layer_norm(x, (D,), g, b, 1e-5)
+    if masked:
+        ref = ref * m.unsqueeze(1)
+    xd = x.cuda()
+    y = torch.empty_like(xd)
+    gd, bd, md = (t.cuda() if t is not None else None for t in (g, b, m))
+    _cabi.check(lib.at_op_layernorm(xd.data_ptr(), _cabi.ptr(gd), _cabi.ptr(bd), _cabi.ptr(md), y.data_ptr(), rows, D,
+                                    _stream(cuda_device)), "at_op_layernorm")
+    torch.cuda.synchronize()
+    assert (y.cpu() - ref).abs().max().item() < 2e-5
+
+
+def test_attention_matches_reference(cuda_device):
+    lib = _cabi.load()
+    g = np.load(os.path.join(G, "attention_a.npz"))
+    w = W.synth_w2vbert_weights(n_layers=1, seed=int(g["weight_seed"]), with_vq=False)
+    B, T = int(g["B"]), int(g["T"])
+    x = torch.from_numpy(prng.irwin_hall("attn.x", (B, T, 1024), 1.0, int(g["x_seed"])))
+    p = "encoder.layers.0.self_attn"
+    wq = torch.cat([torch.from_numpy(w[f"{p}.linear_{n}.weight"]) for n in "qkv"])
+    bq = torch.cat([torch.from_numpy(w[f"{p}.linear_{n}.bias"]) for n in "qkv"])
+    qkv = F.linear(x, wq, bq).reshape(B * T, 3072).cuda().contiguous()
+    de = torch.zeros(80, 64)
+    de[:73] = torch.from_numpy(w[f"{p}.distance_embedding.weight"])
+    ctx = torch.full((B * T, 1024), float("nan"), device="cuda")
+    mask = torch.from_numpy(g["mask"]).reshape(-1).cuda()
+    ded = de.cuda()
+    _cabi.check(lib.at_op_relpos_attention(qkv.data_ptr(), mask.data_ptr(), ded.data_ptr(), ctx.data_ptr(), B, T,
+                                           _stream(cuda_device)), "at_op_relpos_attention")
+    torch.cuda.synchronize()
+    out = F.linear(ctx.cpu().reshape(B, T, 1024), torch.from_numpy(w[f"{p}.linear_out.weight"]), torch.from_numpy(w[f"{p}.linear_out.bias"]))
+    err = (out - torch.from_numpy(g["out"])).abs().max().item()
+    print(f"attention: max abs err after out-proj {err:.3e}")
+    assert err < 1e-4
+
+
+@pytest.mark.parametrize("B,T", [(2, 1500), (1, 130), (3, 64)])
+def test_attention_long_vs_oracle(cuda_device, B, T):
+    """T spanning many key tiles (far-field bias constants) and ragged masks, against the oracle attention."""
+    lib = _cabi.load()
+    w = W.synth_w2vbert_weights(n_layers=1, seed=11, with_vq=False)
+    p = "encoder.layers.0.self_attn"
+    x = torch.from_numpy(prng.irwin_hall("attn.long", (B, T, 1024), 1.0, 2))
+    mask = torch.ones(B, T)
+    if B > 1:
+        mask[1, T * 2 // 3:] = 0
+    add = ((1.0 - mask[:, None, None, :]) * torch.finfo(torch.float32).min).expand(B, 1, T, T)
+    ref = R.relpos_attention(w, p, x, add)
+    wq = torch.cat([torch.from_numpy(w[f"{p}.linear_{n}.weight"]) for n in "qkv"])
+    bq = torch.cat([torch.from_numpy(w[f"{p}.linear_{n}.bias"]) for n in "qkv"])
+    qkv = F.linear(x, wq, bq).reshape(B * T, 3072).cuda().contiguous()
+    de = torch.zeros(80, 64)
+    de[:73] = torch.from_numpy(w[f"{p}.distance_embedding.weight"])
+    ctx = torch.full((B * T, 1024), float("nan"), device="cuda")
+    md, ded = mask.reshape(-1).cuda(), de.cuda()   # keep references: temporaries would be recycled by the allocator
+    _cabi.check(lib.at_op_relpos_attention(qkv.data_ptr(), md.data_ptr(), ded.data_ptr(),
+                                           ctx.data_ptr(), B, T, _stream(cuda_device)), "at_op_relpos_attention")
+    torch.cuda.synchronize()
+    out = F.linear(ctx.cpu().reshape(B, T, 1024), torch.from_numpy(w[f"{p}.linear_out.weight"]), torch.from_numpy(w[f"{p}.linear_out.bias"]))
+    err = (out - ref).abs().max().item()
+    print(f"attention B={B} T={T}: max abs err {err:.3e}")
+    assert err < 1e-4
+
+
+def test_dwconv_ln_swish(cuda_device):
+    lib = _cabi.load()
+    B, T = 2, 77
+    g = torch.from_numpy(prng.irwin_hall("dw.g", (B, T, 1024), 1.0, 4))
+    w = torch.from_numpy(prng.uniform("dw.w", (1024, 1, 31), -0.3, 0.3, 4))
+    gm = torch.from_numpy(prng.uniform("dw.gm", (1024,), 0.5, 1.5, 4))
+    bt = torch.from_numpy(prng.uniform("dw.bt", (1024,), -0.5, 0.5, 4))
+    h = F.conv1d(F.pad(g.transpose(1, 2), (30, 0)), w, groups=1024).transpose(1, 2)
+    ref = F.silu(F.layer_norm(h, (1024,), gm, bt, 1e-5))
+    out = torch.full((B * T, 1024), float("nan"), device="cuda")
+    wt = w[:, 0, :].t().contiguous().cuda()
+    gd, gmd, btd = g.cuda(), gm.cuda(), bt.cuda()
+    _cabi.check(lib.at_op_dwconv_ln_swish(gd.data_ptr(), wt.data_ptr(), gmd.data_ptr(), btd.data_ptr(),
+                                          out.data_ptr(), B, T, _stream(cuda_device)), "at_op_dwconv_ln_swish")
+    torch.cuda.synchronize()
+    assert (out.cpu().reshape(B, T, 1024) - ref).abs().max().item() < 5e-5
+
+
+def test_conformer_matches_hf_golden(enc3):
+    enc, w = enc3
+    g = np.load(os.path.join(G, "conformer_a.npz"))
+    B, N = int(g["B"]), int(g["N"])
+    mask = torch.from_numpy(g["mask"])
+    wave = torch.from_numpy(W.synth_waveform(B, N, 16000, seed=int(g["wave_seed"]))) * mask
+    for nl, key in ((0, "hs0"), (1, "hs1"), (3, "hs_last")):
+        toks, taps = enc(wave.cuda(), mask.cuda(), 2, n_layers=nl, return_taps=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(taps["attention_mask"].cpu().numpy(), g["attention_mask"])
+        err = np.abs(taps["hidden"].cpu().numpy() - g[key]).max()
+        print(f"hidden_states[{nl}] max abs err {err:.3e}")
+        assert err < 1e-3, (key, err)
+    # tokens: bit-identical to the oracle (vector_quantize_pytorch formula) on the same inputs
+    ref = R.semantic_m_encode(w, wave, mask, 2, 3)
+    assert toks.dtype == torch.int16 and tuple(toks.shape) == tuple(ref.shape)
+    assert torch.equal(toks.cpu(), ref)
+
+
+def test_tokens_vs_oracle_ragged(enc3):
+    enc, w = enc3
+    B, N = 3, 16000 * 2 + 250
+    wave = W.synth_waveform(B, N, 16000, seed=31)
+    mask = np.ones((B, N), dtype=np.float32)
+    mask[1, 17000:] = 0
+    mask[2, 4000:] = 0
+    wave = wave * mask
+    toks = enc(torch.from_numpy(wave).cuda(), torch.from_numpy(mask).cuda(), 2)
+    ref = R.semantic_m_encode(w, torch.from_numpy(wave), torch.from_numpy(mask), 2, 3)
+    feats, am = R.processor(torch.from_numpy(wave), torch.from_numpy(mask), 2)
+    valid = am.bool().unsqueeze(1)
+    same = (toks.cpu() == ref)
+    print(f"tokens equal: valid {same[valid].float().mean().item():.4f}, all {same.float().mean().item():.4f}")
+    assert same[valid].all(), "token ids at valid positions must be bit-identical"
