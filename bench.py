@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio-seconds tokenized per wall-second on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload acoustic|semantic_m] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload both|acoustic|semantic_m] [--no-cpu-baseline]
 
 One "step" = one pass of the hot path (the reference's ``self.encoder(input_batch, attention_mask)`` call,
 audiotoken/core.py:276) over one synthetic batch that is already resident in HBM. At N=1 the workload is
@@ -9,6 +9,11 @@ BASELINE.json configs[1]: Tokenizers.acoustic, 256 clips x 10 s @ 24 kHz, 8 code
 torch.distributed.run, one rank per GPU) every rank encodes its own 256-clip shard — clips are independent, so
 there is no data-path collective ("weak" scaling); RCCL is used only for the start barrier, the weight
 broadcast check and the max-over-ranks time.
+
+The metric names two tokenizers ("acoustic + semantic_m"). The top-level fields of the JSON line are the acoustic
+workload (configs[1]); with --workload both (default) the same line carries a "semantic_m" object (BASELINE configs[3]
+per-GPU share: 64 clips x 30 s @16 kHz, 19 conformer layers, VQ 2048) with its own value / roofline / cpu_baseline and
+a "combined" figure = audio-seconds of both / (t_acoustic + t_semantic_m).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   "roofline":     dominant kernel group's achieved rate vs the gfx950 peak, timed with HIP events on the launch stream
@@ -110,34 +115,96 @@ def cpu_baseline_acoustic(n_q: int, budget_s: float = 15.0):
                       f"{t_total:.1f} s of CPU work"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="acoustic", choices=["acoustic"])
-    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step (BASELINE config: 256)")
-    ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--num-codebooks", type=int, default=8)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def semantic_flops_per_clip(T: int, n_layers: int, F: int):
+    """Algorithmic FLOPs per clip by kernel group (bucketed rel-pos)."""
+    H, Fd = 1024, 4096
+    g = {
+        "frontend": 2.0 * F * (400 * 514 + 257 * 80),
+        "feature_projection": 2.0 * T * 160 * H,
+        "ffn": n_layers * 2 * (2.0 * T * H * Fd * 2),
+        "attn_proj": n_layers * (2.0 * T * H * H * 4),
+        "attention": n_layers * (4.0 * T * T * H + 2.0 * T * 80 * H),
+        "conv_module": n_layers * (2.0 * T * H * 2 * H + 2.0 * T * H * H + 2.0 * T * 31 * H),
+        "vq": 2.0 * T * H * 2048,
+    }
+    return g
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        dist = dist_mod
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
 
+def cpu_baseline_semantic(n_layers: int, budget_s: float = 20.0):
+    """CPU oracle (oracle/w2vbert_ref.py, torch-CPU fp32 port of reference Wav2VecBertEncoder.forward on device='cpu')
+    on a bounded sample: one clip whose length is sized by a 1 s probe to ~budget_s of CPU work (max 30 s audio).
+    Uses the first min(n_layers, 4) synthetic layers' weights cyclically to bound host memory/time of weight
+    generation — the arithmetic per layer is identical."""
     from audiotoken_amd import weights as W
-    from audiotoken_amd import _cabi
+    from oracle import w2vbert_ref as R
+
+    torch.set_num_threads(host_threads())
+    nl_w = min(n_layers, 2)
+    w = W.synth_w2vbert_weights(n_layers=nl_w, seed=0, with_vq=True)
+    wt = {k: torch.from_numpy(v) for k, v in w.items()}
+    for i in range(nl_w, n_layers):   # alias layer i -> layer i % nl_w (no copies)
+        for k in list(wt):
+            if k.startswith(f"encoder.layers.{i % nl_w}."):
+                wt[k.replace(f"encoder.layers.{i % nl_w}.", f"encoder.layers.{i}.", 1)] = wt[k]
+    with torch.no_grad():
+        probe = torch.from_numpy(W.synth_waveform(1, 16000, 16000, seed=1))
+        R.semantic_m_encode(wt, probe, torch.ones_like(probe), 2, n_layers)
+        t0 = time.perf_counter()
+        R.semantic_m_encode(wt, probe, torch.ones_like(probe), 2, n_layers)
+        per_s = time.perf_counter() - t0
+        secs = float(max(1.0, min(30.0, budget_s / max(per_s, 1e-3))))
+        n = int(secs * 16000)
+        wav = torch.from_numpy(W.synth_waveform(1, n, 16000, seed=1234))
+        t0 = time.perf_counter()
+        R.semantic_m_encode(wt, wav, torch.ones_like(wav), 2, n_layers)
+        t_total = time.perf_counter() - t0
+    return {"value": round(n / 16000.0 / t_total, 3), "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 clip x {n / 16000.0:.1f} s @16 kHz, {n_layers} conformer layers, oracle/w2vbert_ref.py (torch-CPU fp32), "
+                      f"{t_total:.1f} s of CPU work"}
+
+
+def timed_steps(enc_call, steps, warmup, dist):
+    for _ in range(warmup):
+        out = enc_call()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = enc_call()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    return elapsed, out
+
+
+def max_over_ranks(x: float, dev, dist) -> float:
+    if dist is None:
+        return x
+    t = torch.tensor([x], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def roofline_of(breakdown, flops, nbytes, B):
+    dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
+    d = breakdown[dom]
+    t_mfma = flops[dom] * B / (F32_MFMA_PEAK_TFLOPS * 1e12)
+    t_hbm = (nbytes[dom] * B / (HBM_PEAK_GBS * 1e9)) if nbytes is not None else 0.0
+    launches = max(1, d["launches_per_step"])
+    if t_hbm >= t_mfma:
+        roof = {"bound": "hbm", "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["gbs"] / HBM_PEAK_GBS, 4)}
+    else:
+        roof = {"bound": "mfma", "achieved": d["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(d["tflops"] / F32_MFMA_PEAK_TFLOPS, 4)}
+    roof.update({"kernel": dom, "launches_per_step": launches, "avg_launch_ms": round(d["ms_per_step"] / launches, 4), "traffic": None})
+    return roof
+
+
+def run_acoustic(args, rank, world, dev, dist):
+    from audiotoken_amd import weights as W
     from audiotoken_amd.configs import AcousticEncoderConfig, num_codebooks_to_bandwidth
     from audiotoken_amd.encoder import AcousticEncoder
     from audiotoken_amd.distributed import broadcast_weights
@@ -155,69 +222,150 @@ def main():
     if B > gen_B:  # make repeated clips distinct without regenerating on the host
         wav = (wav * torch.linspace(0.5, 1.0, B, device=dev).unsqueeze(1)).contiguous()
     mask = torch.ones_like(wav)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        codes = enc(wav, mask)
-    barrier()
-    enc.enable_profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        codes = enc(wav, mask)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    if dist is not None:
-        dist.barrier()
-    elapsed = t1 - t0
-    prof = enc.read_profile()  # {group: (total ms over the timed region, launches)}
+    enc(wav, mask)  # allocate workspace outside the timed region
     enc.enable_profile(False)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # warm-up untimed, then the timed region with the HIP-event taps on
+    for _ in range(args.warmup):
+        enc(wav, mask)
+    enc.enable_profile(True)
+    elapsed, codes = timed_steps(lambda: enc(wav, mask), args.steps, 0, dist)
+    prof = enc.read_profile()
+    enc.enable_profile(False)
+    elapsed = max_over_ranks(elapsed, dev, dist)
     checksum = int(codes.to(torch.int64).sum().item())
+    flops, T = acoustic_flops_per_clip(N, n_q)
+    nbytes = acoustic_bytes_per_clip(N, n_q)
+    breakdown = {}
+    for k, (ms, launches) in prof.items():
+        per = ms / args.steps
+        breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches // args.steps,
+                        "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None,
+                        "gbs": round(nbytes[k] * B / (per * 1e-3) / 1e9, 1) if per > 0 else None}
+    res = {
+        "value": round(world * B * args.seconds * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "elapsed": elapsed, "audio_s_per_step": world * B * args.seconds,
+        "config": {"workload": f"Tokenizers.acoustic encode, {B} clips x {args.seconds:g} s @24 kHz per GPU, num_codebooks={n_q}",
+                   "clips_per_gpu": B, "samples_per_clip": N, "frames_per_clip": T, "weights": "synthetic seed 0",
+                   "parallelism": f"clip-sharded x{world}, no data-path collective"},
+        "roofline": roofline_of(breakdown, flops, nbytes, B), "breakdown": breakdown, "token_checksum": checksum,
+    }
+    del enc
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_semantic(args, rank, world, dev, dist):
+    from audiotoken_amd import weights as W
+    from audiotoken_amd.configs import Wav2VecBertConfig
+    from audiotoken_amd.encoder import Wav2VecBertEncoder
+    from audiotoken_amd.distributed import broadcast_weights
+
+    nl = args.sem_layers
+    B, secs = args.sem_batch, args.sem_seconds
+    N = int(round(secs * 16000))
+    weights = W.synth_w2vbert_weights(n_layers=nl, seed=0, with_vq=True) if rank == 0 else None
+    weights = broadcast_weights(weights, dev, dist)
+    enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=nl), device=str(dev), quantize=True, weights=weights)
+    del weights
+    gen_B = min(B, 8)
+    base = torch.from_numpy(W.synth_waveform(gen_B, N, 16000, seed=1234, first_clip=rank * B)).to(dev)
+    wav = base.repeat((B + gen_B - 1) // gen_B, 1)[:B].contiguous()
+    if B > gen_B:
+        wav = (wav * torch.linspace(0.5, 1.0, B, device=dev).unsqueeze(1)).contiguous()
+    mask = torch.ones_like(wav)
+    enc(wav, mask)
+    for _ in range(max(0, args.warmup - 1)):
+        enc(wav, mask)
+    enc.enable_profile(True)
+    elapsed, toks = timed_steps(lambda: enc(wav, mask), args.steps, 0, dist)
+    prof = enc.read_profile()
+    enc.enable_profile(False)
+    elapsed = max_over_ranks(elapsed, dev, dist)
+    T = toks.shape[-1]
+    F = 1 + (N - 400) // 160
+    flops = semantic_flops_per_clip(T, nl, F)
+    breakdown = {}
+    for k, (ms, launches) in prof.items():
+        per = ms / args.steps
+        breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches // args.steps,
+                        "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None, "gbs": None}
+    res = {
+        "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "elapsed": elapsed, "audio_s_per_step": world * B * secs, "dtype": "f32",
+        "config": {"workload": f"Tokenizers.semantic_m encode, {B} clips x {secs:g} s @16 kHz per GPU, {nl} conformer layers, VQ 2048x1024",
+                   "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0",
+                   "parallelism": f"clip-sharded x{world}, no data-path collective"},
+        "roofline": roofline_of(breakdown, flops, None, B), "breakdown": breakdown,
+        "token_checksum": int(toks.to(torch.int64).sum().item()),
+        "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
+    }
+    del enc
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="both", choices=["both", "acoustic", "semantic_m"])
+    ap.add_argument("--batch", type=int, default=256, help="acoustic clips per GPU per step (BASELINE configs[1]: 256)")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--num-codebooks", type=int, default=8)
+    ap.add_argument("--sem-batch", type=int, default=64, help="semantic_m clips per GPU per step (BASELINE configs[3]: 512/8)")
+    ap.add_argument("--sem-seconds", type=float, default=30.0)
+    ap.add_argument("--sem-layers", type=int, default=19)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist = dist_mod
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+
+    ac = sem = None
+    sem_err = None
+    if args.workload in ("both", "acoustic"):
+        ac = run_acoustic(args, rank, world, dev, dist)
+    if args.workload in ("both", "semantic_m"):
+        try:
+            sem = run_semantic(args, rank, world, dev, dist)
+        except Exception as e:  # keep the acoustic line even if the second workload cannot run on this box
+            if args.workload == "semantic_m":
+                raise
+            sem_err = f"{type(e).__name__}: {e}"
 
     if rank == 0:
-        audio_s = world * B * args.seconds * args.steps
-        value = audio_s / elapsed
-        flops, T = acoustic_flops_per_clip(N, n_q)
-        nbytes = acoustic_bytes_per_clip(N, n_q)
-        breakdown = {}
-        for k, (ms, launches) in prof.items():
-            per_step_ms = ms / args.steps
-            breakdown[k] = {"ms_per_step": round(per_step_ms, 3), "launches_per_step": launches // args.steps,
-                            "tflops": round(flops[k] * B / (per_step_ms * 1e-3) / 1e12, 2) if per_step_ms > 0 else None,
-                            "gbs": round(nbytes[k] * B / (per_step_ms * 1e-3) / 1e9, 1) if per_step_ms > 0 else None}
-        dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
-        d = breakdown[dom]
-        # which roofline binds the dominant group: compare time at peak for its flops vs its bytes
-        t_mfma = flops[dom] * B / (F32_MFMA_PEAK_TFLOPS * 1e12)
-        t_hbm = nbytes[dom] * B / (HBM_PEAK_GBS * 1e9)
-        launches = max(1, d["launches_per_step"])
-        if t_hbm >= t_mfma:
-            roof = {"bound": "hbm", "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(d["gbs"] / HBM_PEAK_GBS, 4)}
-        else:
-            roof = {"bound": "mfma", "achieved": d["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(d["tflops"] / F32_MFMA_PEAK_TFLOPS, 4)}
-        roof.update({"kernel": dom, "launches_per_step": launches, "avg_launch_ms": round(d["ms_per_step"] / launches, 4),
-                     "traffic": None})
+        primary = ac if ac is not None else sem
         out = {
-            "metric": "audio-sec tokenized / wall-sec", "value": round(value, 2), "unit": "audio-s/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "metric": "audio-sec tokenized / wall-sec", "value": primary["value"], "unit": "audio-s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Tokenizers.acoustic encode, {B} clips x {args.seconds:g} s @24 kHz per GPU, num_codebooks={n_q}",
-                       "clips_per_gpu": B, "samples_per_clip": N, "frames_per_clip": T, "weights": "synthetic seed 0",
-                       "parallelism": f"clip-sharded x{world}, no data-path collective"},
-            "roofline": roof, "breakdown": breakdown, "token_checksum": checksum,
+            "config": primary["config"], "roofline": primary["roofline"], "breakdown": primary["breakdown"],
+            "token_checksum": primary["token_checksum"],
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_acoustic(n_q)
+            out["cpu_baseline"] = cpu_baseline_acoustic(args.num_codebooks) if ac is not None else cpu_baseline_semantic(args.sem_layers)
+        if ac is not None and sem is not None:
+            s = {k: v for k, v in sem.items() if k not in ("elapsed", "audio_s_per_step")}
+            if not args.no_cpu_baseline and world == 1:
+                s["cpu_baseline"] = cpu_baseline_semantic(args.sem_layers)
+            out["semantic_m"] = s
+            tot_audio = (ac["audio_s_per_step"] + sem["audio_s_per_step"]) * args.steps
+            out["combined"] = {"value": round(tot_audio / (ac["elapsed"] + sem["elapsed"]), 2), "unit": "audio-s/s",
+                               "definition": "audio-seconds of both workloads / (t_acoustic + t_semantic_m)"}
+        elif sem_err:
+            out["semantic_m"] = {"error": sem_err}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
