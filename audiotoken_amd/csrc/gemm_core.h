@@ -10,7 +10,7 @@ constexpr int BK = 32;
 
 // Accumulator ownership after gemm_tile(): lane (r16 = lane&15, q = lane>>4) of wave (wm, wn) holds
 //   acc[i][j] = out[m = m0 + wm*TM*16 + i*16 + r16][n = n0 + wn*TN*16 + j*16 + q*4 .. +3]
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int PRO = PRO_NONE>
 struct GemmTile {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static constexpr int TM = BM / WM / 16;
@@ -32,55 +32,62 @@ struct GemmTile {
         const int kc = tid & 7;     // 16-byte chunk within the 32-float K slice
 
         f4 xreg[XCH], wreg[WCH];
+        f4 ureg[PRO == PRO_POWER ? XCH : 1];
+        unsigned xok = 0u, wok = 0u;
         const int nk = (a.K + BK - 1) / BK;
 
+        // Every load below is UNCONDITIONAL (addresses clamped into range, result masked by a select afterwards):
+        // a load under a per-element runtime branch makes hipcc serialise the whole tile fetch behind
+        // s_waitcnt vmcnt(0) (CDNA guide §5 "three .s-level traps" (c)) — measured 70 -> ~110 TFLOP/s on this kernel.
+        const int Mlast = a.M - 1, Nlast = a.N - 1, Tlast = a.Tin - 1;
         auto load_tile = [&](int kt) {
-            const int kk = kt * BK + kc * 4;
-            const bool kvalid = kk < a.K;
-            const int tap = kvalid ? kk / a.Cin : 0;
+            const int kk0 = kt * BK + kc * 4;
+            const bool kvalid = kk0 < a.K;
+            xok = 0u;
+            wok = 0u;
+            const int kk = kvalid ? kk0 : 0;
+            const int tap = a.ktaps == 1 ? 0 : kk / a.Cin;
             const int ci = kk - tap * a.Cin;
 #pragma unroll
             for (int j = 0; j < XCH; ++j) {
                 const int m = m0 + lrow + j * 32;
-                f4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kvalid && m < a.M) {
-                    int r = m * a.stride + tap - a.pad_left;
-                    bool ok = true;
-                    if (r < 0) {
-                        if (a.pad_mode) r = -r; else ok = false;
-                    } else if (r >= a.Tin) {
-                        if (a.pad_mode) r = 2 * (a.Tin - 1) - r; else ok = false;
-                    }
-                    if (ok) {
-                        v = *reinterpret_cast<const f4*>(Xb + (long long)r * a.ldx + ci);
-                        if (a.pro == PRO_ELU) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
-                        else if (a.pro == PRO_POWER) {
-                            const f4 u = *reinterpret_cast<const f4*>(Xb + (long long)r * a.ldx + ci + a.aux_off);
-                            v = v * v + u * u;
-                        }
-                    }
-                }
-                xreg[j] = v;
+                const int mc = m < a.M ? m : Mlast;
+                int r = mc * a.stride + tap - a.pad_left;
+                bool ok = kvalid && (m < a.M);
+                const bool lo = r < 0, hi = r > Tlast;
+                ok = ok && (a.pad_mode != 0 || !(lo || hi));
+                r = lo ? -r : (hi ? 2 * Tlast - r : r);
+                r = r < 0 ? 0 : (r > Tlast ? Tlast : r);
+                const float* src = Xb + (long long)r * a.ldx + ci;
+                f4 v = *reinterpret_cast<const f4*>(src);
+                if (PRO == PRO_POWER) ureg[j] = *reinterpret_cast<const f4*>(src + a.aux_off);
+                xreg[j] = v;                 // raw: the mask is applied in store_tile so that nothing consumes the
+                xok |= (ok ? 1u : 0u) << j;  // load before the MFMAs of the current tile have been issued
             }
 #pragma unroll
             for (int j = 0; j < WCH; ++j) {
                 const int n = n0 + lrow + j * 32;
-                f4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kvalid && n < a.N && (BN >= 32 || lrow < BN)) v = *reinterpret_cast<const f4*>(a.W + (long long)n * a.K + kk);
-                wreg[j] = v;
+                const int nc = n < a.N ? n : Nlast;
+                wreg[j] = *reinterpret_cast<const f4*>(a.W + (long long)nc * a.K + kk);
+                wok |= ((kvalid && n < a.N) ? 1u : 0u) << j;
             }
         };
         auto store_tile = [&](int buf) {
 #pragma unroll
             for (int j = 0; j < XCH; ++j) {
                 const int row = lrow + j * 32;
-                *reinterpret_cast<f4*>(Xs + buf * BM * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) = xreg[j];
+                f4 v = xreg[j];
+                if (PRO == PRO_POWER) v = v * v + ureg[j] * ureg[j];
+                if (!((xok >> j) & 1u)) v = f4{0.f, 0.f, 0.f, 0.f};
+                if (PRO == PRO_ELU) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }  // ELU(0) = 0
+                *reinterpret_cast<f4*>(Xs + buf * BM * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) = v;
             }
 #pragma unroll
             for (int j = 0; j < WCH; ++j) {
                 const int row = lrow + j * 32;
                 if (BN >= 32 || row < BN)
-                    *reinterpret_cast<f4*>(Ws + buf * BN * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) = wreg[j];
+                    *reinterpret_cast<f4*>(Ws + buf * BN * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) =
+                        ((wok >> j) & 1u) ? wreg[j] : f4{0.f, 0.f, 0.f, 0.f};
             }
         };
 

@@ -36,9 +36,9 @@ __device__ __forceinline__ f4 apply_act4(f4 v, int epi) {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int PRO>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
-    using Tile = GemmTile<BM, BN, WM, WN>;
+    using Tile = GemmTile<BM, BN, WM, WN, PRO>;
     constexpr int TM = Tile::TM, TN = Tile::TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
@@ -82,7 +82,12 @@ template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     using Tile = GemmTile<BM, BN, WM, WN>;
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN>), grid, dim3(256), Tile::LDS_BYTES, stream, a);
+    if (a.pro == PRO_ELU)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, PRO_ELU>), grid, dim3(256), Tile::LDS_BYTES, stream, a);
+    else if (a.pro == PRO_POWER)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, PRO_POWER>), grid, dim3(256), Tile::LDS_BYTES, stream, a);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, PRO_NONE>), grid, dim3(256), Tile::LDS_BYTES, stream, a);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -95,6 +100,7 @@ int check_gemm_args(const GemmArgs& a) {
     AT_REQUIRE(a.pro != PRO_POWER || (a.aux_off % 4 == 0 && a.ktaps == 1), "PRO_POWER needs ktaps == 1 and an aligned aux_off");
     AT_REQUIRE(a.batch >= 1 && a.batch <= 65535, "batch out of range");
     AT_REQUIRE(a.pad_mode == 0 || a.Tin > a.pad_left, "reflect padding needs Tin > pad");
+    AT_REQUIRE(a.pro != PRO_POWER || a.aux_off + a.Cin <= a.ldx, "PRO_POWER: imaginary half must lie inside the input row");
     return 0;
 }
 
