@@ -1,0 +1,195 @@
+"""``AudioToken`` — the reference's public façade (audiotoken/core.py:27-359) over the MI355X HIP library.
+
+Same constructor, attributes, method signatures, return shapes/dtypes and exception types; the differences are
+forced by the environment and stated here:
+* ``device`` must be a HIP device (``"cuda[:i]"`` under PyTorch-ROCm). The reference's ``device="cpu"`` default
+  would need a CPU path, which this package deliberately does not have — constructing with "cpu" raises
+  ``ValueError`` at ``load_encoder`` time.
+* checkpoints cannot be downloaded (no network): pass ``weights=`` / ``quantizer=`` kwargs or set the
+  ``AUDIOTOKEN_*`` environment variables (configs.py); with nothing given, synthetic weights are used and a
+  warning is logged.
+* ``compile`` is accepted and ignored (there is no tracing compiler in the path; kernels are precompiled HIP).
+* ``encode_batch_files`` shards files over ranks when ``torch.distributed`` is initialised (one process per GPU).
+"""
+from __future__ import annotations
+
+import os
+import time
+from pathlib import Path
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from .configs import (AUDIO_EXTS, AcousticDecoderConfig, AcousticEncoderConfig, EncoderConfig, HubertEncoderConfig, Tokenizers,
+                      Wav2VecBertConfig, num_codebooks_to_bandwidth)
+from .harness import batched, collate_fn, iter_chunk, sanitize_path, save_audio_tokens, save_rel_audio_tokens
+from .logger import get_logger
+
+logger = get_logger(__name__, log_file=None, level="WARNING")
+
+
+class AudioToken:
+    def __init__(self, tokenizer: Tokenizers, device: str = "cpu", compile: bool = False, **kwargs):
+        """Reference ``AudioToken.__init__`` (core.py:28-71). Supported kwargs: ``num_codebooks`` in {2,4,8,16}
+        (default 16 — the reference's actual default, core.py:67), ``weights``, ``quantizer``."""
+        self.tokenizer_name = Tokenizers(tokenizer)  # ValueError on unknown names, like the reference's StrEnum
+        self.encoder: Optional[torch.nn.Module] = None
+        self.decoder: Optional[torch.nn.Module] = None
+        self.model_config: EncoderConfig
+        self.transform_func: Optional[Callable] = None
+        self.compile = compile
+        self.kwargs = kwargs
+        self.device = device
+        self.num_codebooks = kwargs.get("num_codebooks", 16)
+        assert self.num_codebooks in [2, 4, 8, 16], "num_codebooks must be one of [2, 4, 8, 16]"
+        self.load_config()
+
+    def load_config(self):
+        """core.py:73-90."""
+        if self.tokenizer_name == Tokenizers.acoustic:
+            self.model_config = AcousticEncoderConfig(bandwidth=num_codebooks_to_bandwidth(self.num_codebooks))
+        elif self.tokenizer_name == Tokenizers.semantic_s:
+            self.model_config = HubertEncoderConfig()
+        elif self.tokenizer_name == Tokenizers.semantic_m:
+            self.model_config = Wav2VecBertConfig()
+        else:
+            raise ValueError(f"Tokenizer {self.tokenizer_name} not supported")
+        if self.kwargs.get("weights") is not None and not isinstance(self.kwargs["weights"], dict):
+            self.model_config.weights = self.kwargs["weights"]
+        if self.kwargs.get("quantizer") is not None and hasattr(self.model_config, "quantizer_path"):
+            self.model_config.quantizer_path = self.kwargs["quantizer"]
+        self.model_sample_rate = self.model_config.model_sample_rate
+
+    def _weights_kw(self):
+        w = self.kwargs.get("weights")
+        return w if isinstance(w, dict) else None
+
+    def load_encoder(self):
+        """core.py:92-118 (lazy construction on first use)."""
+        if self.encoder is None:
+            if self.tokenizer_name == Tokenizers.acoustic:
+                from .encoder import AcousticEncoder
+                self.encoder = AcousticEncoder(device=self.device, config=self.model_config, weights=self._weights_kw())
+            elif self.tokenizer_name == Tokenizers.semantic_s:
+                from .hubert import HubertEncoder, hubert_processor
+                self.encoder = HubertEncoder(config=self.model_config, device=self.device, weights=self._weights_kw())
+                self.transform_func = hubert_processor
+            elif self.tokenizer_name == Tokenizers.semantic_m:
+                from .encoder import Wav2VecBertEncoder
+                self.encoder = Wav2VecBertEncoder(config=self.model_config, device=self.device, quantize=True,
+                                                  weights=self._weights_kw())
+            else:
+                raise ValueError(f"Tokenizer {self.tokenizer_name} not supported")
+            self.encoder.eval()
+
+    def encode(self, audio: Union[torch.Tensor, np.ndarray, os.PathLike, bytes, Path], chunk_size: Optional[int] = None) -> torch.Tensor:
+        """core.py:120-185. ``(1, num_samples)`` array/tensor or a path -> tokens ``(1, K, T)`` on the CPU
+        (``(K, sum T)`` when a path is encoded with ``chunk_size`` — the reference drops the batch dim there)."""
+        self.load_encoder()
+        if isinstance(audio, np.ndarray):
+            assert audio.ndim == 2, "Audio must be 2D array"
+            assert audio.shape[0] == 1, "Audio must mono"
+            return self._encode_single(torch.from_numpy(audio))
+        elif isinstance(audio, torch.Tensor):
+            assert audio.ndim == 2, "Audio must be 2D array"
+            assert audio.shape[0] == 1, "Audio must mono"
+            return self._encode_single(audio)
+        elif isinstance(audio, os.PathLike) or isinstance(audio, Path):
+            from .audio_io import process_audio_chunks, read_audio
+            if chunk_size is None:
+                logger.warning("Chunking not provided. Encoding the complete audio file at once. May run out of memory for larger audio files.")
+                return self._encode_single(read_audio(audio, self.model_config.model_sample_rate))
+            processed = [self._encode_single(chunk)[0]
+                         for chunk, _ in process_audio_chunks(audio, self.model_config.model_sample_rate, chunk_size)]
+            return torch.cat(processed, dim=-1)
+        elif isinstance(audio, bytes):
+            raise NotImplementedError("Encoding bytes not supported yet")
+        else:
+            raise ValueError(f"Unsupported input type {type(audio)}. Should be one of: {np.ndarray, os.PathLike, bytes, Path}")
+
+    def _encode_single(self, audio: torch.Tensor) -> torch.Tensor:
+        """core.py:187-196."""
+        if self.transform_func:
+            audio = self.transform_func(audio)
+        input_batch = audio.to(self.device)
+        attention_mask = torch.ones_like(input_batch, device=self.device)
+        toks = self.encoder(input_batch, attention_mask)
+        return toks.cpu()
+
+    def _chunk_stream(self, files, chunk_size: int):
+        from .audio_io import process_audio_chunks
+        for file_path in files:
+            file_path = str(file_path)
+            if not file_path.endswith(AUDIO_EXTS):
+                logger.error(f"File {file_path} not supported for processing (tar/zip streaming is out of scope here)")
+                continue
+            for waveform, file_name in process_audio_chunks(file_path, self.model_config.model_sample_rate, chunk_size):
+                yield from iter_chunk(waveform, file_name, sample_rate=self.model_config.model_sample_rate, chunk_size=chunk_size,
+                                      model_token_rate=self.model_config.model_token_rate, pad_token=self.model_config.pad_token,
+                                      transform=self.transform_func)
+
+    def encode_batch_files(self, batch_size: int, outdir: os.PathLike, chunk_size: int = 30, num_workers: int = 12,
+                           audio_files: Optional[List[os.PathLike]] = None, audio_dir: Optional[Union[os.PathLike, Path]] = None,
+                           **dataloader_kwargs) -> None:
+        """core.py:198-289. Files -> ``chunk_size``-second segments -> batches -> encoder -> per-row trimmed
+        ``<stem>.npy`` (append semantics as in the reference). Under ``torch.distributed`` every rank takes a
+        contiguous block of files (all chunks of a file stay on one rank, preserving the append order)."""
+        self.load_encoder()
+        assert audio_files or audio_dir, "Either audio_files or audio_dir must be provided"
+        assert not (audio_files and audio_dir), "Provide either audio_files or audio_dir, not both"
+        outdir = sanitize_path(outdir)
+        if audio_files is not None:
+            files = [str(f) for f in audio_files]
+        else:
+            files = sorted(str(p) for ext in AUDIO_EXTS for p in Path(audio_dir).rglob(f"*{ext}"))
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from .distributed import shard_indices
+            files = [files[i] for i in shard_indices(len(files), dist.get_rank(), dist.get_world_size())]
+        start_time = time.time()
+        for batch in batched(self._chunk_stream(files, chunk_size), batch_size):
+            input_ids, attention_masks, file_pointers = collate_fn(batch)
+            input_ids = input_ids.to(self.device)
+            attention_masks = attention_masks.to(self.device)
+            encoded_audio = self.encoder(input_ids, attention_masks)
+            for tokens_batch, file_pointer in zip(encoded_audio, file_pointers):
+                if audio_files is not None:
+                    save_audio_tokens(tokens_batch, file_pointer, str(outdir))
+                else:
+                    save_rel_audio_tokens(tokens_batch, file_pointer, str(outdir), str(audio_dir))
+        logger.debug(f"Encoding batch files took: {time.time() - start_time:.2f}s")
+
+    def load_decoder(self, **kwargs):
+        """core.py:291-315 — only the acoustic decoder exists here (the semantic decoders are out of scope)."""
+        if self.decoder is None:
+            if self.tokenizer_name == Tokenizers.acoustic:
+                from .decoder import AcousticDecoder
+                cfg = AcousticDecoderConfig(bandwidth=num_codebooks_to_bandwidth(self.num_codebooks))
+                if self.kwargs.get("weights") is not None and not isinstance(self.kwargs["weights"], dict):
+                    cfg.weights = self.kwargs["weights"]
+                self.decoder = AcousticDecoder(config=cfg, device=self.device, weights=self._weights_kw(), **kwargs)
+            elif self.tokenizer_name in (Tokenizers.semantic_s, Tokenizers.semantic_m):
+                raise NotImplementedError("semantic decoders (autoregressive GPT + bark fine model) are out of scope of the MI355X hot path")
+            else:
+                raise ValueError(f"Tokenizer {self.tokenizer_name} not supported")
+            self.decoder.eval()
+
+    def decode(self, tokens: Union[torch.Tensor, np.ndarray, os.PathLike, Path], **kwargs) -> torch.Tensor:
+        """core.py:317-353: tokens ``(B, K, T)`` -> audio ``(1, B*320*T)`` on the CPU."""
+        self.load_decoder(**kwargs)
+        if isinstance(tokens, np.ndarray):
+            return self._decode_single(torch.from_numpy(tokens))
+        elif isinstance(tokens, torch.Tensor):
+            return self._decode_single(tokens)
+        elif isinstance(tokens, os.PathLike) or isinstance(tokens, Path):
+            tokens_mem = torch.load(tokens, map_location="cpu")
+            return self._decode_single(tokens_mem)
+        else:
+            raise ValueError(f"Unsupported input type {type(tokens)}. Should be one of: {np.ndarray, os.PathLike, Path}")
+
+    def _decode_single(self, tokens: torch.Tensor) -> torch.Tensor:
+        """core.py:355-359."""
+        input_batch = tokens.to(dtype=torch.long)
+        toks = self.decoder(input_batch)
+        return toks.cpu()

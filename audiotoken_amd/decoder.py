@@ -1,0 +1,47 @@
+"""Decoder callable with the reference's protocol: ``decoder(tokens int64 [B, K, T]) -> float32 [1, B*320*T]``
+(reference audiotoken/decoder.py:50-76), backed by libaudiotoken_hip.so. Only the acoustic decoder is in scope:
+the semantic decoders (nanoGPT sampling + bark, decoder.py:79-245) are stochastic and need private weights."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Union
+
+import numpy as np
+import torch
+
+from . import _cabi
+from . import weights as W
+from .configs import AcousticDecoderConfig
+from .encoder import _EncodecHandle
+from .logger import get_logger
+
+logger = get_logger(__name__)
+
+
+class AcousticDecoder(torch.nn.Module):
+    """Drop-in for reference ``AcousticDecoder`` (audiotoken/decoder.py:50-76)."""
+
+    def __init__(self, config: AcousticDecoderConfig = None, device: str = "cuda:0",
+                 weights: Optional[Union[str, Dict[str, np.ndarray]]] = None):
+        super().__init__()
+        config = config or AcousticDecoderConfig()
+        self.config = config
+        self._h = _EncodecHandle(device, weights if weights is not None else config.weights, with_decoder=True)
+        self.device = self._h.device
+        self._ws: Optional[torch.Tensor] = None
+
+    @torch.no_grad()
+    def forward(self, input_batch: torch.Tensor) -> torch.Tensor:
+        assert input_batch.dim() == 3, "tokens must be [B, K, T]"
+        codes = input_batch.to(device=self.device, dtype=torch.long).contiguous()
+        B, K, T = codes.shape
+        lib = self._h.lib
+        out = torch.empty((1, B * W.ENCODEC_HOP * T), dtype=torch.float32, device=self.device)
+        nbytes = lib.at_encodec_decode_workspace_bytes(self._h.handle, B, T)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = lib.at_encodec_decode(self._h.handle, codes.data_ptr(), B, K, T, out.data_ptr(), self._ws.data_ptr(), nbytes,
+                                       _cabi.current_stream_handle(self.device))
+        _cabi.check(rc, "at_encodec_decode")
+        return out

@@ -150,6 +150,44 @@ def make_conformer():
     print("conformer", hs[n_layers].shape, idx.shape)
 
 
+def make_harness():
+    """Reference-authored harness: datasets.py::_iter_chunk and utils.py::save_audio_tokens via stubs."""
+    import tempfile
+    from _ref_loader import load_reference_modules
+    mods = load_reference_modules()
+    DS = mods["datasets"].AudioBatchDataset
+    out = {}
+    cases = [("a", 69100, 16000, 2, 50), ("b", 240000, 24000, 10, 75), ("c", 24000 * 3 + 1, 24000, 3, 75),
+             ("d", 3199, 16000, 1, 50), ("e", 16000 * 5 + 3300, 16000, 5, 50)]
+    for tag, length, sr, chunk, rate in cases:
+        ds = object.__new__(DS)   # no feeder process
+        ds.sample_rate, ds.model_token_rate, ds.transform, ds.pad_token = sr, rate, None, 0
+        ds.chunk_size, ds.segment_length, ds.stride = chunk, chunk * sr, chunk * sr
+        wave = torch.from_numpy(W.synth_waveform(1, length, sr, seed=3))
+        rows = []
+        sums = []
+        for seg, mask, cfg in ds._iter_chunk(wave, f"x/y/clip_{tag}.v2.wav"):
+            rows.append([cfg.start_idx, cfg.end_idx, int(mask.sum().item()), cfg.length_tokens, seg.shape[0]])
+            sums.append(float(seg.double().sum().item()))
+        out[f"seg_{tag}"] = np.array(rows, dtype=np.int64).reshape(-1, 5)
+        out[f"sum_{tag}"] = np.array(sums)
+        out[f"cfg_{tag}"] = np.array([length, sr, chunk, rate], dtype=np.int64)
+    # save_audio_tokens: trim + append (SURVEY Appendix B.13)
+    AC = mods["configs"].AudioConfig
+    save = mods["utils"].save_audio_tokens
+    with tempfile.TemporaryDirectory() as d:
+        ptr = AC(file_name="x/y/clip.v2.wav", length_seconds=1.0, model_token_rate=50)
+        t1 = torch.arange(2 * 60, dtype=torch.int16).reshape(2, 60)
+        save(t1, ptr, d)
+        first = np.load(os.path.join(d, "clip.npy"))
+        save(t1 + 1000, ptr, d)
+        second = np.load(os.path.join(d, "clip.npy"))
+        out["save_first"], out["save_second"] = first, second
+        out["save_files"] = np.array(sorted(os.listdir(d)))
+    np.savez_compressed(os.path.join(HERE, "harness_a.npz"), **out)
+    print("harness", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["encodec"]
     torch.manual_seed(0)
