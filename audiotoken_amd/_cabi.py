@@ -45,6 +45,9 @@ SIGNATURES = {
     "at_encodec_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "at_encodec_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "at_encodec_encode_checked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "at_encodec_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "at_encodec_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "at_encodec_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "at_encodec_decode_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

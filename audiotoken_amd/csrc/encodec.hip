@@ -13,6 +13,7 @@
 #include <vector>
 #include <cstring>
 #include <cmath>
+#include <cstdlib>
 
 #include "../../include/audiotoken_hip.h"
 #include "at_common.h"
@@ -108,6 +109,7 @@ struct at_encodec {
     ConvW dconv0, dup[4], dres[4][3], dlast;
     const float *dwih[2] = {}, *dwhh[2] = {}, *dbih[2] = {}, *dbhh[2] = {};
     Profiler prof;
+    bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
 };
 
 namespace {
@@ -229,7 +231,7 @@ int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L
 // 2-layer LSTM + skip over [B][T][512]; xg/c/h0 are scratch. y = lstm(x) + x.
 int lstm_skip(const float* const wih[2], const float* const whh[2], const float* const bih[2], const float* const bhh[2],
               const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream,
-              Profiler& prof) {
+              Profiler& prof, unsigned* sync, bool persistent) {
     for (int layer = 0; layer < 2; ++layer) {
         const float* in = layer == 0 ? x : h0;
         float* hout = layer == 0 ? h0 : h1;
@@ -240,6 +242,21 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
         prof.begin("lstm_ih", 1, stream);
         if (int rc = launch_gemm(g, stream)) return rc;
         prof.end(stream);
+        if (persistent) {
+            // whole sequence in one persistent launch per 256-clip block (lstm_seq.hip)
+            const int maxc = lstm_seq_max_clips();
+            prof.begin("lstm_rec", (B + maxc - 1) / maxc, stream);
+            for (int c0 = 0; c0 < B; c0 += maxc) {
+                LstmSeqArgs q;
+                const long long ro = (long long)c0 * T;
+                q.xg = xg + ro * 4 * kH; q.w_hh = whh[layer]; q.b_hh = bhh[layer]; q.h_out = hout + ro * kH;
+                q.y_out = layer == 1 ? y + ro * kH : nullptr; q.skip = x + ro * kH; q.sync = sync;
+                q.B = (B - c0) < maxc ? (B - c0) : maxc; q.T = T; q.n_groups = 0; q.h_bytes = 0;
+                if (int rc = launch_lstm_seq(q, stream)) return rc;
+            }
+            prof.end(stream);
+            continue;
+        }
         prof.begin("lstm_rec", T, stream);
         for (int t = 0; t < T; ++t) {
             GemmArgs s;
@@ -260,7 +277,7 @@ struct EncPlan {
     int L[5];        // lengths: L[0] = N, L[s+1] = ceil(L[s]/ratio)
     int G;           // sub-batch
     size_t off_x[4], off_h[4], off_r[4];  // per-stage sub-batch buffers (floats)
-    size_t off_x4, off_xg, off_h0, off_h1, off_c, off_y, off_emb;
+    size_t off_x4, off_xg, off_h0, off_h1, off_c, off_y, off_emb, off_sync;
     size_t total_floats;
 };
 
@@ -285,6 +302,7 @@ EncPlan make_plan(int B, int N) {
     p.off_c = take((size_t)B * kH);
     p.off_y = take((size_t)B * T * kH);
     p.off_emb = take((size_t)B * T * kDim);
+    p.off_sync = take(128);
     p.total_floats = cur;
     return p;
 }
@@ -292,7 +310,7 @@ EncPlan make_plan(int B, int N) {
 struct DecPlan {
     int L[5];  // L[0] = T, L[s+1] = L[s]*ratio
     int G;
-    size_t off_z, off_x0, off_xg, off_h0, off_h1, off_c, off_y;
+    size_t off_z, off_x0, off_xg, off_h0, off_h1, off_c, off_y, off_sync;
     size_t off_u[4], off_h[4], off_r[4];
     size_t total_floats;
 };
@@ -311,6 +329,7 @@ DecPlan make_dec_plan(int B, int T) {
     p.off_h1 = take((size_t)B * T * kH);
     p.off_c = take((size_t)B * kH);
     p.off_y = take((size_t)B * T * kH);
+    p.off_sync = take(128);
     int C = kH;
     for (int s = 0; s < 4; ++s) {
         C /= 2;
@@ -457,6 +476,12 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
         }
     }
     h->has_decoder = with_decoder != 0;
+    {
+        hipDeviceProp_t prop;
+        AT_CHECK_HIP(hipGetDeviceProperties(&prop, h->device));
+        const char* env = std::getenv("AUDIOTOKEN_LSTM_STEPWISE");
+        h->persistent_lstm = prop.multiProcessorCount >= 256 && !(env && env[0] == '1');
+    }
     h->staged.clear();
     h->finalized = true;
     return 0;
@@ -476,8 +501,8 @@ size_t at_encodec_workspace_bytes(const at_encodec_t* h, int B, int N) {
     return make_plan(B, N).total_floats * sizeof(float);
 }
 
-int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes, int* T_out,
-                      float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream_) {
+static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes, int* T_out,
+                               float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream_, unsigned* status_out) {
     (void)mask;  // the reference's AcousticEncoder.forward ignores attention_mask (audiotoken/encoder.py:44-52)
     AT_REQUIRE(h && h->finalized, "model not finalized");
     AT_REQUIRE(wav && codes && workspace, "null pointer");
@@ -516,8 +541,12 @@ int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int 
     }
     Profiler& prof = h->prof;
     float* y = ws + p.off_y;
-    if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof))
+    unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
+    AT_CHECK_HIP(hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), stream));
+    if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
+                           sync, h->persistent_lstm))
         return rc;
+    if (status_out) AT_CHECK_HIP(hipMemcpyAsync(status_out, sync + 63, sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     float* emb = emb_out ? emb_out : ws + p.off_emb;
     prof.begin("final_conv", 1, stream);
     if (int rc = conv_gemm(h->fin, y, (long long)T * kH, T, emb, (long long)T * kDim, T, B, PRO_ELU, nullptr, 0, stream)) return rc;
@@ -526,6 +555,23 @@ int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int 
     int rc = launch_rvq_encode(emb, (long long)B * T, T, h->codebooks, h->e2, n_q, codes, stream);
     prof.end(stream);
     return rc;
+}
+
+int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes, int* T_out,
+                      float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream) {
+    return encodec_encode_impl(h, wav, mask, B, N, n_q, codes, T_out, emb_out, workspace, workspace_bytes, stream, nullptr);
+}
+
+int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes, int* T_out,
+                              float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream, uint32_t* status_dev) {
+    return encodec_encode_impl(h, wav, mask, B, N, n_q, codes, T_out, emb_out, workspace, workspace_bytes, stream, status_dev);
+}
+
+int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
+    AT_REQUIRE(h && name, "null pointer");
+    if (std::string(name) == "persistent_lstm") { h->persistent_lstm = value != 0; return 0; }
+    set_error(std::string("unknown option ") + name);
+    return -1;
 }
 
 int at_encodec_profile(at_encodec_t* h, int enable) {
@@ -574,7 +620,10 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
     if (int rc = conv_gemm(h->dconv0, z, (long long)T * kDim, T, x0, (long long)T * kH, T, B, PRO_NONE, nullptr, 0, stream)) return rc;
     float* y = ws + p.off_y;
     Profiler noprof;
-    if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof))
+    unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
+    AT_CHECK_HIP(hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), stream));
+    if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,
+                           sync, h->persistent_lstm))
         return rc;
     const int Lout = p.L[4];
     for (int b0 = 0; b0 < B; b0 += p.G) {

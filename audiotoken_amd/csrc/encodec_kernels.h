@@ -14,6 +14,22 @@ struct LstmStepArgs {
     int T, t, H, first;
 };
 
+// One LSTM layer over the whole sequence in a single persistent launch (lstm_seq.hip). <= 256 clips per launch.
+struct LstmSeqArgs {
+    const float* xg;     // [B][T][2048] input-side gates incl. b_ih, gate-interleaved columns
+    const float* w_hh;   // [2048][512] gate-interleaved rows
+    const float* b_hh;   // [2048]
+    float* h_out;        // [B][T][512] (also the exchange buffer between workgroups)
+    float* y_out;        // optional [B][T][512]: h + skip
+    const float* skip;
+    unsigned* sync;      // >= 64 words: [0..31] group counters (zeroed per launch), [63] sticky status
+    int B, T;
+    int n_groups;        // filled by the launcher
+    long long h_bytes;   // filled by the launcher
+};
+int launch_lstm_seq(const LstmSeqArgs& a, hipStream_t stream);
+int lstm_seq_max_clips();
+
 int launch_conv0(const float* wav, const float* w, const float* bias, float* out, int B, int N, hipStream_t stream);
 int launch_lstm_step(const GemmArgs& a, const LstmStepArgs& s, hipStream_t stream);
 int launch_rvq_encode(const float* x, long long rows, int T, const float* codebooks, const float* e2, int n_q,

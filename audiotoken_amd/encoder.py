@@ -104,12 +104,20 @@ class AcousticEncoder(torch.nn.Module):
         if self.n_q > self._h.n_codebooks:
             raise ValueError(f"bandwidth {config.bandwidth} needs {self.n_q} codebooks, checkpoint has {self._h.n_codebooks}")
         self._ws: Optional[torch.Tensor] = None
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def set_option(self, name: str, value: int) -> None:
+        _cabi.check(self._h.lib.at_encodec_set_option(self._h.handle, name.encode(), int(value)), f"at_encodec_set_option({name})")
+
+    def last_status(self) -> int:
+        """0 = ok, 1 = a bounded wait inside the persistent LSTM kernel gave up (synchronises the device)."""
+        return int(self._status.item())
 
     @torch.no_grad()
     def forward(self, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
@@ -127,9 +135,9 @@ class AcousticEncoder(torch.nn.Module):
         t_out = C.c_int(0)
         with torch.cuda.device(self.device):
             stream = _cabi.current_stream_handle(self.device)
-            rc = lib.at_encodec_encode(self._h.handle, x.data_ptr(), 0, B, N, self.n_q, codes.data_ptr(), C.byref(t_out),
-                                       _cabi.ptr(emb), ws.data_ptr(), nbytes, stream)
-        _cabi.check(rc, "at_encodec_encode")
+            rc = lib.at_encodec_encode_checked(self._h.handle, x.data_ptr(), 0, B, N, self.n_q, codes.data_ptr(), C.byref(t_out),
+                                               _cabi.ptr(emb), ws.data_ptr(), nbytes, stream, self._status.data_ptr())
+        _cabi.check(rc, "at_encodec_encode_checked")
         assert t_out.value == T
         logger.info(f'Codes shape: {codes.shape}')
         if return_embeddings:

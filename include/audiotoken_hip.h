@@ -66,6 +66,16 @@ size_t at_encodec_workspace_bytes(const at_encodec_t* h, int B, int N);
 int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes,
                       int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream);
 
+/* Same as at_encodec_encode, plus a device uint32 that receives 0 on success or 1 if a bounded wait inside the
+ * persistent LSTM kernel gave up (the call still terminates; the codes are then invalid). Stream-ordered. */
+int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes,
+                              int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream,
+                              uint32_t* status_dev);
+
+/* Options: "persistent_lstm" 1/0 — whole-sequence persistent LSTM kernel (default on when the device has >= 256 CUs)
+ * or one launch per time step. Both give the same arithmetic. */
+int at_encodec_set_option(at_encodec_t* h, const char* name, int value);
+
 /* Optional timing taps for the benchmark: when enabled, encode brackets each kernel group (conv0, res0..3,
  * down0..3, lstm_ih, lstm_rec, final_conv, rvq) with HIP events recorded on the launch stream.
  * at_encodec_profile(h, enable) resets the accumulated spans. at_encodec_profile_read synchronises on the

@@ -125,3 +125,19 @@ def test_encode_batch_files_end_to_end(tmp_path, enc_weights):
         ref_all = np.hstack(pieces)
         assert got.dtype == np.int16 and got.shape == ref_all.shape
         assert np.array_equal(got, ref_all)
+
+
+def test_persistent_lstm_equals_stepwise(encoders, enc_weights):
+    """The whole-sequence persistent LSTM kernel and the one-launch-per-step path run the same MFMA order:
+    embeddings and codes must be bit-identical, for full and ragged (B % 32 != 0) groups."""
+    enc = encoders[8]
+    for B, N in ((37, 6400), (3, 9600), (64, 3200)):
+        wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=B)).cuda()
+        enc.set_option("persistent_lstm", 1)
+        c1, e1 = enc(wav, None, return_embeddings=True)
+        assert enc.last_status() == 0, "persistent LSTM: a bounded wait gave up"
+        enc.set_option("persistent_lstm", 0)
+        c0, e0 = enc(wav, None, return_embeddings=True)
+        enc.set_option("persistent_lstm", 1)
+        assert torch.equal(e0, e1), (B, (e0 - e1).abs().max().item())
+        assert torch.equal(c0, c1)
