@@ -46,7 +46,10 @@ struct GemmArgs {
     int Tin = 0, Cin = 0;
     int ldx = 0;               // floats between consecutive input rows (= Cin for a dense [T][Cin] clip)
     int ktaps = 1, stride = 1, pad_left = 0, pad_mode = 0;
-    const float* W = nullptr;     // [N][K], K = ktaps*Cin, tap-major then channel
+    const float* X2 = nullptr;    // optional second A source for k >= K1 (ktaps == 1): same row mapping, no prologue
+    long long x2_bstride = 0;
+    int ld2 = 0, K1 = 0;
+    const float* W = nullptr;     // [N][K], K = ktaps*Cin (+ width of X2), tap-major then channel
     const float* bias = nullptr;  // [N] or null
     float* C = nullptr;           // [batch][M][ldc]
     long long c_bstride = 0;

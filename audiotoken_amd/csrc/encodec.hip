@@ -176,6 +176,32 @@ bool pack_convtr(const at_encodec* h, const std::string& prefix, int cin, int co
     return true;
 }
 
+// residual block tail: [W1 (C x C/2) | Wsc (C x C)] rows concatenated along K, biases summed
+bool pack_res_tail(const at_encodec* h, const std::string& p1, const std::string& psc, int C, Packer& p, size_t& w_off, size_t& b_off) {
+    const HostTensor* w1 = find(h, p1 + ".weight");
+    const HostTensor* b1 = find(h, p1 + ".bias");
+    const HostTensor* ws = find(h, psc + ".weight");
+    const HostTensor* bs = find(h, psc + ".bias");
+    if (!w1 || !b1 || !ws || !bs) { set_error("missing tensor " + p1 + " / " + psc); return false; }
+    if (w1->shape != std::vector<int64_t>{C, C / 2, 1} || ws->shape != std::vector<int64_t>{C, C, 1} ||
+        b1->shape != std::vector<int64_t>{C} || bs->shape != std::vector<int64_t>{C}) {
+        set_error("bad shape for " + p1 + " / " + psc);
+        return false;
+    }
+    const int K = C / 2 + C;
+    std::vector<float> w((size_t)C * K), b(C);
+    for (int co = 0; co < C; ++co) {
+        for (int ci = 0; ci < C / 2; ++ci) w[(size_t)co * K + ci] = w1->data[(size_t)co * (C / 2) + ci];
+        for (int ci = 0; ci < C; ++ci) w[(size_t)co * K + C / 2 + ci] = ws->data[(size_t)co * C + ci];
+        // reference order: shortcut(x) + block(x) -> (Wsc.x + bsc) + (W1.h + b1); the GEMM adds ONE bias to the
+        // full dot product, so the two biases are pre-added (a 1-ulp reassociation, inside the 1e-3 budget)
+        b[co] = bs->data[co] + b1->data[co];
+    }
+    w_off = p.add(w);
+    b_off = p.add(b);
+    return true;
+}
+
 bool pack_lstm(const at_encodec* h, const std::string& prefix, Packer& p, size_t off[2][4]) {
     for (int l = 0; l < 2; ++l) {
         const char* names[4] = {"weight_ih", "weight_hh", "bias_ih", "bias_hh"};
@@ -219,13 +245,21 @@ int conv_gemm(const ConvW& c, const float* X, long long x_bstride, int Tin, floa
     return launch_gemm(a, stream);
 }
 
-// SEANet residual block: out = shortcut(x) + conv1(ELU(conv3(ELU(x)))), three windowed GEMMs.
+// SEANet residual block: out = shortcut(x) + conv1(ELU(conv3(ELU(x)))) as TWO windowed GEMMs:
+//   h   = conv3(ELU(x))                                  K = 3C,  N = C/2
+//   out = [ELU(h) | x] . [W1 | Wsc]^T + (b1 + bsc)       K = C/2 + C, N = C   (dual-source A, weights concatenated
+// at finalize) — one pass less over the block output than "shortcut, then accumulate".
 int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L, int batch, hipStream_t stream) {
     const int C = r[2].cout;
     const long long xs = (long long)L * C, hs = (long long)L * (C / 2);
     if (int rc = conv_gemm(r[0], x, xs, L, hbuf, hs, L, batch, PRO_ELU, nullptr, 0, stream)) return rc;
-    if (int rc = conv_gemm(r[2], x, xs, L, out, xs, L, batch, PRO_NONE, nullptr, 0, stream)) return rc;
-    return conv_gemm(r[1], hbuf, hs, L, out, xs, L, batch, PRO_ELU, out, xs, stream);
+    GemmArgs a;
+    a.X = hbuf; a.x_bstride = hs; a.Tin = L; a.Cin = C / 2; a.ldx = C / 2;
+    a.X2 = x; a.x2_bstride = xs; a.ld2 = C; a.K1 = C / 2;
+    a.W = r[1].w; a.bias = r[1].b;     // r[1] holds the concatenated [C][C/2 + C] weight and the summed bias
+    a.C = out; a.c_bstride = xs; a.ldc = C;
+    a.M = L; a.N = C; a.K = C / 2 + C; a.batch = batch; a.pro = PRO_ELU;
+    return launch_gemm(a, stream);
 }
 
 // 2-layer LSTM + skip over [B][T][512]; xg/c/h0 are scratch. y = lstm(x) + x.
@@ -383,8 +417,8 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
     for (int s = 0; s < 4; ++s) {
         const std::string base = "encoder.model." + std::to_string(idx);
         if (!pack_conv(h, base + ".block.1.conv.conv", C, C / 2, 3, p, o_res[s][0].w, o_res[s][0].b)) return -1;
-        if (!pack_conv(h, base + ".block.3.conv.conv", C / 2, C, 1, p, o_res[s][1].w, o_res[s][1].b)) return -1;
-        if (!pack_conv(h, base + ".shortcut.conv.conv", C, C, 1, p, o_res[s][2].w, o_res[s][2].b)) return -1;
+        if (!pack_res_tail(h, base + ".block.3.conv.conv", base + ".shortcut.conv.conv", C, p, o_res[s][1].w, o_res[s][1].b)) return -1;
+        o_res[s][2] = o_res[s][1];
         if (!pack_conv(h, "encoder.model." + std::to_string(idx + 2) + ".conv.conv", C, 2 * C, 2 * kRatiosEnc[s], p,
                        o_down[s].w, o_down[s].b))
             return -1;
@@ -432,8 +466,8 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             Cd /= 2;
             const std::string base = "decoder.model." + std::to_string(di + 1);
             if (!pack_conv(h, base + ".block.1.conv.conv", Cd, Cd / 2, 3, p, d_res[s][0].w, d_res[s][0].b)) return -1;
-            if (!pack_conv(h, base + ".block.3.conv.conv", Cd / 2, Cd, 1, p, d_res[s][1].w, d_res[s][1].b)) return -1;
-            if (!pack_conv(h, base + ".shortcut.conv.conv", Cd, Cd, 1, p, d_res[s][2].w, d_res[s][2].b)) return -1;
+            if (!pack_res_tail(h, base + ".block.3.conv.conv", base + ".shortcut.conv.conv", Cd, p, d_res[s][1].w, d_res[s][1].b)) return -1;
+            d_res[s][2] = d_res[s][1];
             di += 3;
         }
         if (!pack_conv(h, "decoder.model.15.conv.conv", 32, 1, 7, p, d_last.w, d_last.b)) return -1;
@@ -529,7 +563,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             const int C = 32 << s, L = p.L[s], Lo = p.L[s + 1];
             float* x = ws + p.off_x[s];
             float* r = ws + p.off_r[s];
-            prof.begin(kRes[s], 3, stream);
+            prof.begin(kRes[s], 2, stream);
             if (int rc = resblock(h->res[s], x, ws + p.off_h[s], r, L, g, stream)) return rc;
             prof.end(stream);
             float* out = s < 3 ? ws + p.off_x[s + 1] : x4 + (long long)b0 * T * kH;

@@ -34,6 +34,7 @@ struct GemmTile {
         f4 xreg[XCH], wreg[WCH];
         f4 ureg[PRO == PRO_POWER ? XCH : 1];
         unsigned xok = 0u, wok = 0u;
+        bool xsecond = false;
         const int nk = (a.K + BK - 1) / BK;
 
         // Every load below is UNCONDITIONAL (addresses clamped into range, result masked by a select afterwards):
@@ -47,7 +48,13 @@ struct GemmTile {
             wok = 0u;
             const int kk = kvalid ? kk0 : 0;
             const int tap = a.ktaps == 1 ? 0 : kk / a.Cin;
-            const int ci = kk - tap * a.Cin;
+            // optional second A source for k >= K1 (ktaps == 1 only): A = [ pro(X) | X2 ] — lets a SEANet residual
+            // block fuse "conv1x1(ELU(h)) + shortcut1x1(x)" into one GEMM over the concatenated K
+            const bool second = a.X2 != nullptr && kk >= a.K1;
+            xsecond = second;
+            const int ci = second ? kk - a.K1 : kk - tap * a.Cin;
+            const float* Xsrc = second ? a.X2 + (long long)b * a.x2_bstride : Xb;
+            const int ldsrc = second ? a.ld2 : a.ldx;
 #pragma unroll
             for (int j = 0; j < XCH; ++j) {
                 const int m = m0 + lrow + j * 32;
@@ -58,7 +65,7 @@ struct GemmTile {
                 ok = ok && (a.pad_mode != 0 || !(lo || hi));
                 r = lo ? -r : (hi ? 2 * Tlast - r : r);
                 r = r < 0 ? 0 : (r > Tlast ? Tlast : r);
-                const float* src = Xb + (long long)r * a.ldx + ci;
+                const float* src = Xsrc + (long long)r * ldsrc + ci;
                 f4 v = *reinterpret_cast<const f4*>(src);
                 if (PRO == PRO_POWER) ureg[j] = *reinterpret_cast<const f4*>(src + a.aux_off);
                 xreg[j] = v;                 // raw: the mask is applied in store_tile so that nothing consumes the
@@ -79,7 +86,7 @@ struct GemmTile {
                 f4 v = xreg[j];
                 if (PRO == PRO_POWER) v = v * v + ureg[j] * ureg[j];
                 if (!((xok >> j) & 1u)) v = f4{0.f, 0.f, 0.f, 0.f};
-                if (PRO == PRO_ELU) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }  // ELU(0) = 0
+                if (PRO == PRO_ELU && !xsecond) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }  // ELU(0) = 0
                 *reinterpret_cast<f4*>(Xs + buf * BM * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) = v;
             }
 #pragma unroll

@@ -93,7 +93,8 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 }
 
 int check_gemm_args(const GemmArgs& a) {
-    AT_REQUIRE(a.K == a.ktaps * a.Cin, "K must equal ktaps*Cin");
+    AT_REQUIRE(a.X2 ? (a.ktaps == 1 && a.K1 == a.Cin && a.K1 % 4 == 0 && a.K > a.K1 && a.ld2 % 4 == 0 && a.ld2 >= a.K - a.K1)
+                    : a.K == a.ktaps * a.Cin, "K must equal ktaps*Cin (or K1 + width of the second source)");
     AT_REQUIRE(a.Cin % 4 == 0 && a.N % 4 == 0, "Cin and N must be multiples of 4");
     AT_REQUIRE(a.ldx % 4 == 0 && a.ldx >= 4, "ldx must be a positive multiple of 4");
     AT_REQUIRE((a.ldc % 4 == 0 || (a.epi == EPI_GLU && a.ldc % 2 == 0)) && (a.R == nullptr || a.ldr % 4 == 0), "ldc/ldr must be multiples of 4");
