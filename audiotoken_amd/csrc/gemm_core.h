@@ -19,7 +19,22 @@ struct GemmTile {
     static constexpr int WCH = (BN >= 32) ? BN / 32 : 1;  // float4 chunks per thread, weight tile
     static constexpr size_t LDS_BYTES = (size_t)(BM + BN) * BK * 2 * sizeof(float);
 
+    // Two bodies, chosen per workgroup by a scalar branch:
+    //  FAST  — interior tile (every window row inside the clip, full M/N/K tiles, single A source): each thread keeps
+    //          XCH + WCH precomputed pointers and a tile fetch is "pointer + kt*32" — ~20 VALU instead of ~340 per
+    //          K step (PMC: 2.66 VALU per MFMA and 72 % MFMA-pipe busy before this split).
+    //  !FAST — boundary tiles: reflect / zero padding, M/N/K tails, dual-source K; clamped unconditional loads + masks.
     __device__ static __forceinline__ void run(const GemmArgs& a, float* smem, int m0, int n0, int b, f4 (&acc)[TM][TN]) {
+        const int Tlast_ = a.Tin - 1;
+        const bool fast = BN >= 32 && a.X2 == nullptr && (a.K % BK) == 0 && m0 + BM <= a.M && n0 + BN <= a.N &&
+                          (a.ktaps == 1 || a.ldx == a.Cin) && m0 * a.stride - a.pad_left >= 0 &&
+                          (m0 + BM - 1) * a.stride - a.pad_left + a.ktaps - 1 <= Tlast_;
+        if (fast) run_impl<true>(a, smem, m0, n0, b, acc);
+        else run_impl<false>(a, smem, m0, n0, b, acc);
+    }
+
+    template <bool FAST>
+    __device__ static __forceinline__ void run_impl(const GemmArgs& a, float* smem, int m0, int n0, int b, f4 (&acc)[TM][TN]) {
         float* Xs = smem;                // [2][BM*32]
         float* Ws = smem + 2 * BM * BK;  // [2][BN*32]
         const int tid = threadIdx.x;
@@ -41,7 +56,26 @@ struct GemmTile {
         // a load under a per-element runtime branch makes hipcc serialise the whole tile fetch behind
         // s_waitcnt vmcnt(0) (CDNA guide §5 "three .s-level traps" (c)) — measured 70 -> ~110 TFLOP/s on this kernel.
         const int Mlast = a.M - 1, Nlast = a.N - 1, Tlast = a.Tin - 1;
+        const float* xp[XCH];
+        const float* wp[WCH];
+        if (FAST) {
+#pragma unroll
+            for (int j = 0; j < XCH; ++j)
+                xp[j] = Xb + (long long)((m0 + lrow + j * 32) * a.stride - a.pad_left) * a.ldx + kc * 4;
+#pragma unroll
+            for (int j = 0; j < WCH; ++j) wp[j] = a.W + (long long)(n0 + lrow + j * 32) * a.K + kc * 4;
+        }
         auto load_tile = [&](int kt) {
+            if (FAST) {
+#pragma unroll
+                for (int j = 0; j < XCH; ++j) {
+                    xreg[j] = *reinterpret_cast<const f4*>(xp[j] + kt * BK);
+                    if (PRO == PRO_POWER) ureg[j] = *reinterpret_cast<const f4*>(xp[j] + kt * BK + a.aux_off);
+                }
+#pragma unroll
+                for (int j = 0; j < WCH; ++j) wreg[j] = *reinterpret_cast<const f4*>(wp[j] + kt * BK);
+                return;
+            }
             const int kk0 = kt * BK + kc * 4;
             const bool kvalid = kk0 < a.K;
             xok = 0u;
@@ -85,8 +119,8 @@ struct GemmTile {
                 const int row = lrow + j * 32;
                 f4 v = xreg[j];
                 if (PRO == PRO_POWER) v = v * v + ureg[j] * ureg[j];
-                if (!((xok >> j) & 1u)) v = f4{0.f, 0.f, 0.f, 0.f};
-                if (PRO == PRO_ELU && !xsecond) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }  // ELU(0) = 0
+                if (!FAST && !((xok >> j) & 1u)) v = f4{0.f, 0.f, 0.f, 0.f};
+                if (PRO == PRO_ELU && (FAST || !xsecond)) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }  // ELU(0) = 0
                 *reinterpret_cast<f4*>(Xs + buf * BM * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) = v;
             }
 #pragma unroll
@@ -94,7 +128,7 @@ struct GemmTile {
                 const int row = lrow + j * 32;
                 if (BN >= 32 || row < BN)
                     *reinterpret_cast<f4*>(Ws + buf * BN * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) =
-                        ((wok >> j) & 1u) ? wreg[j] : f4{0.f, 0.f, 0.f, 0.f};
+                        (FAST || ((wok >> j) & 1u)) ? wreg[j] : f4{0.f, 0.f, 0.f, 0.f};
             }
         };
 

@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     using Tile = GemmTile<BM, BN, WM, WN, PRO>;
     constexpr int TM = Tile::TM, TN = Tile::TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+    // 1-D grid, n-tile fastest: the blocks in flight cover few m-tiles x all n-tiles, so the activation panel is
+    // fetched from HBM about once and, with the round-robin XCD dispatch, each XCD's L2 keeps N/8 of the weights.
+    const int nt = (a.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / nt) * BM, n0 = (blockIdx.x % nt) * BN, b = blockIdx.z;
     f4 acc[TM][TN];
     Tile::run(a, smem, m0, n0, b, acc);
 
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     using Tile = GemmTile<BM, BN, WM, WN>;
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch);
+    dim3 grid(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN), 1, a.batch);
     if (a.pro == PRO_ELU)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, PRO_ELU>), grid, dim3(256), Tile::LDS_BYTES, stream, a);
     else if (a.pro == PRO_POWER)
