@@ -85,7 +85,24 @@ struct Profiler {
 };
 
 // ---- small helpers shared by kernels ---------------------------------------------------------
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
+// ELU(alpha = 1) = x > 0 ? x : expm1(x), branch-free and ~3x cheaper than ocml expm1f (the ELU prologue of a conv
+// evaluates it k/stride times per element, which made the SEANet conv GEMMs VALU-bound):
+//   -0.5 < x <= 0 : degree-8 Taylor polynomial (truncation |x|^9/9! <= 5.4e-9, below half an ulp of the result)
+//   x <= -0.5     : exp2(x*log2e) - 1 on v_exp_f32 (no cancellation there; abs error < 1e-7)
+__device__ __forceinline__ float elu1(float x) {
+    const float xn = fminf(x, 0.0f);
+    float p = fmaf(xn, 2.4801587e-5f, 1.9841270e-4f);
+    p = fmaf(xn, p, 1.3888889e-3f);
+    p = fmaf(xn, p, 8.3333333e-3f);
+    p = fmaf(xn, p, 4.1666667e-2f);
+    p = fmaf(xn, p, 1.6666667e-1f);
+    p = fmaf(xn, p, 0.5f);
+    p = fmaf(xn, p, 1.0f);
+    p = xn * p;
+    const float e = __expf(xn) - 1.0f;
+    const float neg = xn > -0.5f ? p : e;
+    return x > 0.0f ? x : neg;
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float swishf_(float x) { return x / (1.0f + expf(-x)); }
 

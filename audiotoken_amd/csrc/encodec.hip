@@ -85,7 +85,15 @@ constexpr int kRatiosDec[4] = {8, 5, 4, 2};
 constexpr int kH = 512;
 constexpr int kDim = 128;
 constexpr int kCodes = 1024;
-constexpr int kSubBatch = 32;  // clips per pass through the 24 kHz..75 Hz conv stack (bounds the workspace)
+constexpr int kSubBatchDefault = 256;  // clips per pass through the 24 kHz..75 Hz conv stack (bounds the workspace)
+inline int sub_batch() {
+    static const int v = [] {
+        const char* e = std::getenv("AUDIOTOKEN_SUBBATCH");
+        const int n = e ? std::atoi(e) : 0;
+        return n > 0 ? n : kSubBatchDefault;
+    }();
+    return v;
+}
 
 }  // namespace at
 
@@ -249,7 +257,7 @@ int conv_gemm(const ConvW& c, const float* X, long long x_bstride, int Tin, floa
 //   h   = conv3(ELU(x))                                  K = 3C,  N = C/2
 //   out = [ELU(h) | x] . [W1 | Wsc]^T + (b1 + bsc)       K = C/2 + C, N = C   (dual-source A, weights concatenated
 // at finalize) — one pass less over the block output than "shortcut, then accumulate".
-int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L, int batch, hipStream_t stream) {
+int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L, int batch, hipStream_t stream, int epi = EPI_NONE) {
     const int C = r[2].cout;
     const long long xs = (long long)L * C, hs = (long long)L * (C / 2);
     if (int rc = conv_gemm(r[0], x, xs, L, hbuf, hs, L, batch, PRO_ELU, nullptr, 0, stream)) return rc;
@@ -258,14 +266,14 @@ int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L
     a.X2 = x; a.x2_bstride = xs; a.ld2 = C; a.K1 = C / 2;
     a.W = r[1].w; a.bias = r[1].b;     // r[1] holds the concatenated [C][C/2 + C] weight and the summed bias
     a.C = out; a.c_bstride = xs; a.ldc = C;
-    a.M = L; a.N = C; a.K = C / 2 + C; a.batch = batch; a.pro = PRO_ELU;
+    a.M = L; a.N = C; a.K = C / 2 + C; a.batch = batch; a.pro = PRO_ELU; a.epi = epi;
     return launch_gemm(a, stream);
 }
 
 // 2-layer LSTM + skip over [B][T][512]; xg/c/h0 are scratch. y = lstm(x) + x.
 int lstm_skip(const float* const wih[2], const float* const whh[2], const float* const bih[2], const float* const bhh[2],
               const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream,
-              Profiler& prof, unsigned* sync, bool persistent) {
+              Profiler& prof, unsigned* sync, bool persistent, int y_elu) {
     for (int layer = 0; layer < 2; ++layer) {
         const float* in = layer == 0 ? x : h0;
         float* hout = layer == 0 ? h0 : h1;
@@ -285,7 +293,7 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
                 const long long ro = (long long)c0 * T;
                 q.xg = xg + ro * 4 * kH; q.w_hh = whh[layer]; q.b_hh = bhh[layer]; q.h_out = hout + ro * kH;
                 q.y_out = layer == 1 ? y + ro * kH : nullptr; q.skip = x + ro * kH; q.sync = sync;
-                q.B = (B - c0) < maxc ? (B - c0) : maxc; q.T = T; q.n_groups = 0; q.h_bytes = 0;
+                q.B = (B - c0) < maxc ? (B - c0) : maxc; q.T = T; q.n_groups = 0; q.h_bytes = 0; q.y_elu = y_elu;
                 if (int rc = launch_lstm_seq(q, stream)) return rc;
             }
             prof.end(stream);
@@ -299,7 +307,7 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
             LstmStepArgs ls;
             ls.xg = xg; ls.b_hh = bhh[layer]; ls.c = c; ls.h_out = hout;
             ls.y_out = layer == 1 ? y : nullptr; ls.skip = x;
-            ls.T = T; ls.t = t; ls.H = kH; ls.first = t == 0;
+            ls.T = T; ls.t = t; ls.H = kH; ls.first = t == 0; ls.y_elu = y_elu;
             if (int rc = launch_lstm_step(s, ls, stream)) return rc;
         }
         prof.end(stream);
@@ -319,7 +327,7 @@ EncPlan make_plan(int B, int N) {
     EncPlan p;
     p.L[0] = N;
     for (int s = 0; s < 4; ++s) p.L[s + 1] = out_len(p.L[s], kRatiosEnc[s]);
-    p.G = B < kSubBatch ? B : kSubBatch;
+    p.G = B < sub_batch() ? B : sub_batch();
     size_t cur = 0;
     auto take = [&](size_t n) { size_t o = cur; cur += (n + 63) / 64 * 64; return o; };
     for (int s = 0; s < 4; ++s) {
@@ -353,7 +361,7 @@ DecPlan make_dec_plan(int B, int T) {
     DecPlan p;
     p.L[0] = T;
     for (int s = 0; s < 4; ++s) p.L[s + 1] = p.L[s] * kRatiosDec[s];
-    p.G = B < kSubBatch ? B : kSubBatch;
+    p.G = B < sub_batch() ? B : sub_batch();
     size_t cur = 0;
     auto take = [&](size_t n) { size_t o = cur; cur += (n + 63) / 64 * 64; return o; };
     p.off_z = take((size_t)B * T * kDim);
@@ -564,11 +572,12 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             float* x = ws + p.off_x[s];
             float* r = ws + p.off_r[s];
             prof.begin(kRes[s], 2, stream);
-            if (int rc = resblock(h->res[s], x, ws + p.off_h[s], r, L, g, stream)) return rc;
+            // the block output is only ever consumed through ELU (by the strided conv): apply it once here
+            if (int rc = resblock(h->res[s], x, ws + p.off_h[s], r, L, g, stream, EPI_ELU)) return rc;
             prof.end(stream);
             float* out = s < 3 ? ws + p.off_x[s + 1] : x4 + (long long)b0 * T * kH;
             prof.begin(kDown[s], 1, stream);
-            if (int rc = conv_gemm(h->down[s], r, (long long)L * C, L, out, (long long)Lo * 2 * C, Lo, g, PRO_ELU, nullptr, 0, stream))
+            if (int rc = conv_gemm(h->down[s], r, (long long)L * C, L, out, (long long)Lo * 2 * C, Lo, g, PRO_NONE, nullptr, 0, stream))
                 return rc;
             prof.end(stream);
         }
@@ -578,12 +587,12 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
     AT_CHECK_HIP(hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), stream));
     if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
-                           sync, h->persistent_lstm))
+                           sync, h->persistent_lstm, 1))
         return rc;
     if (status_out) AT_CHECK_HIP(hipMemcpyAsync(status_out, sync + 63, sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     float* emb = emb_out ? emb_out : ws + p.off_emb;
     prof.begin("final_conv", 1, stream);
-    if (int rc = conv_gemm(h->fin, y, (long long)T * kH, T, emb, (long long)T * kDim, T, B, PRO_ELU, nullptr, 0, stream)) return rc;
+    if (int rc = conv_gemm(h->fin, y, (long long)T * kH, T, emb, (long long)T * kDim, T, B, PRO_NONE, nullptr, 0, stream)) return rc;  // y holds ELU(lstm + skip)
     prof.end(stream);
     prof.begin("rvq", 1, stream);
     int rc = launch_rvq_encode(emb, (long long)B * T, T, h->codebooks, h->e2, n_q, codes, stream);
@@ -657,7 +666,7 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
     AT_CHECK_HIP(hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), stream));
     if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,
-                           sync, h->persistent_lstm))
+                           sync, h->persistent_lstm, 0))
         return rc;
     const int Lout = p.L[4];
     for (int b0 = 0; b0 < B; b0 += p.G) {

@@ -12,6 +12,7 @@ struct LstmStepArgs {
     float* y_out;       // optional [B][T][H]: h + skip
     const float* skip;  // [B][T][H] (LSTM stack input) when y_out != null
     int T, t, H, first;
+    int y_elu;          // write ELU(h + skip) instead of h + skip (the only consumer applies ELU first)
 };
 
 // One LSTM layer over the whole sequence in a single persistent launch (lstm_seq.hip). <= 256 clips per launch.
@@ -24,6 +25,7 @@ struct LstmSeqArgs {
     const float* skip;
     unsigned* sync;      // >= 64 words: [0..31] group counters (zeroed per launch), [63] sticky status
     int B, T;
+    int y_elu;           // y_out = ELU(h + skip)
     int n_groups;        // filled by the launcher
     long long h_bytes;   // filled by the launcher
 };

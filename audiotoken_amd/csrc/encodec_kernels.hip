@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(GemmArgs a, LstmStepArgs
             s.c[ci] = c_new;
             const long long oi = ((long long)b * s.T + s.t) * s.H + unit;
             s.h_out[oi] = h_new;
-            if (s.y_out) s.y_out[oi] = h_new + s.skip[oi];
+            if (s.y_out) { const float yv = h_new + s.skip[oi]; s.y_out[oi] = s.y_elu ? elu1(yv) : yv; }
         }
     }
 }

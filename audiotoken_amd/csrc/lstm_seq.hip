@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(LstmSeqArgs a) {
                 const long long oi = ((long long)clip * T + t) * LS_H + unit[jn];
                 __hip_atomic_store(reinterpret_cast<unsigned*>(a.h_out) + oi, __float_as_uint(h_new), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1): no release fence needed
-                if (a.y_out) a.y_out[oi] = h_new + a.skip[oi];
+                if (a.y_out) { const float yv = h_new + a.skip[oi]; a.y_out[oi] = a.y_elu ? elu1(yv) : yv; }
             }
         }
         // ---- publish: every storing wave drains, workgroup barrier, one lane signals ------------------------------

@@ -14,6 +14,48 @@ shapes = [  # (name, M, N, K, epi)
     ("glu 96000x2048x1024", 96000, 2048, 1024, 5),
     ("lstm_ih 192000x2048x512", 192000, 2048, 512, 0),
 ]
+convs = [  # (name, batch, Tin, Cin, k, stride, N, elu)
+    ("down0 k4s2 32->64", 32, 240000, 32, 4, 2, 64, 1),
+    ("down1 k8s4 64->128", 32, 120000, 64, 8, 4, 128, 1),
+    ("down2 k10s5 128->256", 32, 30000, 128, 10, 5, 256, 1),
+    ("down3 k16s8 256->512", 32, 6000, 256, 16, 8, 512, 1),
+    ("res1 k3 64->32", 32, 120000, 64, 3, 1, 32, 1),
+    ("res2 k3 128->64", 32, 30000, 128, 3, 1, 64, 1),
+    ("res3 k3 256->128", 32, 6000, 256, 3, 1, 128, 1),
+    ("final k7 512->128", 256, 750, 512, 7, 1, 128, 1),
+]
+if len(sys.argv) > 1:
+    convs = [c for c in convs if sys.argv[1] in c[0]]
+for name, Bc, Tin, Cin, k, st, N, elu in convs:
+    X = torch.randn(Bc, Tin, Cin, device=dev)
+    K = k * Cin
+    Wt = torch.randn(N, K, device=dev) * 0.03
+    b = torch.randn(N, device=dev)
+    M = -(-Tin // st)
+    out = torch.empty(Bc, M, N, device=dev)
+    d = _cabi.GemmDesc()
+    d.X, d.x_bstride, d.Tin, d.Cin, d.ldx = X.data_ptr(), Tin * Cin, Tin, Cin, Cin
+    d.ktaps, d.stride, d.pad_left, d.pad_mode = k, st, k - st, 1
+    d.W, d.bias = Wt.data_ptr(), b.data_ptr()
+    d.C, d.c_bstride, d.ldc = out.data_ptr(), M * N, N
+    d.R, d.r_bstride, d.ldr = 0, 0, N
+    d.M, d.N, d.K, d.batch, d.pro, d.epi, d.alpha = M, N, K, Bc, elu, 0, 1.0
+    st_ = _cabi.current_stream_handle(dev)
+    for _ in range(2):
+        _cabi.check(lib.at_op_gemm(C.byref(d), st_), "gemm")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 5
+    e0.record()
+    for _ in range(n):
+        lib.at_op_gemm(C.byref(d), st_)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    tf = 2.0 * Bc * M * N * K / (ms * 1e-3) / 1e12
+    gb = 4.0 * Bc * (Tin * Cin + M * N) / (ms * 1e-3) / 1e9
+    print(f"{name:34s} {ms:8.3f} ms  {tf:6.1f} TFLOP/s  {gb:7.0f} GB/s", flush=True)
+    del X, Wt, out
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if sys.argv[1] in s[0]]
 res = {}
