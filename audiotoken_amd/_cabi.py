@@ -64,6 +64,17 @@ SIGNATURES = {
                                     C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "at_w2vbert_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "at_w2vbert_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
+    "at_hubert_create": (C.c_void_p, [C.c_int]),
+    "at_hubert_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "at_hubert_finalize": (C.c_int, [C.c_void_p]),
+    "at_hubert_destroy": (None, [C.c_void_p]),
+    "at_hubert_num_layers": (C.c_int, [C.c_void_p]),
+    "at_hubert_num_tokens": (C.c_int, [C.c_int]),
+    "at_hubert_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "at_hubert_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "at_hubert_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "at_hubert_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "at_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "at_op_relpos_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "at_op_dwconv_ln_swish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

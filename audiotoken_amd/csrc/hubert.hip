@@ -1,0 +1,354 @@
+// semantic_s tokenizer (mHuBERT-base -> LayerNorm -> k-means assignment) — host side. C ABI in
+// include/audiotoken_hip.h. Replaces reference HubertEncoder (audiotoken/encoder.py:60-108): HF HubertModel
+// hidden_states[output_layer = 11], non-affine LayerNorm(768), torch.cdist to 1000 centres + argmin.
+// Arithmetic per SURVEY.md Appendix A.4 (HF modeling_hubert.py). fp32 on the f32 matrix cores throughout.
+//
+// Weight repacking at finalize():
+//   feature-extractor convs [512][Cin][k] -> [512][k*Cin] (tap-major, channels-last windows); conv 0 keeps [512][10]
+//   positional conv (weight-norm folded by the caller) [768][48][128], groups 16 -> 16 x [48][128*48]
+//   q,k,v Linear -> one [2304][768]
+#include <map>
+#include <string>
+#include <vector>
+#include <cstring>
+
+#include "../../include/audiotoken_hip.h"
+#include "at_common.h"
+#include "hubert_kernels.h"
+#include "w2vbert_kernels.h"
+
+using namespace at;
+
+namespace {
+constexpr int kCd = 512, kHid = 768, kFfn = 3072, kHeads = 12, kPosK = 128, kGroups = 16, kGc = 48, kCenters = 1000;
+constexpr int kKs[7] = {10, 3, 3, 3, 3, 2, 2}, kSt[7] = {5, 2, 2, 2, 2, 2, 2};
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+struct LayerW {
+    const float *wqkv, *bqkv, *wo, *bo, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
+};
+}  // namespace
+
+struct at_hubert {
+    int device = 0;
+    bool finalized = false;
+    std::map<std::string, HostTensor> staged;
+    std::vector<float*> allocs;
+    const float* conv_w[7] = {};
+    const float *gn_g = nullptr, *gn_b = nullptr, *fp_ln_g = nullptr, *fp_ln_b = nullptr, *fp_w = nullptr, *fp_b = nullptr;
+    const float *pos_w = nullptr, *pos_b = nullptr, *enc_ln_g = nullptr, *enc_ln_b = nullptr;
+    std::vector<LayerW> layers;
+    const float *centers = nullptr, *c2 = nullptr;
+    Profiler prof;
+};
+
+namespace {
+
+const HostTensor* find(const at_hubert* h, const std::string& name) {
+    auto it = h->staged.find(name);
+    return it == h->staged.end() ? nullptr : &it->second;
+}
+const float* upload(at_hubert* h, const std::vector<float>& v) {
+    float* d = nullptr;
+    const size_t n = (v.size() + 3) / 4 * 4;
+    if (hipMalloc((void**)&d, n * sizeof(float)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    h->allocs.push_back(d);
+    return d;
+}
+const float* take(at_hubert* h, const std::string& name, std::vector<int64_t> shape, bool& ok) {
+    const HostTensor* t = find(h, name);
+    if (!t) { set_error("missing tensor " + name); ok = false; return nullptr; }
+    if (t->shape != shape) { set_error("bad shape for " + name); ok = false; return nullptr; }
+    const float* d = upload(h, t->data);
+    if (!d) { set_error("device allocation/copy failed for " + name); ok = false; }
+    return d;
+}
+
+struct Plan {
+    int L[8];   // L[0] = N, L[i+1] = frames after conv i
+    size_t off_a, off_b, off_part, off_ss, off_fmask, off_x, off_t1, off_big, off_pos;
+    size_t total_floats;
+};
+Plan make_plan(int B, int N) {
+    Plan p;
+    p.L[0] = N;
+    for (int i = 0; i < 7; ++i) p.L[i + 1] = p.L[i] >= kKs[i] ? (p.L[i] - kKs[i]) / kSt[i] + 1 : 0;
+    size_t cur = 0;
+    auto takef = [&](size_t n) { size_t o = cur; cur += (n + 63) / 64 * 64; return o; };
+    const size_t T = p.L[7], M = (size_t)B * T;
+    p.off_a = takef((size_t)B * p.L[1] * kCd);     // ping: conv 0, 2, 4, 6 outputs
+    p.off_b = takef((size_t)B * p.L[2] * kCd);     // pong: conv 1, 3, 5 outputs
+    p.off_part = takef((size_t)B * hub_gn_nslab(p.L[1] > 0 ? p.L[1] : 1) * kCd * 2);
+    p.off_ss = takef((size_t)B * kCd * 2);
+    p.off_fmask = takef(M);
+    p.off_x = takef(M * kHid);
+    p.off_t1 = takef(M * kHid);
+    p.off_pos = takef(M * kHid);
+    p.off_big = takef(M * kFfn);
+    p.total_floats = cur;
+    return p;
+}
+
+int linear(const float* X, int K, const float* W, const float* bias, float* C, int N, long long M, int epi, const float* R,
+           const float* row_mask, int ldc, hipStream_t stream) {
+    GemmArgs a;
+    a.X = X; a.Tin = (int)M; a.Cin = K; a.ldx = K;
+    a.W = W; a.bias = bias; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc;
+    a.M = (int)M; a.N = N; a.K = K; a.batch = 1; a.epi = epi; a.row_mask = row_mask;
+    return launch_gemm(a, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+at_hubert_t* at_hubert_create(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) {
+        set_error("at_hubert_create: no such HIP device " + std::to_string(device_id));
+        return nullptr;
+    }
+    at_hubert* h = new at_hubert();
+    h->device = device_id;
+    return h;
+}
+
+int at_hubert_set_tensor(at_hubert_t* h, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+    AT_REQUIRE(h && name && host_data && shape && ndim >= 1 && ndim <= 4, "bad arguments");
+    AT_REQUIRE(!h->finalized, "model already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(host_data, host_data + n);
+    h->staged[name] = std::move(t);
+    return 0;
+}
+
+int at_hubert_finalize(at_hubert_t* h) {
+    AT_REQUIRE(h && !h->finalized, "bad handle");
+    AT_CHECK_HIP(hipSetDevice(h->device));
+    bool ok = true;
+    for (int i = 0; i < 7; ++i) {
+        const std::string key = "feature_extractor.conv_layers." + std::to_string(i) + ".conv.weight";
+        const HostTensor* t = find(h, key);
+        const int cin = i == 0 ? 1 : kCd, k = kKs[i];
+        AT_REQUIRE(t && t->shape == (std::vector<int64_t>{kCd, cin, k}), "missing / mis-shaped " + key);
+        std::vector<float> w((size_t)kCd * k * cin);
+        for (int co = 0; co < kCd; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int tp = 0; tp < k; ++tp) w[((size_t)co * k + tp) * cin + ci] = t->data[((size_t)co * cin + ci) * k + tp];
+        h->conv_w[i] = upload(h, w);
+        AT_REQUIRE(h->conv_w[i] != nullptr, "device allocation failed");
+    }
+    h->gn_g = take(h, "feature_extractor.conv_layers.0.layer_norm.weight", {kCd}, ok);
+    h->gn_b = take(h, "feature_extractor.conv_layers.0.layer_norm.bias", {kCd}, ok);
+    h->fp_ln_g = take(h, "feature_projection.layer_norm.weight", {kCd}, ok);
+    h->fp_ln_b = take(h, "feature_projection.layer_norm.bias", {kCd}, ok);
+    h->fp_w = take(h, "feature_projection.projection.weight", {kHid, kCd}, ok);
+    h->fp_b = take(h, "feature_projection.projection.bias", {kHid}, ok);
+    h->pos_b = take(h, "encoder.pos_conv_embed.conv.bias", {kHid}, ok);
+    h->enc_ln_g = take(h, "encoder.layer_norm.weight", {kHid}, ok);
+    h->enc_ln_b = take(h, "encoder.layer_norm.bias", {kHid}, ok);
+    if (!ok) return -1;
+    {   // grouped positional conv: folded weight [768][48][128] -> per group [48 out][128 taps][48 in]
+        const HostTensor* t = find(h, "encoder.pos_conv_embed.conv.weight");
+        AT_REQUIRE(t && t->shape == (std::vector<int64_t>{kHid, kGc, kPosK}), "encoder.pos_conv_embed.conv.weight [768,48,128] (weight-norm folded) missing");
+        std::vector<float> w((size_t)kHid * kPosK * kGc);
+        for (int co = 0; co < kHid; ++co)
+            for (int ci = 0; ci < kGc; ++ci)
+                for (int tp = 0; tp < kPosK; ++tp)
+                    w[((size_t)co * kPosK + tp) * kGc + ci] = t->data[((size_t)co * kGc + ci) * kPosK + tp];
+        h->pos_w = upload(h, w);
+        AT_REQUIRE(h->pos_w != nullptr, "device allocation failed");
+    }
+    int nl = 0;
+    while (find(h, "encoder.layers." + std::to_string(nl) + ".layer_norm.weight")) ++nl;
+    for (int i = 0; i < nl; ++i) {
+        const std::string p = "encoder.layers." + std::to_string(i);
+        LayerW L{};
+        std::vector<float> w((size_t)3 * kHid * kHid), b((size_t)3 * kHid);
+        const char* nm[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int j = 0; j < 3; ++j) {
+            const HostTensor* wt = find(h, p + ".attention." + nm[j] + ".weight");
+            const HostTensor* bt = find(h, p + ".attention." + nm[j] + ".bias");
+            AT_REQUIRE(wt && bt && wt->shape == (std::vector<int64_t>{kHid, kHid}) && bt->shape == (std::vector<int64_t>{kHid}),
+                       "attention projection tensors missing or mis-shaped");
+            std::memcpy(&w[(size_t)j * kHid * kHid], wt->data.data(), (size_t)kHid * kHid * sizeof(float));
+            std::memcpy(&b[(size_t)j * kHid], bt->data.data(), kHid * sizeof(float));
+        }
+        L.wqkv = upload(h, w);
+        L.bqkv = upload(h, b);
+        AT_REQUIRE(L.wqkv && L.bqkv, "device allocation failed");
+        L.wo = take(h, p + ".attention.out_proj.weight", {kHid, kHid}, ok);
+        L.bo = take(h, p + ".attention.out_proj.bias", {kHid}, ok);
+        L.ln1_g = take(h, p + ".layer_norm.weight", {kHid}, ok);
+        L.ln1_b = take(h, p + ".layer_norm.bias", {kHid}, ok);
+        L.w1 = take(h, p + ".feed_forward.intermediate_dense.weight", {kFfn, kHid}, ok);
+        L.b1 = take(h, p + ".feed_forward.intermediate_dense.bias", {kFfn}, ok);
+        L.w2 = take(h, p + ".feed_forward.output_dense.weight", {kHid, kFfn}, ok);
+        L.b2 = take(h, p + ".feed_forward.output_dense.bias", {kHid}, ok);
+        L.ln2_g = take(h, p + ".final_layer_norm.weight", {kHid}, ok);
+        L.ln2_b = take(h, p + ".final_layer_norm.bias", {kHid}, ok);
+        if (!ok) return -1;
+        h->layers.push_back(L);
+    }
+    if (const HostTensor* c = find(h, "kmeans.cluster_centers_")) {
+        AT_REQUIRE(c->shape.size() == 2 && c->shape[1] == kHid && c->shape[0] % 4 == 0, "kmeans.cluster_centers_ must be [C,768], C % 4 == 0");
+        h->centers = upload(h, c->data);
+        const int C = (int)c->shape[0];
+        AT_REQUIRE(C == kCenters, "this build is sized for 1000 centres");
+        std::vector<float> c2(C);
+        if (const HostTensor* e = find(h, "kmeans.c2")) {
+            AT_REQUIRE(e->data.size() == (size_t)C, "bad kmeans.c2 shape");
+            c2 = e->data;
+        } else {
+            for (int n2 = 0; n2 < C; ++n2) {
+                float acc = 0.f;
+                for (int k = 0; k < kHid; ++k) { const float v = c->data[(size_t)n2 * kHid + k]; acc += v * v; }
+                c2[n2] = acc;
+            }
+        }
+        h->c2 = upload(h, c2);
+        AT_REQUIRE(h->centers && h->c2, "device allocation failed");
+    }
+    h->staged.clear();
+    h->finalized = true;
+    return 0;
+}
+
+void at_hubert_destroy(at_hubert_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (float* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+int at_hubert_num_layers(const at_hubert_t* h) { return h ? (int)h->layers.size() : 0; }
+
+int at_hubert_num_tokens(int N) {
+    int L = N;
+    for (int i = 0; i < 7; ++i) L = L >= kKs[i] ? (L - kKs[i]) / kSt[i] + 1 : 0;
+    return L;
+}
+
+size_t at_hubert_workspace_bytes(const at_hubert_t* h, int B, int N) {
+    (void)h;
+    if (B <= 0 || at_hubert_num_tokens(N) <= 0) return 0;
+    return make_plan(B, N).total_floats * sizeof(float);
+}
+
+int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B, int N, int n_layers, int16_t* tokens, int* T_out,
+                     float* hidden_out, void* workspace, size_t workspace_bytes, at_stream_t stream_) {
+    AT_REQUIRE(h && h->finalized, "model not finalized");
+    AT_REQUIRE(wav && workspace, "null pointer");
+    AT_REQUIRE(n_layers >= 0 && n_layers <= (int)h->layers.size(), "n_layers exceeds the loaded layers");
+    AT_REQUIRE(tokens == nullptr || h->centers != nullptr, "tokens requested but no k-means centres loaded");
+    const Plan p = make_plan(B, N);
+    AT_REQUIRE(B >= 1 && p.L[7] >= 1, "clip too short (needs at least 400 samples)");
+    AT_REQUIRE(workspace_bytes >= p.total_floats * sizeof(float), "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    float* ws = (float*)workspace;
+    const int T = p.L[7];
+    const long long M = (long long)B * T;
+    if (T_out) *T_out = T;
+    Profiler& prof = h->prof;
+
+    // ---- conv feature encoder (7 valid strided convs, GroupNorm after the first, GELU) ----------------------
+    float* bufs[2] = {ws + p.off_a, ws + p.off_b};
+    prof.begin("feature_extractor", 10, stream);
+    if (int rc = launch_hub_conv0(wav, h->conv_w[0], bufs[0], B, N, p.L[1], stream)) return rc;
+    if (int rc = launch_hub_groupnorm_gelu(bufs[0], h->gn_g, h->gn_b, ws + p.off_part, ws + p.off_ss, B, p.L[1], stream)) return rc;
+    for (int i = 1; i < 7; ++i) {
+        GemmArgs a;
+        a.X = bufs[(i - 1) & 1]; a.x_bstride = (long long)p.L[i] * kCd; a.Tin = p.L[i]; a.Cin = kCd; a.ldx = kCd;
+        a.ktaps = kKs[i]; a.stride = kSt[i]; a.pad_left = 0; a.pad_mode = 0;
+        a.W = h->conv_w[i];
+        a.C = bufs[i & 1]; a.c_bstride = (long long)p.L[i + 1] * kCd; a.ldc = kCd;
+        a.M = p.L[i + 1]; a.N = kCd; a.K = kKs[i] * kCd; a.batch = B; a.epi = EPI_GELU;
+        if (int rc = launch_gemm(a, stream)) return rc;
+    }
+    prof.end(stream);
+    const float* feats = bufs[6 & 1];   // [B][T][512]
+
+    // ---- feature projection, zero padded frames, positional conv, LayerNorm (HF encoder entry) --------------
+    float* fmask = ws + p.off_fmask;
+    float* x = ws + p.off_x;
+    float* t1 = ws + p.off_t1;
+    float* pos = ws + p.off_pos;
+    float* big = ws + p.off_big;
+    prof.begin("projection_posconv", 20, stream);
+    if (int rc = launch_hub_frame_mask(mask, fmask, B, N, T, stream)) return rc;
+    if (int rc = launch_layernorm(feats, h->fp_ln_g, h->fp_ln_b, nullptr, t1, M, kCd, stream)) return rc;
+    if (int rc = linear(t1, kCd, h->fp_w, h->fp_b, x, kHid, M, EPI_NONE, nullptr, fmask, kHid, stream)) return rc;
+    for (int g = 0; g < kGroups; ++g) {   // pos[b][t][g*48 + co] = x + gelu(conv_g(x) + bias)
+        GemmArgs a;
+        a.X = x + g * kGc; a.x_bstride = (long long)T * kHid; a.Tin = T; a.Cin = kGc; a.ldx = kHid;
+        a.ktaps = kPosK; a.stride = 1; a.pad_left = kPosK / 2; a.pad_mode = 0;
+        a.W = h->pos_w + (size_t)g * kGc * kPosK * kGc; a.bias = h->pos_b + g * kGc;
+        a.C = pos + g * kGc; a.c_bstride = (long long)T * kHid; a.ldc = kHid;
+        a.R = x + g * kGc; a.r_bstride = (long long)T * kHid; a.ldr = kHid;
+        a.M = T; a.N = kGc; a.K = kPosK * kGc; a.batch = B; a.epi = EPI_GELU;
+        if (int rc = launch_gemm(a, stream)) return rc;
+    }
+    if (int rc = launch_layernorm(pos, h->enc_ln_g, h->enc_ln_b, nullptr, x, M, kHid, stream)) return rc;
+    prof.end(stream);
+
+    for (int li = 0; li < n_layers; ++li) {
+        const LayerW& L = h->layers[li];
+        prof.begin("attn_proj", 3, stream);
+        if (int rc = linear(x, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, nullptr, nullptr, 3 * kHid, stream)) return rc;
+        prof.end(stream);
+        prof.begin("attention", 1, stream);
+        if (int rc = launch_relpos_attention(big, fmask, nullptr, t1, B, T, stream, kHeads)) return rc;
+        prof.end(stream);
+        prof.begin("attn_proj", 0, stream);
+        if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) return rc;
+        if (int rc = launch_layernorm(x, L.ln1_g, L.ln1_b, nullptr, x, M, kHid, stream)) return rc;
+        prof.end(stream);
+        prof.begin("ffn", 3, stream);
+        if (int rc = linear(x, kHid, L.w1, L.b1, big, kFfn, M, EPI_GELU, nullptr, nullptr, kFfn, stream)) return rc;
+        if (int rc = linear(big, kFfn, L.w2, L.b2, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) return rc;
+        if (int rc = launch_layernorm(x, L.ln2_g, L.ln2_b, nullptr, x, M, kHid, stream)) return rc;
+        prof.end(stream);
+    }
+    if (hidden_out) AT_CHECK_HIP(hipMemcpyAsync(hidden_out, x, (size_t)M * kHid * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (tokens) {
+        prof.begin("kmeans", 3, stream);
+        if (int rc = launch_layernorm(x, nullptr, nullptr, nullptr, t1, M, kHid, stream)) return rc;
+        if (int rc = linear(t1, kHid, h->centers, nullptr, big, kCenters, M, EPI_NONE, nullptr, nullptr, kCenters, stream)) return rc;
+        if (int rc = launch_vq_argmax(t1, big, h->c2, tokens, M, kHid, kCenters, stream)) return rc;
+        prof.end(stream);
+    }
+    return 0;
+}
+
+int at_hubert_profile(at_hubert_t* h, int enable) {
+    AT_REQUIRE(h != nullptr, "null handle");
+    h->prof.reset();
+    h->prof.enabled = enable != 0;
+    return 0;
+}
+
+int at_hubert_profile_read(at_hubert_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups) {
+    AT_REQUIRE(h && names && total_ms && launches, "null pointer");
+    std::vector<float> ms;
+    std::vector<int> ln;
+    if (h->prof.read(ms, ln) != 0) { set_error("profile read: event query failed"); return -2; }
+    std::string joined;
+    int n = 0;
+    for (size_t i = 0; i < h->prof.names.size() && n < max_groups; ++i, ++n) {
+        joined += h->prof.names[i];
+        joined += '\n';
+        total_ms[n] = ms[i];
+        launches[n] = ln[i];
+    }
+    AT_REQUIRE(joined.size() + 1 <= names_cap, "names buffer too small");
+    std::memcpy(names, joined.c_str(), joined.size() + 1);
+    return n;
+}
+
+}  // extern "C"

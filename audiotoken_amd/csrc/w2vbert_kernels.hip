@@ -314,8 +314,8 @@ constexpr int ATT_VT_LD = 68;
 constexpr int ATT_LDS_FLOATS = ATT_KB * ATT_D + ATT_D * ATT_VT_LD + ATT_QB * ATT_QE_LD + ATT_KB;
 
 __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ amask,
-                                                               const float* __restrict__ dist_emb /*[80][64], rows>=73 zero*/,
-                                                               float* __restrict__ ctx, int T) {
+                                                               const float* __restrict__ dist_emb /*[80][64], rows>=73 zero; null = no rel-pos bias*/,
+                                                               float* __restrict__ ctx, int T, int hid /*heads*64*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                              // [64 keys][64 d], chunk ^= key&15
     float* Vt = Ks + ATT_KB * ATT_D;               // [64 dv][68]: Vt[dv][key]
@@ -326,10 +326,11 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
     const int h = blockIdx.y, b = blockIdx.z;
     const int l0 = blockIdx.x * ATT_QB;
     const long long rowbase = (long long)b * T;
-    const int LD = 3072;
+    const int LD = 3 * hid;
     const float* qp = qkv + h * 64;
-    const float* kp = qkv + 1024 + h * 64;
-    const float* vp = qkv + 2048 + h * 64;
+    const float* kp = qkv + hid + h * 64;
+    const float* vp = qkv + 2 * hid + h * 64;
+    const bool relpos = dist_emb != nullptr;
 
     // query fragments (B operand): qf[i][c] = q[l][c*16 + qd*4 .. +3]
     int lq[2];
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
         for (int c = 0; c < 4; ++c) qf[i][c] = *reinterpret_cast<const f4*>(qp + (rowbase + lc) * LD + c * 16 + qd * 4);
     }
     // QE = 0.125 * q . E^T  -> LDS (lane: query r16 of tile i, buckets bt*16 + qd*4 + reg)
+    if (relpos)
 #pragma unroll
     for (int bt = 0; bt < 5; ++bt) {
         f4 ef[4];
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float* qe = QE + (wave * 32 + i * 16 + r16) * ATT_QE_LD;
-            const float c_far = far_left ? qe[0] : qe[72];
+            const float c_far = relpos ? (far_left ? qe[0] : qe[72]) : 0.f;
             float mx = -INFINITY;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     float bias;
-                    if (far_left || far_right) {
+                    if (far_left || far_right || !relpos) {
                         bias = c_far;
                     } else {
                         int dd = (r0 + j * 16 + qd * 4 + reg) - lq[i];
@@ -491,13 +493,13 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
         const float inv = 1.0f / lrun[i];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<f4*>(ctx + (rowbase + lq[i]) * 1024 + h * 64 + dt * 16 + qd * 4) = oacc[i][dt] * inv;
+            *reinterpret_cast<f4*>(ctx + (rowbase + lq[i]) * hid + h * 64 + dt * 16 + qd * 4) = oacc[i][dt] * inv;
     }
 }
 
 int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
-                            hipStream_t stream) {
-    dim3 grid((T + ATT_QB - 1) / ATT_QB, 16, B);
+                            hipStream_t stream, int heads) {
+    dim3 grid((T + ATT_QB - 1) / ATT_QB, heads, B);
     const size_t lds = ATT_LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -505,7 +507,7 @@ int launch_relpos_attention(const float* qkv, const float* amask, const float* d
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(relpos_attention_kernel, grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T);
+    hipLaunchKernelGGL(relpos_attention_kernel, grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T, heads * 64);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,142 @@
+"""semantic_s: ``HubertEncoder`` and ``hubert_processor`` with the reference's protocol
+(audiotoken/encoder.py:20-26, 60-108), backed by libaudiotoken_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Union
+
+import numpy as np
+import torch
+
+from . import _cabi
+from . import weights as W
+from .configs import HubertEncoderConfig
+from .encoder import _device_index
+from .logger import get_logger
+
+logger = get_logger(__name__)
+
+
+def hubert_processor(audio: torch.Tensor, processor=None) -> torch.Tensor:
+    """Reference ``hubert_processor`` (encoder.py:20-26) = HF ``Wav2Vec2FeatureExtractor(do_normalize=True)`` on one
+    clip: zero mean / unit variance over the whole array, ``(x - mean) / sqrt(var + 1e-7)`` in float32. Host-side
+    transform applied before batching, exactly where the reference applies it (core.py:188-189, datasets.py:78-79)."""
+    x = np.asarray(audio, dtype=np.float32)
+    y = (x - x.mean()) / np.sqrt(x.var() + 1e-7)
+    return torch.from_numpy(y.astype(np.float32))
+
+
+def fold_hubert_weights(w: Dict[str, np.ndarray], n_layers: int) -> Dict[str, np.ndarray]:
+    out: Dict[str, np.ndarray] = {}
+    for k, v in w.items():
+        if k.startswith("encoder.layers.") and int(k.split(".")[2]) >= n_layers:
+            continue   # layers past the consumed hidden state are dead compute
+        if k.endswith("pos_conv_embed.conv.weight_g") or k.endswith("parametrizations.weight.original0"):
+            base = k.rsplit(".", 1)[0] if k.endswith("weight_g") else k[: -len(".parametrizations.weight.original0")]
+            vkey = base + ".weight_v" if k.endswith("weight_g") else base + ".parametrizations.weight.original1"
+            folded = torch._weight_norm(torch.from_numpy(np.ascontiguousarray(w[vkey], dtype=np.float32)),
+                                        torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)), 2)
+            out["encoder.pos_conv_embed.conv.weight"] = folded.numpy()
+        elif k.endswith("weight_v") or k.endswith("original1") or k == "masked_spec_embed":
+            continue
+        elif k == "kmeans.cluster_centers_":
+            c = np.ascontiguousarray(v, dtype=np.float32)
+            out[k] = c
+            out["kmeans.c2"] = (torch.from_numpy(c) ** 2).sum(-1).numpy()
+        else:
+            out[k] = np.ascontiguousarray(v, dtype=np.float32)
+    return out
+
+
+def load_hubert_checkpoint(model_dir: str, quantizer_path: Optional[str]) -> Dict[str, np.ndarray]:
+    """HF checkpoint directory (``model.safetensors`` or ``pytorch_model.bin``) + the joblib k-means pickle
+    (reference encoder.py:72, 84-85)."""
+    import os
+    st = os.path.join(model_dir, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.numpy import load_file
+        sd = {k: v.astype(np.float32) for k, v in load_file(st).items()}
+    else:
+        sd = {k: v.float().numpy() for k, v in torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu", weights_only=True).items()}
+    sd = {(k[len("hubert."):] if k.startswith("hubert.") else k): v for k, v in sd.items()}
+    if quantizer_path:
+        import joblib
+        sd["kmeans.cluster_centers_"] = np.asarray(joblib.load(quantizer_path).cluster_centers_, dtype=np.float32)
+    return sd
+
+
+class HubertEncoder(torch.nn.Module):
+    """Drop-in for reference ``HubertEncoder`` (audiotoken/encoder.py:60-108)."""
+
+    def __init__(self, config: HubertEncoderConfig = None, device: str = "cuda:0", quantize: bool = True,
+                 weights: Optional[Union[str, Dict[str, np.ndarray]]] = None):
+        super().__init__()
+        config = config or HubertEncoderConfig()
+        self.config = config
+        self.quantize = quantize
+        self.output_layer = config.output_layer
+        self.lib = _cabi.load()
+        self.device_index = _device_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        if weights is None:
+            weights = config.weights
+        if weights is None:
+            logger.warning("No HuBERT checkpoint given (weights=/AUDIOTOKEN_HUBERT_WEIGHTS): synthetic weights, seed 0")
+            weights = W.synth_hubert_weights(n_layers=self.output_layer, seed=0, with_kmeans=True)
+        elif isinstance(weights, (str, bytes)):
+            weights = load_hubert_checkpoint(weights, config.quantizer_path)
+        self.handle = self.lib.at_hubert_create(self.device_index)
+        if not self.handle:
+            raise _cabi.HipLibraryError(f"at_hubert_create failed: {_cabi.last_error()}")
+        for name, arr in fold_hubert_weights(weights, self.output_layer).items():
+            _cabi.set_tensor(self.lib, self.lib.at_hubert_set_tensor, self.handle, name, arr)
+        _cabi.check(self.lib.at_hubert_finalize(self.handle), "at_hubert_finalize")
+        if self.lib.at_hubert_num_layers(self.handle) < self.output_layer:
+            raise ValueError(f"checkpoint has too few transformer layers for output_layer={self.output_layer}")
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        h = self.__dict__.pop("handle", None)
+        if h:
+            self.lib.at_hubert_destroy(h)
+
+    @torch.no_grad()
+    def forward(self, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, n_layers: Optional[int] = None,
+                return_hidden: bool = False):
+        """``float32 [B, N]`` (normalised) + mask -> ``int16 [B, 1, T]`` on the device (hidden state if quantize=False)."""
+        assert input_batch.dim() == 2, "input_batch must be [B, N]"
+        x = input_batch.to(device=self.device, dtype=torch.float32).contiguous()
+        m = None if attention_mask is None else attention_mask.to(device=self.device, dtype=torch.float32).contiguous()
+        B, N = x.shape
+        T = self.lib.at_hubert_num_tokens(N)
+        nl = self.output_layer if n_layers is None else n_layers
+        tokens = torch.empty((B, 1, T), dtype=torch.int16, device=self.device) if self.quantize else None
+        hidden = torch.empty((B, T, 768), dtype=torch.float32, device=self.device) if (return_hidden or not self.quantize) else None
+        nbytes = self.lib.at_hubert_workspace_bytes(self.handle, B, N)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        t_out = C.c_int(0)
+        with torch.cuda.device(self.device):
+            rc = self.lib.at_hubert_encode(self.handle, x.data_ptr(), _cabi.ptr(m), B, N, nl, _cabi.ptr(tokens), C.byref(t_out),
+                                           _cabi.ptr(hidden), self._ws.data_ptr(), nbytes, _cabi.current_stream_handle(self.device))
+        _cabi.check(rc, "at_hubert_encode")
+        assert t_out.value == T
+        if return_hidden:
+            return tokens, hidden
+        return tokens if self.quantize else hidden
+
+    __call__ = torch.nn.Module.__call__   # the reference defines __call__ directly (encoder.py:87); same call protocol
+
+    def enable_profile(self, on: bool) -> None:
+        _cabi.check(self.lib.at_hubert_profile(self.handle, 1 if on else 0), "at_hubert_profile")
+
+    def read_profile(self) -> Dict[str, tuple]:
+        names = C.create_string_buffer(4096)
+        ms = (C.c_float * 64)()
+        ln = (C.c_int * 64)()
+        n = self.lib.at_hubert_profile_read(self.handle, names, 4096, ms, ln, 64)
+        if n < 0:
+            raise _cabi.HipLibraryError(f"at_hubert_profile_read failed: {_cabi.last_error()}")
+        keys = names.value.decode().split("\n")[:n]
+        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(keys)}

@@ -198,3 +198,67 @@ def synth_w2vbert_weights(n_layers: int = W2V_LAYERS_USED, seed: int = 0, with_v
         # state-dict key of vector_quantize_pytorch.VectorQuantize (reference audiotoken/utils.py:331-339)
         w["vq._codebook.embed"] = prng.irwin_hall("vq._codebook.embed", (1, W2V_CODEBOOK, H), 1.0, seed)
     return w
+
+
+# ----------------------------------------------------------------------------------------------
+# HuBERT-base (semantic_s, mHuBERT) — HF HubertModel state-dict keys (checkpoint naming: weight_g / weight_v for
+# the positional conv); architecture constants
+# ----------------------------------------------------------------------------------------------
+HUB_CONV_KERNEL = (10, 3, 3, 3, 3, 2, 2)
+HUB_CONV_STRIDE = (5, 2, 2, 2, 2, 2, 2)
+HUB_CONV_DIM = 512
+HUB_HIDDEN = 768
+HUB_FFN = 3072
+HUB_HEADS = 12
+HUB_POS_K = 128
+HUB_POS_GROUPS = 16
+HUB_LAYERS_USED = 11          # hidden_states[11] (reference audiotoken/configs.py:53, encoder.py:95)
+HUB_CENTROIDS = 1000
+
+
+def hubert_num_frames(n_samples: int) -> int:
+    """Chained valid-conv length formula floor((L - k)/s) + 1 (HF modeling_hubert.py:664-677)."""
+    L = n_samples
+    for k, s in zip(HUB_CONV_KERNEL, HUB_CONV_STRIDE):
+        L = (L - k) // s + 1
+    return L
+
+
+def synth_hubert_weights(n_layers: int = HUB_LAYERS_USED, seed: int = 0, with_kmeans: bool = True) -> Dict[str, np.ndarray]:
+    w: Dict[str, np.ndarray] = {}
+    H, Fd, Cd = HUB_HIDDEN, HUB_FFN, HUB_CONV_DIM
+
+    def u(name, shape, a):
+        w[name] = prng.uniform(name, shape, -a, a, seed)
+
+    def lin(name, out_f, in_f, gain=1.0):
+        u(name + ".weight", (out_f, in_f), gain * np.sqrt(3.0 / in_f))
+        u(name + ".bias", (out_f,), 0.05)
+
+    def ln(name, dim):
+        w[name + ".weight"] = prng.uniform(name + ".weight", (dim,), 0.8, 1.2, seed)
+        w[name + ".bias"] = prng.uniform(name + ".bias", (dim,), -0.1, 0.1, seed)
+
+    cin = 1
+    for i, k in enumerate(HUB_CONV_KERNEL):
+        u(f"feature_extractor.conv_layers.{i}.conv.weight", (Cd, cin, k), 1.6 * np.sqrt(3.0 / (cin * k)))
+        cin = Cd
+    ln("feature_extractor.conv_layers.0.layer_norm", Cd)       # GroupNorm(512, 512) affine
+    ln("feature_projection.layer_norm", Cd)
+    lin("feature_projection.projection", H, Cd)
+    u("encoder.pos_conv_embed.conv.weight_v", (H, H // HUB_POS_GROUPS, HUB_POS_K), 1.0)
+    w["encoder.pos_conv_embed.conv.weight_g"] = prng.uniform("encoder.pos_conv_embed.conv.weight_g", (1, 1, HUB_POS_K), 1.5, 3.0, seed)
+    u("encoder.pos_conv_embed.conv.bias", (H,), 0.05)
+    ln("encoder.layer_norm", H)
+    for i in range(n_layers):
+        p = f"encoder.layers.{i}"
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            lin(f"{p}.attention.{nm}", H, H, gain=1.6 if nm in ("q_proj", "k_proj") else 1.0)
+        ln(p + ".layer_norm", H)
+        lin(p + ".feed_forward.intermediate_dense", Fd, H, gain=1.4)
+        lin(p + ".feed_forward.output_dense", H, Fd)
+        ln(p + ".final_layer_norm", H)
+    if with_kmeans:
+        # sklearn KMeans.cluster_centers_ [1000, 768] (reference audiotoken/encoder.py:84-85)
+        w["kmeans.cluster_centers_"] = prng.irwin_hall("kmeans.cluster_centers_", (HUB_CENTROIDS, H), 1.0, seed)
+    return w

@@ -125,6 +125,29 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
 int at_w2vbert_profile(at_w2vbert_t* h, int enable);
 int at_w2vbert_profile_read(at_w2vbert_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups);
 
+/* ---- semantic_s tokenizer: mHuBERT-base + k-means ---------------------------------------------------------
+ * Replaces reference HubertEncoder (audiotoken/encoder.py:60-108): ctor = HubertModel.from_pretrained + joblib k-means
+ * centres (:61-85); __call__ = model(..., output_hidden_states=True).hidden_states[output_layer] -> LayerNorm(no
+ * affine) -> torch.cdist -> argmin -> int16 [B,1,T] (:87-108). Input is the waveform AFTER hubert_processor
+ * (zero-mean / unit-variance, encoder.py:20-26), which the reference applies on the host before batching. */
+typedef struct at_hubert at_hubert_t;
+at_hubert_t* at_hubert_create(int device_id);
+/* HF HubertModel state-dict keys; the positional conv's weight-norm pair folded by the caller (dim = 2) into
+ * "encoder.pos_conv_embed.conv.weight" [768,48,128]; "kmeans.cluster_centers_" [1000,768] (optional "kmeans.c2" [1000]). */
+int at_hubert_set_tensor(at_hubert_t* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int at_hubert_finalize(at_hubert_t* h);
+void at_hubert_destroy(at_hubert_t* h);
+int at_hubert_num_layers(const at_hubert_t* h);
+/* T = chained floor((L - k)/s) + 1 over the 7 feature-extractor convs (HF modeling_hubert.py:664-677). */
+int at_hubert_num_tokens(int N);
+size_t at_hubert_workspace_bytes(const at_hubert_t* h, int B, int N);
+/* wav device float32 [B][N] (normalised, 16 kHz); mask device float32 [B][N] or NULL; n_layers = output_layer (11);
+ * tokens device int16 [B][1][T] or NULL; hidden_out optional device float32 [B][T][768] = hidden_states[n_layers]. */
+int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B, int N, int n_layers, int16_t* tokens, int* T_out,
+                     float* hidden_out, void* workspace, size_t workspace_bytes, at_stream_t stream);
+int at_hubert_profile(at_hubert_t* h, int enable);
+int at_hubert_profile_read(at_hubert_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups);
+
 /* ---- operator-level entry points (the kernels behind the models; used by the parity tests) ------------- */
 
 /* Windowed fp32 GEMM: out[b][m][n] = act(alpha*(sum_kk A(b,m,kk)*W[n][kk] + bias[n])) (+ R[b][m][n]) with

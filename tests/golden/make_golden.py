@@ -188,6 +188,40 @@ def make_harness():
     print("harness", {k: v.shape for k, v in out.items()})
 
 
+def make_hubert():
+    """HF HubertModel(HubertConfig()) (= HuBERT-base architecture) with synthetic weights, 3 layers."""
+    from transformers import HubertConfig, HubertModel
+    n_layers = 3
+    w = W.synth_hubert_weights(n_layers=n_layers, seed=7, with_kmeans=True)
+    model = HubertModel(HubertConfig(num_hidden_layers=n_layers)).eval()
+    sd = model.state_dict()
+    for k, v in w.items():
+        if k.startswith("kmeans."):
+            continue
+        hk = k.replace("conv.weight_g", "conv.parametrizations.weight.original0").replace("conv.weight_v", "conv.parametrizations.weight.original1")
+        assert hk in sd and tuple(sd[hk].shape) == tuple(v.shape), (k, hk)
+        sd[hk] = torch.from_numpy(v.copy())
+    model.load_state_dict(sd)
+    B, N = 2, 16000
+    wave = W.synth_waveform(B, N, 16000, seed=41)
+    mask = np.ones((B, N), dtype=np.float32)
+    mask[1, 9000:] = 0
+    wave[1, 9000:] = 0
+    from transformers import Wav2Vec2FeatureExtractor
+    fe = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0, do_normalize=True, return_attention_mask=False)
+    norm = np.stack([fe(wave[i], sampling_rate=16000, return_tensors="np").input_values[0] for i in range(B)])
+    with torch.no_grad():
+        out = model(torch.from_numpy(norm), attention_mask=torch.from_numpy(mask), output_hidden_states=True)
+        hs = out.hidden_states
+        e = torch.nn.functional.layer_norm(hs[n_layers], (768,))
+        d = torch.cdist(e, torch.from_numpy(w["kmeans.cluster_centers_"]))
+        toks = torch.argmin(d, dim=-1, keepdim=True).transpose(1, 2).to(torch.int16)
+    np.savez_compressed(os.path.join(HERE, "hubert_a.npz"), weight_seed=7, wave_seed=41, n_layers=n_layers, B=B, N=N, mask=mask,
+                        normalized=norm.astype(np.float32), hs0=hs[0].numpy(), hs1=hs[1].numpy(), hs_last=hs[n_layers].numpy(),
+                        tokens=toks.numpy())
+    print("hubert", hs[0].shape, toks.shape)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["encodec"]
     torch.manual_seed(0)
