@@ -163,6 +163,68 @@ def cpu_baseline_semantic(n_layers: int, budget_s: float = 20.0):
                       f"{t_total:.1f} s of CPU work"}
 
 
+def hubert_flops_per_clip(N: int, n_layers: int):
+    L = [N]
+    for k, st in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
+        L.append((L[-1] - k) // st + 1)
+    T = L[7]
+    fe = 2.0 * L[1] * 10 * 512 + sum(2.0 * L[i + 1] * k * 512 * 512 for i, k in zip(range(1, 7), (3, 3, 3, 3, 2, 2)))
+    g = {
+        "feature_extractor": fe,
+        "projection_posconv": 2.0 * T * 512 * 768 + 2.0 * T * 768 * 128 * 48,
+        "attn_proj": n_layers * 2.0 * T * 768 * 768 * 4,
+        "attention": n_layers * 4.0 * T * T * 768,
+        "ffn": n_layers * 2.0 * T * 768 * 3072 * 2,
+        "kmeans": 2.0 * T * 768 * 1000,
+    }
+    return g, T
+
+
+def run_hubert(args, rank, world, dev, dist):
+    from audiotoken_amd import weights as W
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    from audiotoken_amd.distributed import broadcast_weights
+
+    nl, B, secs = 11, args.hub_batch, args.sem_seconds
+    N = int(round(secs * 16000))
+    weights = W.synth_hubert_weights(n_layers=nl, seed=0, with_kmeans=True) if rank == 0 else None
+    weights = broadcast_weights(weights, dev, dist)
+    enc = HubertEncoder(HubertEncoderConfig(output_layer=nl), device=str(dev), quantize=True, weights=weights)
+    del weights
+    gen_B = min(B, 8)
+    host = W.synth_waveform(gen_B, N, 16000, seed=1234, first_clip=rank * B)
+    host = np.stack([hubert_processor(torch.from_numpy(host[i:i + 1]))[0].numpy() for i in range(gen_B)])
+    wav = torch.from_numpy(host).to(dev).repeat((B + gen_B - 1) // gen_B, 1)[:B].contiguous()
+    mask = torch.ones_like(wav)
+    enc(wav, mask)
+    for _ in range(max(0, args.warmup - 1)):
+        enc(wav, mask)
+    enc.enable_profile(True)
+    elapsed, toks = timed_steps(lambda: enc(wav, mask), args.steps, 0, dist)
+    prof = enc.read_profile()
+    enc.enable_profile(False)
+    elapsed = max_over_ranks(elapsed, dev, dist)
+    flops, T = hubert_flops_per_clip(N, nl)
+    breakdown = {}
+    for k, (ms, launches) in prof.items():
+        per = ms / args.steps
+        breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches // args.steps,
+                        "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None, "gbs": None}
+    res = {
+        "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "dtype": "f32",
+        "config": {"workload": f"Tokenizers.semantic_s encode, {B} clips x {secs:g} s @16 kHz per GPU, mHuBERT-base 11 layers, k-means 1000",
+                   "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0"},
+        "roofline": roofline_of(breakdown, flops, None, B), "breakdown": breakdown,
+        "token_checksum": int(toks.to(torch.int64).sum().item()),
+        "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
+    }
+    del enc
+    torch.cuda.empty_cache()
+    return res
+
+
 def timed_steps(enc_call, steps, warmup, dist):
     for _ in range(warmup):
         out = enc_call()
@@ -309,7 +371,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="both", choices=["both", "acoustic", "semantic_m"])
+    ap.add_argument("--workload", default="all", choices=["all", "both", "acoustic", "semantic_m", "semantic_s"])
+    ap.add_argument("--hub-batch", type=int, default=128, help="semantic_s clips per GPU per step (BASELINE configs[2]: 128)")
     ap.add_argument("--batch", type=int, default=256, help="acoustic clips per GPU per step (BASELINE configs[1]: 256)")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--num-codebooks", type=int, default=8)
@@ -335,9 +398,17 @@ def main():
 
     ac = sem = None
     sem_err = None
-    if args.workload in ("both", "acoustic"):
+    hub = hub_err = None
+    if args.workload in ("all", "both", "acoustic"):
         ac = run_acoustic(args, rank, world, dev, dist)
-    if args.workload in ("both", "semantic_m"):
+    if args.workload in ("all", "semantic_s"):
+        try:
+            hub = run_hubert(args, rank, world, dev, dist)
+        except Exception as e:
+            if args.workload == "semantic_s":
+                raise
+            hub_err = f"{type(e).__name__}: {e}"
+    if args.workload in ("all", "both", "semantic_m"):
         try:
             sem = run_semantic(args, rank, world, dev, dist)
         except Exception as e:  # keep the acoustic line even if the second workload cannot run on this box
@@ -346,7 +417,7 @@ def main():
             sem_err = f"{type(e).__name__}: {e}"
 
     if rank == 0:
-        primary = ac if ac is not None else sem
+        primary = ac if ac is not None else (sem if sem is not None else hub)
         out = {
             "metric": "audio-sec tokenized / wall-sec", "value": primary["value"], "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
@@ -355,7 +426,10 @@ def main():
             "token_checksum": primary["token_checksum"],
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_acoustic(args.num_codebooks) if ac is not None else cpu_baseline_semantic(args.sem_layers)
+            if ac is not None:
+                out["cpu_baseline"] = cpu_baseline_acoustic(args.num_codebooks)
+            elif sem is not None:
+                out["cpu_baseline"] = cpu_baseline_semantic(args.sem_layers)
         if ac is not None and sem is not None:
             s = {k: v for k, v in sem.items() if k not in ("elapsed", "audio_s_per_step")}
             if not args.no_cpu_baseline and world == 1:
@@ -366,6 +440,10 @@ def main():
                                "definition": "audio-seconds of both workloads / (t_acoustic + t_semantic_m)"}
         elif sem_err:
             out["semantic_m"] = {"error": sem_err}
+        if hub is not None and primary is not hub:
+            out["semantic_s"] = hub
+        elif hub_err:
+            out["semantic_s"] = {"error": hub_err}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
