@@ -375,36 +375,49 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
     const float FMIN = -3.4028234663852886e38f;
 
     const int nkt = (T + ATT_KB - 1) / ATT_KB;
+    // K/V staging goes global -> registers -> LDS, one tile ahead: the loads of tile kt+1 are issued before the MFMAs of
+    // tile kt and written to LDS after them. All loads are unconditional (row clamped, value masked at the LDS store):
+    // loads under a per-lane branch serialise behind s_waitcnt vmcnt(0).
+    const int st_key = tid >> 2, st_cg = (tid & 3) * 4;      // K tile: thread -> key, 4 chunks from st_cg
+    const int st_dv = tid & 63, st_k0 = (tid >> 6) * 16;     // V tile (transposed): thread -> dv, 16 keys from st_k0
+    f4 kv[4];
+    float vv[16];
+    float am = 0.f;
+    auto prefetch = [&](int kt) {
+        const int r0 = kt * ATT_KB;
+        const int r = r0 + st_key;
+        const float* krow = kp + (rowbase + (r < T ? r : T - 1)) * LD + st_cg * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kv[j] = *reinterpret_cast<const f4*>(krow + j * 4);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rr = r0 + st_k0 + e;
+            vv[e] = vp[(rowbase + (rr < T ? rr : T - 1)) * LD + st_dv];
+        }
+        const int rr_m = r0 + (tid & 63);
+        am = amask[rowbase + (rr_m < T ? rr_m : T - 1)];
+    };
+    prefetch(0);
     for (int kt = 0; kt < nkt; ++kt) {
         const int r0 = kt * ATT_KB;
         __syncthreads();  // previous tile fully consumed (also orders the QE stores before first use)
-        {   // K tile: thread -> key = tid>>2, 4 chunks starting at (tid&3)*4
-            const int key = tid >> 2, cg = (tid & 3) * 4;
-            const int r = r0 + key;
+        {
+            const bool rok = (r0 + st_key) < T;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f4 v = {0.f, 0.f, 0.f, 0.f};
-                if (r < T) v = *reinterpret_cast<const f4*>(kp + (rowbase + r) * LD + (cg + j) * 4);
-                *reinterpret_cast<f4*>(Ks + key * ATT_D + (((cg + j) ^ (key & 15)) << 2)) = v;
-            }
-            // V tile transposed: thread -> dv = tid&63, 16 keys starting at (tid>>6)*16
-            const int dv = tid & 63, k0 = (tid >> 6) * 16;
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f4*>(Ks + st_key * ATT_D + (((st_cg + j) ^ (st_key & 15)) << 2)) = rok ? kv[j] : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int rr = r0 + k0 + g * 4 + e;
-                    v[e] = rr < T ? vp[(rowbase + rr) * LD + dv] : 0.f;
-                }
-                *reinterpret_cast<f4*>(Vt + dv * ATT_VT_LD + k0 + g * 4) = v;
+                for (int e = 0; e < 4; ++e) v[e] = (r0 + st_k0 + g * 4 + e) < T ? vv[g * 4 + e] : 0.f;
+                *reinterpret_cast<f4*>(Vt + st_dv * ATT_VT_LD + st_k0 + g * 4) = v;
             }
-            if (tid < ATT_KB) {
-                const int rr = r0 + tid;
-                kb[tid] = rr < T ? (amask[rowbase + rr] != 0.f ? 0.f : FMIN) : -INFINITY;
-            }
+            const int rr_m = r0 + (tid & 63);
+            if (tid < ATT_KB) kb[tid] = rr_m < T ? (am != 0.f ? 0.f : FMIN) : -INFINITY;
         }
         __syncthreads();
+        if (kt + 1 < nkt) prefetch(kt + 1);
         // S^T tiles: lane holds s[i][j][reg] = q_l . k_r for l = lq[i], r = r0 + j*16 + qd*4 + reg
         f4 s[2][4];
 #pragma unroll
@@ -454,13 +467,13 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[i], mx);
-            const float alpha = expf(mrun[i] - mnew);   // exp(-inf) = 0 on the first tile
+            const float alpha = __expf(mrun[i] - mnew);   // exp(-inf) = 0 on the first tile
             float rs = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const float p = expf(s[i][j][reg] - mnew);
+                    const float p = __expf(s[i][j][reg] - mnew);
                     s[i][j][reg] = p;
                     rs += p;
                 }
