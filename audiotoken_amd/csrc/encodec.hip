@@ -117,6 +117,7 @@ struct at_encodec {
     ConvW dconv0, dup[4], dres[4][3], dlast;
     const float *dwih[2] = {}, *dwhh[2] = {}, *dbih[2] = {}, *dbhh[2] = {};
     Profiler prof;
+    bool fused_stage0 = true;       // conv0 + resblock + strided conv in one kernel (seanet_stage0.hip)
     bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
 };
 
@@ -564,10 +565,23 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
         static const char* kRes[4] = {"res0", "res1", "res2", "res3"};
         static const char* kDown[4] = {"down0", "down1", "down2", "down3"};
         Profiler& prof = h->prof;
-        prof.begin("conv0", 1, stream);
-        if (int rc = launch_conv0(wav + (long long)b0 * N, h->conv0.w, h->conv0.b, ws + p.off_x[0], g, N, stream)) return rc;
-        prof.end(stream);
-        for (int s = 0; s < 4; ++s) {
+        const bool fused0 = h->fused_stage0 && (N % 2 == 0);
+        if (fused0) {
+            // conv0 + resblock(32) + ELU + strided conv in one kernel: 4 B in, 128 B out per sample (seanet_stage0.hip)
+            Stage0Args sa;
+            sa.wav = wav + (long long)b0 * N; sa.x1 = ws + p.off_x[1];
+            sa.w0 = h->conv0.w; sa.b0 = h->conv0.b; sa.w3 = h->res[0][0].w; sa.b3 = h->res[0][0].b;
+            sa.wt = h->res[0][1].w; sa.bt = h->res[0][1].b; sa.wd = h->down[0].w; sa.bd = h->down[0].b;
+            sa.B = g; sa.N = N;
+            prof.begin("stage0_fused", 1, stream);
+            if (int rc = launch_seanet_stage0(sa, stream)) return rc;
+            prof.end(stream);
+        } else {
+            prof.begin("conv0", 1, stream);
+            if (int rc = launch_conv0(wav + (long long)b0 * N, h->conv0.w, h->conv0.b, ws + p.off_x[0], g, N, stream)) return rc;
+            prof.end(stream);
+        }
+        for (int s = fused0 ? 1 : 0; s < 4; ++s) {
             const int C = 32 << s, L = p.L[s], Lo = p.L[s + 1];
             float* x = ws + p.off_x[s];
             float* r = ws + p.off_r[s];
@@ -613,6 +627,7 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
 int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     AT_REQUIRE(h && name, "null pointer");
     if (std::string(name) == "persistent_lstm") { h->persistent_lstm = value != 0; return 0; }
+    if (std::string(name) == "fused_stage0") { h->fused_stage0 = value != 0; return 0; }
     set_error(std::string("unknown option ") + name);
     return -1;
 }

@@ -32,6 +32,18 @@ struct LstmSeqArgs {
 int launch_lstm_seq(const LstmSeqArgs& a, hipStream_t stream);
 int lstm_seq_max_clips();
 
+// Fused SEANet stage 0 (seanet_stage0.hip): wav -> conv0 -> resblock(32) -> ELU -> conv k4 s2 -> x1 [B][N/2][64]
+struct Stage0Args {
+    const float* wav;   // [B][N]
+    float* x1;          // [B][N/2][64]
+    const float *w0, *b0;   // conv0 [32][7], [32]
+    const float *w3, *b3;   // resblock conv3 packed [16][3*32], [16]
+    const float *wt, *bt;   // resblock tail packed [32][16 + 32] = [W1 | Wsc], summed bias [32]
+    const float *wd, *bd;   // strided conv packed [64][4*32], [64]
+    int B, N;
+};
+int launch_seanet_stage0(const Stage0Args& a, hipStream_t stream);
+
 int launch_conv0(const float* wav, const float* w, const float* bias, float* out, int B, int N, hipStream_t stream);
 int launch_lstm_step(const GemmArgs& a, const LstmStepArgs& s, hipStream_t stream);
 int launch_rvq_encode(const float* x, long long rows, int T, const float* codebooks, const float* e2, int n_q,

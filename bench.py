@@ -49,6 +49,7 @@ def acoustic_flops_per_clip(N: int, n_q: int):
         g[f"res{s}"] = 2.0 * L[s] * (3 * C * (C // 2) + (C // 2) * C + C * C)
         g[f"down{s}"] = 2.0 * L[s + 1] * (2 * r * C) * (2 * C)
         C *= 2
+    g["stage0_fused"] = g["conv0"] + g["res0"] + g["down0"]
     T = L[4]
     g["lstm_ih"] = 2.0 * T * 512 * 2048 * 2
     g["lstm_rec"] = 2.0 * T * 512 * 2048 * 2
@@ -63,7 +64,7 @@ def acoustic_bytes_per_clip(N: int, n_q: int):
     L = [N]
     for r in (2, 4, 5, 8):
         L.append(-(-L[-1] // r))
-    g = {"conv0": 4.0 * N * (1 + 32)}
+    g = {"conv0": 4.0 * N * (1 + 32), "stage0_fused": 4.0 * (N + L[1] * 64)}
     C = 32
     for s in range(4):
         g[f"res{s}"] = 4.0 * L[s] * (C + C)
