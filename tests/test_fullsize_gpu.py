@@ -1,0 +1,66 @@
+"""GPU: BASELINE.json-size runs checked through size-independent properties (batch independence, causality /
+prefix invariance, determinism) plus one full-depth oracle comparison per tokenizer."""
+import numpy as np
+import pytest
+import torch
+
+from audiotoken_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def test_acoustic_full_batch_properties(cuda_device):
+    """configs[1]: 256 clips x 10 s, 8 codebooks."""
+    from audiotoken_amd.configs import AcousticEncoderConfig
+    from audiotoken_amd.encoder import AcousticEncoder
+    from oracle import encodec_ref as R
+    w = W.synth_encodec_weights(seed=0, with_decoder=False)
+    enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=w)
+    B, N = 256, 240000
+    base = torch.from_numpy(W.synth_waveform(8, N, 24000, seed=1234)).cuda()
+    wav = (base.repeat(B // 8, 1) * torch.linspace(0.5, 1.0, B, device="cuda").unsqueeze(1)).contiguous()
+    codes = enc(wav, None)
+    assert enc.last_status() == 0
+    assert codes.dtype == torch.int16 and tuple(codes.shape) == (B, 8, 750)
+    assert int(codes.min()) >= 0 and int(codes.max()) < 1024
+    # determinism
+    assert torch.equal(codes, enc(wav, None))
+    # batch independence: a clip encoded alone (different sub-batch / LSTM group / RVQ tile position) gives the same ids
+    for i in (0, 37, 255):
+        assert torch.equal(enc(wav[i:i + 1], None)[0], codes[i]), f"clip {i} depends on its batch"
+    # causality: every op is causal (left padding, forward LSTM) => the tokens of a 2 s prefix are a prefix of the tokens
+    pre = enc(wav[:4, :48000], None)
+    assert torch.equal(pre, codes[:4, :, :150])
+    # one clip against the CPU oracle at full length
+    ref = R.acoustic_encode(w, wav[5:6].cpu(), 8)
+    same = (codes[5:6].cpu() == ref).float().mean().item()
+    print(f"acoustic 10 s clip vs oracle: {same:.5f} of ids equal")
+    assert same == 1.0
+
+
+def test_semantic_m_full_depth_properties(cuda_device):
+    """configs[3] per-GPU share: 64 clips x 30 s, 19 conformer layers."""
+    from audiotoken_amd.configs import Wav2VecBertConfig
+    from audiotoken_amd.encoder import Wav2VecBertEncoder
+    from oracle import w2vbert_ref as R
+    w = W.synth_w2vbert_weights(n_layers=19, seed=0, with_vq=True)
+    enc = Wav2VecBertEncoder(Wav2VecBertConfig(), device="cuda:0", quantize=True, weights=w)
+    B, N = 64, 480000
+    base = torch.from_numpy(W.synth_waveform(4, N, 16000, seed=1234)).cuda()
+    wav = (base.repeat(B // 4, 1) * torch.linspace(0.5, 1.0, B, device="cuda").unsqueeze(1)).contiguous()
+    mask = torch.ones_like(wav)
+    mask[3, 300000:] = 0
+    wav[3, 300000:] = 0
+    toks = enc(wav, mask)
+    assert toks.dtype == torch.int16 and tuple(toks.shape) == (B, 1, 1500)
+    assert int(toks.min()) >= 0 and int(toks.max()) < 2048
+    assert torch.equal(toks, enc(wav, mask))                                   # determinism
+    for i in (0, 3, 63):                                                       # batch independence
+        assert torch.equal(enc(wav[i:i + 1], mask[i:i + 1])[0], toks[i]), f"clip {i} depends on its batch"
+    # full-depth oracle comparison on one ragged clip (19 layers, T' = 1500, 937 valid tokens)
+    ref = R.semantic_m_encode({k: torch.from_numpy(v) for k, v in w.items()}, wav[3:4].cpu(), mask[3:4].cpu(), 2, 19)
+    _, am = R.processor(wav[3:4].cpu(), mask[3:4].cpu(), 2)
+    valid = am.bool().unsqueeze(1)
+    eq = (toks[3:4].cpu() == ref)
+    print(f"semantic_m 30 s clip, 19 layers vs oracle: valid {eq[valid].float().mean().item():.5f}, all {eq.float().mean().item():.5f}")
+    assert eq[valid].float().mean().item() >= 0.999    # near-tie flips only; see DESIGN.md §5
