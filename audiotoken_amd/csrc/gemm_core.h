@@ -147,23 +147,35 @@ struct GemmTile {
             if (kt + 1 < nk) load_tile(kt + 1);
             const float* xs = Xs + buf * BM * BK + (wm * TM * 16 + r16) * BK;
             const float* ws = Ws + buf * BN * BK + (wn * TN * 16 + r16) * BK;
+            // both 16-wide K groups' fragments are requested up front (two register sets): the second group's LDS reads
+            // land while the first group's 64 MFMAs issue, instead of being exposed between the groups
+            const int ch0 = ((0 + q) ^ sw) << 2, ch1 = ((4 + q) ^ sw) << 2;
+            f4 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
 #pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-                const int ch = (((kg << 2) + q) ^ sw) << 2;
-                f4 xa[TM], wb[TN];
+            for (int i = 0; i < TM; ++i) xa0[i] = *reinterpret_cast<const f4*>(xs + i * 16 * BK + ch0);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const f4*>(xs + i * 16 * BK + ch);
+            for (int j = 0; j < TN; ++j) wb0[j] = *reinterpret_cast<const f4*>(ws + j * 16 * BK + ch0);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) wb[j] = *reinterpret_cast<const f4*>(ws + j * 16 * BK + ch);
+            for (int i = 0; i < TM; ++i) xa1[i] = *reinterpret_cast<const f4*>(xs + i * 16 * BK + ch1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+            for (int j = 0; j < TN; ++j) wb1[j] = *reinterpret_cast<const f4*>(ws + j * 16 * BK + ch1);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j][e], xa[i][e], acc[i][j], 0, 0, 0);
-            }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb0[j][e], xa0[i][e], acc[i][j], 0, 0, 0);
+            // next tile -> LDS between the two MFMA groups: its ds_writes issue in the shadow of the MFMA pipe instead of
+            // forming a separate non-MFMA phase in front of the barrier
             if (kt + 1 < nk) store_tile(buf ^ 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb1[j][e], xa1[i][e], acc[i][j], 0, 0, 0);
             __syncthreads();
         }
     }

@@ -252,6 +252,16 @@ def max_over_ranks(x: float, dev, dist) -> float:
     return float(t.item())
 
 
+def measured_traffic(group: str):
+    """HBM bytes per launch of a kernel group from the committed rocprofv3 PMC passes (profiles/r01_traffic.json); None if
+    that group was not profiled. PMC collection needs rocprofv3, so it cannot run inside the timed benchmark."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return json.load(f)["kernels"][group]["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def roofline_of(breakdown, flops, nbytes, B):
     dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
     d = breakdown[dom]
@@ -263,7 +273,8 @@ def roofline_of(breakdown, flops, nbytes, B):
     else:
         roof = {"bound": "mfma", "achieved": d["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(d["tflops"] / F32_MFMA_PEAK_TFLOPS, 4)}
-    roof.update({"kernel": dom, "launches_per_step": launches, "avg_launch_ms": round(d["ms_per_step"] / launches, 4), "traffic": None})
+    roof.update({"kernel": dom, "launches_per_step": launches, "avg_launch_ms": round(d["ms_per_step"] / launches, 4),
+                 "traffic": measured_traffic(dom)})
     return roof
 
 
