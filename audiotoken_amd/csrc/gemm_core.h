@@ -144,7 +144,6 @@ struct GemmTile {
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
-            if (kt + 1 < nk) load_tile(kt + 1);
             const float* xs = Xs + buf * BM * BK + (wm * TM * 16 + r16) * BK;
             const float* ws = Ws + buf * BN * BK + (wn * TN * 16 + r16) * BK;
             // both 16-wide K groups' fragments are requested up front (two register sets): the second group's LDS reads
@@ -159,6 +158,9 @@ struct GemmTile {
             for (int i = 0; i < TM; ++i) xa1[i] = *reinterpret_cast<const f4*>(xs + i * 16 * BK + ch1);
 #pragma unroll
             for (int j = 0; j < TN; ++j) wb1[j] = *reinterpret_cast<const f4*>(ws + j * 16 * BK + ch1);
+            // LDS fragment reads are requested first (they gate the first MFMA); the next tile's global loads issue while
+            // those reads are in flight
+            if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
