@@ -17,9 +17,9 @@ import torch
 from .configs import AUDIO_EXTS
 
 
-def _load_wav(path) -> Tuple[torch.Tensor, int]:
+def _load_wav(path_or_file) -> Tuple[torch.Tensor, int]:
     from scipy.io import wavfile
-    sr, data = wavfile.read(str(path))
+    sr, data = wavfile.read(path_or_file if hasattr(path_or_file, "read") else str(path_or_file))
     if data.dtype == np.int16:
         x = data.astype(np.float32) / 32768.0
     elif data.dtype == np.int32:
@@ -33,10 +33,12 @@ def _load_wav(path) -> Tuple[torch.Tensor, int]:
     return torch.from_numpy(np.ascontiguousarray(x.T)), int(sr)
 
 
-def load(path) -> Tuple[torch.Tensor, int]:
+def load(path, file_stream=None) -> Tuple[torch.Tensor, int]:
+    """``path`` names the audio (its extension selects the decoder); ``file_stream`` optionally supplies the bytes
+    (members of tar / zip archives)."""
     ext = os.path.splitext(str(path))[1].lower()
     if ext == ".wav":
-        return _load_wav(path)
+        return _load_wav(file_stream if file_stream is not None else path)
     if ext in AUDIO_EXTS:
         raise NotImplementedError(f"decoding {ext} needs ffmpeg/torchaudio, which this build does not ship; convert to WAV")
     raise ValueError(f"unsupported audio file {path}")
@@ -85,10 +87,10 @@ def read_audio(x, model_sample_rate: int) -> torch.Tensor:
     return convert_audio(audio, sr, model_sample_rate)
 
 
-def process_audio_chunks(file_name, target_sample_rate: int, chunk_size: int) -> Iterator[Tuple[torch.Tensor, str]]:
+def process_audio_chunks(file_name, target_sample_rate: int, chunk_size: int, file_stream=None) -> Iterator[Tuple[torch.Tensor, str]]:
     """Reference ``process_audio_chunks`` (audiotoken/utils.py:71-101): ``chunk_size``-second chunks at the SOURCE
     rate, each resampled on its own (so chunk seams follow the reference), yielded as ``([1, n], file_name)``."""
-    audio, sr = load(file_name)
+    audio, sr = load(file_name, file_stream)
     if audio.shape[0] != 1:
         raise AssertionError(f"Audio needs to be mono, provided {audio.shape[0]} channels for {file_name}")
     step = int(chunk_size * sr)
@@ -97,3 +99,28 @@ def process_audio_chunks(file_name, target_sample_rate: int, chunk_size: int) ->
         if sr != target_sample_rate:
             chunk = resample(chunk, sr, target_sample_rate)
         yield chunk, str(file_name)
+
+
+def iterate_tar(x, model_sample_rate: int, chunk_size: int = 30) -> Iterator[Tuple[torch.Tensor, str]]:
+    """Reference ``iterate_tar`` (audiotoken/utils.py:139-169): member by member, each through process_audio_chunks."""
+    import io
+    import tarfile
+    with tarfile.open(x, "r") as tar:
+        for member in tar.getmembers():
+            if not member.isfile():
+                continue
+            fh = tar.extractfile(member)
+            if fh is None:
+                continue
+            yield from process_audio_chunks(member.name, model_sample_rate, chunk_size, io.BytesIO(fh.read()))
+
+
+def iterate_zip(x, model_sample_rate: int, chunk_size: int = 30) -> Iterator[Tuple[torch.Tensor, str]]:
+    """Reference ``iterate_zip`` (audiotoken/utils.py:104-136)."""
+    import io
+    import zipfile
+    with zipfile.ZipFile(x, "r") as zf:
+        for info in zf.infolist():
+            if info.is_dir():
+                continue
+            yield from process_audio_chunks(info.filename, model_sample_rate, chunk_size, io.BytesIO(zf.read(info.filename)))

@@ -21,7 +21,7 @@ from typing import Callable, List, Optional, Union
 import numpy as np
 import torch
 
-from .configs import (AUDIO_EXTS, AcousticDecoderConfig, AcousticEncoderConfig, EncoderConfig, HubertEncoderConfig, Tokenizers,
+from .configs import (AUDIO_EXTS, TAR_EXTS, ZIP_EXTS, AcousticDecoderConfig, AcousticEncoderConfig, EncoderConfig, HubertEncoderConfig, Tokenizers,
                       Wav2VecBertConfig, num_codebooks_to_bandwidth)
 from .harness import batched, collate_fn, iter_chunk, sanitize_path, save_audio_tokens, save_rel_audio_tokens
 from .logger import get_logger
@@ -118,13 +118,21 @@ class AudioToken:
         return toks.cpu()
 
     def _chunk_stream(self, files, chunk_size: int):
-        from .audio_io import process_audio_chunks
+        """File -> streamed ``chunk_size``-second chunks -> segments (reference datasets.py:107-139)."""
+        from .audio_io import iterate_tar, iterate_zip, process_audio_chunks
+        sr = self.model_config.model_sample_rate
         for file_path in files:
             file_path = str(file_path)
-            if not file_path.endswith(AUDIO_EXTS):
-                logger.error(f"File {file_path} not supported for processing (tar/zip streaming is out of scope here)")
+            if file_path.endswith(AUDIO_EXTS):
+                source = process_audio_chunks(file_path, sr, chunk_size)
+            elif file_path.endswith(TAR_EXTS):
+                source = iterate_tar(file_path, sr, chunk_size)
+            elif file_path.endswith(ZIP_EXTS):
+                source = iterate_zip(file_path, sr, chunk_size)
+            else:
+                logger.error(f"File {file_path} not supported for processing. Only {AUDIO_EXTS + TAR_EXTS + ZIP_EXTS} supported")
                 continue
-            for waveform, file_name in process_audio_chunks(file_path, self.model_config.model_sample_rate, chunk_size):
+            for waveform, file_name in source:
                 yield from iter_chunk(waveform, file_name, sample_rate=self.model_config.model_sample_rate, chunk_size=chunk_size,
                                       model_token_rate=self.model_config.model_token_rate, pad_token=self.model_config.pad_token,
                                       transform=self.transform_func)
@@ -142,7 +150,7 @@ class AudioToken:
         if audio_files is not None:
             files = [str(f) for f in audio_files]
         else:
-            files = sorted(str(p) for ext in AUDIO_EXTS for p in Path(audio_dir).rglob(f"*{ext}"))
+            files = sorted(str(p) for ext in AUDIO_EXTS + TAR_EXTS + ZIP_EXTS for p in Path(audio_dir).rglob(f"*{ext}"))
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             from .distributed import shard_indices

@@ -1,0 +1,131 @@
+"""CPU: input side (WAV / tar / zip streaming, chunk seams) and the real-checkpoint loaders (file formats the
+reference loads: EnCodec .th state dict, HF safetensors + VQ .pkl, HF HuBERT + joblib k-means)."""
+import io
+import os
+import tarfile
+import zipfile
+
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+from audiotoken_amd import audio_io as A
+from audiotoken_amd import weights as W
+
+
+def _write_wav(path, x, sr):
+    wavfile.write(str(path), sr, (np.clip(x, -1, 1) * 32767).astype(np.int16))
+
+
+def test_read_audio_and_chunks(tmp_path):
+    sr = 16000
+    x = W.synth_waveform(1, sr * 3 + 100, sr, seed=2)[0]
+    _write_wav(tmp_path / "a.wav", x, sr)
+    y = A.read_audio(tmp_path / "a.wav", sr)
+    assert tuple(y.shape) == (1, sr * 3 + 100) and y.dtype == torch.float32
+    assert np.abs(y[0].numpy() - x).max() < 1e-4
+    chunks = list(A.process_audio_chunks(tmp_path / "a.wav", sr, 1))
+    assert [c.shape[1] for c, _ in chunks] == [sr, sr, sr, 100]
+    assert all(name.endswith("a.wav") for _, name in chunks)
+    up = A.read_audio(tmp_path / "a.wav", 24000)          # resampled on load
+    assert up.shape[1] == int(np.ceil((sr * 3 + 100) * 1.5))
+    stereo = np.stack([x, -x], 1)
+    wavfile.write(str(tmp_path / "s.wav"), sr, stereo.astype(np.float32))
+    assert float(A.read_audio(tmp_path / "s.wav", sr).abs().max()) < 1e-6       # mono mix of (x, -x)
+    with pytest.raises(NotImplementedError):
+        A.load(tmp_path / "a.mp3")
+
+
+def test_tar_and_zip_members(tmp_path):
+    sr = 24000
+    xs = {f"d/{i}.wav": W.synth_waveform(1, sr + i * 10, sr, seed=i)[0] for i in range(2)}
+    bufs = {}
+    for name, x in xs.items():
+        b = io.BytesIO()
+        wavfile.write(b, sr, x)
+        bufs[name] = b.getvalue()
+    with tarfile.open(tmp_path / "t.tar", "w") as tf:
+        for name, data in bufs.items():
+            ti = tarfile.TarInfo(name)
+            ti.size = len(data)
+            tf.addfile(ti, io.BytesIO(data))
+    with zipfile.ZipFile(tmp_path / "z.zip", "w") as zf:
+        for name, data in bufs.items():
+            zf.writestr(name, data)
+    for it in (A.iterate_tar(tmp_path / "t.tar", sr, 30), A.iterate_zip(tmp_path / "z.zip", sr, 30)):
+        got = list(it)
+        assert [n for _, n in got] == list(xs)
+        for (c, n) in got:
+            assert np.array_equal(c[0].numpy(), xs[n])
+
+
+def test_encodec_checkpoint_roundtrip(tmp_path):
+    from audiotoken_amd.encoder import fold_encodec_weights, load_encodec_checkpoint
+    w = W.synth_encodec_weights(seed=1, with_decoder=True, n_codebooks=4)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    sd["quantizer.vq.layers.0._codebook.inited"] = torch.tensor([1.0])      # buffers present in the real .th file
+    sd["quantizer.vq.layers.0._codebook.cluster_size"] = torch.zeros(1024)
+    sd["quantizer.vq.layers.0._codebook.embed_avg"] = torch.zeros(1024, 128)
+    torch.save(sd, tmp_path / "encodec_24khz.th")
+    got = load_encodec_checkpoint(str(tmp_path / "encodec_24khz.th"))
+    f_ref, f_got = fold_encodec_weights(w), fold_encodec_weights(got)
+    assert list(f_ref) == list(f_got)
+    assert all(np.array_equal(f_ref[k], f_got[k]) for k in f_ref)
+    assert "encoder.model.0.conv.conv.weight" in f_got and "quantizer.vq.layers.3._codebook.e2" in f_got
+    assert not any(k.endswith(("inited", "cluster_size", "embed_avg", "weight_g", "weight_v")) for k in f_got)
+
+
+def test_w2vbert_checkpoint_roundtrip(tmp_path):
+    from safetensors.numpy import save_file
+    from audiotoken_amd.encoder import load_w2vbert_checkpoint
+    w = W.synth_w2vbert_weights(n_layers=1, seed=2, with_vq=True)
+    save_file({k: v for k, v in w.items() if not k.startswith("vq.")}, str(tmp_path / "model.safetensors"))
+    torch.save({"_codebook.embed": torch.from_numpy(w["vq._codebook.embed"]), "_codebook.cluster_size": torch.zeros(1, 2048)},
+               tmp_path / "vq.pkl")
+    got = load_w2vbert_checkpoint(str(tmp_path), str(tmp_path / "vq.pkl"))
+    for k, v in w.items():
+        assert np.array_equal(got[k], v), k
+
+
+def test_hubert_checkpoint_roundtrip(tmp_path):
+    import joblib
+    from safetensors.numpy import save_file
+    from sklearn.cluster import KMeans
+    from audiotoken_amd.hubert import fold_hubert_weights, load_hubert_checkpoint
+    w = W.synth_hubert_weights(n_layers=1, seed=3, with_kmeans=True)
+    save_file({("hubert." + k): v for k, v in w.items() if not k.startswith("kmeans.")}, str(tmp_path / "model.safetensors"))
+    km = KMeans(n_clusters=1000)
+    km.cluster_centers_ = w["kmeans.cluster_centers_"].astype(np.float64)      # sklearn stores float64
+    joblib.dump(km, tmp_path / "km.bin")
+    got = load_hubert_checkpoint(str(tmp_path), str(tmp_path / "km.bin"))
+    f_ref, f_got = fold_hubert_weights(w, 1), fold_hubert_weights(got, 1)
+    assert sorted(f_ref) == sorted(f_got)
+    assert all(np.array_equal(f_ref[k], f_got[k]) for k in f_ref)
+    assert tuple(f_got["encoder.pos_conv_embed.conv.weight"].shape) == (768, 48, 128)
+
+
+def test_batch_files_sharding_logic(tmp_path, monkeypatch):
+    """encode_batch_files: segmentation / batching / per-file save order, with a stand-in encoder (no device)."""
+    from audiotoken_amd import AudioToken, Tokenizers
+    sr = 24000
+    names = []
+    for i in range(3):
+        _write_wav(tmp_path / f"f{i}.wav", W.synth_waveform(1, sr * (i + 1) + 500 * i, sr, seed=i)[0], sr)
+        names.append(tmp_path / f"f{i}.wav")
+    tok = AudioToken(Tokenizers.acoustic, device="cpu", num_codebooks=2)
+    calls = []
+
+    class Fake(torch.nn.Module):
+        def forward(self, x, m):
+            calls.append((tuple(x.shape), m.sum(1).tolist()))
+            return torch.arange(x.shape[0] * 2 * 75, dtype=torch.int16).reshape(x.shape[0], 2, 75)
+
+    tok.encoder = Fake()
+    monkeypatch.setattr(tok, "load_encoder", lambda: None)
+    tok.encode_batch_files(batch_size=4, outdir=tmp_path / "o", chunk_size=1, audio_files=names)
+    segs = [s for shp, ms in calls for s in ms]
+    assert all(shp[1] == sr for shp, _ in calls) and max(shp[0] for shp, _ in calls) == 4
+    assert segs == [sr, sr, sr, sr, sr, sr]            # f1's 500-sample and f2's 1000-sample tails are < 3200: skipped
+    out = {n: np.load(tmp_path / "o" / n) for n in sorted(os.listdir(tmp_path / "o"))}
+    assert {k: v.shape for k, v in out.items()} == {"f0.npy": (2, 75), "f1.npy": (2, 150), "f2.npy": (2, 225)}
