@@ -118,6 +118,7 @@ struct at_encodec {
     const float *dwih[2] = {}, *dwhh[2] = {}, *dbih[2] = {}, *dbhh[2] = {};
     Profiler prof;
     bool fused_stage0 = true;       // conv0 + resblock + strided conv in one kernel (seanet_stage0.hip)
+    bool fused_res64 = true;        // 64-channel residual block in one kernel (seanet_res64.hip)
     bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
 };
 
@@ -585,10 +586,20 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             const int C = 32 << s, L = p.L[s], Lo = p.L[s + 1];
             float* x = ws + p.off_x[s];
             float* r = ws + p.off_r[s];
-            prof.begin(kRes[s], 2, stream);
-            // the block output is only ever consumed through ELU (by the strided conv): apply it once here
-            if (int rc = resblock(h->res[s], x, ws + p.off_h[s], r, L, g, stream, EPI_ELU)) return rc;
-            prof.end(stream);
+            if (s == 1 && h->fused_res64) {
+                // 64-channel block fused into one kernel: 256 B in + 256 B out per row (seanet_res64.hip)
+                Res64Args ra;
+                ra.x = x; ra.out = r; ra.w3 = h->res[1][0].w; ra.b3 = h->res[1][0].b; ra.wt = h->res[1][1].w; ra.bt = h->res[1][1].b;
+                ra.B = g; ra.L = L;
+                prof.begin("res1", 1, stream);
+                if (int rc = launch_seanet_res64(ra, stream)) return rc;
+                prof.end(stream);
+            } else {
+                prof.begin(kRes[s], 2, stream);
+                // the block output is only ever consumed through ELU (by the strided conv): apply it once here
+                if (int rc = resblock(h->res[s], x, ws + p.off_h[s], r, L, g, stream, EPI_ELU)) return rc;
+                prof.end(stream);
+            }
             float* out = s < 3 ? ws + p.off_x[s + 1] : x4 + (long long)b0 * T * kH;
             prof.begin(kDown[s], 1, stream);
             if (int rc = conv_gemm(h->down[s], r, (long long)L * C, L, out, (long long)Lo * 2 * C, Lo, g, PRO_NONE, nullptr, 0, stream))
@@ -628,6 +639,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     AT_REQUIRE(h && name, "null pointer");
     if (std::string(name) == "persistent_lstm") { h->persistent_lstm = value != 0; return 0; }
     if (std::string(name) == "fused_stage0") { h->fused_stage0 = value != 0; return 0; }
+    if (std::string(name) == "fused_res64") { h->fused_res64 = value != 0; return 0; }
     set_error(std::string("unknown option ") + name);
     return -1;
 }

@@ -44,6 +44,16 @@ struct Stage0Args {
 };
 int launch_seanet_stage0(const Stage0Args& a, hipStream_t stream);
 
+// Fused 64-channel SEANet residual block with ELU epilogue (seanet_res64.hip): x [B][L][64] -> out [B][L][64]
+struct Res64Args {
+    const float* x;
+    float* out;
+    const float *w3, *b3;   // conv3 packed [32][3*64], [32]
+    const float *wt, *bt;   // tail packed [64][32 + 64] = [W1 | Wsc], summed bias [64]
+    int B, L;
+};
+int launch_seanet_res64(const Res64Args& a, hipStream_t stream);
+
 int launch_conv0(const float* wav, const float* w, const float* bias, float* out, int B, int N, hipStream_t stream);
 int launch_lstm_step(const GemmArgs& a, const LstmStepArgs& s, hipStream_t stream);
 int launch_rvq_encode(const float* x, long long rows, int T, const float* codebooks, const float* e2, int n_q,
