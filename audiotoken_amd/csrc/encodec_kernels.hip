@@ -75,11 +75,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(GemmArgs a, LstmStepArgs
             const int unit = n >> 2;
             f4 hg = acc[i][j] + *reinterpret_cast<const f4*>(s.b_hh + n);
             f4 g = hg + *reinterpret_cast<const f4*>(s.xg + ((long long)b * s.T + s.t) * (4 * s.H) + n);
-            const float ig = sigmoidf_(g.x), fg = sigmoidf_(g.y), cg = tanhf(g.z), og = sigmoidf_(g.w);
+            const float ig = lstm_sigmoid(g.x), fg = lstm_sigmoid(g.y), cg = lstm_tanh(g.z), og = lstm_sigmoid(g.w);
             const long long ci = (long long)b * s.H + unit;
             const float c_prev = s.first ? 0.f : s.c[ci];
             const float c_new = __fadd_rn(__fmul_rn(fg, c_prev), __fmul_rn(ig, cg));
-            const float h_new = og * tanhf(c_new);
+            const float h_new = og * lstm_tanh(c_new);
             s.c[ci] = c_new;
             const long long oi = ((long long)b * s.T + s.t) * s.H + unit;
             s.h_out[oi] = h_new;
