@@ -85,23 +85,14 @@ struct Profiler {
 };
 
 // ---- small helpers shared by kernels ---------------------------------------------------------
-// ELU(alpha = 1) = x > 0 ? x : expm1(x), branch-free and ~3x cheaper than ocml expm1f (the ELU prologue of a conv
-// evaluates it k/stride times per element, which made the SEANet conv GEMMs VALU-bound):
-//   -0.5 < x <= 0 : degree-8 Taylor polynomial (truncation |x|^9/9! <= 5.4e-9, below half an ulp of the result)
-//   x <= -0.5     : exp2(x*log2e) - 1 on v_exp_f32 (no cancellation there; abs error < 1e-7)
+// ELU(alpha = 1) = x > 0 ? x : expm1(x) as v_mul, v_exp_f32, v_add, v_cmp, v_cndmask. Absolute error <= 1.2e-7 (one ulp
+// of exp(x) <= 1): below the fp32 rounding of the activations it is added to. It is NOT relative-accurate near 0
+// (ocml expm1f is, at ~4x the instruction count) — and instruction count is what matters here: on gfx950 the fp32
+// MFMA and the VALU of a SIMD do not overlap (tools/coissue.hip: MFMA-only 1.90 ms + VALU-only 1.22 ms = 2.94 ms
+// together), so every ELU instruction in a conv kernel is time taken from the matrix pipe.
 __device__ __forceinline__ float elu1(float x) {
-    const float xn = fminf(x, 0.0f);
-    float p = fmaf(xn, 2.4801587e-5f, 1.9841270e-4f);
-    p = fmaf(xn, p, 1.3888889e-3f);
-    p = fmaf(xn, p, 8.3333333e-3f);
-    p = fmaf(xn, p, 4.1666667e-2f);
-    p = fmaf(xn, p, 1.6666667e-1f);
-    p = fmaf(xn, p, 0.5f);
-    p = fmaf(xn, p, 1.0f);
-    p = xn * p;
-    const float e = __expf(xn) - 1.0f;
-    const float neg = xn > -0.5f ? p : e;
-    return x > 0.0f ? x : neg;
+    const float e = __expf(x) - 1.0f;
+    return x > 0.0f ? x : e;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // LSTM gate activations on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each) instead of the
