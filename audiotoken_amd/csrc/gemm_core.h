@@ -6,17 +6,25 @@
 namespace at {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-constexpr int BK = 32;
+constexpr int BK = 32;   // default K tile; GemmTile's BKT parameter may select 16 (see gemm_f32.hip)
 
 // Accumulator ownership after gemm_tile(): lane (r16 = lane&15, q = lane>>4) of wave (wm, wn) holds
 //   acc[i][j] = out[m = m0 + wm*TM*16 + i*16 + r16][n = n0 + wn*TN*16 + j*16 + q*4 .. +3]
-template <int BM, int BN, int WM, int WN, int PRO = PRO_NONE>
+template <int BM, int BN, int WM, int WN, int PRO = PRO_NONE, int BKT = 32>
 struct GemmTile {
+    static_assert(BKT == 32 || BKT == 16, "K tile of 32 or 16");
+    static constexpr int BK = BKT;                        // shadows at::BK inside the struct
+    static constexpr int CPR = BKT / 4;                   // 16-byte chunks per LDS row
+    static constexpr int RPP = 256 / CPR;                 // rows staged per pass of the 256 threads
+    static constexpr int KG = BKT / 16;                   // 16-wide k groups per tile
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static constexpr int TM = BM / WM / 16;
     static constexpr int TN = BN / WN / 16;
-    static constexpr int XCH = BM / 32;                   // float4 chunks per thread, activation tile
-    static constexpr int WCH = (BN >= 32) ? BN / 32 : 1;  // float4 chunks per thread, weight tile
+    static constexpr int XCH = BM / RPP;                  // float4 chunks per thread, activation tile
+    static constexpr int WCH = (BN >= RPP) ? BN / RPP : 1;  // float4 chunks per thread, weight tile
+    static_assert(BM % RPP == 0, "BM must be a multiple of the rows per staging pass");
+    // 16-B chunk swizzle: conflict-free ds_read_b128 (16 rows, same chunk) and ds_write_b128 (all chunks of a row)
+    __device__ static __forceinline__ int swz(int row) { return BKT == 32 ? ((row >> 1) & 7) : ((row >> 1) & 3); }
     static constexpr size_t LDS_BYTES = (size_t)(BM + BN) * BK * 2 * sizeof(float);
 
     // Two bodies, chosen per workgroup by a scalar branch:
@@ -26,7 +34,7 @@ struct GemmTile {
     //  !FAST — boundary tiles: reflect / zero padding, M/N/K tails, dual-source K; clamped unconditional loads + masks.
     __device__ static __forceinline__ void run(const GemmArgs& a, float* smem, int m0, int n0, int b, f4 (&acc)[TM][TN]) {
         const int Tlast_ = a.Tin - 1;
-        const bool fast = BN >= 32 && a.X2 == nullptr && (a.K % BK) == 0 && m0 + BM <= a.M && n0 + BN <= a.N &&
+        const bool fast = BN >= RPP && a.X2 == nullptr && (a.K % BK) == 0 && m0 + BM <= a.M && n0 + BN <= a.N &&
                           (a.ktaps == 1 || a.ldx == a.Cin) && m0 * a.stride - a.pad_left >= 0 &&
                           (m0 + BM - 1) * a.stride - a.pad_left + a.ktaps - 1 <= Tlast_;
         if (fast) run_impl<true>(a, smem, m0, n0, b, acc);
@@ -43,8 +51,8 @@ struct GemmTile {
         const int wm = wave / WN, wn = wave % WN;
         const int r16 = lane & 15, q = lane >> 4;
         const float* Xb = a.X + (long long)b * a.x_bstride;
-        const int lrow = tid >> 3;  // 0..31
-        const int kc = tid & 7;     // 16-byte chunk within the 32-float K slice
+        const int lrow = tid / CPR;  // 0..RPP-1
+        const int kc = tid % CPR;    // 16-byte chunk within the K slice
 
         f4 xreg[XCH], wreg[WCH];
         f4 ureg[PRO == PRO_POWER ? XCH : 1];
@@ -61,9 +69,9 @@ struct GemmTile {
         if (FAST) {
 #pragma unroll
             for (int j = 0; j < XCH; ++j)
-                xp[j] = Xb + (long long)((m0 + lrow + j * 32) * a.stride - a.pad_left) * a.ldx + kc * 4;
+                xp[j] = Xb + (long long)((m0 + lrow + j * RPP) * a.stride - a.pad_left) * a.ldx + kc * 4;
 #pragma unroll
-            for (int j = 0; j < WCH; ++j) wp[j] = a.W + (long long)(n0 + lrow + j * 32) * a.K + kc * 4;
+            for (int j = 0; j < WCH; ++j) wp[j] = a.W + (long long)(n0 + lrow + j * RPP) * a.K + kc * 4;
         }
         auto load_tile = [&](int kt) {
             if (FAST) {
@@ -91,7 +99,7 @@ struct GemmTile {
             const int ldsrc = second ? a.ld2 : a.ldx;
 #pragma unroll
             for (int j = 0; j < XCH; ++j) {
-                const int m = m0 + lrow + j * 32;
+                const int m = m0 + lrow + j * RPP;
                 const int mc = m < a.M ? m : Mlast;
                 int r = mc * a.stride + tap - a.pad_left;
                 bool ok = kvalid && (m < a.M);
@@ -107,7 +115,7 @@ struct GemmTile {
             }
 #pragma unroll
             for (int j = 0; j < WCH; ++j) {
-                const int n = n0 + lrow + j * 32;
+                const int n = n0 + lrow + j * RPP;
                 const int nc = n < a.N ? n : Nlast;
                 wreg[j] = *reinterpret_cast<const f4*>(a.W + (long long)nc * a.K + kk);
                 wok |= ((kvalid && n < a.N) ? 1u : 0u) << j;
@@ -116,18 +124,18 @@ struct GemmTile {
         auto store_tile = [&](int buf) {
 #pragma unroll
             for (int j = 0; j < XCH; ++j) {
-                const int row = lrow + j * 32;
+                const int row = lrow + j * RPP;
                 f4 v = xreg[j];
                 if (PRO == PRO_POWER) v = v * v + ureg[j] * ureg[j];
                 if (!FAST && !((xok >> j) & 1u)) v = f4{0.f, 0.f, 0.f, 0.f};
                 if (PRO == PRO_ELU && (FAST || !xsecond)) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }  // ELU(0) = 0
-                *reinterpret_cast<f4*>(Xs + buf * BM * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) = v;
+                *reinterpret_cast<f4*>(Xs + buf * BM * BK + row * BK + ((kc ^ swz(row)) << 2)) = v;
             }
 #pragma unroll
             for (int j = 0; j < WCH; ++j) {
-                const int row = lrow + j * 32;
-                if (BN >= 32 || row < BN)
-                    *reinterpret_cast<f4*>(Ws + buf * BN * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2)) =
+                const int row = lrow + j * RPP;
+                if (BN >= RPP || row < BN)
+                    *reinterpret_cast<f4*>(Ws + buf * BN * BK + row * BK + ((kc ^ swz(row)) << 2)) =
                         (FAST || ((wok >> j) & 1u)) ? wreg[j] : f4{0.f, 0.f, 0.f, 0.f};
             }
         };
@@ -138,7 +146,7 @@ struct GemmTile {
             for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
         if (nk == 0) return;
 
-        const int sw = (r16 >> 1) & 7;
+        const int sw = swz(r16);
         load_tile(0);
         store_tile(0);
         __syncthreads();
@@ -146,38 +154,36 @@ struct GemmTile {
             const int buf = kt & 1;
             const float* xs = Xs + buf * BM * BK + (wm * TM * 16 + r16) * BK;
             const float* ws = Ws + buf * BN * BK + (wn * TN * 16 + r16) * BK;
-            // both 16-wide K groups' fragments are requested up front (two register sets): the second group's LDS reads
+            // all 16-wide K groups' fragments are requested up front (KG register sets): the second group's LDS reads
             // land while the first group's 64 MFMAs issue, instead of being exposed between the groups
-            const int ch0 = ((0 + q) ^ sw) << 2, ch1 = ((4 + q) ^ sw) << 2;
-            f4 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
+            f4 xa[KG][TM], wb[KG][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) xa0[i] = *reinterpret_cast<const f4*>(xs + i * 16 * BK + ch0);
+            for (int g = 0; g < KG; ++g) {
+                const int ch = ((4 * g + q) ^ sw) << 2;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) wb0[j] = *reinterpret_cast<const f4*>(ws + j * 16 * BK + ch0);
+                for (int i = 0; i < TM; ++i) xa[g][i] = *reinterpret_cast<const f4*>(xs + i * 16 * BK + ch);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) xa1[i] = *reinterpret_cast<const f4*>(xs + i * 16 * BK + ch1);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wb1[j] = *reinterpret_cast<const f4*>(ws + j * 16 * BK + ch1);
+                for (int j = 0; j < TN; ++j) wb[g][j] = *reinterpret_cast<const f4*>(ws + j * 16 * BK + ch);
+            }
             // LDS fragment reads are requested first (they gate the first MFMA); the next tile's global loads issue while
             // those reads are in flight
             if (kt + 1 < nk) load_tile(kt + 1);
+            // the MFMAs of a tile run in two halves (k order unchanged) with the next tile's ds_writes in between: they
+            // issue in the shadow of the MFMA pipe instead of forming a separate non-MFMA phase in front of the barrier
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int s = 0; s < 2 * KG; ++s) {
+                    const int step = half * 2 * KG + s;          // 0 .. 4*KG-1 in k order
+                    const int g = step >> 2, e = step & 3;
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb0[j][e], xa0[i][e], acc[i][j], 0, 0, 0);
-            // next tile -> LDS between the two MFMA groups: its ds_writes issue in the shadow of the MFMA pipe instead of
-            // forming a separate non-MFMA phase in front of the barrier
-            if (kt + 1 < nk) store_tile(buf ^ 1);
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb1[j][e], xa1[i][e], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[g][j][e], xa[g][i][e], acc[i][j], 0, 0, 0);
+                }
+                if (half == 0 && kt + 1 < nk) store_tile(buf ^ 1);
+            }
             __syncthreads();
         }
     }
