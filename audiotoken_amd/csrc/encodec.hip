@@ -119,6 +119,7 @@ struct at_encodec {
     Profiler prof;
     bool fused_stage0 = true;       // conv0 + resblock + strided conv in one kernel (seanet_stage0.hip)
     bool fused_res64 = true;        // 64-channel residual block in one kernel (seanet_res64.hip)
+    bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
     bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
 };
 
@@ -594,6 +595,14 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 prof.begin("res1", 1, stream);
                 if (int rc = launch_seanet_res64(ra, stream)) return rc;
                 prof.end(stream);
+            } else if (s == 2 && h->fused_res128) {
+                // 128-channel block fused: weights stationary in registers, h never leaves the CU (seanet_res128.hip)
+                Res64Args ra;
+                ra.x = x; ra.out = r; ra.w3 = h->res[2][0].w; ra.b3 = h->res[2][0].b; ra.wt = h->res[2][1].w; ra.bt = h->res[2][1].b;
+                ra.B = g; ra.L = L;
+                prof.begin("res2", 1, stream);
+                if (int rc = launch_seanet_res128(ra, stream)) return rc;
+                prof.end(stream);
             } else {
                 prof.begin(kRes[s], 2, stream);
                 // the block output is only ever consumed through ELU (by the strided conv): apply it once here
@@ -640,6 +649,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "persistent_lstm") { h->persistent_lstm = value != 0; return 0; }
     if (std::string(name) == "fused_stage0") { h->fused_stage0 = value != 0; return 0; }
     if (std::string(name) == "fused_res64") { h->fused_res64 = value != 0; return 0; }
+    if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     set_error(std::string("unknown option ") + name);
     return -1;
 }

@@ -53,6 +53,8 @@ struct Res64Args {
     int B, L;
 };
 int launch_seanet_res64(const Res64Args& a, hipStream_t stream);
+// Same block at 128 channels (seanet_res128.hip): x [B][L][128] -> out [B][L][128]; w3 [64][3*128], wt [128][64 + 128]
+int launch_seanet_res128(const Res64Args& a, hipStream_t stream);
 
 int launch_conv0(const float* wav, const float* w, const float* bias, float* out, int B, int N, hipStream_t stream);
 int launch_lstm_step(const GemmArgs& a, const LstmStepArgs& s, hipStream_t stream);
