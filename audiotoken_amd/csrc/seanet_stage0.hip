@@ -18,17 +18,18 @@
 // output; requires N % 2 == 0 so the strided conv needs no right "extra" padding (else the unfused path is used).
 #include "gemm_core.h"
 #include "encodec_kernels.h"
+#include <type_traits>
 
 namespace at {
 
 constexpr int S0_ADV = 126;                // input samples per tile (tile advance)
 constexpr int S0_UO = 63;                  // outputs per tile
-constexpr int S0_XROWS = 132;              // x0 buffer rows (130 used): row i <-> time t0 - 4 + i
+constexpr int S0_XROWS = 144;              // x0 buffer rows (130 used, 9 MFMA row tiles written): row i <-> time t0 - 4 + i
 constexpr int S0_ROWS = 128;               // h / r rows: row j <-> time t0 - 2 + j (8 m-tiles)
 constexpr int S0_RALLOC = 132;             // r rows allocated (the masked 64th output reads rows 126..129)
 constexpr int S0_LDX = 36, S0_LDH = 20, S0_LDR = 36;
 constexpr int S0_WAV = 144;                // waveform segment (136 used)
-constexpr int S0_LDS_FLOATS = 2 * S0_XROWS * S0_LDX + S0_ROWS * S0_LDH + S0_RALLOC * S0_LDR + S0_WAV + 8 * 36 + 112;
+constexpr int S0_LDS_FLOATS = 2 * S0_XROWS * S0_LDX + S0_ROWS * S0_LDH + S0_RALLOC * S0_LDR + S0_WAV + 32 + 112;
 
 __global__ __launch_bounds__(256, 2) void seanet_stage0_kernel(Stage0Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -37,9 +38,8 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0_kernel(Stage0Args a) {
     float* Hs = X0e + S0_XROWS * S0_LDX;             // ELU(conv3 output)
     float* Rs = Hs + S0_ROWS * S0_LDH;               // ELU(block output)
     float* Wv = Rs + S0_RALLOC * S0_LDR;             // waveform segment: Wv[s] = wav[|t0 - 10 + s|]
-    float* W0s = Wv + S0_WAV;                        // conv0 weights [8 channel quads][36]: 4 x (7 taps + bias); the 36-float
-                                                     // quad stride puts the 8 quads a wave reads together on different banks
-    float* Bs = W0s + 8 * 36;                        // biases: b3 [16] | bt [32] | bd [64] (read at epilogue time: registers are full of weights)
+    float* B0s = Wv + S0_WAV;                        // conv0 bias [32]
+    float* Bs = B0s + 32;                            // biases: b3 [16] | bt [32] | bd [64] (read at epilogue time: registers are full of weights)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int N = a.N, L1 = N / 2;
@@ -47,12 +47,13 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0_kernel(Stage0Args a) {
     const long long total_tiles = (long long)a.B * tiles_per_clip;
 
     // ---- weights -> registers, once per workgroup ------------------------------------------------------------------
-    const int c8 = tid & 7;                          // conv0: this thread's 4 output channels
-    if (tid < 32) {
+    if (tid < 32) B0s[tid] = a.b0[tid];
+    // conv0 as a K = 8 MFMA (7 taps + a zero column): A fragment w0f[nt][s] = W0[nt*16 + r16][4s + q]
+    float w0f[2][2];
 #pragma unroll
-        for (int t = 0; t < 7; ++t) W0s[(tid >> 2) * 36 + (tid & 3) * 8 + t] = a.w0[tid * 7 + t];
-        W0s[(tid >> 2) * 36 + (tid & 3) * 8 + 7] = a.b0[tid];
-    }
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w0f[nt][ks] = (4 * ks + q) < 7 ? a.w0[(nt * 16 + r16) * 7 + 4 * ks + q] : 0.f;
     if (tid < 16) Bs[tid] = a.b3[tid];
     if (tid < 32) Bs[16 + tid] = a.bt[tid];
     if (tid < 64) Bs[48 + tid] = a.bd[tid];
@@ -88,27 +89,37 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0_kernel(Stage0Args a) {
         if (tid < S0_WAV) Wv[tid] = wnext;
         wnext = fetch_wav(tile + gridDim.x);
         __syncthreads();
-        // ---- B: conv0 at time |t0 - 4 + i| -> raw and ELU copies ---------------------------------------------------------
-        for (int item = tid; item < 130 * 8; item += 256) {
-            const int i = item >> 3;
-            int tau = t0 - 4 + i;
-            tau = tau < 0 ? -tau : tau;
-            f4 o;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float acc = 0.f;
-#pragma unroll
-                for (int tap = 0; tap < 7; ++tap) {
-                    int idx = tau + tap - 6;
-                    idx = idx < 0 ? -idx : idx;
-                    acc = fmaf(W0s[c8 * 36 + c * 8 + tap], Wv[idx - (t0 - 10)], acc);
-                }
-                o[c] = acc + W0s[c8 * 36 + c * 8 + 7];
+        // ---- B: conv0 at time |t0 - 4 + i| -> raw and ELU copies, on the MFMA (K = 7 taps + a zero column = 2 k-steps;
+        //      the k order 0..6 is the tap order of the scalar conv0 kernel). 9 row tiles cover the 130 rows needed. Only
+        //      the first tile of a clip needs the reflect index map; the rest reads Wv[i + tap] ----------------------------
+        for (int mt = wave; mt < 9; mt += 4) {
+            const int i = mt * 16 + r16;
+            int a0, a1;
+            if (t0 == 0) {
+                int tau = i - 4;
+                tau = tau < 0 ? -tau : tau;
+                a0 = tau + q - 6;
+                a0 = (a0 < 0 ? -a0 : a0) + 10;
+                a1 = tau + q - 2;
+                a1 = (a1 < 0 ? -a1 : a1) + 10;
+            } else {
+                a0 = i + q;
+                a1 = i + 4 + q;
             }
-            *reinterpret_cast<f4*>(X0r + i * S0_LDX + c8 * 4) = o;
-            f4 e;
-            e.x = elu1(o.x); e.y = elu1(o.y); e.z = elu1(o.z); e.w = elu1(o.w);
-            *reinterpret_cast<f4*>(X0e + i * S0_LDX + c8 * 4) = e;
+            a0 = a0 < S0_WAV - 1 ? a0 : S0_WAV - 1;   // rows >= 130 and the zero tap stay inside the (finite) segment
+            a1 = a1 < S0_WAV - 1 ? a1 : S0_WAV - 1;
+            const float x0v = Wv[a0], x1v = Wv[a1];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[nt][0], x0v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[nt][1], x1v, acc, 0, 0, 0);
+                const f4 o = acc + *reinterpret_cast<const f4*>(B0s + nt * 16 + q * 4);
+                *reinterpret_cast<f4*>(X0r + i * S0_LDX + nt * 16 + q * 4) = o;
+                f4 e;
+                e.x = elu1(o.x); e.y = elu1(o.y); e.z = elu1(o.z); e.w = elu1(o.w);
+                *reinterpret_cast<f4*>(X0e + i * S0_LDX + nt * 16 + q * 4) = e;
+            }
         }
         __syncthreads();
         // ---- C + D per row tile (two per wave; the h rows a wave writes are the ones it reads back, so no workgroup
