@@ -82,7 +82,7 @@ Plan make_plan(int B, int N) {
     const size_t T = p.L[7], M = (size_t)B * T;
     p.off_a = takef((size_t)B * p.L[1] * kCd);     // ping: conv 0, 2, 4, 6 outputs
     p.off_b = takef((size_t)B * p.L[2] * kCd);     // pong: conv 1, 3, 5 outputs
-    p.off_part = takef((size_t)B * hub_gn_nslab(p.L[1] > 0 ? p.L[1] : 1) * kCd * 2);
+    p.off_part = takef((size_t)B * hub_ws_nchunk(p.L[1] > 0 ? p.L[1] : 1) * 65 * 2);   // doubles
     p.off_ss = takef((size_t)B * kCd * 2);
     p.off_fmask = takef(M);
     p.off_x = takef(M * kHid);
@@ -259,9 +259,10 @@ int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B,
 
     // ---- conv feature encoder (7 valid strided convs, GroupNorm after the first, GELU) ----------------------
     float* bufs[2] = {ws + p.off_a, ws + p.off_b};
-    prof.begin("feature_extractor", 10, stream);
-    if (int rc = launch_hub_conv0(wav, h->conv_w[0], bufs[0], B, N, p.L[1], stream)) return rc;
-    if (int rc = launch_hub_groupnorm_gelu(bufs[0], h->gn_g, h->gn_b, ws + p.off_part, ws + p.off_ss, B, p.L[1], stream)) return rc;
+    prof.begin("feature_extractor", 9, stream);
+    // conv0 + GroupNorm + GELU: statistics from float64 waveform moments, one pass over the output (hubert_kernels.hip)
+    if (int rc = launch_hub_conv0_gn_gelu(wav, h->conv_w[0], h->gn_g, h->gn_b, ws + p.off_part, ws + p.off_ss, bufs[0], B, N, p.L[1], stream))
+        return rc;
     for (int i = 1; i < 7; ++i) {
         GemmArgs a;
         a.X = bufs[(i - 1) & 1]; a.x_bstride = (long long)p.L[i] * kCd; a.Tin = p.L[i]; a.Cin = kCd; a.ldx = kCd;

@@ -3,8 +3,9 @@
 #include "at_common.h"
 
 namespace at {
-int launch_hub_conv0(const float* wav, const float* w, float* out, int B, int N, int T0, hipStream_t stream);
-int hub_gn_nslab(int T0);
-int launch_hub_groupnorm_gelu(float* x, const float* gamma, const float* beta, float* part, float* ss, int B, int T0, hipStream_t stream);
+// conv0 + GroupNorm + GELU in one pass (statistics from float64 waveform moments); part needs B * hub_ws_nchunk(T0) * 65 doubles
+int hub_ws_nchunk(int T0);
+int launch_hub_conv0_gn_gelu(const float* wav, const float* w, const float* gamma, const float* beta, float* part, float* ss, float* out,
+                             int B, int N, int T0, hipStream_t stream);
 int launch_hub_frame_mask(const float* smask, float* fmask, int B, int N, int T, hipStream_t stream);
 }  // namespace at

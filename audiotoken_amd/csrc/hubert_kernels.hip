@@ -6,10 +6,94 @@
 
 namespace at {
 
-// conv0: [B][N] -> [B][T0][512], k = 10, stride 5, valid, no bias. HBM-bound (20 B in, 2 KB out per frame).
-// One thread = one frame x 4 channels; 128 consecutive threads write one 2-KB row.
-__global__ __launch_bounds__(256) void hub_conv0_kernel(const float* __restrict__ wav, const float* __restrict__ w /*[512][10]*/,
-                                                        float* __restrict__ out, int N, int T0, long long total) {
+// ---- conv0 + GroupNorm + GELU in ONE pass over the 2-KB frame rows ---------------------------------------------------------
+// GroupNorm(512 groups of 1 channel) needs, per (clip, channel), the mean and variance over time of y_c[t] = w_c . x[5t .. 5t+9].
+// Both are quadratic forms of the waveform's windowed moments, which are tiny and cheap:
+//     mean_c = w_c . m,   E[y_c^2] = w_c^T R w_c,    m[k] = mean_t x[5t+k],   R[k][l] = mean_t x[5t+k] x[5t+l]
+// so the statistics come from one float64 sweep over the WAVEFORM (4 B/sample) instead of two sweeps over the conv
+// output (2 KB/frame), and conv0, the affine normalisation and the exact GELU are applied while the output row is
+// written once: 100 GB of HBM traffic (write, 2 x read, read+write) become 25 GB. float64 moments make the quadratic
+// form as accurate as a two-pass variance of the rounded outputs (the reference's own fp32 statistics differ from both
+// by ~1e-6 relative).
+constexpr int WS_CHUNK = 4096;     // frames per partial block
+constexpr int WS_NMOM = 65;        // 10 first moments + 55 second moments (upper triangle)
+
+int hub_ws_nchunk(int T0) { return (T0 + WS_CHUNK - 1) / WS_CHUNK; }
+
+__global__ __launch_bounds__(256) void hub_wavstats_kernel(const float* __restrict__ wav, double* __restrict__ part /*[B][nchunk][65]*/,
+                                                           int N, int T0, int nchunk) {
+    __shared__ double red[4][WS_NMOM];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int t0 = chunk * WS_CHUNK;
+    const int t1 = t0 + WS_CHUNK < T0 ? t0 + WS_CHUNK : T0;
+    const float* x = wav + (long long)b * N;
+    double acc[WS_NMOM];
+#pragma unroll
+    for (int i = 0; i < WS_NMOM; ++i) acc[i] = 0.0;
+    for (int t = t0 + threadIdx.x; t < t1; t += 256) {
+        double xv[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) xv[k] = (double)x[(long long)t * 5 + k];
+        int idx = 10;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            acc[k] += xv[k];
+#pragma unroll
+            for (int l = k; l < 10; ++l) { acc[idx] = fma(xv[k], xv[l], acc[idx]); ++idx; }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < WS_NMOM; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < WS_NMOM)
+        part[((long long)b * nchunk + chunk) * WS_NMOM + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(512) void hub_gn_coeff_kernel(const double* __restrict__ part, const float* __restrict__ w /*[512][10]*/,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ ss /*[B][512][2]: scale, shift*/, int T0, int nchunk) {
+    __shared__ double mom[WS_NMOM];
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c < WS_NMOM) {
+        double s = 0.0;
+        for (int j = 0; j < nchunk; ++j) s += part[((long long)b * nchunk + j) * WS_NMOM + c];   // fixed order: deterministic
+        mom[c] = s / (double)T0;
+    }
+    __syncthreads();
+    double wv[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) wv[k] = (double)w[c * 10 + k];
+    double mean = 0.0, ey2 = 0.0;
+    int idx = 10;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        mean += wv[k] * mom[k];
+#pragma unroll
+        for (int l = k; l < 10; ++l) {
+            const double term = wv[k] * wv[l] * mom[idx++];
+            ey2 += (l == k) ? term : 2.0 * term;
+        }
+    }
+    double var = ey2 - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+    const float scale = rstd * gamma[c];
+    ss[((long long)b * 512 + c) * 2 + 0] = scale;
+    ss[((long long)b * 512 + c) * 2 + 1] = fmaf(-(float)mean, scale, beta[c]);
+}
+
+// conv0: [B][N] -> [B][T0][512], k = 10, stride 5, valid, no bias (20 B in, 2 KB out per frame). One thread = one frame x 4
+// channels; 128 consecutive threads write one 2-KB row: y = fmaf chain over the 10 taps, scale/shift, exact GELU.
+__global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __restrict__ wav, const float* __restrict__ w /*[512][10]*/,
+                                                                const float* __restrict__ ss, float* __restrict__ out, int N, int T0,
+                                                                long long total) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
     const int cg = (int)(gid & 127);
@@ -20,6 +104,7 @@ __global__ __launch_bounds__(256) void hub_conv0_kernel(const float* __restrict_
     float xv[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) xv[k] = x[k];
+    const float* p = ss + (b * 512 + cg * 4) * 2;
     f4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -27,89 +112,22 @@ __global__ __launch_bounds__(256) void hub_conv0_kernel(const float* __restrict_
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 10; ++k) acc = fmaf(wc[k], xv[k], acc);
-        o[c] = acc;
+        const float y = fmaf(acc, p[2 * c], p[2 * c + 1]);
+        o[c] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
     }
     *reinterpret_cast<f4*>(out + bt * 512 + cg * 4) = o;
 }
 
-int launch_hub_conv0(const float* wav, const float* w, float* out, int B, int N, int T0, hipStream_t stream) {
-    const long long total = (long long)B * T0 * 128;
-    hipLaunchKernelGGL(hub_conv0_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wav, w, out, N, T0, total);
+int launch_hub_conv0_gn_gelu(const float* wav, const float* w, const float* gamma, const float* beta, float* part, float* ss, float* out,
+                             int B, int N, int T0, hipStream_t stream) {
+    const int nchunk = hub_ws_nchunk(T0);
+    double* dpart = reinterpret_cast<double*>(part);   // workspace slices are 256-byte aligned
+    hipLaunchKernelGGL(hub_wavstats_kernel, dim3(nchunk, B), dim3(256), 0, stream, wav, dpart, N, T0, nchunk);
     AT_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-// GroupNorm(512 groups, 512 channels) = per (clip, channel) normalisation over ALL T0 frames (padding included, as HF does),
-// eps 1e-5, affine; then exact GELU. Pass 1: per-channel sum / sum of squared deviations in two sweeps over a time slab,
-// combined across slabs with Chan's parallel-variance update on the host-free second kernel. Pass 2: apply in place.
-// Layout [B][T0][512]: a workgroup = (clip, slab of frames); thread = 2 channels... kept simple: 512 threads, 1 channel each.
-constexpr int GN_SLAB = 2048;
-
-__global__ __launch_bounds__(512) void hub_gn_partial_kernel(const float* __restrict__ x, float* __restrict__ part /*[B][nslab][512][2]*/,
-                                                             int T0, int nslab) {
-    const int b = blockIdx.y, slab = blockIdx.x, c = threadIdx.x;
-    const int t0 = slab * GN_SLAB;
-    const int t1 = t0 + GN_SLAB < T0 ? t0 + GN_SLAB : T0;
-    const float* p = x + ((long long)b * T0) * 512 + c;
-    float s = 0.f;
-    for (int t = t0; t < t1; ++t) s += p[(long long)t * 512];
-    const float n = (float)(t1 - t0);
-    const float mean = s / n;
-    float q = 0.f;
-    for (int t = t0; t < t1; ++t) { const float d = p[(long long)t * 512] - mean; q = fmaf(d, d, q); }
-    float* o = part + (((long long)b * nslab + slab) * 512 + c) * 2;
-    o[0] = mean;
-    o[1] = q;
-}
-
-__global__ __launch_bounds__(512) void hub_gn_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ ss /*[B][512][2]: scale, shift*/,
-                                                           int T0, int nslab) {
-    const int b = blockIdx.x, c = threadIdx.x;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int s = 0; s < nslab; ++s) {
-        const float* o = part + (((long long)b * nslab + s) * 512 + c) * 2;
-        const int t0 = s * GN_SLAB;
-        const double nb = (double)((t0 + GN_SLAB < T0 ? t0 + GN_SLAB : T0) - t0);
-        const double delta = (double)o[0] - mean;
-        const double nn = n + nb;
-        mean += delta * nb / nn;
-        m2 += (double)o[1] + delta * delta * n * nb / nn;
-        n = nn;
-    }
-    const float var = (float)(m2 / n);
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    const float scale = rstd * gamma[c];
-    ss[((long long)b * 512 + c) * 2 + 0] = scale;
-    ss[((long long)b * 512 + c) * 2 + 1] = fmaf(-(float)mean, scale, beta[c]);
-}
-
-__global__ __launch_bounds__(256) void hub_gn_apply_gelu_kernel(float* __restrict__ x, const float* __restrict__ ss, int T0, long long total) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread = 4 channels of one frame
-    if (gid >= total) return;
-    const int cg = (int)(gid & 127);
-    const long long bt = gid >> 7;
-    const long long b = bt / T0;
-    f4 v = *reinterpret_cast<const f4*>(x + bt * 512 + cg * 4);
-    const float* p = ss + (b * 512 + cg * 4) * 2;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float y = fmaf(v[k], p[2 * k], p[2 * k + 1]);
-        v[k] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
-    }
-    *reinterpret_cast<f4*>(x + bt * 512 + cg * 4) = v;
-}
-
-int hub_gn_nslab(int T0) { return (T0 + GN_SLAB - 1) / GN_SLAB; }
-
-int launch_hub_groupnorm_gelu(float* x, const float* gamma, const float* beta, float* part, float* ss, int B, int T0, hipStream_t stream) {
-    const int nslab = hub_gn_nslab(T0);
-    hipLaunchKernelGGL(hub_gn_partial_kernel, dim3(nslab, B), dim3(512), 0, stream, x, part, T0, nslab);
-    AT_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(hub_gn_final_kernel, dim3(B), dim3(512), 0, stream, part, gamma, beta, ss, T0, nslab);
+    hipLaunchKernelGGL(hub_gn_coeff_kernel, dim3(B), dim3(512), 0, stream, dpart, w, gamma, beta, ss, T0, nchunk);
     AT_CHECK_HIP(hipGetLastError());
     const long long total = (long long)B * T0 * 128;
-    hipLaunchKernelGGL(hub_gn_apply_gelu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, ss, T0, total);
+    hipLaunchKernelGGL(hub_conv0_gn_gelu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, wav, w, ss, out, N, T0, total);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
