@@ -28,10 +28,10 @@ __device__ __forceinline__ f4 apply_act4(f4 v, int epi) {
     } else if (epi == EPI_ELU) {
         v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
     } else if (epi == EPI_GELU) {
-        v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752440f));
-        v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752440f));
-        v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752440f));
-        v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f));
+        v.x = gelu_erf(v.x);
+        v.y = gelu_erf(v.y);
+        v.z = gelu_erf(v.z);
+        v.w = gelu_erf(v.w);
     } else if (epi == EPI_LOGFLOOR) {
         const float fl = 1.192092955078125e-07f;
         v.x = logf(fmaxf(v.x, fl)); v.y = logf(fmaxf(v.y, fl)); v.z = logf(fmaxf(v.z, fl)); v.w = logf(fmaxf(v.w, fl));
