@@ -309,18 +309,20 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, cons
 // qkv layout: [B*T][3072] = [q | k | v], head h at columns h*64.
 // ------------------------------------------------------------------------------------------------------
 constexpr int ATT_QB = 128, ATT_KB = 64, ATT_D = 64;
+constexpr float ATT_SCALE2 = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e): scores live in the exp2 domain (p = v_exp_f32(s - m))
 constexpr int ATT_QE_LD = 81;   // 73 buckets padded to an odd stride
 constexpr int ATT_VT_LD = 68;
-constexpr int ATT_LDS_FLOATS = ATT_KB * ATT_D + ATT_D * ATT_VT_LD + ATT_QB * ATT_QE_LD + ATT_KB;
+constexpr int ATT_LDS_FLOATS = ATT_KB * ATT_D + ATT_D * ATT_VT_LD + ATT_QB * ATT_QE_LD + ATT_KB + 4;
 
-__global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ amask,
+__global__ __launch_bounds__(256, 2) void relpos_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ amask,
                                                                const float* __restrict__ dist_emb /*[80][64], rows>=73 zero; null = no rel-pos bias*/,
                                                                float* __restrict__ ctx, int T, int hid /*heads*64*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                              // [64 keys][64 d], chunk ^= key&15
     float* Vt = Ks + ATT_KB * ATT_D;               // [64 dv][68]: Vt[dv][key]
-    float* QE = Vt + ATT_D * ATT_VT_LD;            // [128 queries][81]: 0.125 * q.E[bucket]
+    float* QE = Vt + ATT_D * ATT_VT_LD;            // [128 queries][81]: log2(e)/8 * q.E[bucket]
     float* kb = QE + ATT_QB * ATT_QE_LD;           // [64] additive key bias: 0 / finfo.min (padded) / -inf (beyond T)
+    int* kb_any = reinterpret_cast<int*>(kb + ATT_KB);   // [1] any non-zero entry in kb
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, qd = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
                 for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[c][e], qf[i][c][e], acc, 0, 0, 0);
             float* dst = QE + (wave * 32 + i * 16 + r16) * ATT_QE_LD + bt * 16 + qd * 4;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) dst[reg] = 0.125f * acc[reg];
+            for (int reg = 0; reg < 4; ++reg) dst[reg] = ATT_SCALE2 * acc[reg];
         }
     }
     // far-field constants: bucket 0 (r - l <= -64) and bucket 72 (r - l >= 8); own rows, visible after the first barrier
@@ -378,23 +380,31 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
     // K/V staging goes global -> registers -> LDS, one tile ahead: the loads of tile kt+1 are issued before the MFMAs of
     // tile kt and written to LDS after them. All loads are unconditional (row clamped, value masked at the LDS store):
     // loads under a per-lane branch serialise behind s_waitcnt vmcnt(0).
+    // Buffer descriptors over THIS clip's rows only: a key row >= T is out of range and reads as 0 (its score gets -inf from
+    // kb, so any finite value would do) — no clamps, no selects; a tile fetch costs one 32-bit add per load
+    // instead of clamp + 64-bit multiply-add + select (VALU time is not hidden behind the fp32 MFMA).
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const int clip_bytes = T * LD * 4;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(kp + rowbase * LD), 0, clip_bytes - (hid + h * 64) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(vp + rowbase * LD), 0, clip_bytes - (2 * hid + h * 64) * 4, 0x00020000);
     const int st_key = tid >> 2, st_cg = (tid & 3) * 4;      // K tile: thread -> key, 4 chunks from st_cg
     const int st_dv = tid & 63, st_k0 = (tid >> 6) * 16;     // V tile (transposed): thread -> dv, 16 keys from st_k0
-    f4 kv[4];
-    float vv[16];
+    const int k_voff = (st_key * LD + st_cg * 4) * 4;
+    const int v_voff = (st_k0 * LD + st_dv) * 4;
+    const int row_bytes = LD * 4;
+    u4 kv[4];
+    unsigned vv[16];
     float am = 0.f;
     auto prefetch = [&](int kt) {
-        const int r0 = kt * ATT_KB;
-        const int r = r0 + st_key;
-        const float* krow = kp + (rowbase + (r < T ? r : T - 1)) * LD + st_cg * 4;
+        // the whole offset goes through the VGPR operand: only that one is range-checked against num_records
+        const int toff = kt * ATT_KB * row_bytes;
+        const int ko = k_voff + toff;
+        int vo = v_voff + toff;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) kv[j] = *reinterpret_cast<const f4*>(krow + j * 4);
+        for (int j = 0; j < 4; ++j) kv[j] = __builtin_amdgcn_raw_buffer_load_b128(krs, ko + j * 16, 0, 0);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int rr = r0 + st_k0 + e;
-            vv[e] = vp[(rowbase + (rr < T ? rr : T - 1)) * LD + st_dv];
-        }
-        const int rr_m = r0 + (tid & 63);
+        for (int e = 0; e < 16; ++e) { vv[e] = __builtin_amdgcn_raw_buffer_load_b32(vrs, vo, 0, 0); vo += row_bytes; }
+        const int rr_m = kt * ATT_KB + (tid & 63);
         am = amask[rowbase + (rr_m < T ? rr_m : T - 1)];
     };
     prefetch(0);
@@ -402,19 +412,19 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
         const int r0 = kt * ATT_KB;
         __syncthreads();  // previous tile fully consumed (also orders the QE stores before first use)
         {
-            const bool rok = (r0 + st_key) < T;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f4*>(Ks + st_key * ATT_D + (((st_cg + j) ^ (st_key & 15)) << 2)) = rok ? kv[j] : f4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<u4*>(Ks + st_key * ATT_D + (((st_cg + j) ^ (st_key & 15)) << 2)) = kv[j];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (r0 + st_k0 + g * 4 + e) < T ? vv[g * 4 + e] : 0.f;
-                *reinterpret_cast<f4*>(Vt + st_dv * ATT_VT_LD + st_k0 + g * 4) = v;
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<u4*>(Vt + st_dv * ATT_VT_LD + st_k0 + g * 4) = u4{vv[g * 4], vv[g * 4 + 1], vv[g * 4 + 2], vv[g * 4 + 3]};
+            if (tid < ATT_KB) {   // wave 0: additive key bias and "this tile has one" flag
+                const int rr_m = r0 + tid;
+                const float kbv = rr_m < T ? (am != 0.f ? 0.f : FMIN) : -INFINITY;
+                kb[tid] = kbv;
+                const unsigned long long anyb = __builtin_amdgcn_ballot_w64(kbv != 0.f);
+                if (tid == 0) kb_any[0] = anyb != 0ull ? 1 : 0;
             }
-            const int rr_m = r0 + (tid & 63);
-            if (tid < ATT_KB) kb[tid] = rr_m < T ? (am != 0.f ? 0.f : FMIN) : -INFINITY;
         }
         __syncthreads();
         if (kt + 1 < nkt) prefetch(kt + 1);
@@ -437,52 +447,69 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
 #pragma unroll
                     for (int j = 0; j < 4; ++j) s[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][e], qf[i][c][e], s[i][j], 0, 0, 0);
         }
-        // bias + mask, online softmax
+        // bias + mask, online softmax (exp2 domain: the log2(e)/8 factor is folded into the score FMA and into QE)
         const bool far_left = (r0 + ATT_KB - 1) - wl_min <= -64;   // every (l, r) of this wave has r - l <= -64
         const bool far_right = r0 - wl_max >= 8;                   // every (l, r) has r - l >= 8
+        const bool plain = far_left || far_right || !relpos;        // one bias constant per query for the whole tile
+        const bool masked = kb_any[0] != 0;                         // uniform: some key of the tile is padded / beyond T
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float* qe = QE + (wave * 32 + i * 16 + r16) * ATT_QE_LD;
             const float c_far = relpos ? (far_left ? qe[0] : qe[72]) : 0.f;
             float mx = -INFINITY;
+            if (plain && !masked) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f4 kbv = *reinterpret_cast<const f4*>(kb + j * 16 + qd * 4);
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    float bias;
-                    if (far_left || far_right || !relpos) {
-                        bias = c_far;
-                    } else {
-                        int dd = (r0 + j * 16 + qd * 4 + reg) - lq[i];
-                        dd = dd < -64 ? -64 : (dd > 8 ? 8 : dd);
-                        bias = qe[dd + 64];
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float sc = fmaf(ATT_SCALE2, s[i][j][reg], c_far);
+                        s[i][j][reg] = sc;
+                        mx = fmaxf(mx, sc);
                     }
-                    const float t = bias + kbv[reg];
-                    const float sc = fmaf(0.125f, s[i][j][reg], t);
-                    s[i][j][reg] = sc;
-                    mx = fmaxf(mx, sc);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f4 kbv = *reinterpret_cast<const f4*>(kb + j * 16 + qd * 4);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        float bias;
+                        if (plain) {
+                            bias = c_far;
+                        } else {
+                            int dd = (r0 + j * 16 + qd * 4 + reg) - lq[i];
+                            dd = dd < -64 ? -64 : (dd > 8 ? 8 : dd);
+                            bias = qe[dd + 64];
+                        }
+                        const float t = bias + kbv[reg];
+                        const float sc = fmaf(ATT_SCALE2, s[i][j][reg], t);
+                        s[i][j][reg] = sc;
+                        mx = fmaxf(mx, sc);
+                    }
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[i], mx);
-            const float alpha = __expf(mrun[i] - mnew);   // exp(-inf) = 0 on the first tile
             float rs = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const float p = __expf(s[i][j][reg] - mnew);
+                    const float p = __builtin_amdgcn_exp2f(s[i][j][reg] - mnew);
                     s[i][j][reg] = p;
                     rs += p;
                 }
             rs += __shfl_xor(rs, 16);
             rs += __shfl_xor(rs, 32);
-            lrun[i] = lrun[i] * alpha + rs;
-            mrun[i] = mnew;
+            if (__builtin_amdgcn_ballot_w64(mnew != mrun[i]) != 0ull) {   // some query's running maximum moved: rescale
+                const float alpha = __builtin_amdgcn_exp2f(mrun[i] - mnew);   // exp2(-inf) = 0 on the first tile
+                lrun[i] = lrun[i] * alpha + rs;
+                mrun[i] = mnew;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) oacc[i][dt] *= alpha;
+                for (int dt = 0; dt < 4; ++dt) oacc[i][dt] *= alpha;
+            } else {
+                lrun[i] += rs;
+            }
         }
         // O^T += V^T . P^T : A = V^T fragment (dv rows), B = P (lane's own registers)
 #pragma unroll
