@@ -157,3 +157,19 @@ def test_fused_stage0_equals_unfused(encoders):
             enc.set_option(opt, 1)
             assert torch.equal(e0, e1), (opt, B, N, (e0 - e1).abs().max().item())
             assert torch.equal(c0, c1)
+
+
+def test_repeated_encodes_are_identical(encoders):
+    """The persistent LSTM's inter-workgroup hand-off (flags + write-through stores) must never drop or reuse a step: 25
+    encodes of one ragged batch (two 32-clip groups, one partial) give identical tokens and a clean status word."""
+    enc = encoders[8]
+    wav = torch.from_numpy(W.synth_waveform(41, 24000 * 2 + 320 * 7, 24000, seed=77)).cuda()
+    ref = None
+    for it in range(25):
+        codes = enc(wav, None)
+        torch.cuda.synchronize()
+        assert enc.last_status() == 0
+        if ref is None:
+            ref = codes.clone()
+        else:
+            assert torch.equal(ref, codes), it
