@@ -702,8 +702,10 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
     Profiler noprof;
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
     AT_CHECK_HIP(hipMemsetAsync(sync, 0, 512 * sizeof(unsigned), stream));
+    // every activation that is only consumed through ELU is stored already ELU'd (once per element, in the producer's
+    // epilogue) so the transposed convs run the plain-linear GEMM path: y (LSTM + skip) and the block outputs of stages 0-2
     if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,
-                           sync, h->persistent_lstm, 0))
+                           sync, h->persistent_lstm, 1))
         return rc;
     const int Lout = p.L[4];
     for (int b0 = 0; b0 < B; b0 += p.G) {
@@ -713,12 +715,20 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
         for (int s = 0; s < 4; ++s) {
             const int Li = p.L[s], Lo = p.L[s + 1], Co = Cin / 2;
             float* u = ws + p.off_u[s];
-            // ELU -> ConvTranspose1d(k = 2r, stride r) trimmed right by r, as one GEMM with N = r*Cout:
+            // ConvTranspose1d(k = 2r, stride r) of the (already ELU'd) input, trimmed right by r, as one GEMM with N = r*Cout:
             // out[t][p*Cout + co] = x[t-1].W[:, co, p+r] + x[t].W[:, co, p]; [Li][r*Cout] is [Lo][Cout] in memory.
-            if (int rc = conv_gemm(h->dup[s], in, (long long)Li * Cin, Li, u, (long long)Lo * Co, Li, g, PRO_ELU, nullptr, 0, stream, 0))
+            if (int rc = conv_gemm(h->dup[s], in, (long long)Li * Cin, Li, u, (long long)Lo * Co, Li, g, PRO_NONE, nullptr, 0, stream, 0))
                 return rc;
             float* r = ws + p.off_r[s];
-            if (int rc = resblock(h->dres[s], u, ws + p.off_h[s], r, Lo, g, stream)) return rc;
+            if ((Co == 64 && h->fused_res64) || (Co == 128 && h->fused_res128)) {
+                Res64Args ra;
+                ra.x = u; ra.out = r; ra.w3 = h->dres[s][0].w; ra.b3 = h->dres[s][0].b; ra.wt = h->dres[s][1].w; ra.bt = h->dres[s][1].b;
+                ra.B = g; ra.L = Lo;
+                if (int rc = Co == 64 ? launch_seanet_res64(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
+            } else {
+                // the last block's output goes to conv_last, which applies the ELU itself
+                if (int rc = resblock(h->dres[s], u, ws + p.off_h[s], r, Lo, g, stream, s < 3 ? EPI_ELU : EPI_NONE)) return rc;
+            }
             in = r;
             Cin = Co;
         }
