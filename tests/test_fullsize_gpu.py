@@ -64,3 +64,30 @@ def test_semantic_m_full_depth_properties(cuda_device):
     eq = (toks[3:4].cpu() == ref)
     print(f"semantic_m 30 s clip, 19 layers vs oracle: valid {eq[valid].float().mean().item():.5f}, all {eq.float().mean().item():.5f}")
     assert eq[valid].float().mean().item() >= 0.999    # near-tie flips only; see DESIGN.md §5
+
+
+def test_semantic_s_full_depth_properties(cuda_device):
+    """configs[2]: 128 clips x 30 s through HuBERT-base (layer 11) + k-means."""
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    from oracle import hubert_ref as R
+    w = W.synth_hubert_weights(11, 0, True)
+    enc = HubertEncoder(HubertEncoderConfig(), device="cuda:0", quantize=True, weights=w)
+    B, N = 128, 480000
+    base = torch.from_numpy(W.synth_waveform(4, N, 16000, seed=1234))
+    norm = torch.stack([hubert_processor(base[i:i + 1])[0] for i in range(4)]).cuda()   # zero-mean / unit-variance per clip
+    wav = norm.repeat(B // 4, 1).contiguous()
+    wav[5] = wav[5] * 0.5                                        # make some repeated rows distinct
+    mask = torch.ones_like(wav)
+    toks = enc(wav, mask)
+    assert toks.dtype == torch.int16 and tuple(toks.shape) == (B, 1, 1499)
+    assert int(toks.min()) >= 0 and int(toks.max()) < 1000
+    assert torch.equal(toks, enc(wav, mask))                                   # determinism
+    for i in (0, 5, 127):                                                      # batch independence
+        assert torch.equal(enc(wav[i:i + 1], mask[i:i + 1])[0], toks[i]), f"clip {i} depends on its batch"
+    assert torch.equal(toks[1], toks[1 + 4 * 7])                               # identical clips -> identical tokens
+    # one 30 s clip against the CPU oracle at full depth
+    ref = R.semantic_s_encode(w, wav[2:3].cpu(), mask[2:3].cpu(), 11)
+    same = (toks[2:3].cpu() == ref).float().mean().item()
+    print(f"semantic_s 30 s clip, 11 layers vs oracle: {same:.5f} of ids equal")
+    assert same >= 0.999    # near-tie flips only; see DESIGN.md §5
