@@ -347,7 +347,7 @@ EncPlan make_plan(int B, int N) {
     p.off_c = take((size_t)B * kH);
     p.off_y = take((size_t)B * T * kH);
     p.off_emb = take((size_t)B * T * kDim);
-    p.off_sync = take(512);
+    p.off_sync = take(1024);
     p.total_floats = cur;
     return p;
 }
@@ -374,7 +374,7 @@ DecPlan make_dec_plan(int B, int T) {
     p.off_h1 = take((size_t)B * T * kH);
     p.off_c = take((size_t)B * kH);
     p.off_y = take((size_t)B * T * kH);
-    p.off_sync = take(512);
+    p.off_sync = take(1024);
     int C = kH;
     for (int s = 0; s < 4; ++s) {
         C /= 2;
@@ -619,7 +619,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     Profiler& prof = h->prof;
     float* y = ws + p.off_y;
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
-    AT_CHECK_HIP(hipMemsetAsync(sync, 0, 512 * sizeof(unsigned), stream));
+    AT_CHECK_HIP(hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), stream));
     if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
                            sync, h->persistent_lstm, 1))
         return rc;
@@ -701,7 +701,7 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
     float* y = ws + p.off_y;
     Profiler noprof;
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
-    AT_CHECK_HIP(hipMemsetAsync(sync, 0, 512 * sizeof(unsigned), stream));
+    AT_CHECK_HIP(hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), stream));
     // every activation that is only consumed through ELU is stored already ELU'd (once per element, in the producer's
     // epilogue) so the transposed convs run the plain-linear GEMM path: y (LSTM + skip) and the block outputs of stages 0-2
     if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,

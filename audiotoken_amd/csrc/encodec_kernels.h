@@ -23,7 +23,7 @@ struct LstmSeqArgs {
     float* h_out;        // [B][T][512] (also the exchange buffer between workgroups)
     float* y_out;        // optional [B][T][512]: h + skip
     const float* skip;
-    unsigned* sync;      // >= 512 words: [63] sticky status, [128..383] flags[group][slice] (zeroed per launch)
+    unsigned* sync;      // >= 1024 words: [63] sticky status, [128..639] flags[group][slice] (zeroed per launch)
     int B, T;
     int y_elu;           // y_out = ELU(h + skip)
     int n_groups;        // filled by the launcher

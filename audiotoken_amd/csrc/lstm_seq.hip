@@ -5,16 +5,21 @@
 // by launch/dependency latency (measured 21-36 us per step for 3.4 us of MFMA work at B = 256).
 //
 // Decomposition (MI355X: 8 XCDs x 32 CUs, 512 registers per lane at one wave per SIMD, 160 KB LDS per CU):
-//   * clips are cut into groups of 32; a group never talks to another group;
+//   * clips are cut into groups of 16 (one MFMA row tile); a group never talks to another group;
 //   * inside a group, 32 workgroups each own 16 hidden units = 64 interleaved gate rows of W_hh. Those rows stay
-//     RESIDENT IN REGISTERS, already in MFMA A-fragment order (each wave: 32 rows x 512 k = 256 registers per
-//     lane) — W_hh is read from HBM exactly once and costs no LDS bandwidth per step;
-//   * per step the group's h_{t-1} [32 x 512] (64 KB) is staged once into LDS and every wave streams its B
-//     fragments from there (one ds_read_b128 per 8 MFMAs); 256 MFMAs per wave and step = the fp32 floor;
+//     RESIDENT IN REGISTERS, already in MFMA A-fragment order (wave w: gate rows 16w..16w+15 x 512 k = 128 registers
+//     per lane) — W_hh is read from HBM exactly once and costs no LDS bandwidth per step;
+//   * per step the group's h_{t-1} [16 x 512] (32 KB) is staged once into LDS and every wave streams its B
+//     fragments from there (one ds_read_b128 per 4 MFMAs); 128 MFMAs per wave and step;
+//   * ~200 registers and 32 KB of LDS put TWO workgroups — of two different groups — on a CU (16 groups x 32 = 512
+//     workgroups at B = 256): while one waits for its group's hand-off (three dependent memory round trips, ~3 us)
+//     the other one owns the MFMA pipe. With 32-clip groups and one workgroup per CU the pipe idled for that time
+//     (7.9 us per step against 3.4 us of MFMA work);
 //   * the cell update runs on the (clip, unit) pairs a lane's accumulators own — the cell state c never leaves
 //     registers — and the workgroup publishes its 32 x 16 slice of h_t.
 // Group id = blockIdx % n_groups: with the observed round-robin dispatch the 32 members share one XCD and the
-// exchanged h (64 KB per step) stays close to it. That placement is a speed assumption only.
+// exchanged h (32 KB per step) stays close to it. That placement is a speed assumption only (rotating the second half of
+// the grid against the first so that co-resident workgroups are guaranteed to differ in group measured 10 % slower).
 //
 // Hand-off protocol (placement independent; CDNA guide G16 recipe R1 / MI355X_MICROARCH "Valid forms" row 1, with a
 // per-producer flag word instead of a shared counter — a write-through store is acknowledged ~3x sooner than a
@@ -32,19 +37,20 @@
 namespace at {
 
 constexpr int LS_H = 512;          // hidden size
-constexpr int LS_CLIPS = 32;       // clips per group
+constexpr int LS_CLIPS = 16;       // clips per group = one MFMA row tile
 constexpr int LS_SLICES = 32;      // workgroups per group
 constexpr int LS_ROWS = 64;        // gate rows per workgroup = 16 hidden units x 4 gates
 constexpr int LS_KG = LS_H / 16;   // 32 k-groups of 16
-constexpr int LS_H_FLOATS = LS_CLIPS * LS_H;   // 16384 floats = 64 KB
+constexpr int LS_H_FLOATS = LS_CLIPS * LS_H;   // 8192 floats = 32 KB
 constexpr unsigned LS_SPIN_LIMIT = 1u << 18;   // ~0.1-0.3 s of polling; normal waits are microseconds
 constexpr int LS_STATUS = 63;                  // word of a.sync that reports a timed-out wait (sticky for the encode call)
-constexpr int LS_FLAGS = 128;                  // word offset of flags[8 groups][32 slices] in a.sync (512 words)
+constexpr int LS_FLAGS = 128;                  // word offset of flags[16 groups][32 slices] in a.sync (1024 words)
+constexpr int LS_MAX_GROUPS = 16;
 
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 1) void lstm_seq_kernel(LstmSeqArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float Hs[];   // [32 clips][512], 16-B chunk ^= clip & 15
+__global__ __launch_bounds__(256, 2) void lstm_seq_kernel(LstmSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float Hs[];   // [16 clips][512], 16-B chunk ^= clip & 15
     __shared__ int abort_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
@@ -53,35 +59,27 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(LstmSeqArgs a) {
     const int b0 = group * LS_CLIPS;
     const int T = a.T;
 
-    // lane ownership: wave -> clip tile mi and gate tiles {2*nh, 2*nh+1}; acc[jn][reg]: clip = b0 + mi*16 + r16,
-    // unit = slice*16 + (2*nh + jn)*4 + q, gate = reg (i, f, g, o)
-    const int mi = wave >> 1, nh = wave & 1;
-    // ---- this wave's W_hh rows -> registers, once: wr[kg][jn] = W[(2nh+jn)*16 + r16][kg*16 + q*4 .. +3] -------------
-    f4 wr[LS_KG][2];
+    // lane ownership: wave -> gate tile (4 hidden units x 4 gates); acc[reg]: clip = b0 + r16, unit = slice*16 + wave*4 + q,
+    // gate = reg (i, f, g, o)
+    // ---- this wave's W_hh rows -> registers, once: wr[kg] = W[wave*16 + r16][kg*16 + q*4 .. +3] -------------------------
+    f4 wr[LS_KG];
 #pragma unroll
     for (int kg = 0; kg < LS_KG; ++kg)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-            wr[kg][jn] = *reinterpret_cast<const f4*>(a.w_hh + ((long long)slice * LS_ROWS + (2 * nh + jn) * 16 + r16) * LS_H + kg * 16 + q * 4);
+        wr[kg] = *reinterpret_cast<const f4*>(a.w_hh + ((long long)slice * LS_ROWS + wave * 16 + r16) * LS_H + kg * 16 + q * 4);
 
-    const int clip = b0 + mi * 16 + r16;
+    const int clip = b0 + r16;
     const bool clip_ok = clip < a.B;
     const long long own_row = (long long)(clip_ok ? clip : a.B - 1) * T;
-    int unit[2], col[2];
-    f4 bhh[2];
-    float cst[2] = {0.f, 0.f};
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
-        unit[jn] = slice * 16 + (2 * nh + jn) * 4 + q;
-        col[jn] = unit[jn] * 4;
-        bhh[jn] = *reinterpret_cast<const f4*>(a.b_hh + col[jn]);
-    }
-    // h_{t-1} staging: thread -> 16 x (clip row, 16-B chunk) of the [32][512] tile: e = tid + 256*j -> row = e >> 7,
+    const int unit = slice * 16 + wave * 4 + q;
+    const int col = unit * 4;
+    const f4 bhh = *reinterpret_cast<const f4*>(a.b_hh + col);
+    float cst = 0.f;
+    // h_{t-1} staging: thread -> 8 x (clip row, 16-B chunk) of the [16][512] tile: e = tid + 256*j -> row = e >> 7,
     // chunk = tid & 127. Rows beyond B are clamped (their gates are computed on a copy of the last clip, never stored).
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.h_out, 0, (int)a.h_bytes, 0x00020000);
-    int g_off[16], l_off[16];   // byte offset of (row, chunk) at t = 0 in h_out; float offset in Hs
+    int g_off[8], l_off[8];   // byte offset of (row, chunk) at t = 0 in h_out; float offset in Hs
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < 8; ++j) {
         const int row = (tid >> 7) + 2 * j, ch = tid & 127;
         const int cb = b0 + row < a.B ? b0 + row : a.B - 1;
         g_off[j] = (int)((((long long)cb * T) * LS_H + ch * 4) * 4);   // < 2^31: checked by the launcher
@@ -93,21 +91,16 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(LstmSeqArgs a) {
     {
         const int c = q ^ r16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hp[r] = Hs + (mi * 16 + r16) * LS_H + ((((r ^ (c >> 2)) << 2) | (c & 3)) << 2);
+        for (int r = 0; r < 4; ++r) hp[r] = Hs + r16 * LS_H + ((((r ^ (c >> 2)) << 2) | (c & 3)) << 2);
     }
 
     for (int t = 0; t < T; ++t) {
         // input-side gates and the skip input of this step: independent of the recurrence, issued before the wait
-        f4 xg[2];
-        float skipv[2] = {0.f, 0.f};
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) xg[jn] = *reinterpret_cast<const f4*>(a.xg + (own_row + t) * (4 * LS_H) + col[jn]);
-        if (a.y_out) {
-#pragma unroll
-            for (int jn = 0; jn < 2; ++jn) skipv[jn] = a.skip[(own_row + t) * LS_H + unit[jn]];
-        }
+        const f4 xg = *reinterpret_cast<const f4*>(a.xg + (own_row + t) * (4 * LS_H) + col);
+        float skipv = 0.f;
+        if (a.y_out) skipv = a.skip[(own_row + t) * LS_H + unit];
         __builtin_amdgcn_sched_barrier(0);   // keep these loads in front of the wait: their latency hides behind it
-        f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
         if (t > 0) {
             // ---- wait until all 32 slices of this group have published h_{t-1} ---------------------------
             if (wave == 0) {
@@ -130,14 +123,15 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(LstmSeqArgs a) {
             __syncthreads();       // also: every wave has finished reading the previous step's Hs
             if (abort_s) return;   // uniform: a member of the group is not making progress (e.g. not resident)
             // ---- h_{t-1} [32][512] -> LDS: sc1 loads straight to registers, then ds_write ---------------------------
-            u4 stage[16];
+            u4 stage[8];
             const int toff = (t - 1) * (LS_H * 4);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) stage[j] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, g_off[j] + toff, 0, 16);   // aux 16 = sc1
+            for (int j = 0; j < 8; ++j) stage[j] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, g_off[j] + toff, 0, 16);   // aux 16 = sc1
 #pragma unroll
-            for (int j = 0; j < 16; ++j) *reinterpret_cast<u4*>(Hs + l_off[j]) = stage[j];
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<u4*>(Hs + l_off[j]) = stage[j];
             __syncthreads();
-            // ---- gates += h_{t-1} . W_slice^T : 32 k-groups x (4 k-steps x 2 gate tiles) = 256 MFMAs per wave ---------
+            // ---- gates += h_{t-1} . W_slice^T : 32 k-groups x 4 k-steps = 128 MFMAs per wave (one accumulator chain; the
+            //      co-resident workgroup's wave fills the dependent-issue gaps) -----------------------------------------------
             // B fragments are fetched one k-group ahead so the LDS latency hides behind the 8 MFMAs in flight
             f4 hb = *reinterpret_cast<const f4*>(hp[0]);
 #pragma unroll
@@ -146,24 +140,20 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(LstmSeqArgs a) {
                 if (kg + 1 < LS_KG) hbn = *reinterpret_cast<const f4*>(hp[(kg + 1) & 3] + ((kg + 1) >> 2) * 64);
                 __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise re-serialises read -> wait -> MFMAs on one register set
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int jn = 0; jn < 2; ++jn)
-                        acc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[kg][jn][e], hb[e], acc[jn], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[kg][e], hb[e], acc, 0, 0, 0);
                 hb = hbn;
             }
         }
         // ---- cell update (torch CPU LSTMCell order: gates = (hW + b_hh) + igates; c = f*c + i*g unfused) ---------
-        float hn[2];
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const f4 g = (acc[jn] + bhh[jn]) + xg[jn];
+        float hn;
+        {
+            const f4 g = (acc + bhh) + xg;
             const float ig = lstm_sigmoid(g.x), fg = lstm_sigmoid(g.y), cg = lstm_tanh(g.z), og = lstm_sigmoid(g.w);
-            const float c_new = __fadd_rn(__fmul_rn(fg, cst[jn]), __fmul_rn(ig, cg));
-            hn[jn] = og * lstm_tanh(c_new);
-            cst[jn] = c_new;
+            const float c_new = __fadd_rn(__fmul_rn(fg, cst), __fmul_rn(ig, cg));
+            hn = og * lstm_tanh(c_new);
+            cst = c_new;
             if (clip_ok)
-                __hip_atomic_store(reinterpret_cast<unsigned*>(a.h_out) + (own_row + t) * LS_H + unit[jn], __float_as_uint(hn[jn]),
+                __hip_atomic_store(reinterpret_cast<unsigned*>(a.h_out) + (own_row + t) * LS_H + unit, __float_as_uint(hn),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1): no release fence needed
         }
         // ---- publish: every storing wave drains, workgroup barrier, one lane signals ------------------------------
@@ -172,16 +162,13 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(LstmSeqArgs a) {
         if (tid == 0) __hip_atomic_store(flags + slice, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- y = h + skip: not part of the recurrence, so it goes out after the hand-off ------------------------------
         if (a.y_out && clip_ok) {
-#pragma unroll
-            for (int jn = 0; jn < 2; ++jn) {
-                const float yv = hn[jn] + skipv[jn];
-                a.y_out[(own_row + t) * LS_H + unit[jn]] = a.y_elu ? elu1(yv) : yv;
-            }
+            const float yv = hn + skipv;
+            a.y_out[(own_row + t) * LS_H + unit] = a.y_elu ? elu1(yv) : yv;
         }
     }
 }
 
-int lstm_seq_max_clips() { return 8 * LS_CLIPS; }
+int lstm_seq_max_clips() { return LS_MAX_GROUPS * LS_CLIPS; }
 
 int launch_lstm_seq(const LstmSeqArgs& a_in, hipStream_t stream) {
     LstmSeqArgs a = a_in;
@@ -195,7 +182,7 @@ int launch_lstm_seq(const LstmSeqArgs& a_in, hipStream_t stream) {
         AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    AT_CHECK_HIP(hipMemsetAsync(a.sync + LS_FLAGS, 0, 8 * LS_SLICES * sizeof(unsigned), stream));   // flags, every launch
+    AT_CHECK_HIP(hipMemsetAsync(a.sync + LS_FLAGS, 0, LS_MAX_GROUPS * LS_SLICES * sizeof(unsigned), stream));   // flags, every launch
     hipLaunchKernelGGL(lstm_seq_kernel, dim3(a.n_groups * LS_SLICES), dim3(256), lds, stream, a);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
