@@ -120,6 +120,7 @@ struct at_encodec {
     bool fused_stage0 = true;       // conv0 + resblock + strided conv in one kernel (seanet_stage0.hip)
     bool fused_res64 = true;        // 64-channel residual block in one kernel (seanet_res64.hip)
     bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
+    bool fused_down64 = true;       // stage-1 strided conv with register-stationary weights (seanet_down64.hip)
     bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
 };
 
@@ -611,8 +612,13 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             }
             float* out = s < 3 ? ws + p.off_x[s + 1] : x4 + (long long)b0 * T * kH;
             prof.begin(kDown[s], 1, stream);
-            if (int rc = conv_gemm(h->down[s], r, (long long)L * C, L, out, (long long)Lo * 2 * C, Lo, g, PRO_NONE, nullptr, 0, stream))
+            if (s == 1 && h->fused_down64 && L % 4 == 0) {
+                Down64Args da;
+                da.x = r; da.out = out; da.w = h->down[1].w; da.b = h->down[1].b; da.B = g; da.L = L;
+                if (int rc = launch_seanet_down64(da, stream)) return rc;
+            } else if (int rc = conv_gemm(h->down[s], r, (long long)L * C, L, out, (long long)Lo * 2 * C, Lo, g, PRO_NONE, nullptr, 0, stream)) {
                 return rc;
+            }
             prof.end(stream);
         }
     }
@@ -650,6 +656,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_stage0") { h->fused_stage0 = value != 0; return 0; }
     if (std::string(name) == "fused_res64") { h->fused_res64 = value != 0; return 0; }
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
+    if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
     set_error(std::string("unknown option ") + name);
     return -1;
 }

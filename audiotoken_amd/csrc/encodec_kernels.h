@@ -53,6 +53,14 @@ struct Res64Args {
     int B, L;
 };
 int launch_seanet_res64(const Res64Args& a, hipStream_t stream);
+// Encoder stage-1 strided conv (64 -> 128, k 8, stride 4) with register-stationary weights (seanet_down64.hip)
+struct Down64Args {
+    const float* x;     // [B][L][64], already ELU'd
+    float* out;         // [B][L/4][128]
+    const float *w, *b; // packed [128][8*64], [128]
+    int B, L;
+};
+int launch_seanet_down64(const Down64Args& a, hipStream_t stream);
 // Same block at 128 channels (seanet_res128.hip): x [B][L][128] -> out [B][L][128]; w3 [64][3*128], wt [128][64 + 128]
 int launch_seanet_res128(const Res64Args& a, hipStream_t stream);
 

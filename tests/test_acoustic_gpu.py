@@ -147,7 +147,7 @@ def test_fused_stage0_equals_unfused(encoders):
     """seanet_stage0_kernel (conv0 + resblock + strided conv fused) keeps the MFMA / tap order of the separate kernels:
     embeddings and codes must be bit-identical, including the reflect-padded clip start and a ragged last tile."""
     enc = encoders[8]
-    for opt in ("fused_stage0", "fused_res64", "fused_res128"):
+    for opt in ("fused_stage0", "fused_res64", "fused_res128", "fused_down64"):
         for B, N in ((3, 6400), (2, 24000 + 320 * 3), (5, 3200 + 640), (2, 9999)):
             wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=B + 100)).cuda()
             enc.set_option(opt, 1)
