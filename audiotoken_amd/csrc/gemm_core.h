@@ -31,12 +31,15 @@ struct GemmTile {
     //  FAST  — interior tile (every window row inside the clip, full M/N/K tiles, single A source): each thread keeps
     //          XCH + WCH precomputed pointers and a tile fetch is "pointer + kt*32" — ~20 VALU instead of ~340 per
     //          K step (PMC: 2.66 VALU per MFMA and 72 % MFMA-pipe busy before this split).
-    //  !FAST — boundary tiles: reflect / zero padding, M/N/K tails, dual-source K; clamped unconditional loads + masks.
+    //  !FAST — boundary tiles: reflect / zero padding, N/K tails, dual-source K; clamped unconditional loads + masks.
     __device__ static __forceinline__ void run(const GemmArgs& a, float* smem, int m0, int n0, int b, f4 (&acc)[TM][TN]) {
         const int Tlast_ = a.Tin - 1;
-        const bool fast = BN >= RPP && a.X2 == nullptr && (a.K % BK) == 0 && m0 + BM <= a.M && n0 + BN <= a.N &&
+        // an M tail is fine for the FAST body: rows >= M are clamped to row M-1 when the pointers are set up and their
+        // results are dropped by the epilogue
+        const int m_hi = m0 + BM - 1 < a.M - 1 ? m0 + BM - 1 : a.M - 1;
+        const bool fast = BN >= RPP && a.X2 == nullptr && (a.K % BK) == 0 && n0 + BN <= a.N &&
                           (a.ktaps == 1 || a.ldx == a.Cin) && m0 * a.stride - a.pad_left >= 0 &&
-                          (m0 + BM - 1) * a.stride - a.pad_left + a.ktaps - 1 <= Tlast_;
+                          m_hi * a.stride - a.pad_left + a.ktaps - 1 <= Tlast_;
         if (fast) run_impl<true>(a, smem, m0, n0, b, acc);
         else run_impl<false>(a, smem, m0, n0, b, acc);
     }
@@ -68,8 +71,10 @@ struct GemmTile {
         const float* wp[WCH];
         if (FAST) {
 #pragma unroll
-            for (int j = 0; j < XCH; ++j)
-                xp[j] = Xb + (long long)((m0 + lrow + j * RPP) * a.stride - a.pad_left) * a.ldx + kc * 4;
+            for (int j = 0; j < XCH; ++j) {
+                const int m = m0 + lrow + j * RPP;
+                xp[j] = Xb + (long long)((m < a.M ? m : Mlast) * a.stride - a.pad_left) * a.ldx + kc * 4;
+            }
 #pragma unroll
             for (int j = 0; j < WCH; ++j) wp[j] = a.W + (long long)(n0 + lrow + j * RPP) * a.K + kc * 4;
         }
