@@ -94,7 +94,8 @@ __device__ __forceinline__ float elu1(float x) {
     const float e = __expf(x) - 1.0f;
     return x > 0.0f ? x : e;
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid on v_exp_f32 / v_rcp_f32 (~1 ulp each): GEMM epilogues run on the VALU the fp32 MFMA cannot overlap with
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // LSTM gate activations on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each) instead of the
 // branchy ocml expf/tanhf: the cell update sits on the critical path of every one of the 750 dependent steps.
 // Absolute error < 2e-7 (tanh switches to its odd Taylor polynomial below |x| = 1/8 where 1 - 2/(e^2x + 1) cancels).
