@@ -324,6 +324,22 @@ def run_acoustic(args, rank, world, dev, dist):
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
         "roofline": roofline_of(breakdown, flops, nbytes, B), "breakdown": breakdown, "token_checksum": checksum,
     }
+    # PCIe-inclusive rate (host waveforms in pinned memory -> H2D -> encode -> D2H tokens), reported beside `value`, never as it
+    try:
+        host = wav.cpu().pin_memory()
+        out_host = torch.empty(codes.shape, dtype=codes.dtype).pin_memory()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            d = host.to(dev, non_blocking=True)
+            out_host.copy_(enc(d, None), non_blocking=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        res["pcie_inclusive"] = {"value": round(world * B * args.seconds / dt, 2), "unit": "audio-s/s", "ms_per_step": round(dt * 1e3, 3),
+                                 "note": "pinned host waveforms -> H2D -> encode -> D2H tokens, serialized on one stream"}
+        del host, out_host, d
+    except Exception as e:  # pragma: no cover - informational only
+        res["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
     del enc
     torch.cuda.empty_cache()
     return res
@@ -438,6 +454,8 @@ def main():
             "config": primary["config"], "roofline": primary["roofline"], "breakdown": primary["breakdown"],
             "token_checksum": primary["token_checksum"],
         }
+        if "pcie_inclusive" in primary:
+            out["pcie_inclusive"] = primary["pcie_inclusive"]
         if not args.no_cpu_baseline and world == 1:
             if ac is not None:
                 out["cpu_baseline"] = cpu_baseline_acoustic(args.num_codebooks)
