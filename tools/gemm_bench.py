@@ -24,6 +24,11 @@ convs = [  # (name, batch, Tin, Cin, k, stride, N, elu)
     ("res3 k3 256->128", 32, 6000, 256, 3, 1, 128, 1),
     ("final k7 512->128", 256, 750, 512, 7, 1, 128, 1),
 ]
+if len(sys.argv) > 1 and sys.argv[1] == "full":   # the acoustic bench shapes at the full 256-clip batch, producer-side ELU (PRO_NONE)
+    convs = [("down2 k10s5 128->256 B256", 256, 30000, 128, 10, 5, 256, 0), ("down3 k16s8 256->512 B256", 256, 6000, 256, 16, 8, 512, 0),
+             ("res3 k3 256->128 B256 elu", 256, 6000, 256, 3, 1, 128, 1), ("final k7 512->128 B256", 256, 750, 512, 7, 1, 128, 0)]
+    shapes = [("flat 192000x512x4096", 192000, 512, 4096, 0), ("flat 1536000x256x1280", 1536000, 256, 1280, 0)]
+    sys.argv[1] = ""
 if len(sys.argv) > 1:
     convs = [c for c in convs if sys.argv[1] in c[0]]
 for name, Bc, Tin, Cin, k, st, N, elu in convs:
