@@ -40,12 +40,19 @@ struct GemmTile {
         const bool fast = BN >= RPP && a.X2 == nullptr && (a.K % BK) == 0 && n0 + BN <= a.N &&
                           (a.ktaps == 1 || a.ldx == a.Cin) && m0 * a.stride - a.pad_left >= 0 &&
                           m_hi * a.stride - a.pad_left + a.ktaps - 1 <= Tlast_;
-        if (fast) run_impl<true>(a, smem, m0, n0, b, acc);
-        else run_impl<false>(a, smem, m0, n0, b, acc);
+        // TAP body: boundary tiles of windowed convs (reflect / zero padding at the clip ends, N tails, rows that are not
+        // contiguous windows such as grouped convs): a K tile lies inside one tap, so the row pointers are rebuilt only
+        // when the tap changes (every Cin / BK tiles) instead of per K step.
+        const bool tap_ok = BN >= RPP && a.X2 == nullptr && (a.K % BK) == 0 && (a.ktaps == 1 || (a.Cin % BK) == 0);
+        if (fast) run_impl<1>(a, smem, m0, n0, b, acc);
+        else if (tap_ok) run_impl<2>(a, smem, m0, n0, b, acc);
+        else run_impl<0>(a, smem, m0, n0, b, acc);
     }
 
-    template <bool FAST>
+    template <int MODE>   // 1 FAST, 2 TAP, 0 general
     __device__ static __forceinline__ void run_impl(const GemmArgs& a, float* smem, int m0, int n0, int b, f4 (&acc)[TM][TN]) {
+        constexpr bool FAST = MODE == 1;
+        constexpr bool TAP = MODE == 2;
         float* Xs = smem;                // [2][BM*32]
         float* Ws = smem + 2 * BM * BK;  // [2][BN*32]
         const int tid = threadIdx.x;
@@ -78,12 +85,49 @@ struct GemmTile {
 #pragma unroll
             for (int j = 0; j < WCH; ++j) wp[j] = a.W + (long long)(n0 + lrow + j * RPP) * a.K + kc * 4;
         }
+        int tap_cur = 0, tap_off = 0;   // TAP body: current tap and the offset of the K tile inside it
+        if (TAP) {
+#pragma unroll
+            for (int j = 0; j < WCH; ++j) {
+                const int n = n0 + lrow + j * RPP;
+                wp[j] = a.W + (long long)(n < a.N ? n : Nlast) * a.K + kc * 4;   // columns >= N are dropped by the epilogue
+            }
+        }
+        auto tap_rows = [&](int tap) {   // row pointers (and zero-padding mask) of this thread's rows for one tap
+            xok = 0u;
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const int m = m0 + lrow + j * RPP;
+                int r = (m < a.M ? m : Mlast) * a.stride + tap - a.pad_left;
+                const bool lo = r < 0, hi = r > Tlast;
+                const bool ok = a.pad_mode != 0 || !(lo || hi);
+                r = lo ? -r : (hi ? 2 * Tlast - r : r);
+                r = r < 0 ? 0 : (r > Tlast ? Tlast : r);
+                xp[j] = Xb + (long long)r * a.ldx + kc * 4;
+                xok |= (ok ? 1u : 0u) << j;
+            }
+        };
         auto load_tile = [&](int kt) {
             if (FAST) {
 #pragma unroll
                 for (int j = 0; j < XCH; ++j) {
                     xreg[j] = *reinterpret_cast<const f4*>(xp[j] + kt * BK);
                     if (PRO == PRO_POWER) ureg[j] = *reinterpret_cast<const f4*>(xp[j] + kt * BK + a.aux_off);
+                }
+#pragma unroll
+                for (int j = 0; j < WCH; ++j) wreg[j] = *reinterpret_cast<const f4*>(wp[j] + kt * BK);
+                return;
+            }
+            if (TAP) {   // tiles are requested in k order: advance the tap when the tile leaves it
+                if (kt == 0) { tap_cur = 0; tap_off = 0; tap_rows(0); }
+                else {
+                    tap_off += BK;
+                    if (a.ktaps > 1 && tap_off >= a.Cin) { tap_off = 0; ++tap_cur; tap_rows(tap_cur); }
+                }
+#pragma unroll
+                for (int j = 0; j < XCH; ++j) {
+                    xreg[j] = *reinterpret_cast<const f4*>(xp[j] + tap_off);
+                    if (PRO == PRO_POWER) ureg[j] = *reinterpret_cast<const f4*>(xp[j] + tap_off + a.aux_off);
                 }
 #pragma unroll
                 for (int j = 0; j < WCH; ++j) wreg[j] = *reinterpret_cast<const f4*>(wp[j] + kt * BK);
@@ -141,7 +185,7 @@ struct GemmTile {
                 const int row = lrow + j * RPP;
                 if (BN >= RPP || row < BN)
                     *reinterpret_cast<f4*>(Ws + buf * BN * BK + row * BK + ((kc ^ swz(row)) << 2)) =
-                        (FAST || ((wok >> j) & 1u)) ? wreg[j] : f4{0.f, 0.f, 0.f, 0.f};
+                        (FAST || TAP || ((wok >> j) & 1u)) ? wreg[j] : f4{0.f, 0.f, 0.f, 0.f};
             }
         };
 

@@ -116,7 +116,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.N <= 16) return launch_cfg<128, 16, 4, 1>(a, stream);
     if (a.N <= 32) return launch_cfg<128, 32, 4, 1>(a, stream);
-    if (a.N <= 64) return launch_cfg<128, 64, 4, 1>(a, stream);
+    if (a.N <= 64) {
+        // grouped convs (HuBERT positional conv: 48 channels per group): a K tile of 16 keeps every tile inside one tap (TAP body)
+        if (a.ktaps > 1 && a.Cin % 32 != 0 && a.Cin % 16 == 0 && a.K % 16 == 0) return launch_cfg<128, 64, 4, 1, 16>(a, stream);
+        return launch_cfg<128, 64, 4, 1>(a, stream);
+    }
     if ((long long)a.M * a.batch <= 1024) return launch_cfg<64, 64, 2, 2>(a, stream);
     // K tile of 16 for the big tiles: 32 KB of LDS per workgroup and a shorter barrier-to-barrier section measured
     // 4-5 % faster than K tile 32 on the conformer shapes (ffn2 133 -> 139 TFLOP/s); K % 16 != 0 keeps the 32 path
