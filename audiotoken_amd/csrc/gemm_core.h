@@ -43,7 +43,7 @@ struct GemmTile {
         // TAP body: boundary tiles of windowed convs (reflect / zero padding at the clip ends, N tails, rows that are not
         // contiguous windows such as grouped convs): a K tile lies inside one tap, so the row pointers are rebuilt only
         // when the tap changes (every Cin / BK tiles) instead of per K step.
-        const bool tap_ok = BN >= RPP && a.X2 == nullptr && (a.K % BK) == 0 && (a.ktaps == 1 || (a.Cin % BK) == 0);
+        const bool tap_ok = BN >= RPP && (a.K % BK) == 0 && (a.X2 != nullptr ? (a.K1 % BK) == 0 : (a.ktaps == 1 || (a.Cin % BK) == 0));
         if (fast) run_impl<1>(a, smem, m0, n0, b, acc);
         else if (tap_ok) run_impl<2>(a, smem, m0, n0, b, acc);
         else run_impl<0>(a, smem, m0, n0, b, acc);
@@ -107,6 +107,16 @@ struct GemmTile {
                 xok |= (ok ? 1u : 0u) << j;
             }
         };
+        auto second_rows = [&]() {   // dual-source A (ktaps == 1): the K tiles from K1 on come from X2
+            const float* X2b = a.X2 + (long long)b * a.x2_bstride;
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const int m = m0 + lrow + j * RPP;
+                xp[j] = X2b + (long long)(m < a.M ? m : Mlast) * a.ld2 + kc * 4;
+            }
+            xok = ~0u;
+            xsecond = true;
+        };
         auto load_tile = [&](int kt) {
             if (FAST) {
 #pragma unroll
@@ -119,10 +129,11 @@ struct GemmTile {
                 return;
             }
             if (TAP) {   // tiles are requested in k order: advance the tap when the tile leaves it
-                if (kt == 0) { tap_cur = 0; tap_off = 0; tap_rows(0); }
+                if (kt == 0) { tap_cur = 0; tap_off = 0; xsecond = false; tap_rows(0); }
                 else {
                     tap_off += BK;
                     if (a.ktaps > 1 && tap_off >= a.Cin) { tap_off = 0; ++tap_cur; tap_rows(tap_cur); }
+                    else if (a.X2 != nullptr && tap_cur == 0 && tap_off >= a.K1) { tap_off = 0; tap_cur = 1; second_rows(); }
                 }
 #pragma unroll
                 for (int j = 0; j < XCH; ++j) {
