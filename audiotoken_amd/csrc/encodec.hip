@@ -245,7 +245,7 @@ int out_len(int L, int stride) { return (L + stride - 1) / stride; }
 
 // One causal conv as a windowed GEMM over `batch` clips.
 int conv_gemm(const ConvW& c, const float* X, long long x_bstride, int Tin, float* C, long long c_bstride, int M, int batch,
-              int pro, const float* R, long long r_bstride, hipStream_t stream, int pad_mode = 1) {
+              int pro, const float* R, long long r_bstride, hipStream_t stream, int pad_mode = 1, int epi = EPI_NONE) {
     GemmArgs a;
     a.X = X; a.x_bstride = x_bstride; a.Tin = Tin; a.Cin = c.cin; a.ldx = c.cin;
     a.ktaps = c.k; a.stride = c.stride; a.pad_left = c.k - c.stride; a.pad_mode = pad_mode;
@@ -253,24 +253,24 @@ int conv_gemm(const ConvW& c, const float* X, long long x_bstride, int Tin, floa
     a.C = C; a.c_bstride = c_bstride; a.ldc = c.cout;
     a.R = R; a.r_bstride = r_bstride; a.ldr = c.cout;
     a.M = M; a.N = c.cout; a.K = c.k * c.cin; a.batch = batch;
-    a.pro = pro; a.epi = EPI_NONE; a.alpha = 1.0f;
+    a.pro = pro; a.epi = epi; a.alpha = 1.0f;
     return launch_gemm(a, stream);
 }
 
 // SEANet residual block: out = shortcut(x) + conv1(ELU(conv3(ELU(x)))) as TWO windowed GEMMs:
-//   h   = conv3(ELU(x))                                  K = 3C,  N = C/2
-//   out = [ELU(h) | x] . [W1 | Wsc]^T + (b1 + bsc)       K = C/2 + C, N = C   (dual-source A, weights concatenated
+//   h   = ELU(conv3(ELU(x)))                             K = 3C,  N = C/2   (the inner ELU once per element, in the epilogue)
+//   out = [h | x] . [W1 | Wsc]^T + (b1 + bsc)            K = C/2 + C, N = C   (dual-source A, weights concatenated
 // at finalize) — one pass less over the block output than "shortcut, then accumulate".
 int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L, int batch, hipStream_t stream, int epi = EPI_NONE) {
     const int C = r[2].cout;
     const long long xs = (long long)L * C, hs = (long long)L * (C / 2);
-    if (int rc = conv_gemm(r[0], x, xs, L, hbuf, hs, L, batch, PRO_ELU, nullptr, 0, stream)) return rc;
+    if (int rc = conv_gemm(r[0], x, xs, L, hbuf, hs, L, batch, PRO_ELU, nullptr, 0, stream, 1, EPI_ELU)) return rc;
     GemmArgs a;
     a.X = hbuf; a.x_bstride = hs; a.Tin = L; a.Cin = C / 2; a.ldx = C / 2;
     a.X2 = x; a.x2_bstride = xs; a.ld2 = C; a.K1 = C / 2;
     a.W = r[1].w; a.bias = r[1].b;     // r[1] holds the concatenated [C][C/2 + C] weight and the summed bias
     a.C = out; a.c_bstride = xs; a.ldc = C;
-    a.M = L; a.N = C; a.K = C / 2 + C; a.batch = batch; a.pro = PRO_ELU; a.epi = epi;
+    a.M = L; a.N = C; a.K = C / 2 + C; a.batch = batch; a.pro = PRO_NONE; a.epi = epi;
     return launch_gemm(a, stream);
 }
 
