@@ -373,7 +373,9 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_kernel(const float* _
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oacc[i][dt] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    const int wl_min = l0 + wave * 32, wl_max = wl_min + 31;
+    // wave-uniform values are passed through readfirstlane so the far/near and masked/unmasked choices below compile to
+    // scalar branches instead of exec-mask regions
+    const int wl_min = l0 + __builtin_amdgcn_readfirstlane(wave) * 32, wl_max = wl_min + 31;
     const float FMIN = -3.4028234663852886e38f;
 
     const int nkt = (T + ATT_KB - 1) / ATT_KB;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_kernel(const float* _
         const bool far_left = (r0 + ATT_KB - 1) - wl_min <= -64;   // every (l, r) of this wave has r - l <= -64
         const bool far_right = r0 - wl_max >= 8;                   // every (l, r) has r - l >= 8
         const bool plain = far_left || far_right || !relpos;        // one bias constant per query for the whole tile
-        const bool masked = kb_any[0] != 0;                         // uniform: some key of the tile is padded / beyond T
+        const bool masked = __builtin_amdgcn_readfirstlane(kb_any[0]) != 0;   // uniform: some key of the tile is padded / beyond T
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float* qe = QE + (wave * 32 + i * 16 + r16) * ATT_QE_LD;
