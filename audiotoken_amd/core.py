@@ -117,21 +117,25 @@ class AudioToken:
         toks = self.encoder(input_batch, attention_mask)
         return toks.cpu()
 
-    def _chunk_stream(self, files, chunk_size: int):
-        """File -> streamed ``chunk_size``-second chunks -> segments (reference datasets.py:107-139)."""
+    def _chunk_stream(self, files, chunk_size: int, num_workers: int = 0):
+        """File -> streamed ``chunk_size``-second chunks -> segments (reference datasets.py:107-139). Decoding and resampling
+        run ``num_workers`` files ahead on a thread pool (prefetch.py); the segment order equals the sequential one."""
         from .audio_io import iterate_tar, iterate_zip, process_audio_chunks
+        from .prefetch import background, ordered_map
         sr = self.model_config.model_sample_rate
-        for file_path in files:
-            file_path = str(file_path)
+
+        def load(file_path: str):
+            """One unit of host work: plain audio files are decoded completely; archives return a streaming source."""
             if file_path.endswith(AUDIO_EXTS):
-                source = process_audio_chunks(file_path, sr, chunk_size)
-            elif file_path.endswith(TAR_EXTS):
-                source = iterate_tar(file_path, sr, chunk_size)
-            elif file_path.endswith(ZIP_EXTS):
-                source = iterate_zip(file_path, sr, chunk_size)
-            else:
-                logger.error(f"File {file_path} not supported for processing. Only {AUDIO_EXTS + TAR_EXTS + ZIP_EXTS} supported")
-                continue
+                return list(process_audio_chunks(file_path, sr, chunk_size))
+            if file_path.endswith(TAR_EXTS):
+                return background(lambda: iterate_tar(file_path, sr, chunk_size)) if num_workers > 0 else iterate_tar(file_path, sr, chunk_size)
+            if file_path.endswith(ZIP_EXTS):
+                return background(lambda: iterate_zip(file_path, sr, chunk_size)) if num_workers > 0 else iterate_zip(file_path, sr, chunk_size)
+            logger.error(f"File {file_path} not supported for processing. Only {AUDIO_EXTS + TAR_EXTS + ZIP_EXTS} supported")
+            return []
+
+        for source in ordered_map(load, [str(f) for f in files], num_workers):
             for waveform, file_name in source:
                 yield from iter_chunk(waveform, file_name, sample_rate=self.model_config.model_sample_rate, chunk_size=chunk_size,
                                       model_token_rate=self.model_config.model_token_rate, pad_token=self.model_config.pad_token,
@@ -141,8 +145,10 @@ class AudioToken:
                            audio_files: Optional[List[os.PathLike]] = None, audio_dir: Optional[Union[os.PathLike, Path]] = None,
                            **dataloader_kwargs) -> None:
         """core.py:198-289. Files -> ``chunk_size``-second segments -> batches -> encoder -> per-row trimmed
-        ``<stem>.npy`` (append semantics as in the reference). Under ``torch.distributed`` every rank takes a
-        contiguous block of files (all chunks of a file stay on one rank, preserving the append order)."""
+        ``<stem>.npy`` (append semantics as in the reference). ``num_workers`` files are decoded / resampled ahead of the
+        device on a thread pool, in order (the reference's DataLoader workers; 0 = inline). Under ``torch.distributed``
+        every rank takes a contiguous block of files (all chunks of a file stay on one rank, preserving the append
+        order)."""
         self.load_encoder()
         assert audio_files or audio_dir, "Either audio_files or audio_dir must be provided"
         assert not (audio_files and audio_dir), "Provide either audio_files or audio_dir, not both"
@@ -156,7 +162,7 @@ class AudioToken:
             from .distributed import shard_indices
             files = [files[i] for i in shard_indices(len(files), dist.get_rank(), dist.get_world_size())]
         start_time = time.time()
-        for batch in batched(self._chunk_stream(files, chunk_size), batch_size):
+        for batch in batched(self._chunk_stream(files, chunk_size, num_workers), batch_size):
             input_ids, attention_masks, file_pointers = collate_fn(batch)
             input_ids = input_ids.to(self.device)
             attention_masks = attention_masks.to(self.device)

@@ -1,0 +1,81 @@
+"""Ordered host-side prefetch for ``encode_batch_files``.
+
+The reference feeds the encoder from a ``DataLoader`` with ``num_workers`` processes, one file per worker at a time
+(audiotoken/datasets.py:107-139, core.py:244-267), so decoding / resampling overlaps the device work and all chunks of a
+file stay in order. Here the same overlap comes from a small thread pool (WAV parsing, the resampling ``conv1d`` and
+``numpy`` release the GIL): files are loaded ``num_workers`` at a time but YIELDED strictly in the given order, so the
+segment stream — and therefore the batches, the token files and their append order — is identical to the sequential one.
+Archives are streamed member by member by one background thread through a bounded queue (members are not random-access)."""
+from __future__ import annotations
+
+import queue
+import threading
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, Iterable, Iterator, List, TypeVar
+
+T = TypeVar("T")
+R = TypeVar("R")
+_END = object()
+
+
+def ordered_map(fn: Callable[[T], R], items: Iterable[T], num_workers: int) -> Iterator[R]:
+    """``map(fn, items)`` with up to ``num_workers`` calls in flight, results in input order. ``num_workers <= 0`` runs
+    inline (exactly the sequential behaviour). Exceptions surface at the position of the item that raised."""
+    if num_workers <= 0:
+        for it in items:
+            yield fn(it)
+        return
+    with ThreadPoolExecutor(max_workers=num_workers, thread_name_prefix="audiotoken-io") as pool:
+        pending: deque = deque()
+        it = iter(items)
+        try:
+            for item in it:
+                pending.append(pool.submit(fn, item))
+                if len(pending) >= num_workers:
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
+        finally:
+            for f in pending:
+                f.cancel()
+
+
+def background(gen_fn: Callable[[], Iterable[T]], depth: int = 8) -> Iterator[T]:
+    """Run a generator in one background thread, handing its items over through a bounded queue (order preserved)."""
+    q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+    stop = threading.Event()
+
+    def run():
+        try:
+            for x in gen_fn():
+                while not stop.is_set():
+                    try:
+                        q.put(x, timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+                if stop.is_set():
+                    return
+            q.put(_END)
+        except BaseException as e:  # delivered to the consumer
+            q.put(e)
+
+    t = threading.Thread(target=run, name="audiotoken-io-stream", daemon=True)
+    t.start()
+    try:
+        while True:
+            x = q.get()
+            if x is _END:
+                return
+            if isinstance(x, BaseException):
+                raise x
+            yield x
+    finally:
+        stop.set()
+
+
+def chunks_of_files(files: List[str], load_chunks: Callable[[str], list], num_workers: int) -> Iterator:
+    """All chunks of all files, file order and chunk order preserved, ``num_workers`` files decoded ahead."""
+    for chunk_list in ordered_map(load_chunks, files, num_workers):
+        yield from chunk_list
