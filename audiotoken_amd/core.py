@@ -162,11 +162,34 @@ class AudioToken:
             from .distributed import shard_indices
             files = [files[i] for i in shard_indices(len(files), dist.get_rank(), dist.get_world_size())]
         start_time = time.time()
-        for batch in batched(self._chunk_stream(files, chunk_size, num_workers), batch_size):
+        on_gpu = torch.device(self.device).type == "cuda"
+        copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
+
+        def upload(batch):
+            """Collate a batch and start its host->device copy (pinned staging, side stream) so it overlaps the encode of
+            the batch before it; returns (ids, masks, file_pointers, ready_event)."""
             input_ids, attention_masks, file_pointers = collate_fn(batch)
-            input_ids = input_ids.to(self.device)
-            attention_masks = attention_masks.to(self.device)
-            encoded_audio = self.encoder(input_ids, attention_masks)
+            if not on_gpu:
+                return input_ids.to(self.device), attention_masks.to(self.device), file_pointers, None
+            with torch.cuda.stream(copy_stream):
+                ids = input_ids.pin_memory().to(self.device, non_blocking=True)
+                masks = attention_masks.pin_memory().to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return ids, masks, file_pointers, ev
+
+        batches = batched(self._chunk_stream(files, chunk_size, num_workers), batch_size)
+        nxt = next(batches, None)
+        staged = upload(nxt) if nxt is not None else None
+        while staged is not None:
+            input_ids, attention_masks, file_pointers, ev = staged
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                input_ids.record_stream(torch.cuda.current_stream(self.device))
+                attention_masks.record_stream(torch.cuda.current_stream(self.device))
+            encoded_audio = self.encoder(input_ids, attention_masks)      # asynchronous on the device
+            nxt = next(batches, None)
+            staged = upload(nxt) if nxt is not None else None             # next batch's copy flies during this encode
             for tokens_batch, file_pointer in zip(encoded_audio, file_pointers):
                 if audio_files is not None:
                     save_audio_tokens(tokens_batch, file_pointer, str(outdir))
