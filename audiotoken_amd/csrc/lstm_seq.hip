@@ -168,11 +168,29 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_kernel(LstmSeqArgs a) {
     }
 }
 
-int lstm_seq_max_clips() { return LS_MAX_GROUPS * LS_CLIPS; }
+// All workgroups of a launch must be resident at once (they wait for each other): the number of groups per launch follows
+// from what the CURRENT device can hold — CUs x resident workgroups per CU (occupancy query) / 32 slices — so a
+// partitioned or CU-masked GPU gets smaller launches instead of a hand-off timeout. 256 CUs x 2 -> 16 groups = 256 clips.
+int lstm_seq_max_clips() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] == 0) {
+        int cus = 0, per_cu = 0;
+        const size_t lds = (size_t)LS_H_FLOATS * sizeof(float);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(lstm_seq_kernel), 256, lds) != hipSuccess) per_cu = 1;
+        int groups = (cus * (per_cu < 1 ? 1 : per_cu)) / LS_SLICES;
+        groups = groups > LS_MAX_GROUPS ? LS_MAX_GROUPS : groups;
+        cached[dev] = (groups < 1 ? 1 : groups) * LS_CLIPS;   // < 32 resident workgroups cannot run even one group: the status word reports it
+    }
+    return cached[dev];
+}
 
 int launch_lstm_seq(const LstmSeqArgs& a_in, hipStream_t stream) {
     LstmSeqArgs a = a_in;
-    AT_REQUIRE(a.B >= 1 && a.B <= lstm_seq_max_clips() && a.T >= 1, "lstm_seq: 1..256 clips per launch");
+    AT_REQUIRE(a.B >= 1 && a.B <= lstm_seq_max_clips() && a.T >= 1, "lstm_seq: too many clips for one launch on this device");
     a.n_groups = (a.B + LS_CLIPS - 1) / LS_CLIPS;
     a.h_bytes = (long long)a.B * a.T * LS_H * 4;
     AT_REQUIRE(a.h_bytes < (1ll << 31), "lstm_seq: h buffer exceeds the 2 GB buffer-descriptor range");
