@@ -34,3 +34,17 @@ def test_create_without_gpu_fails_loudly_not_silently():
     h = lib.at_encodec_create(0)
     assert not h
     assert "device" in _cabi.last_error()
+
+
+def test_missing_library_fails_loudly():
+    """No CPU or eager fallback: without the built .so, importing the binding's consumers raises HipLibraryError."""
+    import subprocess
+    import sys
+    code = ("import os; os.environ['AUDIOTOKEN_HIP_LIB'] = '/nonexistent/libaudiotoken_hip.so'\n"
+            "from audiotoken_amd import _cabi\n"
+            "try:\n"
+            "    _cabi.load()\n"
+            "except _cabi.HipLibraryError as e:\n"
+            "    print('RAISED', 'no CPU fallback' in str(e))\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
