@@ -15,6 +15,7 @@ from audiotoken_amd.hubert import HubertEncoder, hubert_processor
 from oracle import encodec_ref as RE, w2vbert_ref as RW, hubert_ref as RH
 
 tot = {"acoustic": [0, 0], "semantic_m": [0, 0], "semantic_s": [0, 0]}
+dec_err = 0.0
 for s in range(nseeds):
     # acoustic: 3 clips x 3 s, 8 codebooks
     w = W.synth_encodec_weights(seed=100 + s, with_decoder=False)
@@ -24,6 +25,16 @@ for s in range(nseeds):
     ref = RE.acoustic_encode(w, wav, 8)
     tot["acoustic"][0] += int((got == ref).sum()); tot["acoustic"][1] += ref.numel()
     del enc
+    # decoder: the oracle's codes -> waveform, max abs error
+    from audiotoken_amd.configs import AcousticDecoderConfig
+    from audiotoken_amd.decoder import AcousticDecoder
+    wd = W.synth_encodec_weights(seed=100 + s)
+    dec = AcousticDecoder(config=AcousticDecoderConfig(bandwidth=6), device="cuda:0", weights=wd)
+    codes = torch.randint(0, 1024, (2, 8, 40 + s), dtype=torch.long)
+    got_w = dec(codes.cuda()).cpu()
+    ref_w = RE.acoustic_decode(wd, codes)
+    dec_err = max(dec_err, float((got_w.reshape(-1) - ref_w.reshape(-1)).abs().max()))
+    del dec
     # semantic_m: 4 conformer layers, 2 clips x 4 s, one ragged
     w = W.synth_w2vbert_weights(n_layers=4, seed=200 + s, with_vq=True)
     enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=4), device="cuda:0", quantize=True, weights=w)
@@ -46,4 +57,4 @@ for s in range(nseeds):
     tot["semantic_s"][0] += int((got == ref).sum()); tot["semantic_s"][1] += ref.numel()
     del enc
     print(f"seed {s}: " + ", ".join(f"{k} {v[0]}/{v[1]}" for k, v in tot.items()), flush=True)
-print({k: v[0] / max(v[1], 1) for k, v in tot.items()}, f"{time.time() - t0:.0f} s")
+print({k: v[0] / max(v[1], 1) for k, v in tot.items()}, f"decoder max abs err {dec_err:.2e}", f"{time.time() - t0:.0f} s")
