@@ -121,6 +121,7 @@ struct at_encodec {
     bool fused_res64 = true;        // 64-channel residual block in one kernel (seanet_res64.hip)
     bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
     bool fused_down64 = true;       // stage-1 strided conv with register-stationary weights (seanet_down64.hip)
+    int sub_batch = at::sub_batch();   // clips per pass through the conv stack: bounds the workspace (option "subbatch")
     bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
 };
 
@@ -327,11 +328,11 @@ struct EncPlan {
     size_t total_floats;
 };
 
-EncPlan make_plan(int B, int N) {
+EncPlan make_plan(int B, int N, int sub) {
     EncPlan p;
     p.L[0] = N;
     for (int s = 0; s < 4; ++s) p.L[s + 1] = out_len(p.L[s], kRatiosEnc[s]);
-    p.G = B < sub_batch() ? B : sub_batch();
+    p.G = B < sub ? B : sub;
     size_t cur = 0;
     auto take = [&](size_t n) { size_t o = cur; cur += (n + 63) / 64 * 64; return o; };
     for (int s = 0; s < 4; ++s) {
@@ -361,11 +362,11 @@ struct DecPlan {
     size_t total_floats;
 };
 
-DecPlan make_dec_plan(int B, int T) {
+DecPlan make_dec_plan(int B, int T, int sub) {
     DecPlan p;
     p.L[0] = T;
     for (int s = 0; s < 4; ++s) p.L[s + 1] = p.L[s] * kRatiosDec[s];
-    p.G = B < sub_batch() ? B : sub_batch();
+    p.G = B < sub ? B : sub;
     size_t cur = 0;
     auto take = [&](size_t n) { size_t o = cur; cur += (n + 63) / 64 * 64; return o; };
     p.off_z = take((size_t)B * T * kDim);
@@ -542,9 +543,8 @@ void at_encodec_destroy(at_encodec_t* h) {
 int at_encodec_num_codebooks(const at_encodec_t* h) { return h ? h->n_codebooks : 0; }
 
 size_t at_encodec_workspace_bytes(const at_encodec_t* h, int B, int N) {
-    (void)h;
     if (B <= 0 || N <= 0) return 0;
-    return make_plan(B, N).total_floats * sizeof(float);
+    return make_plan(B, N, h ? h->sub_batch : sub_batch()).total_floats * sizeof(float);
 }
 
 static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes, int* T_out,
@@ -555,7 +555,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     AT_REQUIRE(B >= 1 && N >= 10, "need B >= 1 and N >= 10 samples");
     AT_REQUIRE(n_q >= 1 && n_q <= h->n_codebooks, "n_q out of range for the loaded codebooks");
     hipStream_t stream = (hipStream_t)stream_;
-    const EncPlan p = make_plan(B, N);
+    const EncPlan p = make_plan(B, N, h->sub_batch);
     AT_REQUIRE(workspace_bytes >= p.total_floats * sizeof(float), "workspace too small");
     AT_REQUIRE(p.L[3] > 8, "clip too short for the strided convs");
     float* ws = (float*)workspace;
@@ -657,6 +657,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res64") { h->fused_res64 = value != 0; return 0; }
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
+    if (std::string(name) == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
     set_error(std::string("unknown option ") + name);
     return -1;
 }
@@ -687,9 +688,8 @@ int at_encodec_profile_read(at_encodec_t* h, char* names, size_t names_cap, floa
 }
 
 size_t at_encodec_decode_workspace_bytes(const at_encodec_t* h, int B, int T) {
-    (void)h;
     if (B <= 0 || T <= 0) return 0;
-    return make_dec_plan(B, T).total_floats * sizeof(float);
+    return make_dec_plan(B, T, h ? h->sub_batch : sub_batch()).total_floats * sizeof(float);
 }
 
 int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T, float* wav, void* workspace,
@@ -698,7 +698,7 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
     AT_REQUIRE(codes && wav && workspace, "null pointer");
     AT_REQUIRE(B >= 1 && T >= 7 && K >= 1 && K <= h->n_codebooks, "bad B/T/K");
     hipStream_t stream = (hipStream_t)stream_;
-    const DecPlan p = make_dec_plan(B, T);
+    const DecPlan p = make_dec_plan(B, T, h->sub_batch);
     AT_REQUIRE(workspace_bytes >= p.total_floats * sizeof(float), "workspace too small");
     float* ws = (float*)workspace;
     float* z = ws + p.off_z;

@@ -115,6 +115,25 @@ class AcousticEncoder(torch.nn.Module):
     def set_option(self, name: str, value: int) -> None:
         _cabi.check(self._h.lib.at_encodec_set_option(self._h.handle, name.encode(), int(value)), f"at_encodec_set_option({name})")
 
+    def _sized_workspace(self, B: int, N: int):
+        """Workspace for a [B, N] encode. The conv stack runs in sub-batches of `subbatch` clips (default 256, which needs
+        ~0.22 GB per clip-10-s); when the allocation does not fit, the sub-batch is halved (option "subbatch") and the
+        request repeated — results do not depend on it (clips are independent), only the workspace size does."""
+        lib = self._h.lib
+        sub = getattr(self, "_subbatch", None)
+        while True:
+            nbytes = lib.at_encodec_workspace_bytes(self._h.handle, B, N)
+            try:
+                return nbytes, self._workspace(nbytes)
+            except torch.OutOfMemoryError:
+                sub = max(1, (sub or min(B, 256)) // 2)
+                if sub < 1 or getattr(self, "_subbatch", None) == 1:
+                    raise
+                logger.warning(f"workspace of {nbytes / 2**30:.1f} GiB does not fit: conv-stack sub-batch -> {sub} clips")
+                self.set_option("subbatch", sub)
+                self._subbatch = sub
+                torch.cuda.empty_cache()
+
     def last_status(self) -> int:
         """0 = ok, 1 = a bounded wait inside the persistent LSTM kernel gave up (synchronises the device)."""
         return int(self._status.item())
@@ -130,8 +149,7 @@ class AcousticEncoder(torch.nn.Module):
         lib = self._h.lib
         codes = torch.empty((B, self.n_q, T), dtype=torch.int16, device=self.device)
         emb = torch.empty((B, T, W.ENCODEC_DIM), dtype=torch.float32, device=self.device) if return_embeddings else None
-        nbytes = lib.at_encodec_workspace_bytes(self._h.handle, B, N)
-        ws = self._workspace(nbytes)
+        nbytes, ws = self._sized_workspace(B, N)
         t_out = C.c_int(0)
         with torch.cuda.device(self.device):
             stream = _cabi.current_stream_handle(self.device)

@@ -72,8 +72,11 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
                               int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream,
                               uint32_t* status_dev);
 
-/* Options: "persistent_lstm" 1/0 — whole-sequence persistent LSTM kernel (default on when the device has >= 256 CUs)
- * or one launch per time step. Both give the same arithmetic. */
+/* Options (all leave the results bit-identical; they select kernels or bound memory):
+ *   "persistent_lstm" 1/0 — whole-sequence persistent LSTM kernel (default on) or one launch per time step;
+ *   "fused_stage0", "fused_res64", "fused_res128", "fused_down64" 1/0 — fused SEANet kernels (default on) or the GEMM path;
+ *   "subbatch" n >= 1 — clips per pass through the conv stack (default 256 or $AUDIOTOKEN_SUBBATCH): bounds
+ *   at_encodec_workspace_bytes / at_encodec_decode_workspace_bytes, which must be re-queried after changing it. */
 int at_encodec_set_option(at_encodec_t* h, const char* name, int value);
 
 /* Optional timing taps for the benchmark: when enabled, encode brackets each kernel group (conv0, res0..3,

@@ -173,3 +173,16 @@ def test_repeated_encodes_are_identical(encoders):
             ref = codes.clone()
         else:
             assert torch.equal(ref, codes), it
+
+
+def test_subbatch_option_does_not_change_tokens(encoders):
+    """The conv stack's sub-batch (workspace bound, shrunk automatically on allocation failure) is invisible in the output."""
+    enc = encoders[8]
+    wav = torch.from_numpy(W.synth_waveform(11, 24000 + 320 * 5, 24000, seed=91)).cuda()
+    ref = enc(wav, None).clone()
+    try:
+        for sub in (1, 4, 8):
+            enc.set_option("subbatch", sub)
+            assert torch.equal(enc(wav, None), ref), sub
+    finally:
+        enc.set_option("subbatch", 256)
