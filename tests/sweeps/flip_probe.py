@@ -1,7 +1,7 @@
 """Explain id mismatches vs the oracle: for the frames where ids differ, print the oracle's top-2 distance margin at the first
 differing codebook level (a margin at fp32 rounding level = a legitimate near-tie) and the embedding error there."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from audiotoken_amd import weights as W
 from audiotoken_amd.configs import AcousticEncoderConfig

@@ -1,7 +1,7 @@
 """Randomised parity sweep on the GPU box: several weight seeds x waveform seeds, HIP path vs the CPU oracle.
 Prints the fraction of identical token ids per tokenizer (expected 1.0; a near-tie flip would show up as < 1)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from audiotoken_amd import weights as W
