@@ -145,45 +145,48 @@ int launch_dft_f64(const double* frames, const double* dft, float* spec, long lo
 // ------------------------------------------------------------------------------------------------------
 // Masked per-clip, per-mel-bin mean and POPULATION variance (processors.py:117-135):
 //   mean = sum(x*m)/max(cnt,1);  var = sum(((x*m) - mean)^2 * m)/max(cnt,1)
-// One workgroup (320 threads = 80 bins x 4 frame groups) per clip.
+// One workgroup (320 threads = 80 bins x 4 frame groups) per clip. Sums run in float64 and are rounded once: the
+// normalisation divides by sqrt(var + 1e-7), so on near-stationary input (e.g. a tone whose period divides the 160-sample
+// hop: every frame identical, true variance 0) an fp32 summation-order difference of one ulp in the mean would be amplified
+// 3000x; the exact mean makes x - mean vanish there, as it does in the reference.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(320) void fbank_stats_kernel(const float* __restrict__ logmel, const float* __restrict__ fmask,
                                                           float* __restrict__ stats /*[B][2][80]*/, int F) {
-    __shared__ float red[4][80];
+    __shared__ double red[4][80];
     __shared__ float mean_s[80];
-    __shared__ float cnt_s;
+    __shared__ double cnt_s;
     const int b = blockIdx.x;
     const int bin = threadIdx.x % 80, grp = threadIdx.x / 80;
     const float* x = logmel + (long long)b * F * 80;
     const float* m = fmask + (long long)b * F;
-    float s = 0.f, c = 0.f;
+    double s = 0.0, c = 0.0;
     for (int f = grp; f < F; f += 4) {
         const float mk = m[f];
-        s += x[(long long)f * 80 + bin] * mk;
-        c += mk;
+        s += (double)(x[(long long)f * 80 + bin] * mk);
+        c += (double)mk;
     }
     red[grp][bin] = s;
     __syncthreads();
-    __shared__ float cred[4];  // every bin column sees the same mask: bin 0's four partial counts define cnt
+    __shared__ double cred[4];  // every bin column sees the same mask: bin 0's four partial counts define cnt
     if (bin == 0) cred[grp] = c;
     __syncthreads();
-    if (threadIdx.x == 0) cnt_s = fmaxf(cred[0] + cred[1] + cred[2] + cred[3], 1.0f);
+    if (threadIdx.x == 0) cnt_s = fmax((cred[0] + cred[1]) + (cred[2] + cred[3]), 1.0);
     __syncthreads();
-    if (grp == 0) mean_s[bin] = (red[0][bin] + red[1][bin] + red[2][bin] + red[3][bin]) / cnt_s;
+    if (grp == 0) mean_s[bin] = (float)(((red[0][bin] + red[1][bin]) + (red[2][bin] + red[3][bin])) / cnt_s);
     __syncthreads();
     const float mean = mean_s[bin];
-    float v = 0.f;
+    double v = 0.0;
     for (int f = grp; f < F; f += 4) {
         const float mk = m[f];
         const float d = x[(long long)f * 80 + bin] * mk - mean;
-        v += d * d * mk;
+        v += (double)(d * d * mk);
     }
     __syncthreads();
     red[grp][bin] = v;
     __syncthreads();
     if (grp == 0) {
         stats[((long long)b * 2 + 0) * 80 + bin] = mean;
-        stats[((long long)b * 2 + 1) * 80 + bin] = (red[0][bin] + red[1][bin] + red[2][bin] + red[3][bin]) / cnt_s;
+        stats[((long long)b * 2 + 1) * 80 + bin] = (float)(((red[0][bin] + red[1][bin]) + (red[2][bin] + red[3][bin])) / cnt_s);
     }
 }
 
