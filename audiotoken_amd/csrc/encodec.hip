@@ -121,6 +121,7 @@ struct at_encodec {
     bool fused_res64 = true;        // 64-channel residual block in one kernel (seanet_res64.hip)
     bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
     bool fused_down64 = true;       // stage-1 strided conv with register-stationary weights (seanet_down64.hip)
+    bool fused_dectail = true;      // decoder: last transposed conv + block + final conv in one kernel (seanet_dectail.hip)
     int sub_batch = at::sub_batch();   // clips per pass through the conv stack: bounds the workspace (option "subbatch")
     bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
 };
@@ -657,6 +658,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res64") { h->fused_res64 = value != 0; return 0; }
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
+    if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }
     if (std::string(name) == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
     set_error(std::string("unknown option ") + name);
     return -1;
@@ -719,8 +721,19 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
         const int g = (B - b0) < p.G ? (B - b0) : p.G;
         const float* in = y + (long long)b0 * T * kH;
         int Cin = kH;
+        bool tail_done = false;
         for (int s = 0; s < 4; ++s) {
             const int Li = p.L[s], Lo = p.L[s + 1], Co = Cin / 2;
+            if (s == 3 && h->fused_dectail && Li >= 8) {
+                DecTailArgs da;
+                da.x = in; da.out = wav + (long long)b0 * Lout;
+                da.wu = h->dup[3].w; da.bu = h->dup[3].b; da.w3 = h->dres[3][0].w; da.b3 = h->dres[3][0].b;
+                da.wt = h->dres[3][1].w; da.bt = h->dres[3][1].b; da.wl = h->dlast.w; da.bl = h->dlast.b;
+                da.B = g; da.L = Li;
+                if (int rc = launch_seanet_dectail(da, stream)) return rc;
+                tail_done = true;
+                break;
+            }
             float* u = ws + p.off_u[s];
             // ConvTranspose1d(k = 2r, stride r) of the (already ELU'd) input, trimmed right by r, as one GEMM with N = r*Cout:
             // out[t][p*Cout + co] = x[t-1].W[:, co, p+r] + x[t].W[:, co, p]; [Li][r*Cout] is [Lo][Cout] in memory.
@@ -739,7 +752,8 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
             in = r;
             Cin = Co;
         }
-        if (int rc = launch_conv_last(in, h->dlast.w, h->dlast.b, wav + (long long)b0 * Lout, g, Lout, stream)) return rc;
+        if (!tail_done)
+            if (int rc = launch_conv_last(in, h->dlast.w, h->dlast.b, wav + (long long)b0 * Lout, g, Lout, stream)) return rc;
     }
     return 0;
 }

@@ -61,6 +61,17 @@ struct Down64Args {
     int B, L;
 };
 int launch_seanet_down64(const Down64Args& a, hipStream_t stream);
+// Decoder tail (seanet_dectail.hip): x [B][L][64] (ELU'd) -> transposed conv (64->32, k4 s2) -> resblock(32) -> ELU -> conv k7 -> wav [B][2L]
+struct DecTailArgs {
+    const float* x;
+    float* out;
+    const float *wu, *bu;   // transposed conv as k = 2 GEMM: packed [2*32][2*64], bias [64] (per phase)
+    const float *w3, *b3;   // block conv3 packed [16][3*32], [16]
+    const float *wt, *bt;   // block tail packed [32][16 + 32], summed bias [32]
+    const float *wl, *bl;   // last conv packed [7*32], [1]
+    int B, L;
+};
+int launch_seanet_dectail(const DecTailArgs& a, hipStream_t stream);
 // Same block at 128 channels (seanet_res128.hip): x [B][L][128] -> out [B][L][128]; w3 [64][3*128], wt [128][64 + 128]
 int launch_seanet_res128(const Res64Args& a, hipStream_t stream);
 

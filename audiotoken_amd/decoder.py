@@ -29,6 +29,10 @@ class AcousticDecoder(torch.nn.Module):
         self.device = self._h.device
         self._ws: Optional[torch.Tensor] = None
 
+    def set_option(self, name: str, value: int) -> None:
+        """Kernel-selection switches of the library (results are bit-identical either way; used by the parity tests)."""
+        _cabi.check(self._h.lib.at_encodec_set_option(self._h.handle, name.encode(), int(value)), f"at_encodec_set_option({name})")
+
     @torch.no_grad()
     def forward(self, input_batch: torch.Tensor) -> torch.Tensor:
         assert input_batch.dim() == 3, "tokens must be [B, K, T]"

@@ -74,7 +74,8 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
 
 /* Options (all leave the results bit-identical; they select kernels or bound memory):
  *   "persistent_lstm" 1/0 — whole-sequence persistent LSTM kernel (default on) or one launch per time step;
- *   "fused_stage0", "fused_res64", "fused_res128", "fused_down64" 1/0 — fused SEANet kernels (default on) or the GEMM path;
+ *   "fused_stage0", "fused_res64", "fused_res128", "fused_down64", "fused_dectail" 1/0 — fused SEANet kernels (default on)
+ *   or the GEMM path;
  *   "subbatch" n >= 1 — clips per pass through the conv stack (default 256 or $AUDIOTOKEN_SUBBATCH): bounds
  *   at_encodec_workspace_bytes / at_encodec_decode_workspace_bytes, which must be re-queried after changing it. */
 int at_encodec_set_option(at_encodec_t* h, const char* name, int value);

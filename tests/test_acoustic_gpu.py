@@ -186,3 +186,20 @@ def test_subbatch_option_does_not_change_tokens(encoders):
             assert torch.equal(enc(wav, None), ref), sub
     finally:
         enc.set_option("subbatch", 256)
+
+
+def test_fused_decoder_kernels_equal_unfused(enc_weights):
+    """seanet_dectail_kernel (transposed conv + block + final conv) and the fused residual blocks keep the accumulation order of
+    the GEMM path: decoded waveforms are bit-identical, including the reflect-padded clip start and ragged last tiles."""
+    from audiotoken_amd.configs import AcousticDecoderConfig
+    from audiotoken_amd.decoder import AcousticDecoder
+    dec = AcousticDecoder(config=AcousticDecoderConfig(bandwidth=6), device="cuda:0", weights=enc_weights)
+    g = torch.Generator().manual_seed(5)
+    for B, T in ((2, 7), (3, 25), (1, 40), (5, 13)):
+        codes = torch.randint(0, 1024, (B, 8, T), generator=g, dtype=torch.long).cuda()
+        ref = dec(codes).clone()
+        for opt in ("fused_dectail", "fused_res64", "fused_res128"):
+            dec.set_option(opt, 0)
+            got = dec(codes)
+            dec.set_option(opt, 1)
+            assert torch.equal(ref, got), (opt, B, T, (ref - got).abs().max().item())

@@ -5,7 +5,7 @@ from audiotoken_amd import weights as W
 from audiotoken_amd.configs import AcousticDecoderConfig, num_codebooks_to_bandwidth
 from audiotoken_amd.decoder import AcousticDecoder
 dec = AcousticDecoder(config=AcousticDecoderConfig(bandwidth=num_codebooks_to_bandwidth(8)), device="cuda:0", weights=W.synth_encodec_weights(seed=0))
-B, T = 64, 750
+B, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 750
 codes = torch.randint(0, 1024, (B, 8, T), dtype=torch.long, device="cuda")
 out = dec(codes); torch.cuda.synchronize()
 print(out.shape)
