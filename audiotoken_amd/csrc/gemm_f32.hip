@@ -121,7 +121,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         if (a.ktaps > 1 && a.Cin % 32 != 0 && a.Cin % 16 == 0 && a.K % 16 == 0) return launch_cfg<128, 64, 4, 1, 16>(a, stream);
         return launch_cfg<128, 64, 4, 1>(a, stream);
     }
-    if ((long long)a.M * a.batch <= 1024) return launch_cfg<64, 64, 2, 2>(a, stream);
+    // a launch that cannot fill the 512 tile slots (2 per CU) with 128 x 128 tiles — single-clip latency paths such as
+    // ffn2 of one 30 s clip: 12 x 8 tiles with K = 4096 — runs 4x as many 64 x 64 tiles instead (same k order, same results)
+    const long long tiles128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
+    if ((long long)a.M * a.batch <= 1024 || tiles128 < 256) return launch_cfg<64, 64, 2, 2>(a, stream);
     // K tile of 16 for the big tiles: 32 KB of LDS per workgroup and a shorter barrier-to-barrier section measured
     // 4-5 % faster than K tile 32 on the conformer shapes (ffn2 133 -> 139 TFLOP/s); K % 16 != 0 keeps the 32 path
     static const int bk16 = getenv("AUDIOTOKEN_GEMM_BK16") ? atoi(getenv("AUDIOTOKEN_GEMM_BK16")) : 1;
