@@ -345,6 +345,30 @@ def run_acoustic(args, rank, world, dev, dist):
     return res
 
 
+def run_decode(args, rank, world, dev, dist):
+    """BASELINE configs[4] (C5): 64 clips x 10 s of acoustic tokens -> waveform through the HIP decoder (A11). Extra line only."""
+    from audiotoken_amd import weights as W
+    from audiotoken_amd.configs import AcousticDecoderConfig, num_codebooks_to_bandwidth
+    from audiotoken_amd.decoder import AcousticDecoder
+    from audiotoken_amd.distributed import broadcast_weights
+
+    weights = W.synth_encodec_weights(seed=0) if rank == 0 else None
+    weights = broadcast_weights(weights, dev, dist)
+    dec = AcousticDecoder(config=AcousticDecoderConfig(bandwidth=num_codebooks_to_bandwidth(args.num_codebooks)), device=str(dev), weights=weights)
+    B, T = 64, int(round(args.seconds * 75))
+    g = torch.Generator().manual_seed(1234 + rank)
+    codes = torch.randint(0, 1024, (B, args.num_codebooks, T), generator=g, dtype=torch.long).to(dev)
+    dec(codes)
+    elapsed, out = timed_steps(lambda: dec(codes), args.steps, args.warmup, dist)
+    elapsed = max_over_ranks(elapsed, dev, dist)
+    res = {"value": round(world * B * args.seconds * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "config": {"workload": f"Tokenizers.acoustic decode, {B} clips x {args.seconds:g} s, num_codebooks={args.num_codebooks}"},
+           "checksum": float(out.double().abs().sum().item())}
+    del dec
+    torch.cuda.empty_cache()
+    return res
+
+
 def run_semantic(args, rank, world, dev, dist):
     from audiotoken_amd import weights as W
     from audiotoken_amd.configs import Wav2VecBertConfig
@@ -430,6 +454,12 @@ def main():
     hub = hub_err = None
     if args.workload in ("all", "both", "acoustic"):
         ac = run_acoustic(args, rank, world, dev, dist)
+    dec = None
+    if args.workload == "all":
+        try:
+            dec = run_decode(args, rank, world, dev, dist)
+        except Exception as e:
+            dec = {"error": f"{type(e).__name__}: {e}"}
     if args.workload in ("all", "semantic_s"):
         try:
             hub = run_hubert(args, rank, world, dev, dist)
@@ -471,6 +501,8 @@ def main():
                                "definition": "audio-seconds of both workloads / (t_acoustic + t_semantic_m)"}
         elif sem_err:
             out["semantic_m"] = {"error": sem_err}
+        if dec is not None:
+            out["acoustic_decode"] = dec
         if hub is not None and primary is not hub:
             out["semantic_s"] = hub
         elif hub_err:
