@@ -1,0 +1,27 @@
+// Split-bf16 linear layers (gemm_bf16x3.hip): C = A . W^T with fp32-class accuracy on the bf16 matrix cores.
+#pragma once
+#include "at_common.h"
+
+namespace at {
+
+enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1 };
+
+struct Bf16x3Args {
+    const __bf16* A = nullptr;   // activations: 3 K-blocked pieces [3][K/16][Mpad][16]
+    const __bf16* W = nullptr;   // weights:     3 K-blocked pieces [3][K/16][N][16]
+    const float* bias = nullptr;
+    int M = 0, N = 0, K = 0, Mpad = 0;
+    int epi = XB_EPI_LINEAR;
+    // XB_EPI_LINEAR: C = alpha * (acc + bias) + R, fp32 row-major
+    float* C = nullptr; int ldc = 0;
+    const float* R = nullptr; int ldr = 0;
+    float alpha = 1.0f;
+    // XB_EPI_SWISH_SPLIT: S = split3(swish(acc + bias)) as 3 K-blocked pieces [3][N/16][Spad][16] (the next layer's A operand)
+    __bf16* S = nullptr; int Spad = 0;
+};
+
+// fp32 row-major [rows][ld] (first K columns) -> 3 K-blocked bf16 pieces [3][K/16][rows_pad][16]; rows >= `rows` are zero-filled
+int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream);
+int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream);
+
+}  // namespace at

@@ -1,0 +1,190 @@
+// Linear layers on the bf16 matrix cores with fp32-class accuracy: C = A . W^T where both fp32 operands are split EXACTLY into
+// three bf16 pieces (a = a1 + a2 + a3, 8 + 8 + 8 mantissa bits) and the six leading cross products
+//     a1 w1,  a1 w2,  a2 w1,  a2 w2,  a1 w3,  a3 w1
+// are accumulated by v_mfma_f32_32x32x16_bf16 into fp32. Every product of two bf16 numbers is exact in fp32; what is dropped
+// (a2 w3, a3 w2, a3 w3) is below 2^-24 of the leading term. Measured against a float64 reference (tools/bf16x3_gemm.hip, K = 1024):
+// max error 1.8e-6 for the split scheme vs 2.4e-6 for the k-ordered fp32 FMA chain of the fp32 MFMA path — it is not the less
+// accurate of the two. Six bf16 MFMAs cost 6/16 of the fp32 MFMAs they replace (2.5 PFLOP/s vs 157 TFLOP/s peak).
+//
+// Data layout: every piece is K-BLOCKED, [K/16][rows_pad][16] bf16, so the 256 rows x 16 k of a workgroup's K tile are one
+// contiguous 8 KB run (row-major pieces measured 157-179 instead of 194-196 fp32-equivalent TFLOP/s). Weights are split once
+// at finalize(); activations are split by their producer: a standalone pass for LayerNorm outputs (launch_split_blocked) and
+// the GEMM epilogue itself for the FFN's hidden activation.
+// Tile: 256 x 256 per workgroup, 8 waves as 4 x 2, each 64 x 128 = 2 x 4 MFMA tiles of 32 x 32; K tile 16; LDS 2 x 48 KB,
+// register-staged double buffering; operands swapped (weights as MFMA A) so a lane owns 4 consecutive output channels.
+// Used for the conformer feed-forward layers (w2vbert.hip); everything that has a bit-identical fused twin stays on the fp32 MFMA.
+#include "at_common.h"
+#include "gemm_bf16x3.h"
+
+namespace at {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+constexpr int XB_M = 256, XB_N = 256, XB_K = 16;
+constexpr int XB_PIECE = XB_M * XB_K;                 // bf16 elements of one piece of one operand tile
+constexpr int XB_STAGE = 3 * (XB_M + XB_N) * XB_K;    // bf16 elements per LDS stage (48 KB)
+
+__device__ __forceinline__ void split3(float a, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)a;
+    const float r1 = a - (float)p1;
+    p2 = (__bf16)r1;
+    const float r2 = r1 - (float)p2;
+    p3 = (__bf16)r2;
+}
+
+// fp32 row-major [rows][ld] (first K columns) -> three K-blocked bf16 pieces. Workgroup = 64 rows x 64 k through LDS so that both
+// the reads (256 B per row) and the writes (64 rows x 32 B = 2 KB per k-block) are contiguous.
+__global__ __launch_bounds__(256) void split_blocked_kernel(const float* __restrict__ x, int ld, long long rows, long long rows_pad, int K,
+                                                            __bf16* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int k0 = blockIdx.y * 64;
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {        // 64 rows x 16 float4
+        const int r = e >> 4, c = (e & 15) * 4;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < rows) v = *reinterpret_cast<const f4*>(x + (r0 + r) * ld + k0 + c);
+        tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+    }
+    __syncthreads();
+    const long long ps = rows_pad * (long long)K;
+    // thread -> (k-block kb of 4, row r, quarter qd of the 16 k): 4 values = 8 bytes per piece
+    for (int e = threadIdx.x; e < 4 * 64 * 4; e += 256) {
+        const int qd = e & 3, r = (e >> 2) & 63, kb = e >> 8;
+        bf16x4 p1, p2, p3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __bf16 a, b, c;
+            split3(tile[r][kb * 16 + qd * 4 + i], a, b, c);
+            p1[i] = a; p2[i] = b; p3[i] = c;
+        }
+        const long long o = ((long long)(k0 / 16 + kb) * rows_pad + r0 + r) * 16 + qd * 4;
+        if (r0 + r < rows_pad) {
+            *reinterpret_cast<bf16x4*>(out + o) = p1;
+            *reinterpret_cast<bf16x4*>(out + ps + o) = p2;
+            *reinterpret_cast<bf16x4*>(out + 2 * ps + o) = p3;
+        }
+    }
+}
+
+int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream) {
+    AT_REQUIRE(K % 64 == 0 && ld % 4 == 0 && rows_pad >= rows && rows_pad % 64 == 0, "split_blocked: K % 64, ld % 4, rows_pad % 64");
+    dim3 grid((unsigned)(rows_pad / 64), K / 64);
+    hipLaunchKernelGGL(split_blocked_kernel, grid, dim3(256), 0, stream, x, ld, rows, rows_pad, K, out);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];   // [2 stages][A: 3 x 256 x 16 | W: 3 x 256 x 16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = a.N / XB_N;
+    const int m0 = (blockIdx.x / ntn) * XB_M, n0 = (blockIdx.x % ntn) * XB_N;   // n fastest: the activation tile is fetched once per row of blocks
+    const long long psA = (long long)a.Mpad * a.K, psW = (long long)a.N * a.K;
+    const int nk = a.K / XB_K;
+    u4 st[6];
+    auto load = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            st[p] = *reinterpret_cast<const u4*>(a.A + p * psA + ((long long)kt * a.Mpad + m0) * 16 + tid * 8);
+            st[3 + p] = *reinterpret_cast<const u4*>(a.W + p * psW + ((long long)kt * a.N + n0) * 16 + tid * 8);
+        }
+    };
+    auto store = [&](int buf) {
+        __bf16* s = lds + buf * XB_STAGE;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *reinterpret_cast<u4*>(s + p * XB_PIECE + tid * 8) = st[p];
+            *reinterpret_cast<u4*>(s + (3 + p) * XB_PIECE + tid * 8) = st[3 + p];
+        }
+    };
+    f16v acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    load(0);
+    store(0);
+    __syncthreads();
+    const int frow = lane & 31, fhalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const __bf16* s = lds + (kt & 1) * XB_STAGE;
+        bf16x8 xa[3][2], wb[3][4];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xa[p][i] = *reinterpret_cast<const bf16x8*>(s + p * XB_PIECE + (wm * 64 + i * 32 + frow) * 16 + fhalf * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wb[p][j] = *reinterpret_cast<const bf16x8*>(s + (3 + p) * XB_PIECE + (wn * 128 + j * 32 + frow) * 16 + fhalf * 8);
+        }
+        if (kt + 1 < nk) load(kt + 1);
+        // the six leading cross products, smallest first
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PW[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[PW[t]][j], xa[PA[t]][i], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) store((kt + 1) & 1);
+        __syncthreads();
+    }
+    // lane holds output row m = frow of its 32-row tile and, per register group g, 4 consecutive columns n = 8g + 4 fhalf ..
+    const long long psS = (long long)a.Spad * a.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + frow;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 128 + j * 32 + 8 * g + 4 * fhalf;
+                f4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
+                if (a.epi == XB_EPI_SWISH_SPLIT) {
+                    bf16x4 p1, p2, p3;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float sw = v[k] * __frcp_rn(1.0f + __expf(-v[k]));   // as the fp32 GEMM's swish epilogue
+                        __bf16 x1, x2, x3;
+                        split3(sw, x1, x2, x3);
+                        p1[k] = x1; p2[k] = x2; p3[k] = x3;
+                    }
+                    const long long o = ((long long)(n >> 4) * a.Spad + m) * 16 + (n & 15);   // K-blocked: this output is the next layer's K
+                    *reinterpret_cast<bf16x4*>(a.S + o) = p1;
+                    *reinterpret_cast<bf16x4*>(a.S + psS + o) = p2;
+                    *reinterpret_cast<bf16x4*>(a.S + 2 * psS + o) = p3;
+                } else {
+                    v *= a.alpha;
+                    if (a.R) v += *reinterpret_cast<const f4*>(a.R + (long long)m * a.ldr + n);
+                    *reinterpret_cast<f4*>(a.C + (long long)m * a.ldc + n) = v;
+                }
+            }
+    }
+}
+
+int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
+    AT_REQUIRE(a.A && a.W && a.M >= 1 && a.N % XB_N == 0 && a.K % XB_K == 0 && a.Mpad % XB_M == 0 && a.Mpad >= a.M,
+               "gemm_bf16x3: N % 256, K % 16, Mpad % 256");
+    AT_REQUIRE(a.epi == XB_EPI_SWISH_SPLIT ? (a.S != nullptr && a.Spad >= a.M) : (a.C != nullptr && a.ldc % 4 == 0), "gemm_bf16x3: bad output");
+    const size_t ldsb = 2 * XB_STAGE * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((a.Mpad / XB_M) * (a.N / XB_N)));
+    hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(512), ldsb, stream, a);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace at

@@ -24,6 +24,8 @@
 #include "../../include/audiotoken_hip.h"
 #include "at_common.h"
 #include "w2vbert_kernels.h"
+#include <cstdlib>
+#include "gemm_bf16x3.h"
 
 namespace at {
 const char* last_error_cstr();
@@ -45,6 +47,7 @@ struct LayerW {
     const float *ln_conv_g, *ln_conv_b, *pw1, *dw, *ln_dw_g, *ln_dw_b, *pw2;
     const float *ln_ffn2_g, *ln_ffn2_b, *w2a, *b2a, *w2b, *b2b;
     const float *ln_fin_g, *ln_fin_b;
+    const __bf16 *w1a_s = nullptr, *w1b_s = nullptr, *w2a_s = nullptr, *w2b_s = nullptr;   // split-bf16 FFN weights (gemm_bf16x3.hip)
 };
 }  // namespace
 
@@ -58,10 +61,13 @@ struct at_w2vbert {
     const float *fp_ln_g = nullptr, *fp_ln_b = nullptr, *fp_w = nullptr, *fp_b = nullptr;
     std::vector<LayerW> layers;
     const float *codebook = nullptr, *e2 = nullptr;
+    bool bf16x3_ffn = false;   // feed-forward layers on the bf16 matrix cores with exact 3-way operand splits ($AUDIOTOKEN_BF16X3)
     Profiler prof;
 };
 
 namespace {
+
+constexpr bool kBf16x3Default = true;
 
 const HostTensor* find(const at_w2vbert* h, const std::string& name) {
     auto it = h->staged.find(name);
@@ -96,7 +102,8 @@ int tokens_of(int N, int mult) {
 
 struct Plan {
     int F, Tp;
-    size_t off_frames, off_fmask, off_spec, off_logmel, off_stats, off_feats, off_amask, off_x, off_t1, off_big, off_tok;
+    size_t off_frames, off_fmask, off_spec, off_logmel, off_stats, off_feats, off_amask, off_x, off_t1, off_big, off_tok, off_t1s, off_bigs;
+    size_t Mpad;
     size_t total_floats;
 };
 
@@ -118,6 +125,9 @@ Plan make_plan(int B, int N, int mult) {
     p.off_t1 = takef(M * kHid);
     p.off_big = takef(M * kFfn);
     p.off_tok = takef(M);
+    p.Mpad = (M + 255) / 256 * 256;                       // split-bf16 operands: 3 pieces x 2 bytes = 1.5 floats per element
+    p.off_t1s = takef(p.Mpad * kHid * 3 / 2);
+    p.off_bigs = takef(p.Mpad * kFfn * 3 / 2);
     p.total_floats = cur;
     return p;
 }
@@ -129,6 +139,21 @@ int linear(const float* X, int K, const float* W, const float* bias, float* C, i
     a.W = W; a.bias = bias; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc;
     a.M = (int)M; a.N = N; a.K = K; a.batch = 1; a.epi = epi; a.alpha = alpha; a.row_mask = row_mask;
     return launch_gemm(a, stream);
+}
+
+// x += 0.5 * (swish(t1 . W1^T + b1) . W2^T + b2) on the bf16 matrix cores: t1 is split into 3 bf16 pieces, the hidden activation is
+// written split by the first GEMM's epilogue, the second GEMM adds the residual in fp32 (gemm_bf16x3.hip)
+int ffn_bf16x3(const float* t1, const __bf16* w1s, const float* b1, const __bf16* w2s, const float* b2, float* x, __bf16* t1s, __bf16* bigs,
+               long long M, long long Mpad, hipStream_t stream) {
+    if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream)) return rc;
+    Bf16x3Args a;
+    a.A = t1s; a.W = w1s; a.bias = b1; a.M = (int)M; a.N = kFfn; a.K = kHid; a.Mpad = (int)Mpad;
+    a.epi = XB_EPI_SWISH_SPLIT; a.S = bigs; a.Spad = (int)Mpad;
+    if (int rc = launch_gemm_bf16x3(a, stream)) return rc;
+    Bf16x3Args b;
+    b.A = bigs; b.W = w2s; b.bias = b2; b.M = (int)M; b.N = kHid; b.K = kFfn; b.Mpad = (int)Mpad;
+    b.epi = XB_EPI_LINEAR; b.C = x; b.ldc = kHid; b.R = x; b.ldr = kHid; b.alpha = 0.5f;
+    return launch_gemm_bf16x3(b, stream);
 }
 
 }  // namespace
@@ -284,6 +309,25 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
         AT_REQUIRE(h->codebook && h->e2, "device allocation failed (codebook)");
     }
     h->staged.clear();
+    {
+        const char* e = std::getenv("AUDIOTOKEN_BF16X3");
+        h->bf16x3_ffn = e ? std::atoi(e) != 0 : kBf16x3Default;
+    }
+    if (h->bf16x3_ffn) {
+        for (LayerW& L : h->layers) {
+            const float* src[4] = {L.w1a, L.w1b, L.w2a, L.w2b};
+            const __bf16** dst[4] = {&L.w1a_s, &L.w1b_s, &L.w2a_s, &L.w2b_s};
+            for (int j = 0; j < 4; ++j) {
+                const int n = (j & 1) ? kHid : kFfn, k = (j & 1) ? kFfn : kHid;
+                __bf16* d = nullptr;
+                AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * n * k * sizeof(__bf16)));
+                h->allocs.push_back(reinterpret_cast<float*>(d));
+                if (int rc = launch_split_blocked(src[j], k, n, n, k, d, nullptr)) return rc;
+                *dst[j] = d;
+            }
+        }
+        AT_CHECK_HIP(hipDeviceSynchronize());
+    }
     h->finalized = true;
     return 0;
 }
@@ -371,6 +415,8 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
     float* x = ws + p.off_x;
     float* t1 = ws + p.off_t1;
     float* big = ws + p.off_big;
+    __bf16* t1s = reinterpret_cast<__bf16*>(ws + p.off_t1s);
+    __bf16* bigs = reinterpret_cast<__bf16*>(ws + p.off_bigs);
     prof.begin("feature_projection", 2, stream);
     if (int rc = launch_layernorm(feats, h->fp_ln_g, h->fp_ln_b, nullptr, t1, M, kFeat, stream)) return rc;
     if (int rc = linear(t1, kFeat, h->fp_w, h->fp_b, x, kHid, M, EPI_NONE, 1.f, nullptr, amask, kHid, stream)) return rc;
@@ -380,8 +426,12 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
         const LayerW& L = h->layers[li];
         prof.begin("ffn", 3, stream);
         if (int rc = launch_layernorm(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, t1, M, kHid, stream)) return rc;
-        if (int rc = linear(t1, kHid, L.w1a, L.b1a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
-        if (int rc = linear(big, kFfn, L.w1b, L.b1b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
+        if (h->bf16x3_ffn) {
+            if (int rc = ffn_bf16x3(t1, L.w1a_s, L.b1a, L.w1b_s, L.b1b, x, t1s, bigs, M, (long long)p.Mpad, stream)) return rc;
+        } else {
+            if (int rc = linear(t1, kHid, L.w1a, L.b1a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
+            if (int rc = linear(big, kFfn, L.w1b, L.b1b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
+        }
         prof.end(stream);
 
         prof.begin("attn_proj", 3, stream);
@@ -404,8 +454,12 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
 
         prof.begin("ffn", 4, stream);
         if (int rc = launch_layernorm(x, L.ln_ffn2_g, L.ln_ffn2_b, nullptr, t1, M, kHid, stream)) return rc;
-        if (int rc = linear(t1, kHid, L.w2a, L.b2a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
-        if (int rc = linear(big, kFfn, L.w2b, L.b2b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
+        if (h->bf16x3_ffn) {
+            if (int rc = ffn_bf16x3(t1, L.w2a_s, L.b2a, L.w2b_s, L.b2b, x, t1s, bigs, M, (long long)p.Mpad, stream)) return rc;
+        } else {
+            if (int rc = linear(t1, kHid, L.w2a, L.b2a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
+            if (int rc = linear(big, kFfn, L.w2b, L.b2b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
+        }
         if (int rc = launch_layernorm(x, L.ln_fin_g, L.ln_fin_b, nullptr, x, M, kHid, stream)) return rc;
         prof.end(stream);
     }
