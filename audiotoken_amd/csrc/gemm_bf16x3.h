@@ -4,7 +4,7 @@
 
 namespace at {
 
-enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1 };
+enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2 };
 
 struct Bf16x3Args {
     const __bf16* A = nullptr;   // activations: 3 K-blocked pieces [3][K/16][Mpad][16]
@@ -13,6 +13,7 @@ struct Bf16x3Args {
     int M = 0, N = 0, K = 0, Mpad = 0;
     int epi = XB_EPI_LINEAR;
     // XB_EPI_LINEAR: C = alpha * (acc + bias) + R, fp32 row-major
+    // XB_EPI_GLU: weight rows interleaved (a_c, b_c): C[m][c] = a_c * sigmoid(b_c), N/2 output columns, fp32 row-major
     float* C = nullptr; int ldc = 0;
     const float* R = nullptr; int ldr = 0;
     float alpha = 1.0f;

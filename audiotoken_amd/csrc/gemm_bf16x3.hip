@@ -162,6 +162,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
                     *reinterpret_cast<bf16x4*>(a.S + o) = p1;
                     *reinterpret_cast<bf16x4*>(a.S + psS + o) = p2;
                     *reinterpret_cast<bf16x4*>(a.S + 2 * psS + o) = p3;
+                } else if (a.epi == XB_EPI_GLU) {
+                    float2 o;
+                    o.x = v.x * sigmoidf_(v.y);
+                    o.y = v.z * sigmoidf_(v.w);
+                    *reinterpret_cast<float2*>(a.C + (long long)m * a.ldc + (n >> 1)) = o;
                 } else {
                     v *= a.alpha;
                     if (a.R) v += *reinterpret_cast<const f4*>(a.R + (long long)m * a.ldr + n);
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
     AT_REQUIRE(a.A && a.W && a.M >= 1 && a.N % XB_N == 0 && a.K % XB_K == 0 && a.Mpad % XB_M == 0 && a.Mpad >= a.M,
                "gemm_bf16x3: N % 256, K % 16, Mpad % 256");
-    AT_REQUIRE(a.epi == XB_EPI_SWISH_SPLIT ? (a.S != nullptr && a.Spad >= a.M) : (a.C != nullptr && a.ldc % 4 == 0), "gemm_bf16x3: bad output");
+    AT_REQUIRE(a.epi == XB_EPI_SWISH_SPLIT ? (a.S != nullptr && a.Spad >= a.M) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
     const size_t ldsb = 2 * XB_STAGE * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {

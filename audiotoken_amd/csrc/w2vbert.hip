@@ -47,7 +47,8 @@ struct LayerW {
     const float *ln_conv_g, *ln_conv_b, *pw1, *dw, *ln_dw_g, *ln_dw_b, *pw2;
     const float *ln_ffn2_g, *ln_ffn2_b, *w2a, *b2a, *w2b, *b2b;
     const float *ln_fin_g, *ln_fin_b;
-    const __bf16 *w1a_s = nullptr, *w1b_s = nullptr, *w2a_s = nullptr, *w2b_s = nullptr;   // split-bf16 FFN weights (gemm_bf16x3.hip)
+    // split-bf16 weights of the linear layers (gemm_bf16x3.hip)
+    const __bf16 *w1a_s = nullptr, *w1b_s = nullptr, *w2a_s = nullptr, *w2b_s = nullptr, *wqkv_s = nullptr, *wo_s = nullptr, *pw1_s = nullptr, *pw2_s = nullptr;
 };
 }  // namespace
 
@@ -154,6 +155,16 @@ int ffn_bf16x3(const float* t1, const __bf16* w1s, const float* b1, const __bf16
     b.A = bigs; b.W = w2s; b.bias = b2; b.M = (int)M; b.N = kHid; b.K = kFfn; b.Mpad = (int)Mpad;
     b.epi = XB_EPI_LINEAR; b.C = x; b.ldc = kHid; b.R = x; b.ldr = kHid; b.alpha = 0.5f;
     return launch_gemm_bf16x3(b, stream);
+}
+
+// C = epi(X . W^T): fp32 row-major X [M][1024] is split into 3 bf16 pieces (t1s), then the split-bf16 GEMM
+int linear_x3(const float* X, const __bf16* Ws, const float* bias, float* C, int N, long long M, long long Mpad, int epi, float alpha,
+              const float* R, int ldc, __bf16* t1s, hipStream_t stream) {
+    if (int rc = launch_split_blocked(X, kHid, M, Mpad, kHid, t1s, stream)) return rc;
+    Bf16x3Args a;
+    a.A = t1s; a.W = Ws; a.bias = bias; a.M = (int)M; a.N = N; a.K = kHid; a.Mpad = (int)Mpad;
+    a.epi = epi; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc; a.alpha = alpha;
+    return launch_gemm_bf16x3(a, stream);
 }
 
 }  // namespace
@@ -315,10 +326,11 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
     }
     if (h->bf16x3_ffn) {
         for (LayerW& L : h->layers) {
-            const float* src[4] = {L.w1a, L.w1b, L.w2a, L.w2b};
-            const __bf16** dst[4] = {&L.w1a_s, &L.w1b_s, &L.w2a_s, &L.w2b_s};
-            for (int j = 0; j < 4; ++j) {
-                const int n = (j & 1) ? kHid : kFfn, k = (j & 1) ? kFfn : kHid;
+            const float* src[8] = {L.w1a, L.w1b, L.w2a, L.w2b, L.wqkv, L.wo, L.pw1, L.pw2};
+            const __bf16** dst[8] = {&L.w1a_s, &L.w1b_s, &L.w2a_s, &L.w2b_s, &L.wqkv_s, &L.wo_s, &L.pw1_s, &L.pw2_s};
+            const int ns[8] = {kFfn, kHid, kFfn, kHid, 3 * kHid, kHid, 2 * kHid, kHid}, ks[8] = {kHid, kFfn, kHid, kFfn, kHid, kHid, kHid, kHid};
+            for (int j = 0; j < 8; ++j) {
+                const int n = ns[j], k = ks[j];
                 __bf16* d = nullptr;
                 AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * n * k * sizeof(__bf16)));
                 h->allocs.push_back(reinterpret_cast<float*>(d));
@@ -436,20 +448,36 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
 
         prof.begin("attn_proj", 3, stream);
         if (int rc = launch_layernorm(x, L.ln_att_g, L.ln_att_b, nullptr, t1, M, kHid, stream)) return rc;
-        if (int rc = linear(t1, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, 1.f, nullptr, nullptr, 3 * kHid, stream)) return rc;
+        if (h->bf16x3_ffn) {
+            if (int rc = linear_x3(t1, L.wqkv_s, L.bqkv, big, 3 * kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, nullptr, 3 * kHid, t1s, stream)) return rc;
+        } else if (int rc = linear(t1, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, 1.f, nullptr, nullptr, 3 * kHid, stream)) {
+            return rc;
+        }
         prof.end(stream);
         prof.begin("attention", 1, stream);
         if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
-        if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) return rc;
+        if (h->bf16x3_ffn) {
+            if (int rc = linear_x3(t1, L.wo_s, L.bo, x, kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, x, kHid, t1s, stream)) return rc;
+        } else if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) {
+            return rc;
+        }
         prof.end(stream);
 
         prof.begin("conv_module", 4, stream);
         if (int rc = launch_layernorm(x, L.ln_conv_g, L.ln_conv_b, amask, t1, M, kHid, stream)) return rc;
-        if (int rc = linear(t1, kHid, L.pw1, nullptr, big, 2 * kHid, M, EPI_GLU, 1.f, nullptr, nullptr, kHid, stream)) return rc;
+        if (h->bf16x3_ffn) {
+            if (int rc = linear_x3(t1, L.pw1_s, nullptr, big, 2 * kHid, M, (long long)p.Mpad, XB_EPI_GLU, 1.f, nullptr, kHid, t1s, stream)) return rc;
+        } else if (int rc = linear(t1, kHid, L.pw1, nullptr, big, 2 * kHid, M, EPI_GLU, 1.f, nullptr, nullptr, kHid, stream)) {
+            return rc;
+        }
         if (int rc = launch_dwconv_ln_swish(big, L.dw, L.ln_dw_g, L.ln_dw_b, t1, B, T, stream)) return rc;
-        if (int rc = linear(t1, kHid, L.pw2, nullptr, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) return rc;
+        if (h->bf16x3_ffn) {
+            if (int rc = linear_x3(t1, L.pw2_s, nullptr, x, kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, x, kHid, t1s, stream)) return rc;
+        } else if (int rc = linear(t1, kHid, L.pw2, nullptr, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) {
+            return rc;
+        }
         prof.end(stream);
 
         prof.begin("ffn", 4, stream);
