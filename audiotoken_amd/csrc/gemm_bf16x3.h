@@ -4,7 +4,7 @@
 
 namespace at {
 
-enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2 };
+enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2, XB_EPI_GELU_SPLIT = 3 };
 
 struct Bf16x3Args {
     const __bf16* A = nullptr;   // activations: 3 K-blocked pieces [3][K/16][Mpad][16]
@@ -17,7 +17,7 @@ struct Bf16x3Args {
     float* C = nullptr; int ldc = 0;
     const float* R = nullptr; int ldr = 0;
     float alpha = 1.0f;
-    // XB_EPI_SWISH_SPLIT: S = split3(swish(acc + bias)) as 3 K-blocked pieces [3][N/16][Spad][16] (the next layer's A operand)
+    // XB_EPI_SWISH_SPLIT / XB_EPI_GELU_SPLIT: S = split3(act(acc + bias)) as 3 K-blocked pieces [3][N/16][Spad][16] (the next layer's A operand)
     __bf16* S = nullptr; int Spad = 0;
 };
 

@@ -149,11 +149,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
                 const int n = n0 + wn * 128 + j * 32 + 8 * g + 4 * fhalf;
                 f4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
-                if (a.epi == XB_EPI_SWISH_SPLIT) {
+                if (a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT) {
                     bf16x4 p1, p2, p3;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float sw = v[k] * __frcp_rn(1.0f + __expf(-v[k]));   // as the fp32 GEMM's swish epilogue
+                        const float sw = a.epi == XB_EPI_GELU_SPLIT ? gelu_erf(v[k])
+                                                                    : v[k] * __frcp_rn(1.0f + __expf(-v[k]));   // as the fp32 GEMM's epilogues
                         __bf16 x1, x2, x3;
                         split3(sw, x1, x2, x3);
                         p1[k] = x1; p2[k] = x2; p3[k] = x3;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
     AT_REQUIRE(a.A && a.W && a.M >= 1 && a.N % XB_N == 0 && a.K % XB_K == 0 && a.Mpad % XB_M == 0 && a.Mpad >= a.M,
                "gemm_bf16x3: N % 256, K % 16, Mpad % 256");
-    AT_REQUIRE(a.epi == XB_EPI_SWISH_SPLIT ? (a.S != nullptr && a.Spad >= a.M) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
+    AT_REQUIRE((a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT) ? (a.S != nullptr && a.Spad >= a.M) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
     const size_t ldsb = 2 * XB_STAGE * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {

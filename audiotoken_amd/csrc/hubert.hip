@@ -15,6 +15,8 @@
 #include "../../include/audiotoken_hip.h"
 #include "at_common.h"
 #include "hubert_kernels.h"
+#include "gemm_bf16x3.h"
+#include <cstdlib>
 #include "w2vbert_kernels.h"
 
 using namespace at;
@@ -29,6 +31,7 @@ struct HostTensor {
 };
 struct LayerW {
     const float *wqkv, *bqkv, *wo, *bo, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
+    const __bf16 *wqkv_s = nullptr, *wo_s = nullptr, *w1_s = nullptr, *w2_s = nullptr;   // split-bf16 weights (gemm_bf16x3.hip)
 };
 }  // namespace
 
@@ -42,6 +45,7 @@ struct at_hubert {
     const float *pos_w = nullptr, *pos_b = nullptr, *enc_ln_g = nullptr, *enc_ln_b = nullptr;
     std::vector<LayerW> layers;
     const float *centers = nullptr, *c2 = nullptr;
+    bool bf16x3 = false;   // transformer linear layers on the bf16 matrix cores with exact 3-way operand splits ($AUDIOTOKEN_BF16X3, default on)
     Profiler prof;
 };
 
@@ -70,7 +74,8 @@ const float* take(at_hubert* h, const std::string& name, std::vector<int64_t> sh
 
 struct Plan {
     int L[8];   // L[0] = N, L[i+1] = frames after conv i
-    size_t off_a, off_b, off_part, off_ss, off_fmask, off_x, off_t1, off_big, off_pos;
+    size_t off_a, off_b, off_part, off_ss, off_fmask, off_x, off_t1, off_big, off_pos, off_xs, off_bigs;
+    size_t Mpad;
     size_t total_floats;
 };
 Plan make_plan(int B, int N) {
@@ -89,8 +94,24 @@ Plan make_plan(int B, int N) {
     p.off_t1 = takef(M * kHid);
     p.off_pos = takef(M * kHid);
     p.off_big = takef(M * kFfn);
+    p.Mpad = (M + 255) / 256 * 256;                 // split-bf16 operands: 3 pieces x 2 bytes = 1.5 floats per element
+    p.off_xs = takef(p.Mpad * kHid * 3 / 2);
+    p.off_bigs = takef(p.Mpad * kFfn * 3 / 2);
     p.total_floats = cur;
     return p;
+}
+
+// C = epi(X . W^T) through the split-bf16 GEMM: X fp32 row-major [M][K] is split into xs first (unless it already is: X == nullptr)
+int linear_x3(const float* X, int K, const __bf16* xs, __bf16* xs_w, const __bf16* Ws, const float* bias, float* C, int N, long long M, long long Mpad,
+              int epi, const float* R, int ldc, __bf16* S, hipStream_t stream) {
+    if (X) {
+        if (int rc = launch_split_blocked(X, K, M, Mpad, K, xs_w, stream)) return rc;
+        xs = xs_w;
+    }
+    Bf16x3Args a;
+    a.A = xs; a.W = Ws; a.bias = bias; a.M = (int)M; a.N = N; a.K = K; a.Mpad = (int)Mpad;
+    a.epi = epi; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc; a.alpha = 1.0f; a.S = S; a.Spad = (int)Mpad;
+    return launch_gemm_bf16x3(a, stream);
 }
 
 int linear(const float* X, int K, const float* W, const float* bias, float* C, int N, long long M, int epi, const float* R,
@@ -216,6 +237,25 @@ int at_hubert_finalize(at_hubert_t* h) {
         AT_REQUIRE(h->centers && h->c2, "device allocation failed");
     }
     h->staged.clear();
+    {
+        const char* e = std::getenv("AUDIOTOKEN_BF16X3");
+        h->bf16x3 = e ? std::atoi(e) != 0 : true;
+    }
+    if (h->bf16x3) {
+        for (LayerW& L : h->layers) {
+            const float* src[4] = {L.wqkv, L.wo, L.w1, L.w2};
+            const __bf16** dst[4] = {&L.wqkv_s, &L.wo_s, &L.w1_s, &L.w2_s};
+            const int ns[4] = {3 * kHid, kHid, kFfn, kHid}, ks[4] = {kHid, kHid, kHid, kFfn};
+            for (int j = 0; j < 4; ++j) {
+                __bf16* d = nullptr;
+                AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * ns[j] * ks[j] * sizeof(__bf16)));
+                h->allocs.push_back(reinterpret_cast<float*>(d));
+                if (int rc = launch_split_blocked(src[j], ks[j], ns[j], ns[j], ks[j], d, nullptr)) return rc;
+                *dst[j] = d;
+            }
+        }
+        AT_CHECK_HIP(hipDeviceSynchronize());
+    }
     h->finalized = true;
     return 0;
 }
@@ -280,6 +320,9 @@ int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B,
     float* x = ws + p.off_x;
     float* t1 = ws + p.off_t1;
     float* pos = ws + p.off_pos;
+    __bf16* xs = reinterpret_cast<__bf16*>(ws + p.off_xs);
+    __bf16* bigs = reinterpret_cast<__bf16*>(ws + p.off_bigs);
+    const long long Mpad = (long long)p.Mpad;
     float* big = ws + p.off_big;
     prof.begin("projection_posconv", 20, stream);
     if (int rc = launch_hub_frame_mask(mask, fmask, B, N, T, stream)) return rc;
@@ -301,18 +344,31 @@ int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B,
     for (int li = 0; li < n_layers; ++li) {
         const LayerW& L = h->layers[li];
         prof.begin("attn_proj", 3, stream);
-        if (int rc = linear(x, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, nullptr, nullptr, 3 * kHid, stream)) return rc;
+        if (h->bf16x3) {
+            if (int rc = linear_x3(x, kHid, nullptr, xs, L.wqkv_s, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream)) return rc;
+        } else if (int rc = linear(x, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, nullptr, nullptr, 3 * kHid, stream)) {
+            return rc;
+        }
         prof.end(stream);
         prof.begin("attention", 1, stream);
         if (int rc = launch_relpos_attention(big, fmask, nullptr, t1, B, T, stream, kHeads)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
-        if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) return rc;
+        if (h->bf16x3) {
+            if (int rc = linear_x3(t1, kHid, nullptr, xs, L.wo_s, L.bo, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
+        } else if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) {
+            return rc;
+        }
         if (int rc = launch_layernorm(x, L.ln1_g, L.ln1_b, nullptr, x, M, kHid, stream)) return rc;
         prof.end(stream);
         prof.begin("ffn", 3, stream);
-        if (int rc = linear(x, kHid, L.w1, L.b1, big, kFfn, M, EPI_GELU, nullptr, nullptr, kFfn, stream)) return rc;
-        if (int rc = linear(big, kFfn, L.w2, L.b2, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) return rc;
+        if (h->bf16x3) {   // hidden activation written split by the first GEMM's epilogue
+            if (int rc = linear_x3(x, kHid, nullptr, xs, L.w1_s, L.b1, nullptr, kFfn, M, Mpad, XB_EPI_GELU_SPLIT, nullptr, kFfn, bigs, stream)) return rc;
+            if (int rc = linear_x3(nullptr, kFfn, bigs, nullptr, L.w2_s, L.b2, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
+        } else {
+            if (int rc = linear(x, kHid, L.w1, L.b1, big, kFfn, M, EPI_GELU, nullptr, nullptr, kFfn, stream)) return rc;
+            if (int rc = linear(big, kFfn, L.w2, L.b2, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) return rc;
+        }
         if (int rc = launch_layernorm(x, L.ln2_g, L.ln2_b, nullptr, x, M, kHid, stream)) return rc;
         prof.end(stream);
     }
