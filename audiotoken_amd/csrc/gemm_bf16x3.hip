@@ -24,9 +24,16 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
-constexpr int XB_M = 256, XB_N = 256, XB_K = 16;
-constexpr int XB_PIECE = XB_M * XB_K;                 // bf16 elements of one piece of one operand tile
-constexpr int XB_STAGE = 3 * (XB_M + XB_N) * XB_K;    // bf16 elements per LDS stage (48 KB)
+constexpr int XB_K = 16;
+// Two tile shapes with IDENTICAL per-element arithmetic (the k order and the order of the six products do not depend on the
+// tile), so results do not depend on which one a launch uses: 256 x 256 (8 waves, 4 x 2, each 2 x 4 MFMA tiles) for large
+// launches, 128 x 128 (4 waves, 2 x 2, each 2 x 2) when 256 x 256 tiles would leave most of the 256 CUs idle (single clips).
+template <int WM, int WN, int TI, int TJ>
+struct XbCfg {
+    static constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, NT = WM * WN * 64;
+    static constexpr int PA = BM * XB_K, PW = BN * XB_K;            // bf16 elements of one piece of the A / W tile
+    static constexpr int STAGE = 3 * (PA + PW);                      // bf16 elements per LDS stage
+};
 
 __device__ __forceinline__ void split3(float a, __bf16& p1, __bf16& p2, __bf16& p3) {
     p1 = (__bf16)a;
@@ -78,35 +85,45 @@ int launch_split_blocked(const float* x, int ld, long long rows, long long rows_
     return 0;
 }
 
-__global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
+template <int WM, int WN, int TI, int TJ>
+__global__ __launch_bounds__(WM * WN * 64, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
+    using Cfg = XbCfg<WM, WN, TI, TJ>;
+    constexpr int XB_M = Cfg::BM, XB_N = Cfg::BN, NT = Cfg::NT;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];   // [2 stages][A: 3 x 256 x 16 | W: 3 x 256 x 16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int ntn = a.N / XB_N;
     const int m0 = (blockIdx.x / ntn) * XB_M, n0 = (blockIdx.x % ntn) * XB_N;   // n fastest: the activation tile is fetched once per row of blocks
     const long long psA = (long long)a.Mpad * a.K, psW = (long long)a.N * a.K;
     const int nk = a.K / XB_K;
-    u4 st[6];
+    // staging: one piece of an operand tile is rows x 32 B = 2 * rows chunks of 16 B, contiguous in the K-blocked layout
+    constexpr int CA = (2 * XB_M) / NT, CW = (2 * XB_N) / NT;   // chunks per thread per piece
+    static_assert((2 * XB_M) % NT == 0 && (2 * XB_N) % NT == 0, "tile rows must be a multiple of half the thread count");
+    u4 sa[3][CA], sw[3][CW];
     auto load = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            st[p] = *reinterpret_cast<const u4*>(a.A + p * psA + ((long long)kt * a.Mpad + m0) * 16 + tid * 8);
-            st[3 + p] = *reinterpret_cast<const u4*>(a.W + p * psW + ((long long)kt * a.N + n0) * 16 + tid * 8);
+#pragma unroll
+            for (int c = 0; c < CA; ++c) sa[p][c] = *reinterpret_cast<const u4*>(a.A + p * psA + ((long long)kt * a.Mpad + m0) * 16 + (tid + c * NT) * 8);
+#pragma unroll
+            for (int c = 0; c < CW; ++c) sw[p][c] = *reinterpret_cast<const u4*>(a.W + p * psW + ((long long)kt * a.N + n0) * 16 + (tid + c * NT) * 8);
         }
     };
     auto store = [&](int buf) {
-        __bf16* s = lds + buf * XB_STAGE;
+        __bf16* s = lds + buf * Cfg::STAGE;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            *reinterpret_cast<u4*>(s + p * XB_PIECE + tid * 8) = st[p];
-            *reinterpret_cast<u4*>(s + (3 + p) * XB_PIECE + tid * 8) = st[3 + p];
+#pragma unroll
+            for (int c = 0; c < CA; ++c) *reinterpret_cast<u4*>(s + p * Cfg::PA + (tid + c * NT) * 8) = sa[p][c];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) *reinterpret_cast<u4*>(s + 3 * Cfg::PA + p * Cfg::PW + (tid + c * NT) * 8) = sw[p][c];
         }
     };
-    f16v acc[2][4];
+    f16v acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     load(0);
@@ -114,14 +131,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
     __syncthreads();
     const int frow = lane & 31, fhalf = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
-        const __bf16* s = lds + (kt & 1) * XB_STAGE;
-        bf16x8 xa[3][2], wb[3][4];
+        const __bf16* s = lds + (kt & 1) * Cfg::STAGE;
+        bf16x8 xa[3][TI], wb[3][TJ];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) xa[p][i] = *reinterpret_cast<const bf16x8*>(s + p * XB_PIECE + (wm * 64 + i * 32 + frow) * 16 + fhalf * 8);
+            for (int i = 0; i < TI; ++i) xa[p][i] = *reinterpret_cast<const bf16x8*>(s + p * Cfg::PA + (wm * TI * 32 + i * 32 + frow) * 16 + fhalf * 8);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wb[p][j] = *reinterpret_cast<const bf16x8*>(s + (3 + p) * XB_PIECE + (wn * 128 + j * 32 + frow) * 16 + fhalf * 8);
+            for (int j = 0; j < TJ; ++j) wb[p][j] = *reinterpret_cast<const bf16x8*>(s + 3 * Cfg::PA + p * Cfg::PW + (wn * TJ * 32 + j * 32 + frow) * 16 + fhalf * 8);
         }
         if (kt + 1 < nk) load(kt + 1);
         // the six leading cross products, smallest first
@@ -129,9 +146,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[PW[t]][j], xa[PA[t]][i], acc[i][j], 0, 0, 0);
         if (kt + 1 < nk) store((kt + 1) & 1);
         __syncthreads();
@@ -139,14 +156,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
     // lane holds output row m = frow of its 32-row tile and, per register group g, 4 consecutive columns n = 8g + 4 fhalf ..
     const long long psS = (long long)a.Spad * a.N;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + frow;
+    for (int i = 0; i < TI; ++i) {
+        const int m = m0 + wm * TI * 32 + i * 32 + frow;
         if (m >= a.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 128 + j * 32 + 8 * g + 4 * fhalf;
+                const int n = n0 + wn * TJ * 32 + j * 32 + 8 * g + 4 * fhalf;
                 f4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
                 if (a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT) {
@@ -177,20 +194,28 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
     }
 }
 
-int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
-    AT_REQUIRE(a.A && a.W && a.M >= 1 && a.N % XB_N == 0 && a.K % XB_K == 0 && a.Mpad % XB_M == 0 && a.Mpad >= a.M,
-               "gemm_bf16x3: N % 256, K % 16, Mpad % 256");
-    AT_REQUIRE((a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT) ? (a.S != nullptr && a.Spad >= a.M) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
-    const size_t ldsb = 2 * XB_STAGE * sizeof(__bf16);
+template <int WM, int WN, int TI, int TJ>
+static int launch_xb(const Bf16x3Args& a, hipStream_t stream) {
+    using Cfg = XbCfg<WM, WN, TI, TJ>;
+    const size_t ldsb = 2 * Cfg::STAGE * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<WM, WN, TI, TJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         attr_set = true;
     }
-    const dim3 grid((unsigned)((a.Mpad / XB_M) * (a.N / XB_N)));
-    hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(512), ldsb, stream, a);
+    const dim3 grid((unsigned)((a.Mpad / Cfg::BM) * (a.N / Cfg::BN)));
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TI, TJ>), grid, dim3(Cfg::NT), ldsb, stream, a);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
+    AT_REQUIRE(a.A && a.W && a.M >= 1 && a.N % 256 == 0 && a.K % XB_K == 0 && a.Mpad % 256 == 0 && a.Mpad >= a.M,
+               "gemm_bf16x3: N % 256, K % 16, Mpad % 256");
+    AT_REQUIRE((a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT) ? (a.S != nullptr && a.Spad >= a.M) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
+    const long long tiles256 = (long long)(a.Mpad / 256) * (a.N / 256);
+    if (tiles256 < 256) return launch_xb<2, 2, 2, 2>(a, stream);   // 4x as many 128 x 128 tiles: same arithmetic, fills the chip
+    return launch_xb<4, 2, 2, 4>(a, stream);
 }
 
 }  // namespace at
