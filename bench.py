@@ -36,6 +36,10 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
+# Linear layers of the two semantic tokenizers run as exact 3-way bf16 splits (6 bf16 MFMAs per fp32-equivalent step) unless disabled
+BF16X3 = os.environ.get("AUDIOTOKEN_BF16X3", "1") != "0"
+BF16X3_GROUPS = ("ffn", "attn_proj")
 
 
 def acoustic_flops_per_clip(N: int, n_q: int):
@@ -215,10 +219,10 @@ def run_hubert(args, rank, world, dev, dist):
                         "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None, "gbs": None}
     res = {
         "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "dtype": "f32",
+        "dtype": "f32 (linear layers: exact bf16x3 splits, fp32 accumulate)" if BF16X3 else "f32",
         "config": {"workload": f"Tokenizers.semantic_s encode, {B} clips x {secs:g} s @16 kHz per GPU, mHuBERT-base 11 layers, k-means 1000",
                    "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0"},
-        "roofline": roofline_of(breakdown, flops, None, B), "breakdown": breakdown,
+        "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if BF16X3 else ()), "breakdown": breakdown,
         "token_checksum": int(toks.to(torch.int64).sum().item()),
         "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
     }
@@ -262,9 +266,16 @@ def measured_traffic(group: str):
         return None
 
 
-def roofline_of(breakdown, flops, nbytes, B):
+def roofline_of(breakdown, flops, nbytes, B, split_groups=()):
     dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
     d = breakdown[dom]
+    if dom in split_groups:
+        # executed arithmetic: six bf16 MFMAs per fp32-equivalent multiply-add, priced against the dense bf16 MFMA peak
+        ach = round(6.0 * d["tflops"], 2)
+        return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                "kernel": dom, "launches_per_step": max(1, d["launches_per_step"]),
+                "avg_launch_ms": round(d["ms_per_step"] / max(1, d["launches_per_step"]), 4), "traffic": measured_traffic(dom),
+                "note": f"bf16 MFMA executing exact 3-way operand splits: {d['tflops']} fp32-equivalent TFLOP/s x 6 products"}
     t_mfma = flops[dom] * B / (F32_MFMA_PEAK_TFLOPS * 1e12)
     t_hbm = (nbytes[dom] * B / (HBM_PEAK_GBS * 1e9)) if nbytes is not None else 0.0
     launches = max(1, d["launches_per_step"])
@@ -406,11 +417,12 @@ def run_semantic(args, rank, world, dev, dist):
                         "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None, "gbs": None}
     res = {
         "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "elapsed": elapsed, "audio_s_per_step": world * B * secs, "dtype": "f32",
+        "elapsed": elapsed, "audio_s_per_step": world * B * secs,
+        "dtype": "f32 (linear layers: exact bf16x3 splits, fp32 accumulate)" if BF16X3 else "f32",
         "config": {"workload": f"Tokenizers.semantic_m encode, {B} clips x {secs:g} s @16 kHz per GPU, {nl} conformer layers, VQ 2048x1024",
                    "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0",
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
-        "roofline": roofline_of(breakdown, flops, None, B), "breakdown": breakdown,
+        "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if BF16X3 else ()), "breakdown": breakdown,
         "token_checksum": int(toks.to(torch.int64).sum().item()),
         "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
     }
