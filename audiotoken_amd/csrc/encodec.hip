@@ -18,6 +18,7 @@
 #include "../../include/audiotoken_hip.h"
 #include "at_common.h"
 #include "encodec_kernels.h"
+#include "gemm_bf16x3.h"
 
 namespace at {
 
@@ -85,6 +86,7 @@ constexpr int kRatiosDec[4] = {8, 5, 4, 2};
 constexpr int kH = 512;
 constexpr int kDim = 128;
 constexpr int kCodes = 1024;
+constexpr bool kBf16x3AcousticDefault = true;
 constexpr int kSubBatchDefault = 256;  // clips per pass through the 24 kHz..75 Hz conv stack (bounds the workspace)
 inline int sub_batch() {
     static const int v = [] {
@@ -122,6 +124,10 @@ struct at_encodec {
     bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
     bool fused_down64 = true;       // stage-1 strided conv with register-stationary weights (seanet_down64.hip)
     bool fused_dectail = true;      // decoder: last transposed conv + block + final conv in one kernel (seanet_dectail.hip)
+    bool bf16x3 = false;            // plain linear layers (LSTM input projections) on the split-bf16 GEMM ($AUDIOTOKEN_BF16X3_ACOUSTIC)
+    const __bf16* wih_s[2] = {nullptr, nullptr};
+    const __bf16* dwih_s[2] = {nullptr, nullptr};
+    std::vector<void*> extra_allocs;
     int sub_batch = at::sub_batch();   // clips per pass through the conv stack: bounds the workspace (option "subbatch")
     bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
 };
@@ -279,7 +285,7 @@ int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L
 // 2-layer LSTM + skip over [B][T][512]; xg/c/h0 are scratch. y = lstm(x) + x.
 int lstm_skip(const float* const wih[2], const float* const whh[2], const float* const bih[2], const float* const bhh[2],
               const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream,
-              Profiler& prof, unsigned* sync, bool persistent, int y_elu) {
+              Profiler& prof, unsigned* sync, bool persistent, int y_elu, const __bf16* const* wih_s = nullptr, __bf16* xs = nullptr) {
     for (int layer = 0; layer < 2; ++layer) {
         const float* in = layer == 0 ? x : h0;
         float* hout = layer == 0 ? h0 : h1;
@@ -288,7 +294,16 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
         g.W = wih[layer]; g.bias = bih[layer];
         g.C = xg; g.ldc = 4 * kH; g.M = B * T; g.N = 4 * kH; g.K = kH; g.batch = 1;
         prof.begin("lstm_ih", 1, stream);
-        if (int rc = launch_gemm(g, stream)) return rc;
+        if (wih_s && wih_s[layer] && xs) {   // split-bf16 GEMM (gemm_bf16x3.hip): x -> 3 bf16 pieces, then 6 bf16 MFMAs per step
+            const long long M = (long long)B * T, Mpad = (M + 255) / 256 * 256;
+            if (int rc = launch_split_blocked(in, kH, M, Mpad, kH, xs, stream)) return rc;
+            Bf16x3Args a;
+            a.A = xs; a.W = wih_s[layer]; a.bias = bih[layer]; a.M = (int)M; a.N = 4 * kH; a.K = kH; a.Mpad = (int)Mpad;
+            a.epi = XB_EPI_LINEAR; a.C = xg; a.ldc = 4 * kH; a.alpha = 1.0f;
+            if (int rc = launch_gemm_bf16x3(a, stream)) return rc;
+        } else if (int rc = launch_gemm(g, stream)) {
+            return rc;
+        }
         prof.end(stream);
         if (persistent) {
             // whole sequence in one persistent launch per 256-clip block (lstm_seq.hip)
@@ -325,7 +340,7 @@ struct EncPlan {
     int L[5];        // lengths: L[0] = N, L[s+1] = ceil(L[s]/ratio)
     int G;           // sub-batch
     size_t off_x[4], off_h[4], off_r[4];  // per-stage sub-batch buffers (floats)
-    size_t off_x4, off_xg, off_h0, off_h1, off_c, off_y, off_emb, off_sync;
+    size_t off_x4, off_xg, off_h0, off_h1, off_c, off_y, off_emb, off_sync, off_xs;
     size_t total_floats;
 };
 
@@ -351,6 +366,7 @@ EncPlan make_plan(int B, int N, int sub) {
     p.off_y = take((size_t)B * T * kH);
     p.off_emb = take((size_t)B * T * kDim);
     p.off_sync = take(1024);
+    p.off_xs = take((((size_t)B * T + 255) / 256 * 256) * kH * 3 / 2);   // split-bf16 copy of an LSTM layer's input
     p.total_floats = cur;
     return p;
 }
@@ -358,7 +374,7 @@ EncPlan make_plan(int B, int N, int sub) {
 struct DecPlan {
     int L[5];  // L[0] = T, L[s+1] = L[s]*ratio
     int G;
-    size_t off_z, off_x0, off_xg, off_h0, off_h1, off_c, off_y, off_sync;
+    size_t off_z, off_x0, off_xg, off_h0, off_h1, off_c, off_y, off_sync, off_xs;
     size_t off_u[4], off_h[4], off_r[4];
     size_t total_floats;
 };
@@ -378,6 +394,7 @@ DecPlan make_dec_plan(int B, int T, int sub) {
     p.off_c = take((size_t)B * kH);
     p.off_y = take((size_t)B * T * kH);
     p.off_sync = take(1024);
+    p.off_xs = take((((size_t)B * T + 255) / 256 * 256) * kH * 3 / 2);   // split-bf16 copy of an LSTM layer's input
     int C = kH;
     for (int s = 0; s < 4; ++s) {
         C /= 2;
@@ -531,13 +548,30 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
         h->persistent_lstm = prop.multiProcessorCount >= 256 && !(env && env[0] == '1');
     }
     h->staged.clear();
+    {
+        const char* e = std::getenv("AUDIOTOKEN_BF16X3_ACOUSTIC");
+        h->bf16x3 = e ? std::atoi(e) != 0 : kBf16x3AcousticDefault;
+    }
+    if (h->bf16x3) {
+        for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
+            for (int l = 0; l < 2; ++l) {
+                __bf16* d = nullptr;
+                AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * 4 * kH * kH * sizeof(__bf16)));
+                h->extra_allocs.push_back(d);
+                if (int rc = launch_split_blocked(dec ? h->dwih[l] : h->wih[l], kH, 4 * kH, 4 * kH, kH, d, nullptr)) return rc;
+                (dec ? h->dwih_s : h->wih_s)[l] = d;
+            }
+        AT_CHECK_HIP(hipDeviceSynchronize());
+    }
     h->finalized = true;
     return 0;
 }
 
 void at_encodec_destroy(at_encodec_t* h) {
     if (!h) return;
-    if (h->blob) { (void)hipSetDevice(h->device); (void)hipFree(h->blob); }
+    (void)hipSetDevice(h->device);
+    if (h->blob) (void)hipFree(h->blob);
+    for (void* p : h->extra_allocs) (void)hipFree(p);
     delete h;
 }
 
@@ -628,7 +662,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
     AT_CHECK_HIP(hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), stream));
     if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
-                           sync, h->persistent_lstm, 1))
+                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs)))
         return rc;
     if (status_out) AT_CHECK_HIP(hipMemcpyAsync(status_out, sync + 63, sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     float* emb = emb_out ? emb_out : ws + p.off_emb;
@@ -714,7 +748,7 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
     // every activation that is only consumed through ELU is stored already ELU'd (once per element, in the producer's
     // epilogue) so the transposed convs run the plain-linear GEMM path: y (LSTM + skip) and the block outputs of stages 0-2
     if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,
-                           sync, h->persistent_lstm, 1))
+                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs)))
         return rc;
     const int Lout = p.L[4];
     for (int b0 = 0; b0 < B; b0 += p.G) {
