@@ -4,7 +4,7 @@
 
 namespace at {
 
-enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2, XB_EPI_GELU_SPLIT = 3 };
+enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2, XB_EPI_GELU_SPLIT = 3, XB_EPI_GELU = 4 };
 
 struct Bf16x3Args {
     const __bf16* A = nullptr;   // activations: 3 K-blocked pieces [3][K/16][Mpad][16]
@@ -19,6 +19,12 @@ struct Bf16x3Args {
     float alpha = 1.0f;
     // XB_EPI_SWISH_SPLIT / XB_EPI_GELU_SPLIT: S = split3(act(acc + bias)) as 3 K-blocked pieces [3][N/16][Spad][16] (the next layer's A operand)
     __bf16* S = nullptr; int Spad = 0;
+    // Windowed (conv1d) mode, batch > 1 or taps > 1: A pieces are [3][batch][C/16][Lp][16] (per clip, K-blocked over the Cin channels);
+    // output row m of a clip reads input rows m*stride + tap, K index = tap*Cin + c (the packed conv weight order). M, Mpad, Spad
+    // are PER CLIP; C / R are [batch][M][ldc]; S is [3][batch][N/16][Spad][16]. Defaults describe a plain linear layer.
+    int batch = 1, stride = 1;
+    int cblocks = 0;   // Cin / 16 (0: K / 16, i.e. one tap)
+    int Lp = 0;        // rows of A per clip (0: Mpad)
 };
 
 // fp32 row-major [rows][ld] (first K columns) -> 3 K-blocked bf16 pieces [3][K/16][rows_pad][16]; rows >= `rows` are zero-filled

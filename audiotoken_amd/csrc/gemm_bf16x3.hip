@@ -92,19 +92,27 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_bf16x3_kernel(Bf16x3Args
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];   // [2 stages][A: 3 x 256 x 16 | W: 3 x 256 x 16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int ntn = a.N / XB_N;
-    const int m0 = (blockIdx.x / ntn) * XB_M, n0 = (blockIdx.x % ntn) * XB_N;   // n fastest: the activation tile is fetched once per row of blocks
-    const long long psA = (long long)a.Mpad * a.K, psW = (long long)a.N * a.K;
+    const int ntn = a.N / XB_N, ntm = a.Mpad / XB_M;
+    const int n0 = (blockIdx.x % ntn) * XB_N;   // n fastest: the activation tile is fetched once per row of blocks
+    const int mt = blockIdx.x / ntn;
+    const int clip = mt / ntm, m0 = (mt - clip * ntm) * XB_M;
+    const int cblocks = a.cblocks > 0 ? a.cblocks : a.K / XB_K;
+    const int Lp = a.Lp > 0 ? a.Lp : a.Mpad;
+    const long long a_clip = (long long)cblocks * Lp * 16;           // elements of one clip of one piece
+    const long long psA = a_clip * a.batch, psW = (long long)a.N * a.K;
     const int nk = a.K / XB_K;
+    const __bf16* Ab = a.A + clip * a_clip + (long long)m0 * a.stride * 16;
     // staging: one piece of an operand tile is rows x 32 B = 2 * rows chunks of 16 B, contiguous in the K-blocked layout
     constexpr int CA = (2 * XB_M) / NT, CW = (2 * XB_N) / NT;   // chunks per thread per piece
     static_assert((2 * XB_M) % NT == 0 && (2 * XB_N) % NT == 0, "tile rows must be a multiple of half the thread count");
     u4 sa[3][CA], sw[3][CW];
     auto load = [&](int kt) {
+        const int tapk = kt / cblocks, cbk = kt - tapk * cblocks;   // K tile -> (tap, channel block)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-            for (int c = 0; c < CA; ++c) sa[p][c] = *reinterpret_cast<const u4*>(a.A + p * psA + ((long long)kt * a.Mpad + m0) * 16 + (tid + c * NT) * 8);
+            for (int c = 0; c < CA; ++c)
+                sa[p][c] = *reinterpret_cast<const u4*>(Ab + p * psA + ((long long)cbk * Lp + tapk) * 16 + (long long)((tid + c * NT) >> 1) * a.stride * 16 + ((tid + c * NT) & 1) * 8);
 #pragma unroll
             for (int c = 0; c < CW; ++c) sw[p][c] = *reinterpret_cast<const u4*>(a.W + p * psW + ((long long)kt * a.N + n0) * 16 + (tid + c * NT) * 8);
         }
@@ -154,7 +162,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_bf16x3_kernel(Bf16x3Args
         __syncthreads();
     }
     // lane holds output row m = frow of its 32-row tile and, per register group g, 4 consecutive columns n = 8g + 4 fhalf ..
-    const long long psS = (long long)a.Spad * a.N;
+    const long long s_clip = (long long)a.Spad * a.N;            // elements of one clip of one split output piece
+    const long long psS = s_clip * a.batch;
+    __bf16* Sb = a.S ? a.S + clip * s_clip : nullptr;
+    float* Cb = a.C ? a.C + (long long)clip * a.M * a.ldc : nullptr;
+    const float* Rb = a.R ? a.R + (long long)clip * a.M * a.ldr : nullptr;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int m = m0 + wm * TI * 32 + i * 32 + frow;
@@ -177,18 +189,19 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_bf16x3_kernel(Bf16x3Args
                         p1[k] = x1; p2[k] = x2; p3[k] = x3;
                     }
                     const long long o = ((long long)(n >> 4) * a.Spad + m) * 16 + (n & 15);   // K-blocked: this output is the next layer's K
-                    *reinterpret_cast<bf16x4*>(a.S + o) = p1;
-                    *reinterpret_cast<bf16x4*>(a.S + psS + o) = p2;
-                    *reinterpret_cast<bf16x4*>(a.S + 2 * psS + o) = p3;
+                    *reinterpret_cast<bf16x4*>(Sb + o) = p1;
+                    *reinterpret_cast<bf16x4*>(Sb + psS + o) = p2;
+                    *reinterpret_cast<bf16x4*>(Sb + 2 * psS + o) = p3;
                 } else if (a.epi == XB_EPI_GLU) {
                     float2 o;
                     o.x = v.x * sigmoidf_(v.y);
                     o.y = v.z * sigmoidf_(v.w);
-                    *reinterpret_cast<float2*>(a.C + (long long)m * a.ldc + (n >> 1)) = o;
+                    *reinterpret_cast<float2*>(Cb + (long long)m * a.ldc + (n >> 1)) = o;
                 } else {
+                    if (a.epi == XB_EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
                     v *= a.alpha;
-                    if (a.R) v += *reinterpret_cast<const f4*>(a.R + (long long)m * a.ldr + n);
-                    *reinterpret_cast<f4*>(a.C + (long long)m * a.ldc + n) = v;
+                    if (Rb) v += *reinterpret_cast<const f4*>(Rb + (long long)m * a.ldr + n);
+                    *reinterpret_cast<f4*>(Cb + (long long)m * a.ldc + n) = v;
                 }
             }
     }
@@ -203,7 +216,7 @@ static int launch_xb(const Bf16x3Args& a, hipStream_t stream) {
         AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<WM, WN, TI, TJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         attr_set = true;
     }
-    const dim3 grid((unsigned)((a.Mpad / Cfg::BM) * (a.N / Cfg::BN)));
+    const dim3 grid((unsigned)((long long)a.batch * (a.Mpad / Cfg::BM) * (a.N / Cfg::BN)));
     hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TI, TJ>), grid, dim3(Cfg::NT), ldsb, stream, a);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
@@ -213,7 +226,9 @@ int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
     AT_REQUIRE(a.A && a.W && a.M >= 1 && a.N % 256 == 0 && a.K % XB_K == 0 && a.Mpad % 256 == 0 && a.Mpad >= a.M,
                "gemm_bf16x3: N % 256, K % 16, Mpad % 256");
     AT_REQUIRE((a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT) ? (a.S != nullptr && a.Spad >= a.M) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
-    const long long tiles256 = (long long)(a.Mpad / 256) * (a.N / 256);
+    AT_REQUIRE(a.batch >= 1 && a.stride >= 1 && (a.cblocks == 0 || (a.K / XB_K) % a.cblocks == 0), "gemm_bf16x3: bad window description");
+    AT_REQUIRE((a.Lp > 0 ? a.Lp : a.Mpad) >= (a.Mpad - 1) * a.stride + (a.cblocks > 0 ? (a.K / XB_K) / a.cblocks : 1), "gemm_bf16x3: Lp too small for the last tile");
+    const long long tiles256 = (long long)a.batch * (a.Mpad / 256) * (a.N / 256);
     if (tiles256 < 256) return launch_xb<2, 2, 2, 2>(a, stream);   // 4x as many 128 x 128 tiles: same arithmetic, fills the chip
     return launch_xb<4, 2, 2, 4>(a, stream);
 }

@@ -45,6 +45,7 @@ struct at_hubert {
     const float *pos_w = nullptr, *pos_b = nullptr, *enc_ln_g = nullptr, *enc_ln_b = nullptr;
     std::vector<LayerW> layers;
     const float *centers = nullptr, *c2 = nullptr;
+    const __bf16* conv_ws[7] = {};   // split-bf16 conv weights (layers 1..6)
     bool bf16x3 = false;   // transformer linear layers on the bf16 matrix cores with exact 3-way operand splits ($AUDIOTOKEN_BF16X3, default on)
     Profiler prof;
 };
@@ -76,6 +77,9 @@ struct Plan {
     int L[8];   // L[0] = N, L[i+1] = frames after conv i
     size_t off_a, off_b, off_part, off_ss, off_fmask, off_x, off_t1, off_big, off_pos, off_xs, off_bigs;
     size_t Mpad;
+    int Lp[8];              // rows per clip of the split-bf16 input of conv i (i = 1..6)
+    int Mp[8];              // padded output rows per clip of conv i
+    size_t off_sa, off_sb;  // split-bf16 ping / pong buffers of the conv chain
     size_t total_floats;
 };
 Plan make_plan(int B, int N) {
@@ -95,6 +99,18 @@ Plan make_plan(int B, int N) {
     p.off_pos = takef(M * kHid);
     p.off_big = takef(M * kFfn);
     p.Mpad = (M + 255) / 256 * 256;                 // split-bf16 operands: 3 pieces x 2 bytes = 1.5 floats per element
+    {
+        size_t need[2] = {0, 0};
+        for (int i = 1; i < 7; ++i) {
+            p.Mp[i] = (p.L[i + 1] + 255) / 256 * 256;
+            const int reach = (p.Mp[i] - 1) * kSt[i] + kKs[i];
+            p.Lp[i] = ((p.L[i] > reach ? p.L[i] : reach) + 63) / 64 * 64;
+            const size_t fl = (size_t)B * p.Lp[i] * kCd * 3 / 2 + 64;   // 3 pieces x 2 bytes per element, in floats
+            if (fl > need[i & 1]) need[i & 1] = fl;
+        }
+        p.off_sa = takef(need[1]);   // inputs of conv 1, 3, 5
+        p.off_sb = takef(need[0]);   // inputs of conv 2, 4, 6
+    }
     p.off_xs = takef(p.Mpad * kHid * 3 / 2);
     p.off_bigs = takef(p.Mpad * kFfn * 3 / 2);
     p.total_floats = cur;
@@ -242,6 +258,14 @@ int at_hubert_finalize(at_hubert_t* h) {
         h->bf16x3 = e ? std::atoi(e) != 0 : true;
     }
     if (h->bf16x3) {
+        for (int i = 1; i < 7; ++i) {
+            const int k = kKs[i] * kCd;
+            __bf16* d = nullptr;
+            AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * kCd * k * sizeof(__bf16)));
+            h->allocs.push_back(reinterpret_cast<float*>(d));
+            if (int rc = launch_split_blocked(h->conv_w[i], k, kCd, kCd, k, d, nullptr)) return rc;
+            h->conv_ws[i] = d;
+        }
         for (LayerW& L : h->layers) {
             const float* src[4] = {L.wqkv, L.wo, L.w1, L.w2};
             const __bf16** dst[4] = {&L.wqkv_s, &L.wo_s, &L.w1_s, &L.w2_s};
@@ -301,6 +325,22 @@ int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B,
     float* bufs[2] = {ws + p.off_a, ws + p.off_b};
     prof.begin("feature_extractor", 9, stream);
     // conv0 + GroupNorm + GELU: statistics from float64 waveform moments, one pass over the output (hubert_kernels.hip)
+    if (h->bf16x3) {
+        // the six 512 -> 512 convs as windowed split-bf16 GEMMs (gemm_bf16x3.hip): conv0 writes the K-blocked bf16 pieces of its
+        // output, every conv's GELU epilogue writes the next conv's input the same way, the last one writes fp32 features
+        __bf16* sb[2] = {reinterpret_cast<__bf16*>(ws + p.off_sb), reinterpret_cast<__bf16*>(ws + p.off_sa)};   // [i & 1]
+        if (int rc = launch_hub_conv0_gn_gelu(wav, h->conv_w[0], h->gn_g, h->gn_b, ws + p.off_part, ws + p.off_ss, nullptr, B, N, p.L[1], stream,
+                                              sb[1], p.Lp[1]))
+            return rc;
+        for (int i = 1; i < 7; ++i) {
+            Bf16x3Args a;
+            a.A = sb[i & 1]; a.W = h->conv_ws[i]; a.M = p.L[i + 1]; a.Mpad = p.Mp[i]; a.N = kCd; a.K = kKs[i] * kCd;
+            a.batch = B; a.stride = kSt[i]; a.cblocks = kCd / 16; a.Lp = p.Lp[i];
+            if (i < 6) { a.epi = XB_EPI_GELU_SPLIT; a.S = sb[(i + 1) & 1]; a.Spad = p.Lp[i + 1]; }
+            else { a.epi = XB_EPI_GELU; a.C = bufs[6 & 1]; a.ldc = kCd; }
+            if (int rc = launch_gemm_bf16x3(a, stream)) return rc;
+        }
+    } else {
     if (int rc = launch_hub_conv0_gn_gelu(wav, h->conv_w[0], h->gn_g, h->gn_b, ws + p.off_part, ws + p.off_ss, bufs[0], B, N, p.L[1], stream))
         return rc;
     for (int i = 1; i < 7; ++i) {
@@ -311,6 +351,7 @@ int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B,
         a.C = bufs[i & 1]; a.c_bstride = (long long)p.L[i + 1] * kCd; a.ldc = kCd;
         a.M = p.L[i + 1]; a.N = kCd; a.K = kKs[i] * kCd; a.batch = B; a.epi = EPI_GELU;
         if (int rc = launch_gemm(a, stream)) return rc;
+    }
     }
     prof.end(stream);
     const float* feats = bufs[6 & 1];   // [B][T][512]

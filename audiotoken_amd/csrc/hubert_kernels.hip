@@ -96,7 +96,8 @@ __global__ __launch_bounds__(512) void hub_gn_coeff_kernel(const double* __restr
 constexpr int C0_FRAMES = 64;
 
 __global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __restrict__ wav, const float* __restrict__ w /*[512][10]*/,
-                                                                const float* __restrict__ ss, float* __restrict__ out, int N, int T0) {
+                                                                const float* __restrict__ ss, float* __restrict__ out, int N, int T0,
+                                                                __bf16* __restrict__ split, int Lp) {
     __shared__ float xs[C0_FRAMES * 5 + 8];
     const int b = blockIdx.y, t0 = blockIdx.x * C0_FRAMES;
     const int cg = threadIdx.x & 127, sub = threadIdx.x >> 7;
@@ -128,19 +129,38 @@ __global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __r
             for (int k = 0; k < 10; ++k) acc = fmaf(wr[c][k], xv[k], acc);
             o[c] = gelu_erf(fmaf(acc, sc[c], sh[c]));
         }
-        *reinterpret_cast<f4*>(orow + (long long)f * 512) = o;
+        if (split) {
+            // the next conv runs on the split-bf16 GEMM: write the three K-blocked pieces [3][B][512/16][Lp][16] of this clip
+            // (channels 4cg..4cg+3 = channel block cg/4, quarter cg%4; 64 frames x 32 B of a block are contiguous)
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 p1, p2, p3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const __bf16 a1 = (__bf16)o[k];
+                const float r1 = o[k] - (float)a1;
+                const __bf16 a2 = (__bf16)r1;
+                p1[k] = a1; p2[k] = a2; p3[k] = (__bf16)(r1 - (float)a2);
+            }
+            const long long off = (((long long)b * 32 + (cg >> 2)) * Lp + t0 + f) * 16 + (cg & 3) * 4;
+            const long long ps = (long long)gridDim.y * 32 * Lp * 16;
+            *reinterpret_cast<bf16x4*>(split + off) = p1;
+            *reinterpret_cast<bf16x4*>(split + ps + off) = p2;
+            *reinterpret_cast<bf16x4*>(split + 2 * ps + off) = p3;
+        } else {
+            *reinterpret_cast<f4*>(orow + (long long)f * 512) = o;
+        }
     }
 }
 
 int launch_hub_conv0_gn_gelu(const float* wav, const float* w, const float* gamma, const float* beta, float* part, float* ss, float* out,
-                             int B, int N, int T0, hipStream_t stream) {
+                             int B, int N, int T0, hipStream_t stream, __bf16* split, int Lp) {
     const int nchunk = hub_ws_nchunk(T0);
     double* dpart = reinterpret_cast<double*>(part);   // workspace slices are 256-byte aligned
     hipLaunchKernelGGL(hub_wavstats_kernel, dim3(nchunk, B), dim3(256), 0, stream, wav, dpart, N, T0, nchunk);
     AT_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(hub_gn_coeff_kernel, dim3(B), dim3(512), 0, stream, dpart, w, gamma, beta, ss, T0, nchunk);
     AT_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(hub_conv0_gn_gelu_kernel, dim3((T0 + C0_FRAMES - 1) / C0_FRAMES, B), dim3(256), 0, stream, wav, w, ss, out, N, T0);
+    hipLaunchKernelGGL(hub_conv0_gn_gelu_kernel, dim3((T0 + C0_FRAMES - 1) / C0_FRAMES, B), dim3(256), 0, stream, wav, w, ss, out, N, T0, split, Lp);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
