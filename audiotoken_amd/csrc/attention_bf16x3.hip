@@ -1,0 +1,289 @@
+// Relative-position self-attention (reference audiotoken/modeling_wav2vec2_bert.py:46-73) with both matrix products on the
+// bf16 matrix cores as exact 3-way operand splits (see gemm_bf16x3.hip for the arithmetic): q, k, v and the probabilities p are
+// split in registers / at staging time into three bf16 pieces each, and S^T = K.Q^T and O^T += V^T.P^T take six
+// v_mfma_f32_32x32x16_bf16 per fp32-equivalent 32x32x16 step (6/16 of the fp32 MFMA time of relpos_attention_kernel).
+// Same flash structure as the fp32 kernel (w2vbert_kernels.hip): workgroup = 128 queries of one (clip, head), wave = 32 queries
+// = one MFMA column tile; keys on the MFMA rows so a lane owns, for ONE query, 16 keys of each 32-key tile and P never leaves
+// registers; rel-pos bias table q.E^T (73 buckets) in LDS with far-field constants; exp2-domain online softmax.
+// K/V tiles of 32 keys: K as [3 pieces][32 keys][64 d], V transposed [3 pieces][64 d][32 keys] with the keys of a 16-group
+// permuted so that the 8 keys a lane's P registers hold for one MFMA k-step are contiguous (one ds_read_b128 per fragment).
+// 71 KB of LDS: two workgroups per CU. Also serves HuBERT (12 heads, no rel-pos bias).
+#include "at_common.h"
+#include "w2vbert_kernels.h"
+
+namespace at {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+constexpr int AX_QB = 128, AX_KB = 32;
+constexpr int AX_KLD = 72;    // bf16 per K row (64 d + 8 pad: 144-byte stride, conflict-free 16-byte fragment reads)
+constexpr int AX_VLD = 40;    // bf16 per V^T row (32 keys + 8 pad)
+constexpr int AX_QE_LD = 81;
+constexpr float AX_SCALE2 = 0.125f * 1.4426950408889634f;
+constexpr int AX_K_ELEMS = 3 * AX_KB * AX_KLD, AX_V_ELEMS = 3 * 64 * AX_VLD;
+constexpr size_t AX_LDS_BYTES = (size_t)(AX_K_ELEMS + AX_V_ELEMS) * 2 + (size_t)(AX_QB * AX_QE_LD + AX_KB + 4) * 4;
+
+__device__ __forceinline__ void ax_split(float a, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)a;
+    const float r1 = a - (float)p1;
+    p2 = (__bf16)r1;
+    p3 = (__bf16)(r1 - (float)p2);
+}
+
+__global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ amask,
+                                                                     const float* __restrict__ dist_emb, float* __restrict__ ctx, int T, int hid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);            // [3][32 keys][72]
+    __bf16* Vt = Ks + AX_K_ELEMS;                                // [3][64 d][40], keys permuted inside each 16-group
+    float* QE = reinterpret_cast<float*>(Vt + AX_V_ELEMS);       // [128 queries][81]: log2(e)/8 * q.E[bucket]
+    float* kb = QE + AX_QB * AX_QE_LD;                           // [32] additive key bias: 0 / finfo.min (padded) / -inf (beyond T)
+    int* kb_any = reinterpret_cast<int*>(kb + AX_KB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int l0 = blockIdx.x * AX_QB;
+    const long long rowbase = (long long)b * T;
+    const int LD = 3 * hid;
+    const float* qp = qkv + h * 64;
+    const float* kp = qkv + hid + h * 64;
+    const float* vp = qkv + 2 * hid + h * 64;
+    const bool relpos = dist_emb != nullptr;
+
+    // ---- rel-pos table QE = log2(e)/8 * q . E^T on the fp32 MFMA, once per workgroup (as relpos_attention_kernel) ---------------
+    if (relpos) {
+        const int r16 = lane & 15, qd = lane >> 4;
+        f4 qf[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int l = l0 + wave * 32 + i * 16 + r16;
+            const int lc = l < T ? l : T - 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qf[i][c] = *reinterpret_cast<const f4*>(qp + (rowbase + lc) * LD + c * 16 + qd * 4);
+        }
+#pragma unroll
+        for (int bt = 0; bt < 5; ++bt) {
+            f4 ef[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ef[c] = *reinterpret_cast<const f4*>(dist_emb + (bt * 16 + r16) * 64 + c * 16 + qd * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[c][e], qf[i][c][e], acc, 0, 0, 0);
+                float* dst = QE + (wave * 32 + i * 16 + r16) * AX_QE_LD + bt * 16 + qd * 4;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) dst[reg] = AX_SCALE2 * acc[reg];
+            }
+        }
+    }
+    // ---- this lane's query (column l32 of the wave's tile): 3 bf16 pieces of q[lq][dstep*16 + 8*hh .. +7] -------------------
+    const int lq = l0 + wave * 32 + l32;
+    bf16x8 qpc[3][4];
+    {
+        const int lc = lq < T ? lq : T - 1;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            const f4 a = *reinterpret_cast<const f4*>(qp + (rowbase + lc) * LD + ds * 16 + 8 * hh);
+            const f4 c = *reinterpret_cast<const f4*>(qp + (rowbase + lc) * LD + ds * 16 + 8 * hh + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __bf16 x1, x2, x3;
+                ax_split(a[k], x1, x2, x3); qpc[0][ds][k] = x1; qpc[1][ds][k] = x2; qpc[2][ds][k] = x3;
+                ax_split(c[k], x1, x2, x3); qpc[0][ds][4 + k] = x1; qpc[1][ds][4 + k] = x2; qpc[2][ds][4 + k] = x3;
+            }
+        }
+    }
+    f16v oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    const int wl_min = l0 + __builtin_amdgcn_readfirstlane(wave) * 32, wl_max = wl_min + 31;
+    const float FMIN = -3.4028234663852886e38f;
+    const int nkt = (T + AX_KB - 1) / AX_KB;
+
+    // ---- K/V staging: global (fp32, per-clip buffer descriptors: rows >= T read 0) -> registers -> split -> LDS -----------------
+    const int clip_bytes = T * LD * 4;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(kp + rowbase * LD), 0, clip_bytes - (hid + h * 64) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(vp + rowbase * LD), 0, clip_bytes - (2 * hid + h * 64) * 4, 0x00020000);
+    const int sk_key = tid >> 3, sk_d = (tid & 7) * 8;          // K: thread -> key, 8 consecutive d
+    const int sv_d = tid & 63, sv_g = tid >> 6;                 // V: thread -> dv, keys 8*sv_g .. +7
+    const int row_bytes = LD * 4;
+    const int k_voff = (sk_key * LD + sk_d) * 4, v_voff = (sv_g * 8 * LD + sv_d) * 4;
+    u4 kreg[2];
+    unsigned vreg[8];
+    float am = 0.f;
+    auto prefetch = [&](int kt) {
+        const int toff = kt * AX_KB * row_bytes;
+        kreg[0] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_voff + toff, 0, 0);
+        kreg[1] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_voff + toff + 16, 0, 0);
+        int vo = v_voff + toff;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { vreg[e] = __builtin_amdgcn_raw_buffer_load_b32(vrs, vo, 0, 0); vo += row_bytes; }
+        const int rr = kt * AX_KB + (tid & 31);
+        am = amask[rowbase + (rr < T ? rr : T - 1)];
+    };
+    prefetch(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int r0 = kt * AX_KB;
+        __syncthreads();   // previous tile fully consumed (also orders the QE stores before first use)
+        {
+            bf16x8 k1, k2, k3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 x1, x2, x3;
+                ax_split(__uint_as_float(kreg[e >> 2][e & 3]), x1, x2, x3);
+                k1[e] = x1; k2[e] = x2; k3[e] = x3;
+            }
+            __bf16* kd = Ks + sk_key * AX_KLD + sk_d;
+            *reinterpret_cast<bf16x8*>(kd) = k1;
+            *reinterpret_cast<bf16x8*>(kd + AX_KB * AX_KLD) = k2;
+            *reinterpret_cast<bf16x8*>(kd + 2 * AX_KB * AX_KLD) = k3;
+            // V^T: keys 8*sv_g + e -> 16-group g = sv_g >> 1, position 8*((e >> 2)) + 4*(sv_g & 1) + (e & 3) inside it
+            bf16x4 v1[2], v2[2], v3[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 x1, x2, x3;
+                ax_split(__uint_as_float(vreg[e]), x1, x2, x3);
+                v1[e >> 2][e & 3] = x1; v2[e >> 2][e & 3] = x2; v3[e >> 2][e & 3] = x3;
+            }
+            __bf16* vd = Vt + sv_d * AX_VLD + (sv_g >> 1) * 16 + 4 * (sv_g & 1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {   // u = e >> 2 selects the half hh whose lanes read this key quartet
+                *reinterpret_cast<bf16x4*>(vd + 8 * u) = v1[u];
+                *reinterpret_cast<bf16x4*>(vd + 8 * u + 64 * AX_VLD) = v2[u];
+                *reinterpret_cast<bf16x4*>(vd + 8 * u + 2 * 64 * AX_VLD) = v3[u];
+            }
+            if (tid < AX_KB) {
+                const int rr = r0 + tid;
+                const float kbv = rr < T ? (am != 0.f ? 0.f : FMIN) : -INFINITY;
+                kb[tid] = kbv;
+                const unsigned long long anyb = __builtin_amdgcn_ballot_w64(kbv != 0.f);
+                if (tid == 0) kb_any[0] = anyb != 0ull ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) prefetch(kt + 1);
+        // ---- S^T = K . Q^T: lane holds s[r] = q_lq . k_(r0 + 8*(r/4) + 4*hh + r%4) ------------------------------------------------
+        f16v s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            bf16x8 kf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8*>(Ks + p * AX_KB * AX_KLD + l32 * AX_KLD + ds * 16 + 8 * hh);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qpc[PB[t]][ds], s, 0, 0, 0);
+        }
+        // ---- bias + mask, online softmax in the exp2 domain ------------------------------------------------------------------------
+        const bool far_left = (r0 + AX_KB - 1) - wl_min <= -64;
+        const bool far_right = r0 - wl_max >= 8;
+        const bool plain = far_left || far_right || !relpos;
+        const bool masked = __builtin_amdgcn_readfirstlane(kb_any[0]) != 0;
+        const float* qe = QE + (wave * 32 + l32) * AX_QE_LD;
+        const float c_far = relpos ? (far_left ? qe[0] : qe[72]) : 0.f;
+        float mx = -INFINITY;
+        if (plain && !masked) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sc = fmaf(AX_SCALE2, s[r], c_far);
+                s[r] = sc;
+                mx = fmaxf(mx, sc);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 8 * (r >> 2) + 4 * hh + (r & 3);
+                float bias;
+                if (plain) {
+                    bias = c_far;
+                } else {
+                    int dd = (r0 + key) - lq;
+                    dd = dd < -64 ? -64 : (dd > 8 ? 8 : dd);
+                    bias = qe[dd + 64];
+                }
+                const float sc = fmaf(AX_SCALE2, s[r], bias + kb[key]);
+                s[r] = sc;
+                mx = fmaxf(mx, sc);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(mrun, mx);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[r] - mnew);
+            s[r] = p;
+            rs += p;
+        }
+        rs += __shfl_xor(rs, 32);
+        if (__builtin_amdgcn_ballot_w64(mnew != mrun) != 0ull) {
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);   // exp2(-inf) = 0 on the first tile
+            lrun = lrun * alpha + rs;
+            mrun = mnew;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        } else {
+            lrun += rs;
+        }
+        // ---- P pieces (B operand of P.V: k-step ks uses registers 8ks .. 8ks+7 = keys 16ks + {0..3, 8..11} + 4hh) -----------------
+        bf16x8 pp[3][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                __bf16 x1, x2, x3;
+                ax_split(s[8 * ks + j], x1, x2, x3);
+                pp[0][ks][j] = x1; pp[1][ks][j] = x2; pp[2][ks][j] = x3;
+            }
+        // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 vf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const bf16x8*>(Vt + p * 64 * AX_VLD + (dt * 32 + l32) * AX_VLD + ks * 16 + 8 * hh);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[t]], pp[PB[t]][ks], oacc[dt], 0, 0, 0);
+            }
+    }
+    // lane holds O[lq][dv = 32 dt + 8*(r/4) + 4 hh + r%4]
+    if (lq < T) {
+        const float inv = 1.0f / lrun;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f4 v = {oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv};
+                *reinterpret_cast<f4*>(ctx + (rowbase + lq) * hid + h * 64 + dt * 32 + 8 * g + 4 * hh) = v;
+            }
+    }
+}
+
+int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads) {
+    AT_REQUIRE(B >= 1 && T >= 1 && heads >= 1 && heads <= 64, "relpos_attention_x3: bad shape");
+    AT_REQUIRE((long long)T * 3 * heads * 64 * 4 < (1ll << 31), "relpos_attention_x3: one clip's qkv rows exceed the buffer-descriptor range");
+    dim3 grid((T + AX_QB - 1) / AX_QB, heads, B);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AX_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(relpos_attention_x3_kernel, grid, dim3(256), AX_LDS_BYTES, stream, qkv, amask, dist_emb, ctx, T, heads * 64);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace at

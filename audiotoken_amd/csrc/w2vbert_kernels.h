@@ -13,6 +13,8 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, cons
                      hipStream_t stream);
 int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
                             hipStream_t stream, int heads = 16);
+// the same attention with both products as exact 3-way bf16 splits on the bf16 matrix cores (attention_bf16x3.hip)
+int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads);
 int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,
                            hipStream_t stream);
 int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,

@@ -3,6 +3,7 @@
 // GEMM-shaped work (DFT, mel projection, all Linear layers) goes through gemm_core.h.
 #include "gemm_core.h"
 #include "w2vbert_kernels.h"
+#include <cstdlib>
 
 namespace at {
 
@@ -311,6 +312,7 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, cons
 // each 16-key tile — exactly the B-operand fragment of the P.V MFMA, so P never leaves registers.
 // qkv layout: [B*T][3072] = [q | k | v], head h at columns h*64.
 // ------------------------------------------------------------------------------------------------------
+constexpr bool kAttnX3Default = true;   // split-bf16 attention kernel (attention_bf16x3.hip); $AUDIOTOKEN_ATTN_X3 overrides
 constexpr int ATT_QB = 128, ATT_KB = 64, ATT_D = 64;
 constexpr float ATT_SCALE2 = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e): scores live in the exp2 domain (p = v_exp_f32(s - m))
 constexpr int ATT_QE_LD = 81;   // 73 buckets padded to an odd stride
@@ -544,6 +546,8 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_kernel(const float* _
 
 int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
                             hipStream_t stream, int heads) {
+    static const bool x3 = std::getenv("AUDIOTOKEN_ATTN_X3") ? std::atoi(std::getenv("AUDIOTOKEN_ATTN_X3")) != 0 : kAttnX3Default;
+    if (x3) return launch_relpos_attention_x3(qkv, amask, dist_emb, ctx, B, T, stream, heads);
     dim3 grid((T + ATT_QB - 1) / ATT_QB, heads, B);
     const size_t lds = ATT_LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
