@@ -10,11 +10,12 @@
 // contiguous 8 KB run (row-major pieces measured 157-179 instead of 194-196 fp32-equivalent TFLOP/s). Weights are split once
 // at finalize(); activations are split by their producer: a standalone pass for LayerNorm outputs (launch_split_blocked) and
 // the GEMM epilogue itself for the FFN's hidden activation.
-// Tile: 256 x 256 per workgroup, 8 waves as 4 x 2, each 64 x 128 = 2 x 4 MFMA tiles of 32 x 32; K tile 16; LDS 2 x 48 KB,
-// register-staged double buffering; operands swapped (weights as MFMA A) so a lane owns 4 consecutive output channels.
+// Tiles: 256 x 128 per workgroup (4 waves, each 64 x 128 = 2 x 4 MFMA tiles of 32 x 32, two workgroups per CU), 256 x 256
+// (8 waves) or 128 x 128 for small launches; K tile 16; register-staged double-buffered LDS; operands swapped (weights as MFMA A) so a lane owns 4 consecutive output channels.
 // Used for the conformer feed-forward layers (w2vbert.hip); everything that has a bit-identical fused twin stays on the fp32 MFMA.
 #include "at_common.h"
 #include "gemm_bf16x3.h"
+#include <cstdlib>
 
 namespace at {
 
@@ -86,7 +87,7 @@ int launch_split_blocked(const float* x, int ld, long long rows, long long rows_
 }
 
 template <int WM, int WN, int TI, int TJ>
-__global__ __launch_bounds__(WM * WN * 64, 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
     using Cfg = XbCfg<WM, WN, TI, TJ>;
     constexpr int XB_M = Cfg::BM, XB_N = Cfg::BN, NT = Cfg::NT;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];   // [2 stages][A: 3 x 256 x 16 | W: 3 x 256 x 16]
@@ -230,6 +231,11 @@ int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
     AT_REQUIRE((a.Lp > 0 ? a.Lp : a.Mpad) >= (a.Mpad - 1) * a.stride + (a.cblocks > 0 ? (a.K / XB_K) / a.cblocks : 1), "gemm_bf16x3: Lp too small for the last tile");
     const long long tiles256 = (long long)a.batch * (a.Mpad / 256) * (a.N / 256);
     if (tiles256 < 256) return launch_xb<2, 2, 2, 2>(a, stream);   // 4x as many 128 x 128 tiles: same arithmetic, fills the chip
+    // large launches: 256 x 128 tiles, 4 waves, TWO workgroups per CU (one loads while the other multiplies) measured 1-2 % ahead of
+    // 256 x 256 with 8 waves and one workgroup per CU (less operand traffic, no overlap); $AUDIOTOKEN_XB_TILE=0 selects the latter.
+    // The kernel is bound by the L2 -> LDS operand stream: time = 1.67 ms + 0.41 ms per product on the FFN shape (tools/bf16x3_gemm.hip).
+    static const int big = std::getenv("AUDIOTOKEN_XB_TILE") ? std::atoi(std::getenv("AUDIOTOKEN_XB_TILE")) : 1;
+    if (big == 1) return launch_xb<4, 1, 2, 4>(a, stream);
     return launch_xb<4, 2, 2, 4>(a, stream);
 }
 
