@@ -19,12 +19,17 @@ struct Bf16x3Args {
     float alpha = 1.0f;
     // XB_EPI_SWISH_SPLIT / XB_EPI_GELU_SPLIT: S = split3(act(acc + bias)) as 3 K-blocked pieces [3][N/16][Spad][16] (the next layer's A operand)
     __bf16* S = nullptr; int Spad = 0;
-    // Windowed (conv1d) mode, batch > 1 or taps > 1: A pieces are [3][batch][C/16][Lp][16] (per clip, K-blocked over the Cin channels);
-    // output row m of a clip reads input rows m*stride + tap, K index = tap*Cin + c (the packed conv weight order). M, Mpad, Spad
-    // are PER CLIP; C / R are [batch][M][ldc]; S is [3][batch][N/16][Spad][16]. Defaults describe a plain linear layer.
+    // Windowed (conv1d) mode, batch > 1 or taps > 1: A pieces are [3][batch][C/16][stride][Lp][16] — per clip, K-blocked over the
+    // Cin channels and PHASE-MAJOR in time: input row t lives in plane t % stride at index t / stride (+ any front padding the
+    // producer added), so output row m of tap j reads plane j % stride, index m + j / stride: consecutive output rows are
+    // consecutive 32-byte chunks for every tap (a row-major time axis gave stride-spaced chunks: 20-30 % slower).
+    // K index = tap*Cin + c (the packed conv weight order). M, Mpad, Spad are PER CLIP; C / R are [batch][M][ldc];
+    // S is [3][batch][N/16][Sphases][Spad][16] with output row m in plane m % Sphases at index m / Sphases + Sfront.
+    // Defaults describe a plain linear layer.
     int batch = 1, stride = 1;
     int cblocks = 0;   // Cin / 16 (0: K / 16, i.e. one tap)
-    int Lp = 0;        // rows of A per clip (0: Mpad)
+    int Lp = 0;        // rows per phase plane of A (0: Mpad)
+    int Sphases = 1, Sfront = 0;
 };
 
 // fp32 row-major [rows][ld] (first K columns) -> 3 K-blocked bf16 pieces [3][K/16][rows_pad][16]; rows >= `rows` are zero-filled

@@ -99,21 +99,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
     const int clip = mt / ntm, m0 = (mt - clip * ntm) * XB_M;
     const int cblocks = a.cblocks > 0 ? a.cblocks : a.K / XB_K;
     const int Lp = a.Lp > 0 ? a.Lp : a.Mpad;
-    const long long a_clip = (long long)cblocks * Lp * 16;           // elements of one clip of one piece
+    const long long a_clip = (long long)cblocks * a.stride * Lp * 16;   // elements of one clip of one piece
     const long long psA = a_clip * a.batch, psW = (long long)a.N * a.K;
     const int nk = a.K / XB_K;
-    const __bf16* Ab = a.A + clip * a_clip + (long long)m0 * a.stride * 16;
+    const __bf16* Ab = a.A + clip * a_clip + (long long)m0 * 16;
     // staging: one piece of an operand tile is rows x 32 B = 2 * rows chunks of 16 B, contiguous in the K-blocked layout
     constexpr int CA = (2 * XB_M) / NT, CW = (2 * XB_N) / NT;   // chunks per thread per piece
     static_assert((2 * XB_M) % NT == 0 && (2 * XB_N) % NT == 0, "tile rows must be a multiple of half the thread count");
     u4 sa[3][CA], sw[3][CW];
     auto load = [&](int kt) {
-        const int tapk = kt / cblocks, cbk = kt - tapk * cblocks;   // K tile -> (tap, channel block)
+        const int tapk = kt / cblocks, cbk = kt - tapk * cblocks;   // K tile -> (tap, channel block) -> (phase plane, row offset)
+        const int offk = tapk / a.stride, planek = tapk - offk * a.stride;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
             for (int c = 0; c < CA; ++c)
-                sa[p][c] = *reinterpret_cast<const u4*>(Ab + p * psA + ((long long)cbk * Lp + tapk) * 16 + (long long)((tid + c * NT) >> 1) * a.stride * 16 + ((tid + c * NT) & 1) * 8);
+                sa[p][c] = *reinterpret_cast<const u4*>(Ab + p * psA + (((long long)cbk * a.stride + planek) * Lp + offk) * 16 + (tid + c * NT) * 8);
 #pragma unroll
             for (int c = 0; c < CW; ++c) sw[p][c] = *reinterpret_cast<const u4*>(a.W + p * psW + ((long long)kt * a.N + n0) * 16 + (tid + c * NT) * 8);
         }
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
         __syncthreads();
     }
     // lane holds output row m = frow of its 32-row tile and, per register group g, 4 consecutive columns n = 8g + 4 fhalf ..
-    const long long s_clip = (long long)a.Spad * a.N;            // elements of one clip of one split output piece
+    const long long s_clip = (long long)a.Spad * a.Sphases * a.N;   // elements of one clip of one split output piece
     const long long psS = s_clip * a.batch;
     __bf16* Sb = a.S ? a.S + clip * s_clip : nullptr;
     float* Cb = a.C ? a.C + (long long)clip * a.M * a.ldc : nullptr;
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
                         split3(sw, x1, x2, x3);
                         p1[k] = x1; p2[k] = x2; p3[k] = x3;
                     }
-                    const long long o = ((long long)(n >> 4) * a.Spad + m) * 16 + (n & 15);   // K-blocked: this output is the next layer's K
+                    const int sq = m / a.Sphases, sp = m - sq * a.Sphases;                        // phase-major time axis of the consumer
+                    const long long o = (((long long)(n >> 4) * a.Sphases + sp) * a.Spad + sq + a.Sfront) * 16 + (n & 15);   // K-blocked: this output is the next layer's K
                     *reinterpret_cast<bf16x4*>(Sb + o) = p1;
                     *reinterpret_cast<bf16x4*>(Sb + psS + o) = p2;
                     *reinterpret_cast<bf16x4*>(Sb + 2 * psS + o) = p3;
@@ -226,9 +228,9 @@ static int launch_xb(const Bf16x3Args& a, hipStream_t stream) {
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
     AT_REQUIRE(a.A && a.W && a.M >= 1 && a.N % 256 == 0 && a.K % XB_K == 0 && a.Mpad % 256 == 0 && a.Mpad >= a.M,
                "gemm_bf16x3: N % 256, K % 16, Mpad % 256");
-    AT_REQUIRE((a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT) ? (a.S != nullptr && a.Spad >= a.M) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
+    AT_REQUIRE((a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT) ? (a.S != nullptr && a.Sphases >= 1 && (long long)a.Spad * a.Sphases >= a.M + (long long)a.Sfront * a.Sphases) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
     AT_REQUIRE(a.batch >= 1 && a.stride >= 1 && (a.cblocks == 0 || (a.K / XB_K) % a.cblocks == 0), "gemm_bf16x3: bad window description");
-    AT_REQUIRE((a.Lp > 0 ? a.Lp : a.Mpad) >= (a.Mpad - 1) * a.stride + (a.cblocks > 0 ? (a.K / XB_K) / a.cblocks : 1), "gemm_bf16x3: Lp too small for the last tile");
+    AT_REQUIRE((a.Lp > 0 ? a.Lp : a.Mpad) >= a.Mpad + ((a.cblocks > 0 ? (a.K / XB_K) / a.cblocks : 1) - 1) / a.stride, "gemm_bf16x3: Lp too small for the last tile");
     const long long tiles256 = (long long)a.batch * (a.Mpad / 256) * (a.N / 256);
     if (tiles256 < 256) return launch_xb<2, 2, 2, 2>(a, stream);   // 4x as many 128 x 128 tiles: same arithmetic, fills the chip
     // large launches: 256 x 128 tiles, 4 waves, TWO workgroups per CU (one loads while the other multiplies) measured 1-2 % ahead of

@@ -77,7 +77,7 @@ struct Plan {
     int L[8];   // L[0] = N, L[i+1] = frames after conv i
     size_t off_a, off_b, off_part, off_ss, off_fmask, off_x, off_t1, off_big, off_pos, off_xs, off_bigs;
     size_t Mpad;
-    int Lp[8];              // rows per clip of the split-bf16 input of conv i (i = 1..6)
+    int Lp[8];              // rows per phase plane of the split-bf16 input of conv i (i = 1..6)
     int Mp[8];              // padded output rows per clip of conv i
     size_t off_sa, off_sb;  // split-bf16 ping / pong buffers of the conv chain
     size_t total_floats;
@@ -103,9 +103,10 @@ Plan make_plan(int B, int N) {
         size_t need[2] = {0, 0};
         for (int i = 1; i < 7; ++i) {
             p.Mp[i] = (p.L[i + 1] + 255) / 256 * 256;
-            const int reach = (p.Mp[i] - 1) * kSt[i] + kKs[i];
-            p.Lp[i] = ((p.L[i] > reach ? p.L[i] : reach) + 63) / 64 * 64;
-            const size_t fl = (size_t)B * p.Lp[i] * kCd * 3 / 2 + 64;   // 3 pieces x 2 bytes per element, in floats
+            // phase-major time axis: kSt planes of Lp rows each; the last tile of tap j reads rows up to Mp + (k - 1) / stride
+            const int reach = p.Mp[i] + (kKs[i] - 1) / kSt[i], have = (p.L[i] + kSt[i] - 1) / kSt[i];
+            p.Lp[i] = ((have > reach ? have : reach) + 63) / 64 * 64;
+            const size_t fl = (size_t)B * kSt[i] * p.Lp[i] * kCd * 3 / 2 + 64;   // 3 pieces x 2 bytes per element, in floats
             if (fl > need[i & 1]) need[i & 1] = fl;
         }
         p.off_sa = takef(need[1]);   // inputs of conv 1, 3, 5
@@ -336,7 +337,7 @@ int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B,
             Bf16x3Args a;
             a.A = sb[i & 1]; a.W = h->conv_ws[i]; a.M = p.L[i + 1]; a.Mpad = p.Mp[i]; a.N = kCd; a.K = kKs[i] * kCd;
             a.batch = B; a.stride = kSt[i]; a.cblocks = kCd / 16; a.Lp = p.Lp[i];
-            if (i < 6) { a.epi = XB_EPI_GELU_SPLIT; a.S = sb[(i + 1) & 1]; a.Spad = p.Lp[i + 1]; }
+            if (i < 6) { a.epi = XB_EPI_GELU_SPLIT; a.S = sb[(i + 1) & 1]; a.Spad = p.Lp[i + 1]; a.Sphases = kSt[i + 1]; }
             else { a.epi = XB_EPI_GELU; a.C = bufs[6 & 1]; a.ldc = kCd; }
             if (int rc = launch_gemm_bf16x3(a, stream)) return rc;
         }

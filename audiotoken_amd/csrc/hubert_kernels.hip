@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __r
             o[c] = gelu_erf(fmaf(acc, sc[c], sh[c]));
         }
         if (split) {
-            // the next conv runs on the split-bf16 GEMM: write the three K-blocked pieces [3][B][512/16][Lp][16] of this clip
-            // (channels 4cg..4cg+3 = channel block cg/4, quarter cg%4; 64 frames x 32 B of a block are contiguous)
+            // the next conv runs on the split-bf16 GEMM: write the three K-blocked pieces [3][B][512/16][2][Lp][16] of this clip
+            // (channels 4cg..4cg+3 = channel block cg/4, quarter cg%4)
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 p1, p2, p3;
 #pragma unroll
@@ -141,8 +141,10 @@ __global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __r
                 const __bf16 a2 = (__bf16)r1;
                 p1[k] = a1; p2[k] = a2; p3[k] = (__bf16)(r1 - (float)a2);
             }
-            const long long off = (((long long)b * 32 + (cg >> 2)) * Lp + t0 + f) * 16 + (cg & 3) * 4;
-            const long long ps = (long long)gridDim.y * 32 * Lp * 16;
+            // phase-major time axis for the stride-2 conv that follows: frame t -> plane t & 1, index t >> 1 (Lp rows per plane)
+            const int t = t0 + f;
+            const long long off = ((((long long)b * 32 + (cg >> 2)) * 2 + (t & 1)) * Lp + (t >> 1)) * 16 + (cg & 3) * 4;
+            const long long ps = (long long)gridDim.y * 32 * 2 * Lp * 16;
             *reinterpret_cast<bf16x4*>(split + off) = p1;
             *reinterpret_cast<bf16x4*>(split + ps + off) = p2;
             *reinterpret_cast<bf16x4*>(split + 2 * ps + off) = p3;
