@@ -123,6 +123,7 @@ struct at_encodec {
     bool fused_res64 = true;        // 64-channel residual block in one kernel (seanet_res64.hip)
     bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
     bool fused_down64 = true;       // stage-1 strided conv with register-stationary weights (seanet_down64.hip)
+    bool down64_x3 = true;          // ... on the bf16 matrix cores with 3-way split operands (seanet_down64x3.hip); follows bf16x3
     bool fused_dectail = true;      // decoder: last transposed conv + block + final conv in one kernel (seanet_dectail.hip)
     bool bf16x3 = false;            // plain linear layers (LSTM input projections) on the split-bf16 GEMM ($AUDIOTOKEN_BF16X3_ACOUSTIC)
     const __bf16* wih_s[2] = {nullptr, nullptr};
@@ -650,7 +651,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             if (s == 1 && h->fused_down64 && L % 4 == 0) {
                 Down64Args da;
                 da.x = r; da.out = out; da.w = h->down[1].w; da.b = h->down[1].b; da.B = g; da.L = L;
-                if (int rc = launch_seanet_down64(da, stream)) return rc;
+                if (int rc = (h->down64_x3 && h->bf16x3) ? launch_seanet_down64x3(da, stream) : launch_seanet_down64(da, stream)) return rc;
             } else if (int rc = conv_gemm(h->down[s], r, (long long)L * C, L, out, (long long)Lo * 2 * C, Lo, g, PRO_NONE, nullptr, 0, stream)) {
                 return rc;
             }
@@ -692,6 +693,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res64") { h->fused_res64 = value != 0; return 0; }
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
+    if (std::string(name) == "down64_x3") { h->down64_x3 = value != 0; return 0; }
     if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }
     if (std::string(name) == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
     set_error(std::string("unknown option ") + name);

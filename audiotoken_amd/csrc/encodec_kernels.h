@@ -61,6 +61,8 @@ struct Down64Args {
     int B, L;
 };
 int launch_seanet_down64(const Down64Args& a, hipStream_t stream);
+// the same conv on the bf16 matrix cores with exact 3-way bf16 splits of both operands (seanet_down64x3.hip)
+int launch_seanet_down64x3(const Down64Args& a, hipStream_t stream);
 // Decoder tail (seanet_dectail.hip): x [B][L][64] (ELU'd) -> transposed conv (64->32, k4 s2) -> resblock(32) -> ELU -> conv k7 -> wav [B][2L]
 struct DecTailArgs {
     const float* x;

@@ -1,0 +1,211 @@
+// SEANet stage-1 strided conv (64 -> 128 channels, k = 8, stride 4, causal) on the bf16 matrix cores: the same register-stationary
+// scheme as seanet_down64.hip, but with both operands as exact 3-way bf16 splits (see gemm_bf16x3.hip for the arithmetic and its
+// measured accuracy) and six v_mfma_f32_16x16x32_bf16 (16 cycles each) per 32-wide K step instead of eight 32-cycle fp32 MFMAs:
+// 6/16 of the matrix time. Weights: wave w keeps output channels 32w..32w+31 x K = 512 as three bf16 pieces in 384 registers
+// (one wave per SIMD owns 512) for the lifetime of the persistent workgroup — unlike the split GEMM (bound by the L2 -> LDS
+// operand stream) this kernel streams only the activations. A tile of 32 output rows = 132 input rows is split while it is staged
+// into LDS ([3 pieces][132 rows][64 ch] bf16, 16-byte chunks XOR-swizzled by (row >> 2) & 7 so that the 16 rows 4 apart a fragment
+// read touches fall on different banks), double-buffered: tile t+1 is split into the other buffer in the shadow of tile t's MFMAs
+// (a bf16 MFMA leaves half of its cycles to VALU issue) and tile t+2's loads are in flight — one barrier per tile.
+// The arithmetic differs from the fp32 k-ordered chain of the GEMM path in rounding only (both are within 2e-6 of float64): this
+// kernel is compared with the unfused path by tolerance, not bit-identity (tests/test_acoustic_gpu.py).
+#include "gemm_core.h"
+#include "encodec_kernels.h"
+
+namespace at {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DX_TU = 32;                  // output rows per tile
+constexpr int DX_ROWS = 4 * DX_TU + 4;     // input rows per tile: row i <-> time 4*u0 - 4 + i
+constexpr int DX_CHUNKS = DX_ROWS * 16;    // float4 chunks of the input tile
+constexpr int DX_PRE = (DX_CHUNKS + 255) / 256;
+constexpr int DX_AHEAD = 18;               // K steps between a chunk's global load and its split into LDS
+constexpr int DX_PIECE = DX_PRE * 16 * 64; // bf16 elements of one piece of the tile: 144 rows, the last 12 only absorb the (unused) tail of the last chunk
+// physical LDS row: rows 32 apart (fragment lanes r16 and r16 + 8) swap odd/even so that they fall in different halves of the banks
+// scheduling pattern for one K step: after each of the 12 MFMAs up to 4 vector instructions of the side work (the rest follows)
+__device__ __forceinline__ void dx_interleave() {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+}
+__device__ __forceinline__ int dx_row(int row) { return row ^ ((row >> 5) & 1); }
+
+__global__ __launch_bounds__(256, 1) void seanet_down64x3_kernel(Down64Args a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 Xp[];   // [2 buffers][3][132 rows][64], chunk (8 ch) ^= (row >> 2) & 7
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int L = a.L, Lo = L / 4;
+    const int tiles_per_clip = (Lo + DX_TU - 1) / DX_TU;
+    const int total_tiles = a.B * tiles_per_clip;   // < 2^31: checked by the launcher
+
+    // ---- weights -> 3 bf16 pieces in registers, once: wr[p][n][ks] = split(W[32w + 16n + r16][32 ks + 8 q .. +7]) ------------------
+    bf16x8 wr[3][2][16];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const float* src = a.w + (wave * 32 + n * 16 + r16) * 512 + ks * 32 + q * 8;
+            const f4 lo = *reinterpret_cast<const f4*>(src), hi = *reinterpret_cast<const f4*>(src + 4);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = k < 4 ? lo[k] : hi[k - 4];
+                const __bf16 p1 = (__bf16)v;
+                const float r1 = v - (float)p1;
+                const __bf16 p2 = (__bf16)r1;
+                wr[0][n][ks][k] = p1; wr[1][n][ks][k] = p2; wr[2][n][ks][k] = (__bf16)(r1 - (float)p2);
+            }
+        }
+    f4 pre[DX_PRE];
+    // chunk j of a tile: 16-byte piece c = tid + 256 j of its 132 x 64 input rows
+    auto load_chunk = [&](int j, const float* xb, int u0) {
+        int c = tid + 256 * j;
+        c = c < DX_CHUNKS ? c : DX_CHUNKS - 1;
+        int tau = 4 * u0 - 4 + (c >> 4);
+        tau = tau < 0 ? -tau : tau;            // causal reflect padding at the clip start
+        tau = tau > L - 1 ? L - 1 : tau;       // rows past the end only feed outputs that are never stored
+        pre[j] = *reinterpret_cast<const f4*>(xb + (unsigned)(tau * 64 + (c & 15) * 4));
+    };
+    // split chunk j into the three bf16 pieces of LDS buffer X
+    auto stage_chunk = [&](int j, __bf16* X) {
+        const int c = tid + 256 * j;
+        {   // chunks past the tile (tid >= 64 of the last j) land in the pad rows: no branch, so the work can sit between MFMAs
+            const int row = c >> 4, c4 = c & 15;          // 4 channels 4 c4 .. 4 c4 + 3 = half of the 8-channel chunk c4 >> 1
+            bf16x4 p1, p2, p3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = pre[j][k];
+                const __bf16 x1 = (__bf16)v;
+                const float r1 = v - (float)x1;
+                const __bf16 x2 = (__bf16)r1;
+                p1[k] = x1; p2[k] = x2; p3[k] = (__bf16)(r1 - (float)x2);
+            }
+            __bf16* d = X + dx_row(row) * 64 + ((((c4 >> 1) ^ ((row >> 2) & 7)) << 3) | ((c4 & 1) << 2));
+            *reinterpret_cast<bf16x4*>(d) = p1;
+            *reinterpret_cast<bf16x4*>(d + DX_PIECE) = p2;
+            *reinterpret_cast<bf16x4*>(d + 2 * DX_PIECE) = p3;
+        }
+    };
+    auto clip_base = [&](int tile, int& u0) {
+        const int b = tile / tiles_per_clip;
+        u0 = (tile - b * tiles_per_clip) * DX_TU;
+        return a.x + (long long)b * L * 64;
+    };
+    const int stride = gridDim.x;
+    if ((int)blockIdx.x < total_tiles) {
+        int u0;
+        const float* xb = clip_base(blockIdx.x, u0);
+#pragma unroll
+        for (int j = 0; j < DX_PRE; ++j) load_chunk(j, xb, u0);
+#pragma unroll
+        for (int j = 0; j < DX_PRE; ++j) stage_chunk(j, Xp);
+        const int t1 = blockIdx.x + stride;
+        xb = clip_base(t1 < total_tiles ? t1 : total_tiles - 1, u0);
+#pragma unroll
+        for (int j = 0; j < DX_PRE; ++j)
+            if (3 * j + 2 - DX_AHEAD < 0) load_chunk(j, xb, u0);   // what the previous iteration would have issued
+    }
+    __syncthreads();
+
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += stride, buf ^= 1) {
+        const int b = tile / tiles_per_clip;
+        const int u0 = (tile - b * tiles_per_clip) * DX_TU;
+        const __bf16* X = Xp + buf * (3 * DX_PIECE);
+        __bf16* Xn = Xp + (buf ^ 1) * (3 * DX_PIECE);
+        // branch-free side work: past the end the last tile is loaded / staged again into buffers nobody reads
+        int u1, u2;
+        const int t1 = tile + stride, t2 = tile + 2 * stride;
+        const float* xb1 = clip_base(t1 < total_tiles ? t1 : total_tiles - 1, u1);
+        const float* xb2 = clip_base(t2 < total_tiles ? t2 : total_tiles - 1, u2);
+        constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+        // One 16-row m-tile at a time (8 accumulator registers live), the K loop software-pipelined one step ahead on the LDS
+        // reads. Spread over the 32 K steps: chunk j of the NEXT tile (loaded during the previous iteration) is split into the other
+        // buffer and the same registers are refilled with chunk j of the tile after it — the vector work sits between the MFMAs
+        // (a 16x16x32 bf16 MFMA holds vector issue for 8 of its 16 cycles) instead of in a phase of its own.
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            auto xread = [&](int ks, bf16x8 (&xf)[3]) {
+                const int tap = ks >> 1, ch = (ks & 1) * 4 + q;    // 8-channel chunk of this lane's K slice
+                const int row = 4 * (16 * m + r16) + tap;
+                const __bf16* src = X + dx_row(row) * 64 + ((ch ^ ((row >> 2) & 7)) << 3);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(src + p * DX_PIECE);
+            };
+            auto side_work = [&](int step) {   // step = 16 m + ks
+#ifndef DX_PROBE_NO_STAGE
+                if (step % 3 == 2 && step / 3 < DX_PRE) stage_chunk(step / 3, Xn);
+#endif
+#ifndef DX_PROBE_NO_PREFETCH
+                // chunk j is loaded DX_AHEAD = 18 steps before it is split (about 5 of the 9 chunks are in flight at a time: the
+                // whole tile in registers does not fit beside 384 weight registers): in this iteration for j >= 6, else in the previous
+#pragma unroll
+                for (int j = 0; j < DX_PRE; ++j) {
+                    if (3 * j + 2 - DX_AHEAD >= 0 && step == 3 * j + 2 - DX_AHEAD) load_chunk(j, xb1, u1);
+                    if (3 * j + 2 - DX_AHEAD < 0 && step == 3 * j + 2 - DX_AHEAD + 32) load_chunk(j, xb2, u2);
+                }
+#endif
+            };
+            bf16x8 xa[3], xb[3];
+            xread(0, xa);
+#ifdef DX_PROBE_KS
+            for (int ks = 0; ks < DX_PROBE_KS; ks += 2) {
+#else
+#pragma unroll
+            for (int ks = 0; ks < 16; ks += 2) {
+#endif
+                xread(ks + 1, xb);
+                __builtin_amdgcn_sched_barrier(0);   // keep the reads one step ahead of their MFMAs
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[PW[t]][n][ks], xa[PX[t]], acc[n], 0, 0, 0);
+                side_work(16 * m + ks);
+                dx_interleave();
+                if (ks + 2 < 16) xread(ks + 2, xa);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[PW[t]][n][ks + 1], xb[PX[t]], acc[n], 0, 0, 0);
+                side_work(16 * m + ks + 1);
+                dx_interleave();
+            }
+            const int u = u0 + m * 16 + r16;
+#ifdef DX_PROBE_NO_STORE
+            if (u < Lo && acc[0][0] == 123.456f) {
+#else
+            if (u < Lo) {
+#endif
+                float* dst = a.out + ((long long)b * Lo + u) * 128 + wave * 32 + q * 4;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) *reinterpret_cast<f4*>(dst + n * 16) = acc[n] + *reinterpret_cast<const f4*>(a.b + wave * 32 + n * 16 + q * 4);
+            }
+        }
+        __syncthreads();   // buffer buf ^ 1 is complete, buffer buf is free
+    }
+}
+
+int launch_seanet_down64x3(const Down64Args& a, hipStream_t stream) {
+    AT_REQUIRE(a.L >= 8 && a.L % 4 == 0 && a.B >= 1, "register-stationary stride-4 conv needs L % 4 == 0");
+    const size_t lds = (size_t)2 * 3 * DX_PIECE * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_down64x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long long tiles = (long long)a.B * ((a.L / 4 + DX_TU - 1) / DX_TU);
+    AT_REQUIRE(tiles < (1LL << 30) && (long long)a.L * 64 < (1LL << 30), "tile / offset arithmetic is 32-bit");
+    const int grid = (int)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(seanet_down64x3_kernel, dim3(grid), dim3(256), lds, stream, a);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace at

@@ -147,6 +147,7 @@ def test_fused_stage0_equals_unfused(encoders):
     """seanet_stage0_kernel (conv0 + resblock + strided conv fused) keeps the MFMA / tap order of the separate kernels:
     embeddings and codes must be bit-identical, including the reflect-padded clip start and a ragged last tile."""
     enc = encoders[8]
+    enc.set_option("down64_x3", 0)   # the split-bf16 variant rounds differently: test_down64_x3_matches_fp32 below
     for opt in ("fused_stage0", "fused_res64", "fused_res128", "fused_down64"):
         for B, N in ((3, 6400), (2, 24000 + 320 * 3), (5, 3200 + 640), (2, 9999)):
             wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=B + 100)).cuda()
@@ -157,6 +158,23 @@ def test_fused_stage0_equals_unfused(encoders):
             enc.set_option(opt, 1)
             assert torch.equal(e0, e1), (opt, B, N, (e0 - e1).abs().max().item())
             assert torch.equal(c0, c1)
+    enc.set_option("down64_x3", 1)
+
+
+def test_down64_x3_matches_fp32(encoders):
+    """seanet_down64x3_kernel (exact 3-way bf16 splits, six bf16 MFMAs) against the fp32-MFMA kernel: a different rounding of the
+    same sums, so embeddings agree to ~1e-6 of their scale rather than bit for bit, and the tokens are the same."""
+    enc = encoders[8]
+    for B, N in ((3, 6400), (2, 24000 + 320 * 3), (5, 3200 + 640), (2, 9999), (40, 24000)):
+        wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=B + 300)).cuda()
+        enc.set_option("down64_x3", 1)
+        c1, e1 = enc(wav, None, return_embeddings=True)
+        enc.set_option("down64_x3", 0)
+        c0, e0 = enc(wav, None, return_embeddings=True)
+        enc.set_option("down64_x3", 1)
+        scale = e0.abs().max().item()
+        assert (e0 - e1).abs().max().item() <= 2e-5 * scale, (B, N, (e0 - e1).abs().max().item(), scale)
+        assert (c0 != c1).float().mean().item() <= 1e-3, (B, N)
 
 
 def test_repeated_encodes_are_identical(encoders):
