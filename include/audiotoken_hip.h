@@ -72,10 +72,12 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
                               int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream,
                               uint32_t* status_dev);
 
-/* Options (all leave the results bit-identical; they select kernels or bound memory):
+/* Options (they select kernels or bound memory; all but "down64_x3" leave the results bit-identical):
  *   "persistent_lstm" 1/0 — whole-sequence persistent LSTM kernel (default on) or one launch per time step;
  *   "fused_stage0", "fused_res64", "fused_res128", "fused_down64", "fused_dectail" 1/0 — fused SEANet kernels (default on)
  *   or the GEMM path;
+ *   "down64_x3" 1/0 — stage-1 strided conv on the split-bf16 matrix-core kernel (default on; 0 = the fp32-MFMA kernel:
+ *   same tokens, embeddings differ in the last bits);
  *   "subbatch" n >= 1 — clips per pass through the conv stack (default 256 or $AUDIOTOKEN_SUBBATCH): bounds
  *   at_encodec_workspace_bytes / at_encodec_decode_workspace_bytes, which must be re-queried after changing it. */
 int at_encodec_set_option(at_encodec_t* h, const char* name, int value);
