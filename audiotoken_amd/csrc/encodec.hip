@@ -124,6 +124,7 @@ struct at_encodec {
     bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
     bool fused_down64 = true;       // stage-1 strided conv with register-stationary weights (seanet_down64.hip)
     bool down64_x3 = true;          // ... on the bf16 matrix cores with 3-way split operands (seanet_down64x3.hip); follows bf16x3
+    bool res128_x3 = true;          // 128-channel residual block on the bf16 matrix cores (seanet_res128x3.hip); follows bf16x3
     bool fused_dectail = true;      // decoder: last transposed conv + block + final conv in one kernel (seanet_dectail.hip)
     bool bf16x3 = false;            // plain linear layers (LSTM input projections) on the split-bf16 GEMM ($AUDIOTOKEN_BF16X3_ACOUSTIC)
     const __bf16* wih_s[2] = {nullptr, nullptr};
@@ -638,7 +639,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 ra.x = x; ra.out = r; ra.w3 = h->res[2][0].w; ra.b3 = h->res[2][0].b; ra.wt = h->res[2][1].w; ra.bt = h->res[2][1].b;
                 ra.B = g; ra.L = L;
                 prof.begin("res2", 1, stream);
-                if (int rc = launch_seanet_res128(ra, stream)) return rc;
+                if (int rc = (h->res128_x3 && h->bf16x3) ? launch_seanet_res128x3(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
                 prof.end(stream);
             } else {
                 prof.begin(kRes[s], 2, stream);
@@ -694,6 +695,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
     if (std::string(name) == "down64_x3") { h->down64_x3 = value != 0; return 0; }
+    if (std::string(name) == "res128_x3") { h->res128_x3 = value != 0; return 0; }
     if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }
     if (std::string(name) == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
     set_error(std::string("unknown option ") + name);
@@ -780,7 +782,8 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
                 Res64Args ra;
                 ra.x = u; ra.out = r; ra.w3 = h->dres[s][0].w; ra.b3 = h->dres[s][0].b; ra.wt = h->dres[s][1].w; ra.bt = h->dres[s][1].b;
                 ra.B = g; ra.L = Lo;
-                if (int rc = Co == 64 ? launch_seanet_res64(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
+                if (int rc = Co == 64 ? launch_seanet_res64(ra, stream)
+                                      : (h->res128_x3 && h->bf16x3) ? launch_seanet_res128x3(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
             } else {
                 // the last block's output goes to conv_last, which applies the ELU itself
                 if (int rc = resblock(h->dres[s], u, ws + p.off_h[s], r, Lo, g, stream, s < 3 ? EPI_ELU : EPI_NONE)) return rc;

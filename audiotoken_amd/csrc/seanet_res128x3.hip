@@ -1,0 +1,236 @@
+// SEANet residual block at 128 channels on the bf16 matrix cores — the block of seanet_res128.hip
+//   out = ELU( [W1 | Wsc] . [ELU(W3 * ELU(x) + b3) | x] + (b1 + bsc) )          (k3 128->64, k1 64->128, k1 shortcut)
+// with every operand as an exact 3-way bf16 split and six v_mfma_f32_16x16x32_bf16 (16 cycles) per 32-wide K step instead of
+// eight 32-cycle fp32 MFMAs (arithmetic and accuracy: gemm_bf16x3.hip). Same decomposition as the fp32 kernel: weights stationary
+// in REGISTERS, split over the output channels — wave w keeps W3 rows 16w..16w+15 (K = 384) and [W1 | Wsc] rows 32w..32w+31
+// (K = 192) as three bf16 pieces = 288 registers; activations stream through LDS in 64-row tiles:
+//   Xe = split(ELU(x)), Xr = split(x): [3][72 rows][128 ch + 8 pad] bf16 each;  H = split(ELU(conv3 + b3)): [3][64][64 + 8 pad].
+// The splits cost vector instructions (17 per input value: ELU 5 + two splits 6 each) which a single wave per SIMD cannot hide
+// behind another wave; the MFMA time saved is larger.
+// Rounds differently from the fp32 chain of the GEMM / seanet_res128 path: compared by tolerance and identical tokens
+// (tests/test_acoustic_gpu.py::test_x3_kernels_match_fp32). (EnCodec architecture: SURVEY.md Appendix A.1.)
+#include "gemm_core.h"
+#include "encodec_kernels.h"
+
+namespace at {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RX_TT = 64;                    // time rows per tile
+constexpr int RX_XROWS = 66;                 // row i <-> time t0 - 2 + i
+constexpr int RX_PRE = (RX_XROWS * 32 + 255) / 256;   // float4 chunks per thread: 9
+constexpr int RX_LDX = 136, RX_LDH = 72;     // row strides (bf16): + 16 B, so the 16 consecutive rows of a fragment read hit 16 distinct bank groups
+constexpr int RX_XP = RX_PRE * 8 * RX_LDX;   // bf16 elements of one piece of an x tile: 72 rows (the last 6 absorb the tail of the last chunk)
+constexpr int RX_HP = RX_TT * RX_LDH;        // one piece of the h tile
+
+// linear in (row, chunk): every fragment address is one per-lane base plus an immediate offset
+__device__ __forceinline__ int rx_xoff(int row, int chunk) { return row * RX_LDX + (chunk << 3); }
+__device__ __forceinline__ int rx_hoff(int row, int chunk) { return row * RX_LDH + (chunk << 3); }
+__device__ __forceinline__ void rx_split(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)v;
+    const float r1 = v - (float)p1;
+    p2 = (__bf16)r1;
+    p3 = (__bf16)(r1 - (float)p2);
+}
+
+__global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 rx_lds[];
+    __bf16* Xe = rx_lds;                 // split(ELU(x))
+    __bf16* Xr = Xe + 3 * RX_XP;         // split(x)
+    __bf16* Hs = Xr + 3 * RX_XP;         // split(ELU(conv3 + b3))
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int L = a.L;
+    const int tiles_per_clip = (L + RX_TT - 1) / RX_TT;
+    const int total_tiles = a.B * tiles_per_clip;   // < 2^30: checked by the launcher
+
+    // ---- weights -> 3 bf16 pieces in registers, once per workgroup (MFMA A operand: row r16, k = 32 ks + 8 q .. + 7) -------------
+    bf16x8 w3p[3][12], wtp[3][2][6];
+    auto wsplit = [&](const float* src, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+        const f4 lo = *reinterpret_cast<const f4*>(src), hi = *reinterpret_cast<const f4*>(src + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __bf16 x1, x2, x3;
+            rx_split(k < 4 ? lo[k] : hi[k - 4], x1, x2, x3);
+            p1[k] = x1; p2[k] = x2; p3[k] = x3;
+        }
+    };
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) wsplit(a.w3 + (wave * 16 + r16) * 384 + ks * 32 + q * 8, w3p[0][ks], w3p[1][ks], w3p[2][ks]);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) wsplit(a.wt + (wave * 32 + n * 16 + r16) * 192 + ks * 32 + q * 8, wtp[0][n][ks], wtp[1][n][ks], wtp[2][n][ks]);
+    const f4 b3 = *reinterpret_cast<const f4*>(a.b3 + wave * 16 + q * 4);
+
+    // input staging: chunk c = tid + 256 j -> (row = c / 32, float4 = c % 32)
+    f4 pre[RX_PRE];
+    auto prefetch = [&](int tile) {
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * RX_TT;
+        const float* xb = a.x + (long long)b * L * 128;
+#pragma unroll
+        for (int j = 0; j < RX_PRE; ++j) {
+            const int c = tid + 256 * j;
+            int tau = t0 - 2 + (c >> 5);           // rows 66..71 of the last chunk are loaded (clamped) and never read
+            tau = tau < 0 ? -tau : tau;            // causal reflect padding at the clip start
+            tau = tau > L - 1 ? L - 1 : tau;       // rows past the end are never stored
+            pre[j] = *reinterpret_cast<const f4*>(xb + (unsigned)(tau * 128 + (c & 31) * 4));
+        }
+    };
+    if ((int)blockIdx.x < total_tiles) prefetch(blockIdx.x);
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * RX_TT;
+        __syncthreads();   // previous tile's readers are done
+#pragma unroll
+        for (int j = 0; j < RX_PRE; ++j) {
+            const int c = tid + 256 * j;
+            const int row = c >> 5, c4 = c & 31;          // float4 c4 = half (c4 & 1) of the 8-channel chunk c4 >> 1
+            const f4 v = pre[j];
+            bf16x4 r1, r2, r3, e1, e2, e3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __bf16 x1, x2, x3;
+                rx_split(v[k], x1, x2, x3);
+                r1[k] = x1; r2[k] = x2; r3[k] = x3;
+                rx_split(elu1(v[k]), x1, x2, x3);
+                e1[k] = x1; e2[k] = x2; e3[k] = x3;
+            }
+            const int off = rx_xoff(row, c4 >> 1) + ((c4 & 1) << 2);
+            *reinterpret_cast<bf16x4*>(Xr + off) = r1;
+            *reinterpret_cast<bf16x4*>(Xr + RX_XP + off) = r2;
+            *reinterpret_cast<bf16x4*>(Xr + 2 * RX_XP + off) = r3;
+            *reinterpret_cast<bf16x4*>(Xe + off) = e1;
+            *reinterpret_cast<bf16x4*>(Xe + RX_XP + off) = e2;
+            *reinterpret_cast<bf16x4*>(Xe + 2 * RX_XP + off) = e3;
+        }
+        __syncthreads();
+        // ---- h[:, 16w..16w+15] = ELU(conv3(ELU(x)) + b3): output row j uses x rows j, j+1, j+2; K step ks = (tap, 32 channels) --------
+#pragma unroll 1   // (unrolled, the compiler's schedule needs > 512 registers and spills weights)
+        for (int mp = 0; mp < 4; mp += 2) {   // two 16-row tiles at a time: 24 fragment registers per buffer
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            auto xread = [&](int ks, bf16x8 (&xf)[3][2]) {
+                const int tap = ks >> 2, chunk = (ks & 3) * 4 + q;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const __bf16* src = Xe + rx_xoff(16 * (mp + m) + r16 + tap, chunk);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) xf[p][m] = *reinterpret_cast<const bf16x8*>(src + p * RX_XP);
+                }
+            };
+            bf16x8 xa[3][2], xb[3][2];
+            xread(0, xa);
+#pragma unroll
+            for (int ks = 0; ks < 12; ks += 2) {
+                xread(ks + 1, xb);
+                __builtin_amdgcn_sched_barrier(0);   // keep the reads one step ahead of their MFMAs (one wave per SIMD)
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3p[PW[t]][ks], xa[PX[t]][m], acc[m], 0, 0, 0);
+                if (ks + 2 < 12) xread(ks + 2, xa);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3p[PW[t]][ks + 1], xb[PX[t]][m], acc[m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const f4 v = acc[m] + b3;
+                bf16x4 h1, h2, h3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __bf16 x1, x2, x3;
+                    rx_split(elu1(v[k]), x1, x2, x3);
+                    h1[k] = x1; h2[k] = x2; h3[k] = x3;
+                }
+                const int off = rx_hoff(16 * (mp + m) + r16, 2 * wave + (q >> 1)) + ((q & 1) << 2);   // channels 16 w + 4 q .. + 3
+                *reinterpret_cast<bf16x4*>(Hs + off) = h1;
+                *reinterpret_cast<bf16x4*>(Hs + RX_HP + off) = h2;
+                *reinterpret_cast<bf16x4*>(Hs + 2 * RX_HP + off) = h3;
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < total_tiles) prefetch(tile + gridDim.x);   // flies during the tail MFMAs and the next tile's staging wait
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- out[:, 32w..32w+31] = ELU([h | x] . [W1 | Wsc]^T + (b1 + bsc)): output row j uses h row j and x row j + 2 ----------------
+#pragma unroll
+        for (int mp = 0; mp < 4; mp += 2) {
+            f4 acc[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = f4{0.f, 0.f, 0.f, 0.f};
+            auto tread = [&](int ks, bf16x8 (&xf)[3][2]) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int row = 16 * (mp + m) + r16;
+                    const __bf16* src = ks < 2 ? Hs + rx_hoff(row, ks * 4 + q) : Xr + rx_xoff(row + 2, (ks - 2) * 4 + q);
+                    const int ps = ks < 2 ? RX_HP : RX_XP;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) xf[p][m] = *reinterpret_cast<const bf16x8*>(src + p * ps);
+                }
+            };
+            bf16x8 xa[3][2], xb[3][2];
+            tread(0, xa);
+#pragma unroll
+            for (int ks = 0; ks < 6; ks += 2) {
+                tread(ks + 1, xb);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wtp[PW[t]][n][ks], xa[PX[t]][m], acc[m][n], 0, 0, 0);
+                if (ks + 2 < 6) tread(ks + 2, xa);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wtp[PW[t]][n][ks + 1], xb[PX[t]][m], acc[m][n], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int t = t0 + (mp + m) * 16 + r16;
+                if (t < L) {
+                    float* dst = a.out + ((long long)b * L + t) * 128 + wave * 32 + q * 4;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const f4 v = acc[m][n] + *reinterpret_cast<const f4*>(a.bt + wave * 32 + n * 16 + q * 4);
+                        f4 o;
+                        o.x = elu1(v.x); o.y = elu1(v.y); o.z = elu1(v.z); o.w = elu1(v.w);
+                        *reinterpret_cast<f4*>(dst + n * 16) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int launch_seanet_res128x3(const Res64Args& a, hipStream_t stream) {
+    AT_REQUIRE(a.L >= 4 && a.B >= 1, "fused resblock needs at least 4 rows");
+    const long long tiles = (long long)a.B * ((a.L + RX_TT - 1) / RX_TT);
+    AT_REQUIRE(tiles < (1LL << 30) && (long long)a.L * 128 < (1LL << 30), "tile / offset arithmetic is 32-bit");
+    const size_t lds = (size_t)(6 * RX_XP + 3 * RX_HP) * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_res128x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int grid = (int)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(seanet_res128x3_kernel, dim3(grid), dim3(256), lds, stream, a);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace at

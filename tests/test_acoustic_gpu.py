@@ -147,8 +147,9 @@ def test_fused_stage0_equals_unfused(encoders):
     """seanet_stage0_kernel (conv0 + resblock + strided conv fused) keeps the MFMA / tap order of the separate kernels:
     embeddings and codes must be bit-identical, including the reflect-padded clip start and a ragged last tile."""
     enc = encoders[8]
-    enc.set_option("down64_x3", 0)   # the split-bf16 variant rounds differently: test_down64_x3_matches_fp32 below
-    for opt in ("fused_stage0", "fused_res64", "fused_res128", "fused_down64"):
+    enc.set_option("down64_x3", 0)   # the split-bf16 variants round differently: test_x3_kernels_match_fp32 below
+    enc.set_option("res128_x3", 0)
+    for opt in ("fused_stage0", "fused_res64", "fused_res128", "fused_down64"):   # (res128_x3 / down64_x3 are off here)
         for B, N in ((3, 6400), (2, 24000 + 320 * 3), (5, 3200 + 640), (2, 9999)):
             wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=B + 100)).cuda()
             enc.set_option(opt, 1)
@@ -159,22 +160,25 @@ def test_fused_stage0_equals_unfused(encoders):
             assert torch.equal(e0, e1), (opt, B, N, (e0 - e1).abs().max().item())
             assert torch.equal(c0, c1)
     enc.set_option("down64_x3", 1)
+    enc.set_option("res128_x3", 1)
 
 
-def test_down64_x3_matches_fp32(encoders):
-    """seanet_down64x3_kernel (exact 3-way bf16 splits, six bf16 MFMAs) against the fp32-MFMA kernel: a different rounding of the
-    same sums, so embeddings agree to ~1e-6 of their scale rather than bit for bit, and the tokens are the same."""
+@pytest.mark.parametrize("opt", ["down64_x3", "res128_x3"])
+def test_x3_kernels_match_fp32(encoders, opt):
+    """seanet_down64x3_kernel / seanet_res128x3_kernel (exact 3-way bf16 splits, six bf16 MFMAs) against the fp32-MFMA kernels:
+    a different rounding of the same sums, so embeddings agree to ~1e-6 of their scale rather than bit for bit, and the tokens
+    are the same."""
     enc = encoders[8]
     for B, N in ((3, 6400), (2, 24000 + 320 * 3), (5, 3200 + 640), (2, 9999), (40, 24000)):
         wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=B + 300)).cuda()
-        enc.set_option("down64_x3", 1)
+        enc.set_option(opt, 1)
         c1, e1 = enc(wav, None, return_embeddings=True)
-        enc.set_option("down64_x3", 0)
+        enc.set_option(opt, 0)
         c0, e0 = enc(wav, None, return_embeddings=True)
-        enc.set_option("down64_x3", 1)
+        enc.set_option(opt, 1)
         scale = e0.abs().max().item()
-        assert (e0 - e1).abs().max().item() <= 2e-5 * scale, (B, N, (e0 - e1).abs().max().item(), scale)
-        assert (c0 != c1).float().mean().item() <= 1e-3, (B, N)
+        assert (e0 - e1).abs().max().item() <= 2e-5 * scale, (opt, B, N, (e0 - e1).abs().max().item(), scale)
+        assert (c0 != c1).float().mean().item() <= 1e-3, (opt, B, N)
 
 
 def test_repeated_encodes_are_identical(encoders):
@@ -215,9 +219,13 @@ def test_fused_decoder_kernels_equal_unfused(enc_weights):
     g = torch.Generator().manual_seed(5)
     for B, T in ((2, 7), (3, 25), (1, 40), (5, 13)):
         codes = torch.randint(0, 1024, (B, 8, T), generator=g, dtype=torch.long).cuda()
+        x3 = dec(codes).clone()
+        dec.set_option("res128_x3", 0)   # the split-bf16 block rounds differently: compared by tolerance
         ref = dec(codes).clone()
+        assert (ref - x3).abs().max().item() <= 2e-5 * ref.abs().max().item(), (B, T, (ref - x3).abs().max().item())
         for opt in ("fused_dectail", "fused_res64", "fused_res128"):
             dec.set_option(opt, 0)
             got = dec(codes)
             dec.set_option(opt, 1)
             assert torch.equal(ref, got), (opt, B, T, (ref - got).abs().max().item())
+        dec.set_option("res128_x3", 1)
