@@ -124,6 +124,7 @@ struct at_encodec {
     bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
     bool fused_down64 = true;       // stage-1 strided conv with register-stationary weights (seanet_down64.hip)
     bool down64_x3 = true;          // ... on the bf16 matrix cores with 3-way split operands (seanet_down64x3.hip); follows bf16x3
+    bool res64_x3 = true;           // 64-channel residual block on the bf16 matrix cores (seanet_res64x3.hip); follows bf16x3
     bool res128_x3 = true;          // 128-channel residual block on the bf16 matrix cores (seanet_res128x3.hip); follows bf16x3
     bool fused_dectail = true;      // decoder: last transposed conv + block + final conv in one kernel (seanet_dectail.hip)
     bool bf16x3 = false;            // plain linear layers (LSTM input projections) on the split-bf16 GEMM ($AUDIOTOKEN_BF16X3_ACOUSTIC)
@@ -553,6 +554,10 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
     {
         const char* e = std::getenv("AUDIOTOKEN_BF16X3_ACOUSTIC");
         h->bf16x3 = e ? std::atoi(e) != 0 : kBf16x3AcousticDefault;
+        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block
+        const char* m = std::getenv("AUDIOTOKEN_X3_KERNELS");
+        const int mask = m ? std::atoi(m) : 7;
+        h->down64_x3 = (mask & 1) != 0; h->res128_x3 = (mask & 2) != 0; h->res64_x3 = (mask & 4) != 0;
     }
     if (h->bf16x3) {
         for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
@@ -631,7 +636,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 ra.x = x; ra.out = r; ra.w3 = h->res[1][0].w; ra.b3 = h->res[1][0].b; ra.wt = h->res[1][1].w; ra.bt = h->res[1][1].b;
                 ra.B = g; ra.L = L;
                 prof.begin("res1", 1, stream);
-                if (int rc = launch_seanet_res64(ra, stream)) return rc;
+                if (int rc = (h->res64_x3 && h->bf16x3) ? launch_seanet_res64x3(ra, stream) : launch_seanet_res64(ra, stream)) return rc;
                 prof.end(stream);
             } else if (s == 2 && h->fused_res128) {
                 // 128-channel block fused: weights stationary in registers, h never leaves the CU (seanet_res128.hip)
@@ -695,6 +700,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
     if (std::string(name) == "down64_x3") { h->down64_x3 = value != 0; return 0; }
+    if (std::string(name) == "res64_x3") { h->res64_x3 = value != 0; return 0; }
     if (std::string(name) == "res128_x3") { h->res128_x3 = value != 0; return 0; }
     if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }
     if (std::string(name) == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
@@ -782,7 +788,7 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
                 Res64Args ra;
                 ra.x = u; ra.out = r; ra.w3 = h->dres[s][0].w; ra.b3 = h->dres[s][0].b; ra.wt = h->dres[s][1].w; ra.bt = h->dres[s][1].b;
                 ra.B = g; ra.L = Lo;
-                if (int rc = Co == 64 ? launch_seanet_res64(ra, stream)
+                if (int rc = Co == 64 ? ((h->res64_x3 && h->bf16x3) ? launch_seanet_res64x3(ra, stream) : launch_seanet_res64(ra, stream))
                                       : (h->res128_x3 && h->bf16x3) ? launch_seanet_res128x3(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
             } else {
                 // the last block's output goes to conv_last, which applies the ELU itself

@@ -55,6 +55,7 @@ struct Res64Args {
 int launch_seanet_res64(const Res64Args& a, hipStream_t stream);
 // the 128-channel block on the bf16 matrix cores with exact 3-way bf16 splits of all operands (seanet_res128x3.hip)
 int launch_seanet_res128x3(const Res64Args& a, hipStream_t stream);
+int launch_seanet_res64x3(const Res64Args& a, hipStream_t stream);   // seanet_res64x3.hip
 // Encoder stage-1 strided conv (64 -> 128, k 8, stride 4) with register-stationary weights (seanet_down64.hip)
 struct Down64Args {
     const float* x;     // [B][L][64], already ELU'd

@@ -1,0 +1,208 @@
+// SEANet residual block at 64 channels on the bf16 matrix cores — the block of seanet_res64.hip
+//   out = ELU( [W1 | Wsc] . [ELU(W3 * ELU(x) + b3) | x] + (b1 + bsc) )          (k3 64->32, k1 32->64, k1 shortcut)
+// with every operand as an exact 3-way bf16 split and six v_mfma_f32_16x16x32_bf16 per 32-wide K step (arithmetic and accuracy:
+// gemm_bf16x3.hip; structure: seanet_res128x3.hip). Work split as in the fp32 kernel: conv3 wave = (channel tile w & 1, row half
+// w >> 1), tail wave = channel tile w; the weights a wave needs are 108 registers of bf16 pieces, so TWO workgroups fit a CU
+// (72 KB of LDS each) and one stages / splits (vector work) while the other multiplies — a bf16 MFMA leaves half of its cycles
+// to vector issue, unlike the fp32 MFMA.
+//   Xe = split(ELU(x)), Xr = split(x): [3][66 rows][64 ch + 8 pad] bf16 each;  H = split(ELU(conv3 + b3)): [3][64][32 + 8 pad]
+// (the 16-byte pads put the 16 consecutive rows of a fragment read on 16 distinct bank groups with plain linear addresses).
+// Rounds differently from the fp32 chain: compared by tolerance and identical tokens (tests/test_acoustic_gpu.py).
+#include "gemm_core.h"
+#include "encodec_kernels.h"
+
+namespace at {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RY_TT = 64;                    // time rows per tile
+constexpr int RY_XROWS = 66;                 // row i <-> time t0 - 2 + i
+constexpr int RY_CHUNKS = RY_XROWS * 16;     // float4 chunks of the input tile
+constexpr int RY_PRE = (RY_CHUNKS + 255) / 256;
+constexpr int RY_LDX = 72, RY_LDH = 40;      // row strides (bf16)
+constexpr int RY_XP = RY_XROWS * RY_LDX;     // bf16 elements of one piece of an x tile
+constexpr int RY_HP = RY_TT * RY_LDH;
+
+__device__ __forceinline__ void ry_split(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)v;
+    const float r1 = v - (float)p1;
+    p2 = (__bf16)r1;
+    p3 = (__bf16)(r1 - (float)p2);
+}
+
+__global__ __launch_bounds__(256, 2) void seanet_res64x3_kernel(Res64Args a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 ry_lds[];
+    __bf16* Xe = ry_lds;                 // split(ELU(x))
+    __bf16* Xr = Xe + 3 * RY_XP;         // split(x)
+    __bf16* Hs = Xr + 3 * RY_XP;         // split(ELU(conv3 + b3))
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int L = a.L;
+    const int tiles_per_clip = (L + RY_TT - 1) / RY_TT;
+    const int total_tiles = a.B * tiles_per_clip;   // < 2^30: checked by the launcher
+    const int cn = wave & 1, mh = wave >> 1;        // conv3: channel tile, row half
+
+    // ---- weights -> 3 bf16 pieces in registers, once per workgroup (MFMA A operand: row r16, k = 32 ks + 8 q .. + 7) -------------
+    bf16x8 w3p[3][6], wtp[3][3];
+    auto wsplit = [&](const float* src, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+        const f4 lo = *reinterpret_cast<const f4*>(src), hi = *reinterpret_cast<const f4*>(src + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __bf16 x1, x2, x3;
+            ry_split(k < 4 ? lo[k] : hi[k - 4], x1, x2, x3);
+            p1[k] = x1; p2[k] = x2; p3[k] = x3;
+        }
+    };
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) wsplit(a.w3 + (cn * 16 + r16) * 192 + ks * 32 + q * 8, w3p[0][ks], w3p[1][ks], w3p[2][ks]);
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) wsplit(a.wt + (wave * 16 + r16) * 96 + ks * 32 + q * 8, wtp[0][ks], wtp[1][ks], wtp[2][ks]);
+    const f4 b3 = *reinterpret_cast<const f4*>(a.b3 + cn * 16 + q * 4);
+    const f4 bt = *reinterpret_cast<const f4*>(a.bt + wave * 16 + q * 4);
+
+    // input staging: chunk c = tid + 256 j -> (row = c / 16, float4 = c % 16)
+    f4 pre[RY_PRE];
+    auto prefetch = [&](int tile) {
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * RY_TT;
+        const float* xb = a.x + (long long)b * L * 64;
+#pragma unroll
+        for (int j = 0; j < RY_PRE; ++j) {
+            int c = tid + 256 * j;
+            c = c < RY_CHUNKS ? c : RY_CHUNKS - 1;
+            int tau = t0 - 2 + (c >> 4);
+            tau = tau < 0 ? -tau : tau;            // causal reflect padding at the clip start
+            tau = tau > L - 1 ? L - 1 : tau;       // rows past the end are never stored
+            pre[j] = *reinterpret_cast<const f4*>(xb + (unsigned)(tau * 64 + (c & 15) * 4));
+        }
+    };
+    if ((int)blockIdx.x < total_tiles) prefetch(blockIdx.x);
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * RY_TT;
+        __syncthreads();   // previous tile's readers are done
+#pragma unroll
+        for (int j = 0; j < RY_PRE; ++j) {
+            const int c = tid + 256 * j;
+            if (c < RY_CHUNKS) {
+                const int row = c >> 4, c4 = c & 15;
+                const f4 v = pre[j];
+                bf16x4 r1, r2, r3, e1, e2, e3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __bf16 x1, x2, x3;
+                    ry_split(v[k], x1, x2, x3);
+                    r1[k] = x1; r2[k] = x2; r3[k] = x3;
+                    ry_split(elu1(v[k]), x1, x2, x3);
+                    e1[k] = x1; e2[k] = x2; e3[k] = x3;
+                }
+                const int off = row * RY_LDX + c4 * 4;
+                *reinterpret_cast<bf16x4*>(Xr + off) = r1;
+                *reinterpret_cast<bf16x4*>(Xr + RY_XP + off) = r2;
+                *reinterpret_cast<bf16x4*>(Xr + 2 * RY_XP + off) = r3;
+                *reinterpret_cast<bf16x4*>(Xe + off) = e1;
+                *reinterpret_cast<bf16x4*>(Xe + RY_XP + off) = e2;
+                *reinterpret_cast<bf16x4*>(Xe + 2 * RY_XP + off) = e3;
+            }
+        }
+        __syncthreads();
+        // ---- h[32 mh .. + 31, 16 cn .. + 15] = ELU(conv3(ELU(x)) + b3): output row j uses x rows j, j+1, j+2; ks = (tap, 32 channels) ----
+        {
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            auto xread = [&](int ks, bf16x8 (&xf)[3][2]) {
+                const int tap = ks >> 1, chunk = (ks & 1) * 4 + q;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const __bf16* src = Xe + (32 * mh + 16 * m + r16 + tap) * RY_LDX + chunk * 8;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) xf[p][m] = *reinterpret_cast<const bf16x8*>(src + p * RY_XP);
+                }
+            };
+            bf16x8 xa[3][2], xb[3][2];
+            xread(0, xa);
+#pragma unroll
+            for (int ks = 0; ks < 6; ks += 2) {
+                xread(ks + 1, xb);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3p[PW[t]][ks], xa[PX[t]][m], acc[m], 0, 0, 0);
+                if (ks + 2 < 6) xread(ks + 2, xa);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3p[PW[t]][ks + 1], xb[PX[t]][m], acc[m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const f4 v = acc[m] + b3;
+                bf16x4 h1, h2, h3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __bf16 x1, x2, x3;
+                    ry_split(elu1(v[k]), x1, x2, x3);
+                    h1[k] = x1; h2[k] = x2; h3[k] = x3;
+                }
+                const int off = (32 * mh + 16 * m + r16) * RY_LDH + cn * 16 + q * 4;
+                *reinterpret_cast<bf16x4*>(Hs + off) = h1;
+                *reinterpret_cast<bf16x4*>(Hs + RY_HP + off) = h2;
+                *reinterpret_cast<bf16x4*>(Hs + 2 * RY_HP + off) = h3;
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < total_tiles) prefetch(tile + gridDim.x);   // flies during the tail MFMAs and the barrier wait
+        // ---- out[:, 16w..16w+15] = ELU([h | x] . [W1 | Wsc]^T + (b1 + bsc)): output row j uses h row j and x row j + 2 ----------------
+#pragma unroll 1
+        for (int mp = 0; mp < 4; mp += 2) {
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            bf16x8 xf[3][3][2];   // [k step][piece][row tile]
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int row = 16 * (mp + m) + r16;
+                    const __bf16* src = ks == 0 ? Hs + row * RY_LDH + q * 8 : Xr + (row + 2) * RY_LDX + ((ks - 1) * 4 + q) * 8;
+                    const int ps = ks == 0 ? RY_HP : RY_XP;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) xf[ks][p][m] = *reinterpret_cast<const bf16x8*>(src + p * ps);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wtp[PW[t]][ks], xf[ks][PX[t]][m], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int t = t0 + (mp + m) * 16 + r16;
+                if (t < L) {
+                    const f4 v = acc[m] + bt;
+                    f4 o;
+                    o.x = elu1(v.x); o.y = elu1(v.y); o.z = elu1(v.z); o.w = elu1(v.w);
+                    *reinterpret_cast<f4*>(a.out + ((long long)b * L + t) * 64 + wave * 16 + q * 4) = o;
+                }
+            }
+        }
+    }
+}
+
+int launch_seanet_res64x3(const Res64Args& a, hipStream_t stream) {
+    AT_REQUIRE(a.L >= 4 && a.B >= 1, "fused resblock needs at least 4 rows");
+    const long long tiles = (long long)a.B * ((a.L + RY_TT - 1) / RY_TT);
+    AT_REQUIRE(tiles < (1LL << 30) && (long long)a.L * 64 < (1LL << 30), "tile / offset arithmetic is 32-bit");
+    const size_t lds = (size_t)(6 * RY_XP + 3 * RY_HP) * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_res64x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int grid = (int)(tiles < 512 ? tiles : 512);   // two workgroups per CU
+    hipLaunchKernelGGL(seanet_res64x3_kernel, dim3(grid), dim3(256), lds, stream, a);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace at

@@ -149,6 +149,7 @@ def test_fused_stage0_equals_unfused(encoders):
     enc = encoders[8]
     enc.set_option("down64_x3", 0)   # the split-bf16 variants round differently: test_x3_kernels_match_fp32 below
     enc.set_option("res128_x3", 0)
+    enc.set_option("res64_x3", 0)
     for opt in ("fused_stage0", "fused_res64", "fused_res128", "fused_down64"):   # (res128_x3 / down64_x3 are off here)
         for B, N in ((3, 6400), (2, 24000 + 320 * 3), (5, 3200 + 640), (2, 9999)):
             wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=B + 100)).cuda()
@@ -161,9 +162,10 @@ def test_fused_stage0_equals_unfused(encoders):
             assert torch.equal(c0, c1)
     enc.set_option("down64_x3", 1)
     enc.set_option("res128_x3", 1)
+    enc.set_option("res64_x3", 1)
 
 
-@pytest.mark.parametrize("opt", ["down64_x3", "res128_x3"])
+@pytest.mark.parametrize("opt", ["down64_x3", "res128_x3", "res64_x3"])
 def test_x3_kernels_match_fp32(encoders, opt):
     """seanet_down64x3_kernel / seanet_res128x3_kernel (exact 3-way bf16 splits, six bf16 MFMAs) against the fp32-MFMA kernels:
     a different rounding of the same sums, so embeddings agree to ~1e-6 of their scale rather than bit for bit, and the tokens
@@ -220,7 +222,8 @@ def test_fused_decoder_kernels_equal_unfused(enc_weights):
     for B, T in ((2, 7), (3, 25), (1, 40), (5, 13)):
         codes = torch.randint(0, 1024, (B, 8, T), generator=g, dtype=torch.long).cuda()
         x3 = dec(codes).clone()
-        dec.set_option("res128_x3", 0)   # the split-bf16 block rounds differently: compared by tolerance
+        dec.set_option("res128_x3", 0)   # the split-bf16 blocks round differently: compared by tolerance
+        dec.set_option("res64_x3", 0)
         ref = dec(codes).clone()
         assert (ref - x3).abs().max().item() <= 2e-5 * ref.abs().max().item(), (B, T, (ref - x3).abs().max().item())
         for opt in ("fused_dectail", "fused_res64", "fused_res128"):
@@ -229,3 +232,4 @@ def test_fused_decoder_kernels_equal_unfused(enc_weights):
             dec.set_option(opt, 1)
             assert torch.equal(ref, got), (opt, B, T, (ref - got).abs().max().item())
         dec.set_option("res128_x3", 1)
+        dec.set_option("res64_x3", 1)
