@@ -124,6 +124,7 @@ struct at_encodec {
     bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
     bool fused_down64 = true;       // stage-1 strided conv with register-stationary weights (seanet_down64.hip)
     bool down64_x3 = true;          // ... on the bf16 matrix cores with 3-way split operands (seanet_down64x3.hip); follows bf16x3
+    bool stage0_x3 = true;          // fused stage 0 on the bf16 matrix cores (seanet_stage0x3.hip); follows bf16x3
     bool res64_x3 = true;           // 64-channel residual block on the bf16 matrix cores (seanet_res64x3.hip); follows bf16x3
     bool res128_x3 = true;          // 128-channel residual block on the bf16 matrix cores (seanet_res128x3.hip); follows bf16x3
     bool fused_dectail = true;      // decoder: last transposed conv + block + final conv in one kernel (seanet_dectail.hip)
@@ -554,10 +555,10 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
     {
         const char* e = std::getenv("AUDIOTOKEN_BF16X3_ACOUSTIC");
         h->bf16x3 = e ? std::atoi(e) != 0 : kBf16x3AcousticDefault;
-        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block
+        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0
         const char* m = std::getenv("AUDIOTOKEN_X3_KERNELS");
-        const int mask = m ? std::atoi(m) : 7;
-        h->down64_x3 = (mask & 1) != 0; h->res128_x3 = (mask & 2) != 0; h->res64_x3 = (mask & 4) != 0;
+        const int mask = m ? std::atoi(m) : 15;
+        h->down64_x3 = (mask & 1) != 0; h->res128_x3 = (mask & 2) != 0; h->res64_x3 = (mask & 4) != 0; h->stage0_x3 = (mask & 8) != 0;
     }
     if (h->bf16x3) {
         for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
@@ -619,7 +620,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             sa.wt = h->res[0][1].w; sa.bt = h->res[0][1].b; sa.wd = h->down[0].w; sa.bd = h->down[0].b;
             sa.B = g; sa.N = N;
             prof.begin("stage0_fused", 1, stream);
-            if (int rc = launch_seanet_stage0(sa, stream)) return rc;
+            if (int rc = (h->stage0_x3 && h->bf16x3) ? launch_seanet_stage0x3(sa, stream) : launch_seanet_stage0(sa, stream)) return rc;
             prof.end(stream);
         } else {
             prof.begin("conv0", 1, stream);
@@ -700,6 +701,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
     if (std::string(name) == "down64_x3") { h->down64_x3 = value != 0; return 0; }
+    if (std::string(name) == "stage0_x3") { h->stage0_x3 = value != 0; return 0; }
     if (std::string(name) == "res64_x3") { h->res64_x3 = value != 0; return 0; }
     if (std::string(name) == "res128_x3") { h->res128_x3 = value != 0; return 0; }
     if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }

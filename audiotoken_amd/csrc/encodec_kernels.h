@@ -43,6 +43,7 @@ struct Stage0Args {
     int B, N;
 };
 int launch_seanet_stage0(const Stage0Args& a, hipStream_t stream);
+int launch_seanet_stage0x3(const Stage0Args& a, hipStream_t stream);   // the same stage with split-bf16 contractions (seanet_stage0x3.hip)
 
 // Fused 64-channel SEANet residual block with ELU epilogue (seanet_res64.hip): x [B][L][64] -> out [B][L][64]
 struct Res64Args {

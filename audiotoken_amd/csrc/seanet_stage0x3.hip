@@ -1,0 +1,243 @@
+// SEANet encoder stage 0 on the bf16 matrix cores — the fused kernel of seanet_stage0.hip
+//   waveform -> conv0 (1->32, k7) -> residual block (ELU, k3 32->16, ELU, k1 16->32, + k1 shortcut) -> ELU -> strided conv (32->64, k4 s2)
+// with the three 32/16-channel contractions as exact 3-way bf16 splits on v_mfma_f32_16x16x32_bf16 (six per 32-wide K step;
+// arithmetic and accuracy: gemm_bf16x3.hip). conv0 (K = 7 taps) stays on the fp32 MFMA exactly as in the fp32 kernel.
+// Tile = 62 input samples (31 outputs): 64 rows of the block = 4 MFMA row tiles, one per wave (conv3 + tail per wave on its own rows,
+// no barrier in between); the strided conv is split over the OUTPUT channels instead (wave = 16 channels, all 32 output slots), so a
+// wave's weights are 132 registers of bf16 pieces and 65 KB of LDS per workgroup put TWO workgroups on a CU — one splits / applies
+// ELUs (vector work) while the other multiplies; a bf16 MFMA leaves half of its cycles to vector issue.
+// LDS (bf16 pieces, rows padded by 16 B so that fragment reads of 16 consecutive rows are conflict-free with linear addresses):
+//   X0e = split(ELU(x0)), X0r = split(x0): [3][80 rows][32 + 8]   row i <-> time t0 - 4 + i
+//   Hs  = split(ELU(conv3 + b3)):          [3][64][16 + 8]        row j <-> time t0 - 2 + j
+//   Rs  = split(ELU(block output)):        [3][2 planes][34][32 + 8]: row j in plane j & 1 at j >> 1, so that the stride-2 rows of
+//         the strided conv's fragment reads are consecutive.
+// The tail's K = 48 = [h 16 | x0 32] runs as two K steps of 32 with a zero-weight quarter.
+// Rounds differently from the fp32 chain: compared by tolerance and identical tokens (tests/test_acoustic_gpu.py).
+// Causal reflect padding as in seanet_stage0.hip (conv0 evaluated at |t|, two mirrored rows of the block output); N % 2 == 0.
+#include "gemm_core.h"
+#include "encodec_kernels.h"
+
+namespace at {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SX_ADV = 62;                 // input samples per tile
+constexpr int SX_UO = 31;                  // outputs per tile
+constexpr int SX_XROWS = 80;               // x0 rows written (5 MFMA row tiles; 66 used)
+constexpr int SX_ROWS = 64;                // h / r rows
+constexpr int SX_RIDX = 34;                // r rows per parity plane (the masked 32nd output reads rows 62..65)
+constexpr int SX_LDX = 40, SX_LDH = 24, SX_LDR = 40;
+constexpr int SX_XP = SX_XROWS * SX_LDX, SX_HP = SX_ROWS * SX_LDH, SX_RP = 2 * SX_RIDX * SX_LDR;   // elements per piece
+constexpr int SX_WAV = 88;                 // waveform segment: Wv[s] = wav[|t0 - 10 + s|]
+constexpr int SX_LDS_BYTES = (6 * SX_XP + 3 * SX_HP + 3 * SX_RP) * 2 + (SX_WAV + 32 + 112) * 4;
+
+__device__ __forceinline__ void sx_split(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)v;
+    const float r1 = v - (float)p1;
+    p2 = (__bf16)r1;
+    p3 = (__bf16)(r1 - (float)p2);
+}
+// 4 consecutive channels -> the three pieces at element offset `off` (piece stride ps)
+__device__ __forceinline__ void sx_store4(__bf16* base, int off, int ps, const f4& v) {
+    bf16x4 a, b, c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        __bf16 x1, x2, x3;
+        sx_split(v[k], x1, x2, x3);
+        a[k] = x1; b[k] = x2; c[k] = x3;
+    }
+    *reinterpret_cast<bf16x4*>(base + off) = a;
+    *reinterpret_cast<bf16x4*>(base + ps + off) = b;
+    *reinterpret_cast<bf16x4*>(base + 2 * ps + off) = c;
+}
+__device__ __forceinline__ f4 sx_elu4(const f4& v) { return f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)}; }
+
+__global__ __launch_bounds__(256, 2) void seanet_stage0x3_kernel(Stage0Args a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 sx_lds[];
+    __bf16* X0e = sx_lds;
+    __bf16* X0r = X0e + 3 * SX_XP;
+    __bf16* Hs = X0r + 3 * SX_XP;
+    __bf16* Rs = Hs + 3 * SX_HP;
+    float* Wv = reinterpret_cast<float*>(Rs + 3 * SX_RP);
+    float* B0s = Wv + SX_WAV;                        // conv0 bias [32]
+    float* Bs = B0s + 32;                            // b3 [16] | bt [32] | bd [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int N = a.N, L1 = N / 2;
+    const int tiles_per_clip = (N + SX_ADV - 1) / SX_ADV;
+    const int total_tiles = a.B * tiles_per_clip;   // < 2^30: checked by the launcher
+
+    // ---- weights -> registers, once per workgroup ------------------------------------------------------------------
+    if (tid < 32) B0s[tid] = a.b0[tid];
+    if (tid < 16) Bs[tid] = a.b3[tid];
+    if (tid < 32) Bs[16 + tid] = a.bt[tid];
+    if (tid < 64) Bs[48 + tid] = a.bd[tid];
+    float w0f[2][2];   // conv0 as a K = 8 fp32 MFMA (7 taps + a zero column): A fragment w0f[nt][s] = W0[nt*16 + r16][4s + q]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w0f[nt][ks] = (4 * ks + q) < 7 ? a.w0[(nt * 16 + r16) * 7 + 4 * ks + q] : 0.f;
+    // bf16 pieces of the A operands (row r16, k = 32 ks + 8 q .. + 7); `kmax` zero-fills the tail's K padding
+    auto wsplit = [&](const float* row, int k0, int kmax, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = (k0 + k) < kmax ? row[k0 + k] : 0.f;
+            __bf16 x1, x2, x3;
+            sx_split(v, x1, x2, x3);
+            p1[k] = x1; p2[k] = x2; p3[k] = x3;
+        }
+    };
+    bf16x8 w3p[3][3], wtp[3][2][2], wdp[3][4];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) wsplit(a.w3 + r16 * 96, ks * 32 + q * 8, 96, w3p[0][ks], w3p[1][ks], w3p[2][ks]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wsplit(a.wt + (nt * 16 + r16) * 48, ks * 32 + q * 8, 48, wtp[0][nt][ks], wtp[1][nt][ks], wtp[2][nt][ks]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wsplit(a.wd + (wave * 16 + r16) * 128, ks * 32 + q * 8, 128, wdp[0][ks], wdp[1][ks], wdp[2][ks]);
+
+    auto fetch_wav = [&](int tile) -> float {
+        if (tile >= total_tiles || tid >= SX_WAV) return 0.f;
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * SX_ADV;
+        int w = t0 - 10 + tid;
+        w = w < 0 ? -w : w;
+        w = w > N - 1 ? N - 1 : w;
+        return a.wav[(long long)b * N + w];
+    };
+    float wnext = fetch_wav(blockIdx.x);
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * SX_ADV;
+        __syncthreads();   // previous tile's readers are done with every buffer
+        // ---- A: waveform segment ----------------------------------------------------------------------------------------
+        if (tid < SX_WAV) Wv[tid] = wnext;
+        wnext = fetch_wav(tile + gridDim.x);
+        __syncthreads();
+        // ---- B: conv0 at time |t0 - 4 + i| on the fp32 MFMA (as seanet_stage0.hip) -> split raw and ELU copies ------------------
+        for (int mt = wave; mt < 5; mt += 4) {
+            const int i = mt * 16 + r16;
+            int a0, a1;
+            if (t0 == 0) {
+                int tau = i - 4;
+                tau = tau < 0 ? -tau : tau;
+                a0 = tau + q - 6;
+                a0 = (a0 < 0 ? -a0 : a0) + 10;
+                a1 = tau + q - 2;
+                a1 = (a1 < 0 ? -a1 : a1) + 10;
+            } else {
+                a0 = i + q;
+                a1 = i + 4 + q;
+            }
+            a0 = a0 < SX_WAV - 1 ? a0 : SX_WAV - 1;   // rows >= 66 and the zero tap stay inside the (finite) segment
+            a1 = a1 < SX_WAV - 1 ? a1 : SX_WAV - 1;
+            const float x0v = Wv[a0], x1v = Wv[a1];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[nt][0], x0v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[nt][1], x1v, acc, 0, 0, 0);
+                const f4 o = acc + *reinterpret_cast<const f4*>(B0s + nt * 16 + q * 4);
+                const int off = i * SX_LDX + nt * 16 + q * 4;
+                sx_store4(X0r, off, SX_XP, o);
+                sx_store4(X0e, off, SX_XP, sx_elu4(o));
+            }
+        }
+        __syncthreads();
+        // ---- C + D on the wave's own 16 rows: h = ELU(conv3(ELU(x0)) + b3), row j uses x0 rows j..j+2 (K step = tap);
+        //      r = ELU([h | x0] . [W1 | Wsc]^T + (b1 + bsc)), row j uses h row j and raw x0 row j + 2 -----------------------------
+        {
+            const int row = wave * 16 + r16;
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            bf16x8 xf[3][3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) xf[ks][p] = *reinterpret_cast<const bf16x8*>(X0e + p * SX_XP + (row + ks) * SX_LDX + q * 8);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3p[PW[t]][ks], xf[ks][PX[t]], acc, 0, 0, 0);
+            sx_store4(Hs, row * SX_LDH + q * 4, SX_HP, sx_elu4(acc + *reinterpret_cast<const f4*>(Bs + q * 4)));
+            // K step 0: k 0..15 = h (lanes q < 2), k 16..31 = x0 channels 0..15; K step 1: k 32..47 = x0 channels 16..31 (q < 2),
+            // k 48..63 zero weights (the lanes re-read finite x0 data)
+            const __bf16* s0 = q < 2 ? Hs + row * SX_LDH + q * 8 : X0r + (row + 2) * SX_LDX + (q - 2) * 8;
+            const int ps0 = q < 2 ? SX_HP : SX_XP;
+            const __bf16* s1 = X0r + (row + 2) * SX_LDX + (2 + (q & 1)) * 8;
+            bf16x8 tf[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                tf[0][p] = *reinterpret_cast<const bf16x8*>(s0 + p * ps0);
+                tf[1][p] = *reinterpret_cast<const bf16x8*>(s1 + p * SX_XP);
+            }
+            f4 acc2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wtp[PW[t]][nt][ks], tf[ks][PX[t]], acc2[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                sx_store4(Rs, ((row & 1) * SX_RIDX + (row >> 1)) * SX_LDR + nt * 16 + q * 4, SX_RP,
+                          sx_elu4(acc2[nt] + *reinterpret_cast<const f4*>(Bs + 16 + nt * 16 + q * 4)));
+        }
+        __syncthreads();
+        if (t0 == 0) {   // reflect padding of the strided conv's input at the clip start: r[-1] = r[1], r[-2] = r[2]
+            if (tid < 48) {
+                const int p = tid >> 4, j = (tid >> 3) & 1, c = (tid & 7) * 4;   // j = 0 <-> t = -2 (copy of row 4); j = 1 <-> t = -1 (row 3)
+                const int src = 4 - j;
+                *reinterpret_cast<bf16x4*>(Rs + p * SX_RP + ((j & 1) * SX_RIDX + (j >> 1)) * SX_LDR + c) =
+                    *reinterpret_cast<const bf16x4*>(Rs + p * SX_RP + ((src & 1) * SX_RIDX + (src >> 1)) * SX_LDR + c);
+            }
+            __syncthreads();
+        }
+        // ---- E: x1[u][16 wave .. + 15] = down0(ELU(r)): output u uses r rows 2u .. 2u+3 (K step = tap) ---------------------------
+        {
+            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            bf16x8 rf[4][3][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int om = 0; om < 2; ++om)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        rf[ks][p][om] = *reinterpret_cast<const bf16x8*>(Rs + p * SX_RP + ((ks & 1) * SX_RIDX + om * 16 + r16 + (ks >> 1)) * SX_LDR + q * 8);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int om = 0; om < 2; ++om)
+                        acc[om] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdp[PW[t]][ks], rf[ks][PX[t]][om], acc[om], 0, 0, 0);
+            const f4 bd = *reinterpret_cast<const f4*>(Bs + 48 + wave * 16 + q * 4);
+#pragma unroll
+            for (int om = 0; om < 2; ++om) {
+                const int u = om * 16 + r16, tout = t0 / 2 + u;
+                if (u < SX_UO && tout < L1) *reinterpret_cast<f4*>(a.x1 + ((long long)b * L1 + tout) * 64 + wave * 16 + q * 4) = acc[om] + bd;
+            }
+        }
+    }
+}
+
+int launch_seanet_stage0x3(const Stage0Args& a, hipStream_t stream) {
+    AT_REQUIRE(a.N % 2 == 0 && a.N >= 16 && a.B >= 1, "fused stage 0 needs an even sample count");
+    const long long tiles = (long long)a.B * ((a.N + SX_ADV - 1) / SX_ADV);
+    AT_REQUIRE(tiles < (1LL << 30), "tile arithmetic is 32-bit");
+    static bool attr_set = false;
+    if (!attr_set) {
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_stage0x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SX_LDS_BYTES));
+        attr_set = true;
+    }
+    const int grid = (int)(tiles < 512 ? tiles : 512);   // two resident workgroups per CU
+    hipLaunchKernelGGL(seanet_stage0x3_kernel, dim3(grid), dim3(256), SX_LDS_BYTES, stream, a);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace at
