@@ -30,7 +30,7 @@ constexpr int SX_RIDX = 34;                // r rows per parity plane (the maske
 constexpr int SX_LDX = 40, SX_LDH = 24, SX_LDR = 40;
 constexpr int SX_XP = SX_XROWS * SX_LDX, SX_HP = SX_ROWS * SX_LDH, SX_RP = 2 * SX_RIDX * SX_LDR;   // elements per piece
 constexpr int SX_WAV = 88;                 // waveform segment: Wv[s] = wav[|t0 - 10 + s|]
-constexpr int SX_LDS_BYTES = (6 * SX_XP + 3 * SX_HP + 3 * SX_RP) * 2 + (SX_WAV + 32 + 112) * 4;
+constexpr int SX_LDS_BYTES = (6 * SX_XP + 3 * SX_HP + 3 * SX_RP) * 2 + (2 * SX_WAV + 32 + 112) * 4;
 
 __device__ __forceinline__ void sx_split(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
     p1 = (__bf16)v;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0x3_kernel(Stage0Args a) {
     __bf16* Hs = X0r + 3 * SX_XP;
     __bf16* Rs = Hs + 3 * SX_HP;
     float* Wv = reinterpret_cast<float*>(Rs + 3 * SX_RP);
-    float* B0s = Wv + SX_WAV;                        // conv0 bias [32]
+    float* B0s = Wv + 2 * SX_WAV;                    // conv0 bias [32]  (Wv: two segments, alternating tiles)
     float* Bs = B0s + 32;                            // b3 [16] | bt [32] | bd [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
@@ -107,19 +107,13 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0x3_kernel(Stage0Args a) {
         w = w > N - 1 ? N - 1 : w;
         return a.wav[(long long)b * N + w];
     };
-    float wnext = fetch_wav(blockIdx.x);
-    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
-
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_clip;
-        const int t0 = (tile - b * tiles_per_clip) * SX_ADV;
-        __syncthreads();   // previous tile's readers are done with every buffer
-        // ---- A: waveform segment ----------------------------------------------------------------------------------------
-        if (tid < SX_WAV) Wv[tid] = wnext;
-        wnext = fetch_wav(tile + gridDim.x);
-        __syncthreads();
-        // ---- B: conv0 at time |t0 - 4 + i| on the fp32 MFMA (as seanet_stage0.hip) -> split raw and ELU copies ------------------
-        for (int mt = wave; mt < 5; mt += 4) {
+    // ---- B: conv0 of a tile at time |t0 - 4 + i| on the fp32 MFMA (as seanet_stage0.hip) -> split raw and ELU copies. 10 units of
+    //      (row tile, channel tile) over the 4 waves. Only the first tile of a clip needs the reflect index map ------------------------
+    auto conv0_tile = [&](int tile, const float* Wseg) {
+        if (tile >= total_tiles) return;
+        const int t0 = (tile % tiles_per_clip) * SX_ADV;
+        for (int unit = wave; unit < 10; unit += 4) {
+            const int mt = unit >> 1, nt = unit & 1;
             const int i = mt * 16 + r16;
             int a0, a1;
             if (t0 == 0) {
@@ -135,19 +129,33 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0x3_kernel(Stage0Args a) {
             }
             a0 = a0 < SX_WAV - 1 ? a0 : SX_WAV - 1;   // rows >= 66 and the zero tap stay inside the (finite) segment
             a1 = a1 < SX_WAV - 1 ? a1 : SX_WAV - 1;
-            const float x0v = Wv[a0], x1v = Wv[a1];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                f4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[nt][0], x0v, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0f[nt][1], x1v, acc, 0, 0, 0);
-                const f4 o = acc + *reinterpret_cast<const f4*>(B0s + nt * 16 + q * 4);
-                const int off = i * SX_LDX + nt * 16 + q * 4;
-                sx_store4(X0r, off, SX_XP, o);
-                sx_store4(X0e, off, SX_XP, sx_elu4(o));
-            }
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nt ? w0f[1][0] : w0f[0][0], Wseg[a0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nt ? w0f[1][1] : w0f[0][1], Wseg[a1], acc, 0, 0, 0);
+            const f4 o = acc + *reinterpret_cast<const f4*>(B0s + nt * 16 + q * 4);
+            const int off = i * SX_LDX + nt * 16 + q * 4;
+            sx_store4(X0r, off, SX_XP, o);
+            sx_store4(X0e, off, SX_XP, sx_elu4(o));
         }
+    };
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+    // Software pipeline over the workgroup's tiles (two barriers per tile): while tile t is in its strided-conv phase the same
+    // waves run conv0 of tile t+1 into the (by then free) x0 buffers and park the waveform segment of tile t+2 in the other Wv buffer.
+    const int stride = gridDim.x;
+    {
+        const float w0v = fetch_wav(blockIdx.x), w1v = fetch_wav(blockIdx.x + stride);
+        __syncthreads();   // biases
+        if (tid < SX_WAV) { Wv[tid] = w0v; Wv[SX_WAV + tid] = w1v; }
         __syncthreads();
+        conv0_tile(blockIdx.x, Wv);
+    }
+    float wnext = fetch_wav(blockIdx.x + 2 * stride);
+    __syncthreads();
+
+    int par = 0;   // Wv[par] holds the segment of the current tile
+    for (int tile = blockIdx.x; tile < total_tiles; tile += stride, par ^= 1) {
+        const int b = tile / tiles_per_clip;
+        const int t0 = (tile - b * tiles_per_clip) * SX_ADV;
         // ---- C + D on the wave's own 16 rows: h = ELU(conv3(ELU(x0)) + b3), row j uses x0 rows j..j+2 (K step = tap);
         //      r = ELU([h | x0] . [W1 | Wsc]^T + (b1 + bsc)), row j uses h row j and raw x0 row j + 2 -----------------------------
         {
@@ -222,6 +230,12 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0x3_kernel(Stage0Args a) {
                 if (u < SX_UO && tout < L1) *reinterpret_cast<f4*>(a.x1 + ((long long)b * L1 + tout) * 64 + wave * 16 + q * 4) = acc[om] + bd;
             }
         }
+        // ---- B of the next tile, A of the one after it (the x0 buffers were last read before the barrier above; Wv[par] before the
+        //      previous one) ------------------------------------------------------------------------------------------------------
+        conv0_tile(tile + stride, Wv + (par ^ 1) * SX_WAV);
+        if (tid < SX_WAV) Wv[par * SX_WAV + tid] = wnext;
+        wnext = fetch_wav(tile + 3 * stride);
+        __syncthreads();   // x0 of the next tile complete; Rs and Hs free
     }
 }
 
