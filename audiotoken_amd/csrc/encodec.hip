@@ -124,6 +124,8 @@ struct at_encodec {
     bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
     bool fused_down64 = true;       // stage-1 strided conv with register-stationary weights (seanet_down64.hip)
     bool down64_x3 = true;          // ... on the bf16 matrix cores with 3-way split operands (seanet_down64x3.hip); follows bf16x3
+    bool down128_x3 = true;         // stage-2 strided conv as a windowed split-bf16 GEMM fed by seanet_res128x3's split epilogue; follows bf16x3
+    const __bf16* down2_s = nullptr;
     bool stage0_x3 = true;          // fused stage 0 on the bf16 matrix cores (seanet_stage0x3.hip); follows bf16x3
     bool res64_x3 = true;           // 64-channel residual block on the bf16 matrix cores (seanet_res64x3.hip); follows bf16x3
     bool res128_x3 = true;          // 128-channel residual block on the bf16 matrix cores (seanet_res128x3.hip); follows bf16x3
@@ -345,6 +347,7 @@ struct EncPlan {
     int G;           // sub-batch
     size_t off_x[4], off_h[4], off_r[4];  // per-stage sub-batch buffers (floats)
     size_t off_x4, off_xg, off_h0, off_h1, off_c, off_y, off_emb, off_sync, off_xs;
+    int Mp2, Lp2;    // stage-2 strided conv as a windowed split-bf16 GEMM: padded output rows, rows per phase plane of its input pieces
     size_t total_floats;
 };
 
@@ -359,7 +362,15 @@ EncPlan make_plan(int B, int N, int sub) {
         const size_t C = 32u << s;
         p.off_x[s] = take((size_t)p.G * p.L[s] * C);
         p.off_h[s] = take((size_t)p.G * p.L[s] * (C / 2));
-        p.off_r[s] = take((size_t)p.G * p.L[s] * C);
+        size_t rn = (size_t)p.G * p.L[s] * C;
+        if (s == 2) {   // r[2] doubles as the K-blocked phase-major bf16 pieces of ELU(block output) (3 pieces x 2 B = 1.5 floats per element)
+            p.Mp2 = (p.L[3] + 255) / 256 * 256;
+            const int reach = p.Mp2 + (10 - 1) / 5, have = (p.L[2] + 5 + 4) / 5;
+            p.Lp2 = ((have > reach ? have : reach) + 63) / 64 * 64;
+            const size_t pn = (size_t)p.G * 5 * p.Lp2 * C * 3 / 2 + 64;
+            rn = pn > rn ? pn : rn;
+        }
+        p.off_r[s] = take(rn);
     }
     const size_t T = p.L[4];
     p.off_x4 = take((size_t)B * T * kH);
@@ -555,10 +566,11 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
     {
         const char* e = std::getenv("AUDIOTOKEN_BF16X3_ACOUSTIC");
         h->bf16x3 = e ? std::atoi(e) != 0 : kBf16x3AcousticDefault;
-        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0
+        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0, bit 4 stage-2 strided conv (GEMM)
         const char* m = std::getenv("AUDIOTOKEN_X3_KERNELS");
-        const int mask = m ? std::atoi(m) : 15;
+        const int mask = m ? std::atoi(m) : 31;
         h->down64_x3 = (mask & 1) != 0; h->res128_x3 = (mask & 2) != 0; h->res64_x3 = (mask & 4) != 0; h->stage0_x3 = (mask & 8) != 0;
+        h->down128_x3 = (mask & 16) != 0;
     }
     if (h->bf16x3) {
         for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
@@ -569,6 +581,13 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
                 if (int rc = launch_split_blocked(dec ? h->dwih[l] : h->wih[l], kH, 4 * kH, 4 * kH, kH, d, nullptr)) return rc;
                 (dec ? h->dwih_s : h->wih_s)[l] = d;
             }
+        {   // stage-2 strided conv weights [256][10 * 128] as K-blocked bf16 pieces
+            __bf16* d = nullptr;
+            AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * 256 * 1280 * sizeof(__bf16)));
+            h->extra_allocs.push_back(d);
+            if (int rc = launch_split_blocked(h->down[2].w, 1280, 256, 256, 1280, d, nullptr)) return rc;
+            h->down2_s = d;
+        }
         AT_CHECK_HIP(hipDeviceSynchronize());
     }
     h->finalized = true;
@@ -631,6 +650,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             const int C = 32 << s, L = p.L[s], Lo = p.L[s + 1];
             float* x = ws + p.off_x[s];
             float* r = ws + p.off_r[s];
+            bool down2_gemm = false;
             if (s == 1 && h->fused_res64) {
                 // 64-channel block fused into one kernel: 256 B in + 256 B out per row (seanet_res64.hip)
                 Res64Args ra;
@@ -644,8 +664,13 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 Res64Args ra;
                 ra.x = x; ra.out = r; ra.w3 = h->res[2][0].w; ra.b3 = h->res[2][0].b; ra.wt = h->res[2][1].w; ra.bt = h->res[2][1].b;
                 ra.B = g; ra.L = L;
-                prof.begin("res2", 1, stream);
+                // with the strided conv as a split-bf16 GEMM the block writes that GEMM's operand pieces instead of fp32 rows
+                down2_gemm = h->down128_x3 && h->res128_x3 && h->bf16x3 && h->down2_s && L % 5 == 0 && L >= 10;
+                if (down2_gemm) { ra.S = reinterpret_cast<__bf16*>(r); ra.Lp = p.Lp2; }
+                prof.begin("res2", down2_gemm ? 2 : 1, stream);
                 if (int rc = (h->res128_x3 && h->bf16x3) ? launch_seanet_res128x3(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
+                if (down2_gemm)
+                    if (int rc = launch_reflect_front5(ra.S, g, 8, p.Lp2, stream)) return rc;
                 prof.end(stream);
             } else {
                 prof.begin(kRes[s], 2, stream);
@@ -659,6 +684,13 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 Down64Args da;
                 da.x = r; da.out = out; da.w = h->down[1].w; da.b = h->down[1].b; da.B = g; da.L = L;
                 if (int rc = (h->down64_x3 && h->bf16x3) ? launch_seanet_down64x3(da, stream) : launch_seanet_down64(da, stream)) return rc;
+            } else if (s == 2 && down2_gemm) {
+                Bf16x3Args ga;
+                ga.A = reinterpret_cast<const __bf16*>(r); ga.W = h->down2_s; ga.bias = h->down[2].b;
+                ga.M = Lo; ga.Mpad = p.Mp2; ga.N = 256; ga.K = 1280;
+                ga.batch = g; ga.stride = 5; ga.cblocks = 8; ga.Lp = p.Lp2;
+                ga.epi = XB_EPI_LINEAR; ga.C = out; ga.ldc = 256;
+                if (int rc = launch_gemm_bf16x3(ga, stream)) return rc;
             } else if (int rc = conv_gemm(h->down[s], r, (long long)L * C, L, out, (long long)Lo * 2 * C, Lo, g, PRO_NONE, nullptr, 0, stream)) {
                 return rc;
             }
@@ -701,6 +733,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
     if (std::string(name) == "down64_x3") { h->down64_x3 = value != 0; return 0; }
+    if (std::string(name) == "down128_x3") { h->down128_x3 = value != 0; return 0; }
     if (std::string(name) == "stage0_x3") { h->stage0_x3 = value != 0; return 0; }
     if (std::string(name) == "res64_x3") { h->res64_x3 = value != 0; return 0; }
     if (std::string(name) == "res128_x3") { h->res128_x3 = value != 0; return 0; }

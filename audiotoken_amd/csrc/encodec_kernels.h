@@ -52,7 +52,13 @@ struct Res64Args {
     const float *w3, *b3;   // conv3 packed [32][3*64], [32]
     const float *wt, *bt;   // tail packed [64][32 + 64] = [W1 | Wsc], summed bias [64]
     int B, L;
+    // seanet_res128x3 only: when set, the output is written as the three K-blocked bf16 pieces a stride-5 windowed split-bf16 GEMM
+    // reads (gemm_bf16x3.h: [3][B][C/16][5 planes][Lp][16], row t in plane t % 5 at index t / 5 + 1) instead of fp32 rows
+    __bf16* S = nullptr;
+    int Lp = 0;
 };
+// fills the causal reflect padding (5 front rows = index 0 of every plane) of those pieces
+int launch_reflect_front5(__bf16* S, int B, int cblocks, int Lp, hipStream_t stream);
 int launch_seanet_res64(const Res64Args& a, hipStream_t stream);
 // the 128-channel block on the bf16 matrix cores with exact 3-way bf16 splits of all operands (seanet_res128x3.hip)
 int launch_seanet_res128x3(const Res64Args& a, hipStream_t stream);

@@ -204,17 +204,52 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
                 const int t = t0 + (mp + m) * 16 + r16;
                 if (t < L) {
                     float* dst = a.out + ((long long)b * L + t) * 128 + wave * 32 + q * 4;
+                    const int plane = t % 5, idx = t / 5 + 1;
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         const f4 v = acc[m][n] + *reinterpret_cast<const f4*>(a.bt + wave * 32 + n * 16 + q * 4);
                         f4 o;
                         o.x = elu1(v.x); o.y = elu1(v.y); o.z = elu1(v.z); o.w = elu1(v.w);
-                        *reinterpret_cast<f4*>(dst + n * 16) = o;
+                        if (a.S) {   // the consumer is the stride-5 split-bf16 GEMM: K-blocked, phase-major pieces
+                            bf16x4 s1, s2, s3;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                __bf16 x1, x2, x3;
+                                rx_split(o[k], x1, x2, x3);
+                                s1[k] = x1; s2[k] = x2; s3[k] = x3;
+                            }
+                            const long long ps = (long long)a.B * 8 * 5 * a.Lp * 16;
+                            __bf16* d = a.S + ((((long long)b * 8 + wave * 2 + n) * 5 + plane) * a.Lp + idx) * 16 + q * 4;
+                            *reinterpret_cast<bf16x4*>(d) = s1;
+                            *reinterpret_cast<bf16x4*>(d + ps) = s2;
+                            *reinterpret_cast<bf16x4*>(d + 2 * ps) = s3;
+                        } else {
+                            *reinterpret_cast<f4*>(dst + n * 16) = o;
+                        }
                     }
                 }
             }
         }
     }
+}
+
+// index 0 of plane i = padded row i = time i - 5 = reflect of time 5 - i (plane (5 - i) % 5, index (5 - i) / 5 + 1)
+__global__ void reflect_front5_kernel(__bf16* S, int B, int cblocks, int Lp) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;          // (piece, clip, cblock, plane, 4-channel group)
+    const int total = 3 * B * cblocks * 5 * 4;
+    if (gid >= total) return;
+    const int c4 = gid & 3, i = (gid >> 2) % 5, rest = (gid >> 2) / 5;   // rest = (piece * B + clip) * cblocks + cblock
+    const int t = 5 - i;
+    __bf16* base = S + (long long)rest * 5 * Lp * 16;
+    *reinterpret_cast<bf16x4*>(base + ((long long)i * Lp) * 16 + c4 * 4) =
+        *reinterpret_cast<const bf16x4*>(base + ((long long)(t % 5) * Lp + t / 5 + 1) * 16 + c4 * 4);
+}
+
+int launch_reflect_front5(__bf16* S, int B, int cblocks, int Lp, hipStream_t stream) {
+    const int total = 3 * B * cblocks * 5 * 4;
+    hipLaunchKernelGGL(reflect_front5_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, S, B, cblocks, Lp);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_seanet_res128x3(const Res64Args& a, hipStream_t stream) {
