@@ -72,12 +72,13 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
                               int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream,
                               uint32_t* status_dev);
 
-/* Options (they select kernels or bound memory; all but "down64_x3" leave the results bit-identical):
+/* Options (they select kernels or bound memory; all but the "*_x3" ones leave the results bit-identical):
  *   "persistent_lstm" 1/0 — whole-sequence persistent LSTM kernel (default on) or one launch per time step;
  *   "fused_stage0", "fused_res64", "fused_res128", "fused_down64", "fused_dectail" 1/0 — fused SEANet kernels (default on)
  *   or the GEMM path;
- *   "down64_x3" 1/0 — stage-1 strided conv on the split-bf16 matrix-core kernel (default on; 0 = the fp32-MFMA kernel:
- *   same tokens, embeddings differ in the last bits);
+ *   "stage0_x3", "res64_x3", "res128_x3", "down64_x3", "down128_x3" 1/0 — the fused kernels / the stage-2 strided conv on the
+ *   bf16 matrix cores with exact 3-way bf16 splits of every operand (default on, $AUDIOTOKEN_X3_KERNELS bit mask in that
+ *   order from bit 3, 2, 1, 0, 4; 0 = the fp32-MFMA kernels: same tokens, embeddings differ in the last bits);
  *   "subbatch" n >= 1 — clips per pass through the conv stack (default 256 or $AUDIOTOKEN_SUBBATCH): bounds
  *   at_encodec_workspace_bytes / at_encodec_decode_workspace_bytes, which must be re-queried after changing it. */
 int at_encodec_set_option(at_encodec_t* h, const char* name, int value);

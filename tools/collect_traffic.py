@@ -17,9 +17,10 @@ from collections import defaultdict
 
 GROUPS = {  # bench.py group -> kernel name prefix
     "lstm_rec": "at::lstm_seq_kernel",
-    "stage0_fused": "at::seanet_stage0_kernel",
-    "res1": "at::seanet_res64_kernel",
-    "res2": "at::seanet_res128_kernel",
+    "stage0_fused": "at::seanet_stage0",      # seanet_stage0_kernel / seanet_stage0x3_kernel, whichever ran
+    "res1": "at::seanet_res64",
+    "down1": "at::seanet_down64",
+    "res2": "at::seanet_res128",
     "rvq": "at::rvq_encode_kernel",
 }
 
@@ -28,6 +29,7 @@ def per_kernel(directory, counter):
     files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no *counter_collection.csv under {directory}")
+    files = [max(files, key=os.path.getmtime)]   # gpurun merges successive runs into one directory: keep the newest
     tot, cnt = defaultdict(float), defaultdict(int)
     seen = set()
     for f in files:
