@@ -126,6 +126,8 @@ struct at_encodec {
     bool down64_x3 = true;          // ... on the bf16 matrix cores with 3-way split operands (seanet_down64x3.hip); follows bf16x3
     bool down128_x3 = true;         // stage-2 strided conv as a windowed split-bf16 GEMM fed by seanet_res128x3's split epilogue; follows bf16x3
     const __bf16* down2_s = nullptr;
+    bool down256_x3 = true;         // stage-3 strided conv as a windowed split-bf16 GEMM behind a split pass; follows bf16x3
+    const __bf16* down3_s = nullptr;
     bool stage0_x3 = true;          // fused stage 0 on the bf16 matrix cores (seanet_stage0x3.hip); follows bf16x3
     bool res64_x3 = true;           // 64-channel residual block on the bf16 matrix cores (seanet_res64x3.hip); follows bf16x3
     bool res128_x3 = true;          // 128-channel residual block on the bf16 matrix cores (seanet_res128x3.hip); follows bf16x3
@@ -347,6 +349,7 @@ struct EncPlan {
     int G;           // sub-batch
     size_t off_x[4], off_h[4], off_r[4];  // per-stage sub-batch buffers (floats)
     size_t off_x4, off_xg, off_h0, off_h1, off_c, off_y, off_emb, off_sync, off_xs;
+    int Mp3, Lp3; size_t off_s3;   // stage-3 strided conv the same way, its input split by a separate pass
     int Mp2, Lp2;    // stage-2 strided conv as a windowed split-bf16 GEMM: padded output rows, rows per phase plane of its input pieces
     size_t total_floats;
 };
@@ -371,6 +374,12 @@ EncPlan make_plan(int B, int N, int sub) {
             rn = pn > rn ? pn : rn;
         }
         p.off_r[s] = take(rn);
+    }
+    {
+        p.Mp3 = (p.L[4] + 255) / 256 * 256;
+        const int reach = p.Mp3 + (16 - 1) / 8, have = (p.L[3] + 8 + 7) / 8;
+        p.Lp3 = ((have > reach ? have : reach) + 63) / 64 * 64;
+        p.off_s3 = take((size_t)p.G * 8 * p.Lp3 * 256 * 3 / 2 + 64);
     }
     const size_t T = p.L[4];
     p.off_x4 = take((size_t)B * T * kH);
@@ -566,11 +575,12 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
     {
         const char* e = std::getenv("AUDIOTOKEN_BF16X3_ACOUSTIC");
         h->bf16x3 = e ? std::atoi(e) != 0 : kBf16x3AcousticDefault;
-        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0, bit 4 stage-2 strided conv (GEMM)
+        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0, bit 4 / 5 stage-2 / stage-3 strided conv (GEMM)
         const char* m = std::getenv("AUDIOTOKEN_X3_KERNELS");
-        const int mask = m ? std::atoi(m) : 31;
+        const int mask = m ? std::atoi(m) : 63;
         h->down64_x3 = (mask & 1) != 0; h->res128_x3 = (mask & 2) != 0; h->res64_x3 = (mask & 4) != 0; h->stage0_x3 = (mask & 8) != 0;
         h->down128_x3 = (mask & 16) != 0;
+        h->down256_x3 = (mask & 32) != 0;
     }
     if (h->bf16x3) {
         for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
@@ -587,6 +597,13 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             h->extra_allocs.push_back(d);
             if (int rc = launch_split_blocked(h->down[2].w, 1280, 256, 256, 1280, d, nullptr)) return rc;
             h->down2_s = d;
+        }
+        {   // stage-3 strided conv weights [512][16 * 256]
+            __bf16* d = nullptr;
+            AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * 512 * 4096 * sizeof(__bf16)));
+            h->extra_allocs.push_back(d);
+            if (int rc = launch_split_blocked(h->down[3].w, 4096, 512, 512, 4096, d, nullptr)) return rc;
+            h->down3_s = d;
         }
         AT_CHECK_HIP(hipDeviceSynchronize());
     }
@@ -691,6 +708,15 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 ga.batch = g; ga.stride = 5; ga.cblocks = 8; ga.Lp = p.Lp2;
                 ga.epi = XB_EPI_LINEAR; ga.C = out; ga.ldc = 256;
                 if (int rc = launch_gemm_bf16x3(ga, stream)) return rc;
+            } else if (s == 3 && h->down256_x3 && h->bf16x3 && h->down3_s && L % 8 == 0 && L >= 16) {
+                __bf16* s3 = reinterpret_cast<__bf16*>(ws + p.off_s3);
+                if (int rc = launch_split_phase_major(r, g, L, 256, 8, p.Lp3, s3, stream)) return rc;
+                Bf16x3Args ga;
+                ga.A = s3; ga.W = h->down3_s; ga.bias = h->down[3].b;
+                ga.M = Lo; ga.Mpad = p.Mp3; ga.N = 512; ga.K = 4096;
+                ga.batch = g; ga.stride = 8; ga.cblocks = 16; ga.Lp = p.Lp3;
+                ga.epi = XB_EPI_LINEAR; ga.C = out; ga.ldc = 512;
+                if (int rc = launch_gemm_bf16x3(ga, stream)) return rc;
             } else if (int rc = conv_gemm(h->down[s], r, (long long)L * C, L, out, (long long)Lo * 2 * C, Lo, g, PRO_NONE, nullptr, 0, stream)) {
                 return rc;
             }
@@ -733,6 +759,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
     if (std::string(name) == "down64_x3") { h->down64_x3 = value != 0; return 0; }
+    if (std::string(name) == "down256_x3") { h->down256_x3 = value != 0; return 0; }
     if (std::string(name) == "down128_x3") { h->down128_x3 = value != 0; return 0; }
     if (std::string(name) == "stage0_x3") { h->stage0_x3 = value != 0; return 0; }
     if (std::string(name) == "res64_x3") { h->res64_x3 = value != 0; return 0; }

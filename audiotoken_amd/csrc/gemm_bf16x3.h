@@ -34,6 +34,8 @@ struct Bf16x3Args {
 
 // fp32 row-major [rows][ld] (first K columns) -> 3 K-blocked bf16 pieces [3][K/16][rows_pad][16]; rows >= `rows` are zero-filled
 int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream);
+// fp32 [B][L][C] -> the windowed-mode pieces of a causal strided conv with kernel = 2 * stride (reflect front padding included)
+int launch_split_phase_major(const float* x, int B, int L, int C, int stride, int Lp, __bf16* out, hipStream_t stream);
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream);
 
 }  // namespace at

@@ -78,6 +78,51 @@ __global__ __launch_bounds__(256) void split_blocked_kernel(const float* __restr
     }
 }
 
+// fp32 [B][L][C] -> the pieces a causal strided conv (kernel = 2 x stride, left reflect padding of `stride` rows) reads as a windowed
+// GEMM: [3][B][C/16][stride planes][Lp][16], padded row i = t + stride in plane i % stride at index i / stride; rows i < stride
+// are the reflection x[stride - i]. A wave owns one 16-channel block of one (clip, plane): lanes = (4-channel group, 16 consecutive
+// indices), so a wave-store covers 512 contiguous bytes per piece and the reads are 64-byte runs.
+__global__ __launch_bounds__(256) void split_phase_major_kernel(const float* __restrict__ x, int L, int C, int stride, int Lp, int nidx,
+                                                                long long piece_stride, __bf16* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = lane & 3, ii = lane >> 2;
+    const int cb = blockIdx.y * 4 + wave, cblocks = C / 16;
+    const int b = blockIdx.z / stride, plane = blockIdx.z - b * stride;
+    if (cb >= cblocks) return;
+    const float* xb = x + (long long)b * L * C + cb * 16 + k * 4;
+    __bf16* ob = out + (((long long)b * cblocks + cb) * stride + plane) * Lp * 16 + k * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = blockIdx.x * 64 + j * 16 + ii;
+        if (idx >= nidx) continue;
+        int t = idx * stride + plane - stride;
+        t = t < 0 ? -t : t;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < L) v = *reinterpret_cast<const f4*>(xb + (long long)t * C);
+        bf16x4 p1, p2, p3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __bf16 a, bb, c;
+            split3(v[i], a, bb, c);
+            p1[i] = a; p2[i] = bb; p3[i] = c;
+        }
+        __bf16* d = ob + (long long)idx * 16;
+        *reinterpret_cast<bf16x4*>(d) = p1;
+        *reinterpret_cast<bf16x4*>(d + piece_stride) = p2;
+        *reinterpret_cast<bf16x4*>(d + 2 * piece_stride) = p3;
+    }
+}
+
+int launch_split_phase_major(const float* x, int B, int L, int C, int stride, int Lp, __bf16* out, hipStream_t stream) {
+    AT_REQUIRE(C % 16 == 0 && L > stride && stride >= 1, "split_phase_major: C % 16, L > stride");
+    const int nidx = (L + stride + stride - 1) / stride;
+    AT_REQUIRE(nidx <= Lp, "split_phase_major: Lp too small");
+    dim3 grid((nidx + 63) / 64, (C / 16 + 3) / 4, B * stride);
+    hipLaunchKernelGGL(split_phase_major_kernel, grid, dim3(256), 0, stream, x, L, C, stride, Lp, nidx, (long long)B * (C / 16) * stride * Lp * 16, out);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream) {
     AT_REQUIRE(K % 64 == 0 && ld % 4 == 0 && rows_pad >= rows && rows_pad % 64 == 0, "split_blocked: K % 64, ld % 4, rows_pad % 64");
     dim3 grid((unsigned)(rows_pad / 64), K / 64);
