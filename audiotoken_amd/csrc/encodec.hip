@@ -126,6 +126,8 @@ struct at_encodec {
     bool down64_x3 = true;          // ... on the bf16 matrix cores with 3-way split operands (seanet_down64x3.hip); follows bf16x3
     bool down128_x3 = true;         // stage-2 strided conv as a windowed split-bf16 GEMM fed by seanet_res128x3's split epilogue; follows bf16x3
     const __bf16* down2_s = nullptr;
+    bool res256_x3 = true;          // 256-channel block as two split-bf16 GEMMs chained between the stage-2 and stage-3 strided convs; follows bf16x3
+    const __bf16 *res3c_s = nullptr, *res3t_s = nullptr;
     bool down256_x3 = true;         // stage-3 strided conv as a windowed split-bf16 GEMM behind a split pass; follows bf16x3
     const __bf16* down3_s = nullptr;
     bool stage0_x3 = true;          // fused stage 0 on the bf16 matrix cores (seanet_stage0x3.hip); follows bf16x3
@@ -349,7 +351,8 @@ struct EncPlan {
     int G;           // sub-batch
     size_t off_x[4], off_h[4], off_r[4];  // per-stage sub-batch buffers (floats)
     size_t off_x4, off_xg, off_h0, off_h1, off_c, off_y, off_emb, off_sync, off_xs;
-    int Mp3, Lp3; size_t off_s3;   // stage-3 strided conv the same way, its input split by a separate pass
+    int Mp3, Lp3; size_t off_s3;   // stage-3 strided conv the same way, its input split by a separate pass or by the block's tail GEMM
+    int Mpc, Lpc; size_t off_ac3, off_at3;   // 256-channel block as two split-bf16 GEMMs: pieces of ELU(x) (2 front rows) and of [h | x]
     int Mp2, Lp2;    // stage-2 strided conv as a windowed split-bf16 GEMM: padded output rows, rows per phase plane of its input pieces
     size_t total_floats;
 };
@@ -380,6 +383,10 @@ EncPlan make_plan(int B, int N, int sub) {
         const int reach = p.Mp3 + (16 - 1) / 8, have = (p.L[3] + 8 + 7) / 8;
         p.Lp3 = ((have > reach ? have : reach) + 63) / 64 * 64;
         p.off_s3 = take((size_t)p.G * 8 * p.Lp3 * 256 * 3 / 2 + 64);
+        p.Mpc = (p.L[3] + 255) / 256 * 256;
+        p.Lpc = (p.Mpc + 2 + 63) / 64 * 64;
+        p.off_ac3 = take((size_t)p.G * p.Lpc * 256 * 3 / 2 + 64);
+        p.off_at3 = take((size_t)p.G * p.Mpc * 384 * 3 / 2 + 64);
     }
     const size_t T = p.L[4];
     p.off_x4 = take((size_t)B * T * kH);
@@ -575,12 +582,13 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
     {
         const char* e = std::getenv("AUDIOTOKEN_BF16X3_ACOUSTIC");
         h->bf16x3 = e ? std::atoi(e) != 0 : kBf16x3AcousticDefault;
-        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0, bit 4 / 5 stage-2 / stage-3 strided conv (GEMM)
+        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0, bit 4 / 5 stage-2 / stage-3 strided conv (GEMM), bit 6 256-channel block (GEMMs)
         const char* m = std::getenv("AUDIOTOKEN_X3_KERNELS");
-        const int mask = m ? std::atoi(m) : 63;
+        const int mask = m ? std::atoi(m) : 127;
         h->down64_x3 = (mask & 1) != 0; h->res128_x3 = (mask & 2) != 0; h->res64_x3 = (mask & 4) != 0; h->stage0_x3 = (mask & 8) != 0;
         h->down128_x3 = (mask & 16) != 0;
         h->down256_x3 = (mask & 32) != 0;
+        h->res256_x3 = (mask & 64) != 0;
     }
     if (h->bf16x3) {
         for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
@@ -604,6 +612,15 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             h->extra_allocs.push_back(d);
             if (int rc = launch_split_blocked(h->down[3].w, 4096, 512, 512, 4096, d, nullptr)) return rc;
             h->down3_s = d;
+        }
+        {   // 256-channel block: conv3 [128][3 * 256] and tail [256][128 + 256]
+            __bf16 *d0 = nullptr, *d1 = nullptr;
+            AT_CHECK_HIP(hipMalloc((void**)&d0, (size_t)3 * 128 * 768 * sizeof(__bf16)));
+            AT_CHECK_HIP(hipMalloc((void**)&d1, (size_t)3 * 256 * 384 * sizeof(__bf16)));
+            h->extra_allocs.push_back(d0); h->extra_allocs.push_back(d1);
+            if (int rc = launch_split_blocked(h->res[3][0].w, 768, 128, 128, 768, d0, nullptr)) return rc;
+            if (int rc = launch_split_blocked(h->res[3][1].w, 384, 256, 256, 384, d1, nullptr)) return rc;
+            h->res3c_s = d0; h->res3t_s = d1;
         }
         AT_CHECK_HIP(hipDeviceSynchronize());
     }
@@ -663,6 +680,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             if (int rc = launch_conv0(wav + (long long)b0 * N, h->conv0.w, h->conv0.b, ws + p.off_x[0], g, N, stream)) return rc;
             prof.end(stream);
         }
+        bool chain3 = false;   // stage-2 strided conv -> 256-channel block -> stage-3 strided conv as chained split-bf16 GEMMs (no fp32 in between)
         for (int s = fused0 ? 1 : 0; s < 4; ++s) {
             const int C = 32 << s, L = p.L[s], Lo = p.L[s + 1];
             float* x = ws + p.off_x[s];
@@ -689,6 +707,25 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 if (down2_gemm)
                     if (int rc = launch_reflect_front5(ra.S, g, 8, p.Lp2, stream)) return rc;
                 prof.end(stream);
+            } else if (s == 3 && chain3) {
+                // conv3 (k3, 256 -> 128) on the ELU pieces the stage-2 GEMM wrote; its ELU_SPLIT epilogue fills K-blocks 0..7 of the tail's
+                // operand (blocks 8..23 = the raw x pieces, also from the stage-2 GEMM); the tail's epilogue writes the stage-3 conv's operand
+                __bf16* ac3 = reinterpret_cast<__bf16*>(ws + p.off_ac3);
+                __bf16* at3 = reinterpret_cast<__bf16*>(ws + p.off_at3);
+                __bf16* s3 = reinterpret_cast<__bf16*>(ws + p.off_s3);
+                prof.begin(kRes[s], 3, stream);
+                Bf16x3Args ca;
+                ca.A = ac3; ca.W = h->res3c_s; ca.bias = h->res[3][0].b; ca.M = L; ca.Mpad = p.Mpc; ca.N = 128; ca.K = 768;
+                ca.batch = g; ca.stride = 1; ca.cblocks = 16; ca.Lp = p.Lpc;
+                ca.epi = XB_EPI_ELU_SPLIT; ca.S = at3; ca.Spad = p.Mpc; ca.Sphases = 1; ca.Sfront = 0; ca.Sblocks = 24; ca.Sblock0 = 0;
+                if (int rc = launch_gemm_bf16x3(ca, stream)) return rc;
+                Bf16x3Args ta;
+                ta.A = at3; ta.W = h->res3t_s; ta.bias = h->res[3][1].b; ta.M = L; ta.Mpad = p.Mpc; ta.N = 256; ta.K = 384;
+                ta.batch = g; ta.stride = 1; ta.cblocks = 24; ta.Lp = p.Mpc;
+                ta.epi = XB_EPI_ELU_SPLIT; ta.S = s3; ta.Spad = p.Lp3; ta.Sphases = 8; ta.Sfront = 1;
+                if (int rc = launch_gemm_bf16x3(ta, stream)) return rc;
+                if (int rc = launch_reflect_front(s3, g, 16, 8, p.Lp3, 8, stream)) return rc;
+                prof.end(stream);
             } else {
                 prof.begin(kRes[s], 2, stream);
                 // the block output is only ever consumed through ELU (by the strided conv): apply it once here
@@ -706,11 +743,21 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 ga.A = reinterpret_cast<const __bf16*>(r); ga.W = h->down2_s; ga.bias = h->down[2].b;
                 ga.M = Lo; ga.Mpad = p.Mp2; ga.N = 256; ga.K = 1280;
                 ga.batch = g; ga.stride = 5; ga.cblocks = 8; ga.Lp = p.Lp2;
-                ga.epi = XB_EPI_LINEAR; ga.C = out; ga.ldc = 256;
+                chain3 = h->res256_x3 && h->down256_x3 && h->res3c_s && h->down3_s && Lo % 8 == 0 && Lo >= 16;
+                if (chain3) {   // the next block reads pieces: raw x -> K-blocks 8..23 of its tail operand, ELU(x) (2 causal front rows) -> its conv3 operand
+                    ga.epi = XB_EPI_RAW_ELU_SPLIT2;
+                    ga.S = reinterpret_cast<__bf16*>(ws + p.off_at3); ga.Spad = p.Mpc; ga.Sphases = 1; ga.Sfront = 0; ga.Sblocks = 24; ga.Sblock0 = 8;
+                    ga.S2 = reinterpret_cast<__bf16*>(ws + p.off_ac3); ga.S2pad = p.Lpc; ga.S2phases = 1; ga.S2front = 2;
+                } else {
+                    ga.epi = XB_EPI_LINEAR; ga.C = out; ga.ldc = 256;
+                }
                 if (int rc = launch_gemm_bf16x3(ga, stream)) return rc;
+                if (chain3)
+                    if (int rc = launch_reflect_front(ga.S2, g, 16, 1, p.Lpc, 2, stream)) return rc;
             } else if (s == 3 && h->down256_x3 && h->bf16x3 && h->down3_s && L % 8 == 0 && L >= 16) {
                 __bf16* s3 = reinterpret_cast<__bf16*>(ws + p.off_s3);
-                if (int rc = launch_split_phase_major(r, g, L, 256, 8, p.Lp3, s3, stream)) return rc;
+                if (!chain3)
+                    if (int rc = launch_split_phase_major(r, g, L, 256, 8, p.Lp3, s3, stream)) return rc;
                 Bf16x3Args ga;
                 ga.A = s3; ga.W = h->down3_s; ga.bias = h->down[3].b;
                 ga.M = Lo; ga.Mpad = p.Mp3; ga.N = 512; ga.K = 4096;
@@ -759,6 +806,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
     if (std::string(name) == "down64_x3") { h->down64_x3 = value != 0; return 0; }
+    if (std::string(name) == "res256_x3") { h->res256_x3 = value != 0; return 0; }
     if (std::string(name) == "down256_x3") { h->down256_x3 = value != 0; return 0; }
     if (std::string(name) == "down128_x3") { h->down128_x3 = value != 0; return 0; }
     if (std::string(name) == "stage0_x3") { h->stage0_x3 = value != 0; return 0; }

@@ -4,7 +4,7 @@
 
 namespace at {
 
-enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2, XB_EPI_GELU_SPLIT = 3, XB_EPI_GELU = 4 };
+enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2, XB_EPI_GELU_SPLIT = 3, XB_EPI_GELU = 4, XB_EPI_ELU_SPLIT = 5, XB_EPI_RAW_ELU_SPLIT2 = 6 };
 
 struct Bf16x3Args {
     const __bf16* A = nullptr;   // activations: 3 K-blocked pieces [3][K/16][Mpad][16]
@@ -30,7 +30,17 @@ struct Bf16x3Args {
     int cblocks = 0;   // Cin / 16 (0: K / 16, i.e. one tap)
     int Lp = 0;        // rows per phase plane of A (0: Mpad)
     int Sphases = 1, Sfront = 0;
+    // The split output may be a block range of a wider per-clip buffer (an operand K-concatenated from two producers): Sblocks =
+    // 16-channel blocks per clip of that buffer (0: N / 16), Sblock0 = the block output column 0 maps to.
+    int Sblocks = 0, Sblock0 = 0;
+    // XB_EPI_ELU_SPLIT: S = split3(ELU(acc + bias)). XB_EPI_RAW_ELU_SPLIT2: S = split3(acc + bias) and S2 = split3(ELU(acc + bias)),
+    // each with its own phase / padding / block description (SEANet: the residual block's shortcut operand and its conv operand).
+    __bf16* S2 = nullptr;
+    int S2pad = 0, S2phases = 1, S2front = 0, S2blocks = 0, S2block0 = 0;
 };
+// fills the causal reflect padding of windowed-mode pieces [3][B][blocks][phases][Lp][16]: padded rows i < pad (row i lives in plane
+// i % phases at index i / phases) become copies of padded row 2 * pad - i
+int launch_reflect_front(__bf16* S, int B, int blocks, int phases, int Lp, int pad, hipStream_t stream);
 
 // fp32 row-major [rows][ld] (first K columns) -> 3 K-blocked bf16 pieces [3][K/16][rows_pad][16]; rows >= `rows` are zero-filled
 int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream);

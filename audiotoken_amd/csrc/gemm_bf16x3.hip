@@ -113,6 +113,25 @@ __global__ __launch_bounds__(256) void split_phase_major_kernel(const float* __r
     }
 }
 
+__global__ void reflect_front_kernel(__bf16* S, int B, int blocks, int phases, int Lp, int pad) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;          // (piece, clip, block) x pad row x 4-channel group
+    const long long total = 3LL * B * blocks * pad * 4;
+    if (gid >= total) return;
+    const int c4 = (int)(gid & 3), i = (int)((gid >> 2) % pad);
+    const long long rest = (gid >> 2) / pad;   // (piece * B + clip) * blocks + block
+    const int j = 2 * pad - i;
+    __bf16* base = S + rest * phases * Lp * 16 + c4 * 4;
+    *reinterpret_cast<bf16x4*>(base + ((long long)(i % phases) * Lp + i / phases) * 16) =
+        *reinterpret_cast<const bf16x4*>(base + ((long long)(j % phases) * Lp + j / phases) * 16);
+}
+
+int launch_reflect_front(__bf16* S, int B, int blocks, int phases, int Lp, int pad, hipStream_t stream) {
+    const long long total = 3LL * B * blocks * pad * 4;
+    hipLaunchKernelGGL(reflect_front_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, S, B, blocks, phases, Lp, pad);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_split_phase_major(const float* x, int B, int L, int C, int stride, int Lp, __bf16* out, hipStream_t stream) {
     AT_REQUIRE(C % 16 == 0 && L > stride && stride >= 1, "split_phase_major: C % 16, L > stride");
     const int nidx = (L + stride + stride - 1) / stride;
@@ -131,7 +150,8 @@ int launch_split_blocked(const float* x, int ld, long long rows, long long rows_
     return 0;
 }
 
-template <int WM, int WN, int TI, int TJ>
+// DUAL: the XB_EPI_RAW_ELU_SPLIT2 epilogue as its own instantiation (in the general kernel its two split writers spilled)
+template <int WM, int WN, int TI, int TJ, bool DUAL = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
     using Cfg = XbCfg<WM, WN, TI, TJ>;
     constexpr int XB_M = Cfg::BM, XB_N = Cfg::BN, NT = Cfg::NT;
@@ -209,9 +229,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
         __syncthreads();
     }
     // lane holds output row m = frow of its 32-row tile and, per register group g, 4 consecutive columns n = 8g + 4 fhalf ..
-    const long long s_clip = (long long)a.Spad * a.Sphases * a.N;   // elements of one clip of one split output piece
-    const long long psS = s_clip * a.batch;
-    __bf16* Sb = a.S ? a.S + clip * s_clip : nullptr;
+    // split outputs: [3][batch][blocks][phases][pad][16]; output row m lives in plane m % phases at index m / phases + front
+    auto write_split = [&](__bf16* S, int pad, int phases, int front, int blocks, int block0, int m, int n, const f4& v) {
+        const int nb = blocks > 0 ? blocks : a.N / 16;
+        const long long s_clip = (long long)pad * phases * nb * 16;   // elements of one clip of one piece
+        const long long psS = s_clip * a.batch;
+        bf16x4 p1, p2, p3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __bf16 x1, x2, x3;
+            split3(v[k], x1, x2, x3);
+            p1[k] = x1; p2[k] = x2; p3[k] = x3;
+        }
+        const int sq = m / phases, sp = m - sq * phases;
+        __bf16* d = S + clip * s_clip + (((long long)(block0 + (n >> 4)) * phases + sp) * pad + sq + front) * 16 + (n & 15);
+        *reinterpret_cast<bf16x4*>(d) = p1;
+        *reinterpret_cast<bf16x4*>(d + psS) = p2;
+        *reinterpret_cast<bf16x4*>(d + 2 * psS) = p3;
+    };
     float* Cb = a.C ? a.C + (long long)clip * a.M * a.ldc : nullptr;
     const float* Rb = a.R ? a.R + (long long)clip * a.M * a.ldr : nullptr;
 #pragma unroll
@@ -225,21 +260,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
                 const int n = n0 + wn * TJ * 32 + j * 32 + 8 * g + 4 * fhalf;
                 f4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
-                if (a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT) {
-                    bf16x4 p1, p2, p3;
+                if constexpr (DUAL) {
+                    write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, v);
+                    const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
+                    write_split(a.S2, a.S2pad, a.S2phases, a.S2front, a.S2blocks, a.S2block0, m, n, e);
+                } else if (a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT || a.epi == XB_EPI_ELU_SPLIT) {
+                    f4 w;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float sw = a.epi == XB_EPI_GELU_SPLIT ? gelu_erf(v[k])
-                                                                    : v[k] * __frcp_rn(1.0f + __expf(-v[k]));   // as the fp32 GEMM's epilogues
-                        __bf16 x1, x2, x3;
-                        split3(sw, x1, x2, x3);
-                        p1[k] = x1; p2[k] = x2; p3[k] = x3;
-                    }
-                    const int sq = m / a.Sphases, sp = m - sq * a.Sphases;                        // phase-major time axis of the consumer
-                    const long long o = (((long long)(n >> 4) * a.Sphases + sp) * a.Spad + sq + a.Sfront) * 16 + (n & 15);   // K-blocked: this output is the next layer's K
-                    *reinterpret_cast<bf16x4*>(Sb + o) = p1;
-                    *reinterpret_cast<bf16x4*>(Sb + psS + o) = p2;
-                    *reinterpret_cast<bf16x4*>(Sb + 2 * psS + o) = p3;
+                    for (int k = 0; k < 4; ++k)
+                        w[k] = a.epi == XB_EPI_GELU_SPLIT ? gelu_erf(v[k])
+                             : a.epi == XB_EPI_ELU_SPLIT ? elu1(v[k])
+                                                         : v[k] * __frcp_rn(1.0f + __expf(-v[k]));   // as the fp32 GEMM's epilogues
+                    write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
                 } else if (a.epi == XB_EPI_GLU) {
                     float2 o;
                     o.x = v.x * sigmoidf_(v.y);
@@ -255,29 +287,32 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
     }
 }
 
-template <int WM, int WN, int TI, int TJ>
+template <int WM, int WN, int TI, int TJ, bool DUAL = false>
 static int launch_xb(const Bf16x3Args& a, hipStream_t stream) {
     using Cfg = XbCfg<WM, WN, TI, TJ>;
     const size_t ldsb = 2 * Cfg::STAGE * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<WM, WN, TI, TJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<WM, WN, TI, TJ, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         attr_set = true;
     }
     const dim3 grid((unsigned)((long long)a.batch * (a.Mpad / Cfg::BM) * (a.N / Cfg::BN)));
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TI, TJ>), grid, dim3(Cfg::NT), ldsb, stream, a);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TI, TJ, DUAL>), grid, dim3(Cfg::NT), ldsb, stream, a);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
-    AT_REQUIRE(a.A && a.W && a.M >= 1 && a.N % 256 == 0 && a.K % XB_K == 0 && a.Mpad % 256 == 0 && a.Mpad >= a.M,
-               "gemm_bf16x3: N % 256, K % 16, Mpad % 256");
-    AT_REQUIRE((a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT) ? (a.S != nullptr && a.Sphases >= 1 && (long long)a.Spad * a.Sphases >= a.M + (long long)a.Sfront * a.Sphases) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
+    AT_REQUIRE(a.A && a.W && a.M >= 1 && a.N % 128 == 0 && a.K % XB_K == 0 && a.Mpad % 256 == 0 && a.Mpad >= a.M,
+               "gemm_bf16x3: N % 128, K % 16, Mpad % 256");
+    const bool split_out = a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT || a.epi == XB_EPI_ELU_SPLIT || a.epi == XB_EPI_RAW_ELU_SPLIT2;
+    AT_REQUIRE(split_out ? (a.S != nullptr && a.Sphases >= 1 && (long long)a.Spad * a.Sphases >= a.M + (long long)a.Sfront * a.Sphases) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
+    AT_REQUIRE(a.epi != XB_EPI_RAW_ELU_SPLIT2 || (a.S2 != nullptr && a.S2phases >= 1 && (long long)a.S2pad * a.S2phases >= a.M + (long long)a.S2front * a.S2phases), "gemm_bf16x3: bad second output");
     AT_REQUIRE(a.batch >= 1 && a.stride >= 1 && (a.cblocks == 0 || (a.K / XB_K) % a.cblocks == 0), "gemm_bf16x3: bad window description");
     AT_REQUIRE((a.Lp > 0 ? a.Lp : a.Mpad) >= a.Mpad + ((a.cblocks > 0 ? (a.K / XB_K) / a.cblocks : 1) - 1) / a.stride, "gemm_bf16x3: Lp too small for the last tile");
-    const long long tiles256 = (long long)a.batch * (a.Mpad / 256) * (a.N / 256);
-    if (tiles256 < 256) return launch_xb<2, 2, 2, 2>(a, stream);   // 4x as many 128 x 128 tiles: same arithmetic, fills the chip
+    const long long tiles256 = (long long)a.batch * (a.Mpad / 256) * ((a.N + 255) / 256);
+    if (a.epi == XB_EPI_RAW_ELU_SPLIT2) return launch_xb<4, 1, 2, 4, true>(a, stream);
+    if (tiles256 < 256 || a.N % 256 != 0) return launch_xb<2, 2, 2, 2>(a, stream);   // 4x as many 128 x 128 tiles: same arithmetic, fills the chip
     // large launches: 256 x 128 tiles, 4 waves, TWO workgroups per CU (one loads while the other multiplies) measured 1-2 % ahead of
     // 256 x 256 with 8 waves and one workgroup per CU (less operand traffic, no overlap); $AUDIOTOKEN_XB_TILE=0 selects the latter.
     // The kernel is bound by the L2 -> LDS operand stream: time = 1.67 ms + 0.41 ms per product on the FFN shape (tools/bf16x3_gemm.hip).
