@@ -82,6 +82,15 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
     if ((int)blockIdx.x < total_tiles) prefetch(blockIdx.x);
     constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
 
+    // Which tile row a fragment column of the TAIL stands for. The 1x1 tail may take its rows in any order; with the split output the
+    // 64 rows are sorted by (row % 5, row / 5): the 16 lanes of a row tile then hold consecutive indices of (mostly) one phase plane
+    // and their 32-byte piece stores join into runs of up to 416 bytes instead of 96.
+    const bool phase_order = a.S != nullptr;
+    auto tail_row = [&](int pos) {
+        if (!phase_order) return pos;
+        const int pl = pos < 52 ? pos / 13 : 4;
+        return 5 * (pos - 13 * pl) + pl;
+    };
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip;
         const int t0 = (tile - b * tiles_per_clip) * RX_TT;
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
             auto tread = [&](int ks, bf16x8 (&xf)[3][2]) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const int row = 16 * (mp + m) + r16;
+                    const int row = tail_row(16 * (mp + m) + r16);
                     const __bf16* src = ks < 2 ? Hs + rx_hoff(row, ks * 4 + q) : Xr + rx_xoff(row + 2, (ks - 2) * 4 + q);
                     const int ps = ks < 2 ? RX_HP : RX_XP;
 #pragma unroll
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const int t = t0 + (mp + m) * 16 + r16;
+                const int t = t0 + tail_row((mp + m) * 16 + r16);
                 if (t < L) {
                     float* dst = a.out + ((long long)b * L + t) * 128 + wave * 32 + q * 4;
                     const int plane = t % 5, idx = t / 5 + 1;
