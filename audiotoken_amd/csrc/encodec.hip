@@ -126,6 +126,7 @@ struct at_encodec {
     bool down64_x3 = true;          // ... on the bf16 matrix cores with 3-way split operands (seanet_down64x3.hip); follows bf16x3
     bool down128_x3 = true;         // stage-2 strided conv as a windowed split-bf16 GEMM fed by seanet_res128x3's split epilogue; follows bf16x3
     const __bf16* down2_s = nullptr;
+    bool lstm_x3 = true;            // persistent LSTM with the recurrent product on the bf16 matrix cores (lstm_seq_x3.hip); follows bf16x3
     bool res256_x3 = true;          // 256-channel block as two split-bf16 GEMMs chained between the stage-2 and stage-3 strided convs; follows bf16x3
     const __bf16 *res3c_s = nullptr, *res3t_s = nullptr;
     bool down256_x3 = true;         // stage-3 strided conv as a windowed split-bf16 GEMM behind a split pass; follows bf16x3
@@ -295,7 +296,8 @@ int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L
 // 2-layer LSTM + skip over [B][T][512]; xg/c/h0 are scratch. y = lstm(x) + x.
 int lstm_skip(const float* const wih[2], const float* const whh[2], const float* const bih[2], const float* const bhh[2],
               const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream,
-              Profiler& prof, unsigned* sync, bool persistent, int y_elu, const __bf16* const* wih_s = nullptr, __bf16* xs = nullptr) {
+              Profiler& prof, unsigned* sync, bool persistent, int y_elu, const __bf16* const* wih_s = nullptr, __bf16* xs = nullptr,
+              bool rec_x3 = false) {
     for (int layer = 0; layer < 2; ++layer) {
         const float* in = layer == 0 ? x : h0;
         float* hout = layer == 0 ? h0 : h1;
@@ -317,7 +319,7 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
         prof.end(stream);
         if (persistent) {
             // whole sequence in one persistent launch per 256-clip block (lstm_seq.hip)
-            const int maxc = lstm_seq_max_clips();
+            const int maxc = rec_x3 ? lstm_seq_x3_max_clips() : lstm_seq_max_clips();
             prof.begin("lstm_rec", (B + maxc - 1) / maxc, stream);
             for (int c0 = 0; c0 < B; c0 += maxc) {
                 LstmSeqArgs q;
@@ -325,7 +327,7 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
                 q.xg = xg + ro * 4 * kH; q.w_hh = whh[layer]; q.b_hh = bhh[layer]; q.h_out = hout + ro * kH;
                 q.y_out = layer == 1 ? y + ro * kH : nullptr; q.skip = x + ro * kH; q.sync = sync;
                 q.B = (B - c0) < maxc ? (B - c0) : maxc; q.T = T; q.n_groups = 0; q.h_bytes = 0; q.y_elu = y_elu;
-                if (int rc = launch_lstm_seq(q, stream)) return rc;
+                if (int rc = rec_x3 ? launch_lstm_seq_x3(q, stream) : launch_lstm_seq(q, stream)) return rc;
             }
             prof.end(stream);
             continue;
@@ -582,13 +584,14 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
     {
         const char* e = std::getenv("AUDIOTOKEN_BF16X3_ACOUSTIC");
         h->bf16x3 = e ? std::atoi(e) != 0 : kBf16x3AcousticDefault;
-        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0, bit 4 / 5 stage-2 / stage-3 strided conv (GEMM), bit 6 256-channel block (GEMMs)
+        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0, bit 4 / 5 stage-2 / stage-3 strided conv (GEMM), bit 6 256-channel block (GEMMs), bit 7 LSTM recurrence
         const char* m = std::getenv("AUDIOTOKEN_X3_KERNELS");
-        const int mask = m ? std::atoi(m) : 127;
+        const int mask = m ? std::atoi(m) : 255;
         h->down64_x3 = (mask & 1) != 0; h->res128_x3 = (mask & 2) != 0; h->res64_x3 = (mask & 4) != 0; h->stage0_x3 = (mask & 8) != 0;
         h->down128_x3 = (mask & 16) != 0;
         h->down256_x3 = (mask & 32) != 0;
         h->res256_x3 = (mask & 64) != 0;
+        h->lstm_x3 = (mask & 128) != 0;
     }
     if (h->bf16x3) {
         for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
@@ -775,7 +778,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
     AT_CHECK_HIP(hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), stream));
     if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
-                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs)))
+                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3))
         return rc;
     if (status_out) AT_CHECK_HIP(hipMemcpyAsync(status_out, sync + 63, sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     float* emb = emb_out ? emb_out : ws + p.off_emb;
@@ -806,6 +809,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
     if (std::string(name) == "down64_x3") { h->down64_x3 = value != 0; return 0; }
+    if (std::string(name) == "lstm_x3") { h->lstm_x3 = value != 0; return 0; }
     if (std::string(name) == "res256_x3") { h->res256_x3 = value != 0; return 0; }
     if (std::string(name) == "down256_x3") { h->down256_x3 = value != 0; return 0; }
     if (std::string(name) == "down128_x3") { h->down128_x3 = value != 0; return 0; }
@@ -868,7 +872,7 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
     // every activation that is only consumed through ELU is stored already ELU'd (once per element, in the producer's
     // epilogue) so the transposed convs run the plain-linear GEMM path: y (LSTM + skip) and the block outputs of stages 0-2
     if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,
-                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs)))
+                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3))
         return rc;
     const int Lout = p.L[4];
     for (int b0 = 0; b0 < B; b0 += p.G) {

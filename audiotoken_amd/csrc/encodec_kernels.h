@@ -31,6 +31,9 @@ struct LstmSeqArgs {
 };
 int launch_lstm_seq(const LstmSeqArgs& a, hipStream_t stream);
 int lstm_seq_max_clips();
+// the same layer with the recurrent product as split-bf16 MFMAs: 16 workgroups of 32 hidden units per 16-clip group (lstm_seq_x3.hip)
+int launch_lstm_seq_x3(const LstmSeqArgs& a, hipStream_t stream);
+int lstm_seq_x3_max_clips();
 
 // Fused SEANet stage 0 (seanet_stage0.hip): wav -> conv0 -> resblock(32) -> ELU -> conv k4 s2 -> x1 [B][N/2][64]
 struct Stage0Args {

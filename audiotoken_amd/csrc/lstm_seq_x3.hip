@@ -1,0 +1,226 @@
+// Whole-sequence LSTM layer with the recurrent product on the bf16 matrix cores: the persistent kernel of lstm_seq.hip (same
+// decomposition idea, same hand-off protocol, same gate-interleaved weight / xg / h layouts) with W_hh and h_{t-1} as exact
+// 3-way bf16 splits and six v_mfma_f32_16x16x32_bf16 per 32-wide K step (arithmetic and accuracy: gemm_bf16x3.hip).
+// What changes in the decomposition: a workgroup owns 32 hidden units = 128 gate rows (wave w: two 16-row tiles = 8 units),
+// its weights are 384 registers of bf16 pieces per lane (one wave per SIMD owns 512), so a group of 16 clips has 16 workgroups
+// instead of 32 and ONE workgroup sits on a CU: 192 MFMAs of 16 cycles per step and wave instead of 2 x 128 of 32 cycles for the
+// two co-resident fp32 workgroups, and half as many producers to wait for. h_{t-1} is split while it is staged into LDS
+// ([3 pieces][16 clips][512 + 8 pad] bf16: the 16-byte pad puts the 16 clip rows of a fragment read on 16 bank groups).
+// The result differs from the fp32 chain in rounding only (both ~1e-6 of float64 per step); it is compared with the fp32
+// persistent kernel and the per-step path by tolerance and by identical tokens (tests/test_acoustic_gpu.py).
+#include "gemm_core.h"
+#include "encodec_kernels.h"
+
+namespace at {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+constexpr int LX_H = 512;
+constexpr int LX_CLIPS = 16;       // clips per group = one MFMA row tile
+constexpr int LX_SLICES = 16;      // workgroups per group: 32 hidden units each
+constexpr int LX_LDH = LX_H + 8;   // LDS row stride (bf16)
+constexpr int LX_HP = LX_CLIPS * LX_LDH;       // elements of one piece
+constexpr unsigned LX_SPIN_LIMIT = 1u << 18;
+constexpr int LX_STATUS = 63;      // as lstm_seq.hip
+constexpr int LX_FLAGS = 128;      // flags[16 groups][32 words] (16 used)
+constexpr int LX_FLAG_STRIDE = 32;
+constexpr int LX_MAX_GROUPS = 16;
+
+__device__ __forceinline__ void lx_split(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)v;
+    const float r1 = v - (float)p1;
+    p2 = (__bf16)r1;
+    p3 = (__bf16)(r1 - (float)p2);
+}
+
+__global__ __launch_bounds__(256, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 Hp[];   // [3][16 clips][520]
+    __shared__ int abort_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int group = blockIdx.x % a.n_groups;
+    const int slice = blockIdx.x / a.n_groups;     // 0..15: hidden units [32*slice, 32*slice + 32)
+    const int b0 = group * LX_CLIPS;
+    const int T = a.T;
+
+    // row tile j of wave w = tile nt = 2w + j of the 8 tiles of this slice; in the weight layout of lstm_seq.hip (64-row blocks of 16 units,
+    // rows = unit * 4 + gate) that is block 2*slice + (nt >> 2), rows 16*(nt & 3) ..; lane (r16, q) then owns unit .. + q, gates = acc[0..3]
+    int unit[2];
+    bf16x8 wp[3][2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nt = 2 * wave + j;
+        const int blk = 2 * slice + (nt >> 2), sub = nt & 3;
+        unit[j] = blk * 16 + sub * 4 + q;
+        const float* wrow = a.w_hh + ((long long)blk * 64 + sub * 16 + r16) * LX_H;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const f4 lo = *reinterpret_cast<const f4*>(wrow + ks * 32 + q * 8), hi = *reinterpret_cast<const f4*>(wrow + ks * 32 + q * 8 + 4);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                __bf16 x1, x2, x3;
+                lx_split(k < 4 ? lo[k] : hi[k - 4], x1, x2, x3);
+                wp[0][j][ks][k] = x1; wp[1][j][ks][k] = x2; wp[2][j][ks][k] = x3;
+            }
+        }
+    }
+    const int clip = b0 + r16;
+    const bool clip_ok = clip < a.B;
+    const long long own_row = (long long)(clip_ok ? clip : a.B - 1) * T;
+    f4 bhh[2];
+    float cst[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bhh[j] = *reinterpret_cast<const f4*>(a.b_hh + unit[j] * 4);
+    // h_{t-1} staging: thread -> 8 x (clip row, 16-B chunk) of the [16][512] tile: e = tid + 256*j -> row = e >> 7, chunk = tid & 127
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.h_out, 0, (int)a.h_bytes, 0x00020000);
+    int g_off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (tid >> 7) + 2 * j, ch = tid & 127;
+        const int cb = b0 + row < a.B ? b0 + row : a.B - 1;
+        g_off[j] = (int)((((long long)cb * T) * LX_H + ch * 4) * 4);   // < 2^31: checked by the launcher
+    }
+    const int l_off0 = (tid >> 7) * LX_LDH + (tid & 127) * 4;            // + 2 j rows
+    unsigned* flags = a.sync + LX_FLAGS + group * LX_FLAG_STRIDE;
+    const __bf16* hb = Hp + r16 * LX_LDH + q * 8;                        // fragment base: + 32 ks elements, + piece
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+
+    for (int t = 0; t < T; ++t) {
+        // input-side gates and the skip inputs of this step: independent of the recurrence, issued before the wait
+        f4 xg[2];
+        float skipv[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            xg[j] = *reinterpret_cast<const f4*>(a.xg + (own_row + t) * (4 * LX_H) + unit[j] * 4);
+            if (a.y_out) skipv[j] = a.skip[(own_row + t) * LX_H + unit[j]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        if (t > 0) {
+            // ---- wait until all 16 slices of this group have published h_{t-1} (protocol: lstm_seq.hip) -------------------------
+            if (wave == 0) {
+                const unsigned target = (unsigned)t;
+                unsigned spins = 0;
+                int give_up = 0;
+                for (;;) {
+                    const unsigned f = __hip_atomic_load(flags + (lane & (LX_SLICES - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_ballot_w64(f < target) == 0ull) break;
+                    ++spins;
+                    if (spins > LX_SPIN_LIMIT) { give_up = 1; break; }
+                    if ((spins & 1023u) == 0u &&
+                        __hip_atomic_load(a.sync + LX_STATUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { give_up = 1; break; }
+                }
+                if (lane == 0) {
+                    abort_s = give_up;
+                    if (give_up) __hip_atomic_store(a.sync + LX_STATUS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();       // also: every wave has finished reading the previous step's pieces
+            if (abort_s) return;   // uniform: a member of the group is not making progress
+            // ---- h_{t-1} [16][512] -> sc1 loads to registers -> split -> LDS pieces -----------------------------------------------
+            u4 stage[8];
+            const int toff = (t - 1) * (LX_H * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stage[j] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, g_off[j] + toff, 0, 16);   // aux 16 = sc1
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bf16x4 p1, p2, p3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __bf16 x1, x2, x3;
+                    lx_split(__uint_as_float(stage[j][k]), x1, x2, x3);
+                    p1[k] = x1; p2[k] = x2; p3[k] = x3;
+                }
+                __bf16* d = Hp + l_off0 + 2 * j * LX_LDH;
+                *reinterpret_cast<bf16x4*>(d) = p1;
+                *reinterpret_cast<bf16x4*>(d + LX_HP) = p2;
+                *reinterpret_cast<bf16x4*>(d + 2 * LX_HP) = p3;
+            }
+            __syncthreads();
+            // ---- gates += h_{t-1} . W_slice^T: 16 K steps x 6 products x 2 row tiles = 192 MFMAs per wave; fragments one K step ahead ----
+            bf16x8 xa[3], xb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) xa[p] = *reinterpret_cast<const bf16x8*>(hb + p * LX_HP);
+#pragma unroll
+            for (int ks = 0; ks < 16; ks += 2) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) xb[p] = *reinterpret_cast<const bf16x8*>(hb + p * LX_HP + (ks + 1) * 32);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[PW[tt]][j][ks], xa[PX[tt]], acc[j], 0, 0, 0);
+                if (ks + 2 < 16) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) xa[p] = *reinterpret_cast<const bf16x8*>(hb + p * LX_HP + (ks + 2) * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[PW[tt]][j][ks + 1], xb[PX[tt]], acc[j], 0, 0, 0);
+            }
+        }
+        // ---- cell update (torch CPU LSTMCell order: gates = (hW + b_hh) + igates; c = f*c + i*g unfused) -----------------------------
+        float hn[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f4 g = (acc[j] + bhh[j]) + xg[j];
+            const float ig = lstm_sigmoid(g.x), fg = lstm_sigmoid(g.y), cg = lstm_tanh(g.z), og = lstm_sigmoid(g.w);
+            const float c_new = __fadd_rn(__fmul_rn(fg, cst[j]), __fmul_rn(ig, cg));
+            hn[j] = og * lstm_tanh(c_new);
+            cst[j] = c_new;
+            if (clip_ok)
+                __hip_atomic_store(reinterpret_cast<unsigned*>(a.h_out) + (own_row + t) * LX_H + unit[j], __float_as_uint(hn[j]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1): no release fence needed
+        }
+        // ---- publish: every storing wave drains, workgroup barrier, one lane signals ----------------------------------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + slice, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.y_out && clip_ok) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float yv = hn[j] + skipv[j];
+                a.y_out[(own_row + t) * LX_H + unit[j]] = a.y_elu ? elu1(yv) : yv;
+            }
+        }
+    }
+}
+
+// clips one launch can take: all workgroups must be resident (one per CU), 16 per group of 16 clips
+int lstm_seq_x3_max_clips() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        int groups = cus / LX_SLICES;
+        groups = groups > LX_MAX_GROUPS ? LX_MAX_GROUPS : groups;
+        cached[dev] = (groups < 1 ? 1 : groups) * LX_CLIPS;
+    }
+    return cached[dev];
+}
+
+int launch_lstm_seq_x3(const LstmSeqArgs& a_in, hipStream_t stream) {
+    LstmSeqArgs a = a_in;
+    AT_REQUIRE(a.B >= 1 && a.B <= lstm_seq_x3_max_clips() && a.T >= 1, "lstm_seq_x3: too many clips for one launch on this device");
+    a.n_groups = (a.B + LX_CLIPS - 1) / LX_CLIPS;
+    a.h_bytes = (long long)a.B * a.T * LX_H * 4;
+    AT_REQUIRE(a.h_bytes < (1ll << 31), "lstm_seq_x3: h buffer exceeds the 2 GB buffer-descriptor range");
+    const size_t lds = (size_t)3 * LX_HP * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    AT_CHECK_HIP(hipMemsetAsync(a.sync + LX_FLAGS, 0, LX_MAX_GROUPS * LX_FLAG_STRIDE * sizeof(unsigned), stream));   // flags, every launch
+    hipLaunchKernelGGL(lstm_seq_x3_kernel, dim3(a.n_groups * LX_SLICES), dim3(256), lds, stream, a);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace at
