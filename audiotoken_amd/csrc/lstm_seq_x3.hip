@@ -10,6 +10,7 @@
 // persistent kernel and the per-step path by tolerance and by identical tokens (tests/test_acoustic_gpu.py).
 #include "gemm_core.h"
 #include "encodec_kernels.h"
+#include <cstdlib>
 
 namespace at {
 
@@ -35,7 +36,10 @@ __device__ __forceinline__ void lx_split(float v, __bf16& p1, __bf16& p2, __bf16
     p3 = (__bf16)(r1 - (float)p2);
 }
 
-__global__ __launch_bounds__(256, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
+// NJ = row tiles per wave: 2 -> 4 waves (384 weight registers, one wave per SIMD), 1 -> 8 waves (192, two waves per SIMD)
+template <int NJ>
+__global__ __launch_bounds__(512 / NJ, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
+    constexpr int NTHR = 512 / NJ, NST = 2048 / NTHR;   // threads; 16-byte staging chunks per thread
     extern __shared__ __attribute__((aligned(16))) __bf16 Hp[];   // [3][16 clips][520]
     __shared__ int abort_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,11 +51,11 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
 
     // row tile j of wave w = tile nt = 2w + j of the 8 tiles of this slice; in the weight layout of lstm_seq.hip (64-row blocks of 16 units,
     // rows = unit * 4 + gate) that is block 2*slice + (nt >> 2), rows 16*(nt & 3) ..; lane (r16, q) then owns unit .. + q, gates = acc[0..3]
-    int unit[2];
-    bf16x8 wp[3][2][16];
+    int unit[NJ];
+    bf16x8 wp[3][NJ][16];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int nt = 2 * wave + j;
+    for (int j = 0; j < NJ; ++j) {
+        const int nt = NJ * wave + j;
         const int blk = 2 * slice + (nt >> 2), sub = nt & 3;
         unit[j] = blk * 16 + sub * 4 + q;
         const float* wrow = a.w_hh + ((long long)blk * 64 + sub * 16 + r16) * LX_H;
@@ -69,35 +73,40 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
     const int clip = b0 + r16;
     const bool clip_ok = clip < a.B;
     const long long own_row = (long long)(clip_ok ? clip : a.B - 1) * T;
-    f4 bhh[2];
-    float cst[2] = {0.f, 0.f};
+    f4 bhh[NJ];
+    float cst[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bhh[j] = *reinterpret_cast<const f4*>(a.b_hh + unit[j] * 4);
+    for (int j = 0; j < NJ; ++j) cst[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bhh[j] = *reinterpret_cast<const f4*>(a.b_hh + unit[j] * 4);
     // h_{t-1} staging: thread -> 8 x (clip row, 16-B chunk) of the [16][512] tile: e = tid + 256*j -> row = e >> 7, chunk = tid & 127
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.h_out, 0, (int)a.h_bytes, 0x00020000);
-    int g_off[8];
+    int g_off[NST];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int row = (tid >> 7) + 2 * j, ch = tid & 127;
+    for (int j = 0; j < NST; ++j) {
+        const int row = (tid >> 7) + (NTHR / 128) * j, ch = tid & 127;
         const int cb = b0 + row < a.B ? b0 + row : a.B - 1;
         g_off[j] = (int)((((long long)cb * T) * LX_H + ch * 4) * 4);   // < 2^31: checked by the launcher
     }
-    const int l_off0 = (tid >> 7) * LX_LDH + (tid & 127) * 4;            // + 2 j rows
+    const int l_off0 = (tid >> 7) * LX_LDH + (tid & 127) * 4;            // + (NTHR / 128) j rows
     unsigned* flags = a.sync + LX_FLAGS + group * LX_FLAG_STRIDE;
     const __bf16* hb = Hp + r16 * LX_LDH + q * 8;                        // fragment base: + 32 ks elements, + piece
     constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
 
     for (int t = 0; t < T; ++t) {
         // input-side gates and the skip inputs of this step: independent of the recurrence, issued before the wait
-        f4 xg[2];
-        float skipv[2] = {0.f, 0.f};
+        f4 xg[NJ];
+        float skipv[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
+            skipv[j] = 0.f;
             xg[j] = *reinterpret_cast<const f4*>(a.xg + (own_row + t) * (4 * LX_H) + unit[j] * 4);
             if (a.y_out) skipv[j] = a.skip[(own_row + t) * LX_H + unit[j]];
         }
         __builtin_amdgcn_sched_barrier(0);
-        f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        f4 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = f4{0.f, 0.f, 0.f, 0.f};
         if (t > 0) {
             // ---- wait until all 16 slices of this group have published h_{t-1} (protocol: lstm_seq.hip) -------------------------
             if (wave == 0) {
@@ -120,12 +129,12 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
             __syncthreads();       // also: every wave has finished reading the previous step's pieces
             if (abort_s) return;   // uniform: a member of the group is not making progress
             // ---- h_{t-1} [16][512] -> sc1 loads to registers -> split -> LDS pieces -----------------------------------------------
-            u4 stage[8];
+            u4 stage[NST];
             const int toff = (t - 1) * (LX_H * 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) stage[j] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, g_off[j] + toff, 0, 16);   // aux 16 = sc1
+            for (int j = 0; j < NST; ++j) stage[j] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, g_off[j] + toff, 0, 16);   // aux 16 = sc1
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NST; ++j) {
                 bf16x4 p1, p2, p3;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
                     lx_split(__uint_as_float(stage[j][k]), x1, x2, x3);
                     p1[k] = x1; p2[k] = x2; p3[k] = x3;
                 }
-                __bf16* d = Hp + l_off0 + 2 * j * LX_LDH;
+                __bf16* d = Hp + l_off0 + (NTHR / 128) * j * LX_LDH;
                 *reinterpret_cast<bf16x4*>(d) = p1;
                 *reinterpret_cast<bf16x4*>(d + LX_HP) = p2;
                 *reinterpret_cast<bf16x4*>(d + 2 * LX_HP) = p3;
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
 #pragma unroll
                 for (int tt = 0; tt < 6; ++tt)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[PW[tt]][j][ks], xa[PX[tt]], acc[j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[PW[tt]][j][ks], xa[PX[tt]], acc[j], 0, 0, 0);
                 if (ks + 2 < 16) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p) xa[p] = *reinterpret_cast<const bf16x8*>(hb + p * LX_HP + (ks + 2) * 32);
@@ -160,13 +169,13 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
 #pragma unroll
                 for (int tt = 0; tt < 6; ++tt)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[PW[tt]][j][ks + 1], xb[PX[tt]], acc[j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[PW[tt]][j][ks + 1], xb[PX[tt]], acc[j], 0, 0, 0);
             }
         }
         // ---- cell update (torch CPU LSTMCell order: gates = (hW + b_hh) + igates; c = f*c + i*g unfused) -----------------------------
-        float hn[2];
+        float hn[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const f4 g = (acc[j] + bhh[j]) + xg[j];
             const float ig = lstm_sigmoid(g.x), fg = lstm_sigmoid(g.y), cg = lstm_tanh(g.z), og = lstm_sigmoid(g.w);
             const float c_new = __fadd_rn(__fmul_rn(fg, cst[j]), __fmul_rn(ig, cg));
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
         if (tid == 0) __hip_atomic_store(flags + slice, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.y_out && clip_ok) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const float yv = hn[j] + skipv[j];
                 a.y_out[(own_row + t) * LX_H + unit[j]] = a.y_elu ? elu1(yv) : yv;
             }
@@ -214,11 +223,14 @@ int launch_lstm_seq_x3(const LstmSeqArgs& a_in, hipStream_t stream) {
     const size_t lds = (size_t)3 * LX_HP * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    static const int waves8 = std::getenv("AUDIOTOKEN_LSTM_X3_WAVES8") ? std::atoi(std::getenv("AUDIOTOKEN_LSTM_X3_WAVES8")) : 1;
     AT_CHECK_HIP(hipMemsetAsync(a.sync + LX_FLAGS, 0, LX_MAX_GROUPS * LX_FLAG_STRIDE * sizeof(unsigned), stream));   // flags, every launch
-    hipLaunchKernelGGL(lstm_seq_x3_kernel, dim3(a.n_groups * LX_SLICES), dim3(256), lds, stream, a);
+    if (waves8) hipLaunchKernelGGL(lstm_seq_x3_kernel<1>, dim3(a.n_groups * LX_SLICES), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL(lstm_seq_x3_kernel<2>, dim3(a.n_groups * LX_SLICES), dim3(256), lds, stream, a);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
