@@ -40,6 +40,11 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 # Linear layers of the two semantic tokenizers run as exact 3-way bf16 splits (6 bf16 MFMAs per fp32-equivalent step) unless disabled
 BF16X3 = os.environ.get("AUDIOTOKEN_BF16X3", "1") != "0"
 BF16X3_GROUPS = ("ffn", "attn_proj", "feature_extractor")   # feature_extractor: HuBERT only (its six 512->512 convs)
+# acoustic kernel groups that execute as exact 3-way bf16 splits (library defaults; same switches as csrc/encodec.hip)
+BF16X3_ACOUSTIC = os.environ.get("AUDIOTOKEN_BF16X3_ACOUSTIC", "1") != "0"
+_X3_MASK = int(os.environ.get("AUDIOTOKEN_X3_KERNELS", "255"))
+ACOUSTIC_X3_GROUPS = tuple(g for bit, g in enumerate(("down1", "res2", "res1", "stage0_fused", "down2", "down3", "res3", "lstm_rec"))
+                           if BF16X3_ACOUSTIC and (_X3_MASK >> bit) & 1) + (("lstm_ih",) if BF16X3_ACOUSTIC else ())
 
 
 def acoustic_flops_per_clip(N: int, n_q: int):
@@ -333,7 +338,7 @@ def run_acoustic(args, rank, world, dev, dist):
         "config": {"workload": f"Tokenizers.acoustic encode, {B} clips x {args.seconds:g} s @24 kHz per GPU, num_codebooks={n_q}",
                    "clips_per_gpu": B, "samples_per_clip": N, "frames_per_clip": T, "weights": "synthetic seed 0",
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
-        "roofline": roofline_of(breakdown, flops, nbytes, B), "breakdown": breakdown, "token_checksum": checksum,
+        "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS), "breakdown": breakdown, "token_checksum": checksum,
     }
     # PCIe-inclusive rate (host waveforms in pinned memory -> H2D -> encode -> D2H tokens), reported beside `value`, never as it
     try:
@@ -492,7 +497,8 @@ def main():
         out = {
             "metric": "audio-sec tokenized / wall-sec", "value": primary["value"], "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (convs, LSTM: exact bf16x3 splits, fp32 accumulate; RVQ search fp32)" if ACOUSTIC_X3_GROUPS else "f32", "data": "synthetic",
             "config": primary["config"], "roofline": primary["roofline"], "breakdown": primary["breakdown"],
             "token_checksum": primary["token_checksum"],
         }
