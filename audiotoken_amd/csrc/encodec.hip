@@ -126,6 +126,8 @@ struct at_encodec {
     bool down64_x3 = true;          // ... on the bf16 matrix cores with 3-way split operands (seanet_down64x3.hip); follows bf16x3
     bool down128_x3 = true;         // stage-2 strided conv as a windowed split-bf16 GEMM fed by seanet_res128x3's split epilogue; follows bf16x3
     const __bf16* down2_s = nullptr;
+    bool rvq_x3 = true;             // RVQ search with the dot products on the bf16 matrix cores (rvq_encode_x3.hip); follows bf16x3
+    const __bf16* cb_s = nullptr;   // codebooks as 3 bf16 pieces [3][n_cb * 1024][128]
     bool lstm_x3 = true;            // persistent LSTM with the recurrent product on the bf16 matrix cores (lstm_seq_x3.hip); follows bf16x3
     bool res256_x3 = true;          // 256-channel block as two split-bf16 GEMMs chained between the stage-2 and stage-3 strided convs; follows bf16x3
     const __bf16 *res3c_s = nullptr, *res3t_s = nullptr;
@@ -584,14 +586,15 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
     {
         const char* e = std::getenv("AUDIOTOKEN_BF16X3_ACOUSTIC");
         h->bf16x3 = e ? std::atoi(e) != 0 : kBf16x3AcousticDefault;
-        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0, bit 4 / 5 stage-2 / stage-3 strided conv (GEMM), bit 6 256-channel block (GEMMs), bit 7 LSTM recurrence
+        // which fused SEANet kernels use the split-bf16 variants: bit 0 stage-1 strided conv, bit 1 128-channel block, bit 2 64-channel block, bit 3 stage 0, bit 4 / 5 stage-2 / stage-3 strided conv (GEMM), bit 6 256-channel block (GEMMs), bit 7 LSTM recurrence, bit 8 RVQ search
         const char* m = std::getenv("AUDIOTOKEN_X3_KERNELS");
-        const int mask = m ? std::atoi(m) : 255;
+        const int mask = m ? std::atoi(m) : 511;
         h->down64_x3 = (mask & 1) != 0; h->res128_x3 = (mask & 2) != 0; h->res64_x3 = (mask & 4) != 0; h->stage0_x3 = (mask & 8) != 0;
         h->down128_x3 = (mask & 16) != 0;
         h->down256_x3 = (mask & 32) != 0;
         h->res256_x3 = (mask & 64) != 0;
         h->lstm_x3 = (mask & 128) != 0;
+        h->rvq_x3 = (mask & 256) != 0;
     }
     if (h->bf16x3) {
         for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
@@ -602,6 +605,14 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
                 if (int rc = launch_split_blocked(dec ? h->dwih[l] : h->wih[l], kH, 4 * kH, 4 * kH, kH, d, nullptr)) return rc;
                 (dec ? h->dwih_s : h->wih_s)[l] = d;
             }
+        {   // codebooks as plain (row-major) bf16 pieces for the RVQ search
+            __bf16* d = nullptr;
+            const long long n = (long long)h->n_codebooks * kCodes * kDim;
+            AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * n * sizeof(__bf16)));
+            h->extra_allocs.push_back(d);
+            if (int rc = launch_split_plain(h->codebooks, n, d, nullptr)) return rc;
+            h->cb_s = d;
+        }
         {   // stage-2 strided conv weights [256][10 * 128] as K-blocked bf16 pieces
             __bf16* d = nullptr;
             AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * 256 * 1280 * sizeof(__bf16)));
@@ -786,7 +797,9 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     if (int rc = conv_gemm(h->fin, y, (long long)T * kH, T, emb, (long long)T * kDim, T, B, PRO_NONE, nullptr, 0, stream)) return rc;  // y holds ELU(lstm + skip)
     prof.end(stream);
     prof.begin("rvq", 1, stream);
-    int rc = launch_rvq_encode(emb, (long long)B * T, T, h->codebooks, h->e2, n_q, codes, stream);
+    int rc = (h->rvq_x3 && h->bf16x3 && h->cb_s)
+                 ? launch_rvq_encode_x3(emb, (long long)B * T, T, h->codebooks, h->cb_s, (long long)h->n_codebooks * kCodes * kDim, h->e2, n_q, codes, stream)
+                 : launch_rvq_encode(emb, (long long)B * T, T, h->codebooks, h->e2, n_q, codes, stream);
     prof.end(stream);
     return rc;
 }
@@ -809,6 +822,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
     if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
     if (std::string(name) == "down64_x3") { h->down64_x3 = value != 0; return 0; }
+    if (std::string(name) == "rvq_x3") { h->rvq_x3 = value != 0; return 0; }
     if (std::string(name) == "lstm_x3") { h->lstm_x3 = value != 0; return 0; }
     if (std::string(name) == "res256_x3") { h->res256_x3 = value != 0; return 0; }
     if (std::string(name) == "down256_x3") { h->down256_x3 = value != 0; return 0; }

@@ -34,6 +34,10 @@ int lstm_seq_max_clips();
 // the same layer with the recurrent product as split-bf16 MFMAs: 16 workgroups of 32 hidden units per 16-clip group (lstm_seq_x3.hip)
 int launch_lstm_seq_x3(const LstmSeqArgs& a, hipStream_t stream);
 int lstm_seq_x3_max_clips();
+// RVQ search with split-bf16 dot products (rvq_encode_x3.hip); cb_s = codebooks as [3][n_cb * 1024][128] bf16 pieces (launch_split_plain)
+int launch_split_plain(const float* x, long long n, __bf16* out, hipStream_t stream);
+int launch_rvq_encode_x3(const float* x, long long rows, int T, const float* codebooks, const __bf16* cb_s, long long cb_piece,
+                         const float* e2, int n_q, int16_t* codes, hipStream_t stream);
 
 // Fused SEANet stage 0 (seanet_stage0.hip): wav -> conv0 -> resblock(32) -> ELU -> conv k4 s2 -> x1 [B][N/2][64]
 struct Stage0Args {

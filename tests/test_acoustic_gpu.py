@@ -175,7 +175,7 @@ def test_fused_stage0_equals_unfused(encoders):
     enc.set_option("res256_x3", 1)
 
 
-@pytest.mark.parametrize("opt", ["down64_x3", "res128_x3", "res64_x3", "stage0_x3", "down128_x3", "down256_x3", "res256_x3", "lstm_x3"])
+@pytest.mark.parametrize("opt", ["down64_x3", "res128_x3", "res64_x3", "stage0_x3", "down128_x3", "down256_x3", "res256_x3", "lstm_x3", "rvq_x3"])
 def test_x3_kernels_match_fp32(encoders, opt):
     """seanet_down64x3_kernel / seanet_res128x3_kernel (exact 3-way bf16 splits, six bf16 MFMAs) against the fp32-MFMA kernels:
     a different rounding of the same sums, so embeddings agree to ~1e-6 of their scale rather than bit for bit, and the tokens
