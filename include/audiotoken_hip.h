@@ -76,9 +76,9 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
  *   "persistent_lstm" 1/0 — whole-sequence persistent LSTM kernel (default on) or one launch per time step;
  *   "fused_stage0", "fused_res64", "fused_res128", "fused_down64", "fused_dectail" 1/0 — fused SEANet kernels (default on)
  *   or the GEMM path;
- *   "stage0_x3", "res64_x3", "res128_x3", "down64_x3", "down128_x3", "down256_x3", "res256_x3", "lstm_x3" 1/0 — the fused kernels, the
- *   stage-2 / stage-3 convs + 256-channel block (as chained GEMMs) and the LSTM recurrence on the bf16 matrix cores with exact 3-way bf16 splits of every
- *   operand (default on; $AUDIOTOKEN_X3_KERNELS bit mask, bits 3, 2, 1, 0, 4, 5, 6, 7 in that order; 0 = the fp32-MFMA kernels:
+ *   "stage0_x3", "res64_x3", "res128_x3", "down64_x3", "down128_x3", "down256_x3", "res256_x3", "lstm_x3", "rvq_x3" 1/0 — the fused kernels, the
+ *   stage-2 / stage-3 convs + 256-channel block (as chained GEMMs) the LSTM recurrence and the RVQ search on the bf16 matrix cores with exact 3-way bf16 splits of every
+ *   operand (default on; $AUDIOTOKEN_X3_KERNELS bit mask, bits 3, 2, 1, 0, 4, 5, 6, 7, 8 in that order; 0 = the fp32-MFMA kernels:
  *   same tokens, embeddings differ in the last bits);
  *   "subbatch" n >= 1 — clips per pass through the conv stack (default 256 or $AUDIOTOKEN_SUBBATCH): bounds
  *   at_encodec_workspace_bytes / at_encodec_decode_workspace_bytes, which must be re-queried after changing it. */

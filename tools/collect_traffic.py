@@ -16,12 +16,12 @@ import sys
 from collections import defaultdict
 
 GROUPS = {  # bench.py group -> kernel name prefix
-    "lstm_rec": "at::lstm_seq_kernel",
+    "lstm_rec": "at::lstm_seq",   # lstm_seq_kernel / lstm_seq_x3_kernel<..>
     "stage0_fused": "at::seanet_stage0",      # seanet_stage0_kernel / seanet_stage0x3_kernel, whichever ran
     "res1": "at::seanet_res64",
     "down1": "at::seanet_down64",
     "res2": "at::seanet_res128",
-    "rvq": "at::rvq_encode_kernel",
+    "rvq": "at::rvq_encode",
 }
 
 
@@ -59,8 +59,8 @@ def main():
         out[counter] = {k: tot[k] / max(cnt[k], 1) for k in rows}
     kernels = {}
     for group, pref in GROUPS.items():
-        f = next((v for k, v in out["FETCH_SIZE"].items() if k.startswith(pref)), None)
-        w = next((v for k, v in out["WRITE_SIZE"].items() if k.startswith(pref)), None)
+        f = next((v for k, v in out["FETCH_SIZE"].items() if k.replace("void ", "").startswith(pref)), None)
+        w = next((v for k, v in out["WRITE_SIZE"].items() if k.replace("void ", "").startswith(pref)), None)
         if f is None or w is None:
             continue
         kernels[group] = {"kernel": pref, "FETCH_SIZE_KiB_per_launch": round(f, 1), "WRITE_SIZE_KiB_per_launch": round(w, 1),
