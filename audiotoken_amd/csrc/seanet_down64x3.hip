@@ -11,6 +11,7 @@
 // kernel is compared with the unfused path by tolerance, not bit-identity (tests/test_acoustic_gpu.py).
 #include "gemm_core.h"
 #include "encodec_kernels.h"
+#include <cstdlib>
 
 namespace at {
 
@@ -20,22 +21,31 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int DX_TU = 32;                  // output rows per tile
 constexpr int DX_ROWS = 4 * DX_TU + 4;     // input rows per tile: row i <-> time 4*u0 - 4 + i
 constexpr int DX_CHUNKS = DX_ROWS * 16;    // float4 chunks of the input tile
-constexpr int DX_PRE = (DX_CHUNKS + 255) / 256;
-constexpr int DX_AHEAD = 18;               // K steps between a chunk's global load and its split into LDS
-constexpr int DX_PIECE = DX_PRE * 16 * 64; // bf16 elements of one piece of the tile: 144 rows, the last 12 only absorb the (unused) tail of the last chunk
+constexpr int DX_PL = 40, DX_LD = 72;      // input row i lives in plane i & 3 at index i >> 2 (40 per plane: 33 used + the tail of the last chunk), 64 + 8 channels per row
+constexpr int DX_PIECE = 4 * DX_PL * DX_LD; // bf16 elements of one piece of the tile
 // physical LDS row: rows 32 apart (fragment lanes r16 and r16 + 8) swap odd/even so that they fall in different halves of the banks
 // scheduling pattern for one K step: after each of the 12 MFMAs up to 4 vector instructions of the side work (the rest follows)
+template <int NMFMA>
 __device__ __forceinline__ void dx_interleave() {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < NMFMA; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
     }
 }
-__device__ __forceinline__ int dx_row(int row) { return row ^ ((row >> 5) & 1); }
+// plane-major rows: the 16 rows 4 apart that a fragment read touches are consecutive (stride 144 B: 16 distinct bank groups) and every
+// fragment address is a per-lane base plus a compile-time offset (the XOR swizzle this replaces cost ~40 address registers)
+__device__ __forceinline__ int dx_off(int row) { return ((row & 3) * DX_PL + (row >> 2)) * DX_LD; }
 
-__global__ __launch_bounds__(256, 1) void seanet_down64x3_kernel(Down64Args a) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 Xp[];   // [2 buffers][3][132 rows][64], chunk (8 ch) ^= (row >> 2) & 7
+// NN = channel tiles per wave: 2 -> 4 waves x 384 weight registers (one wave per SIMD; the compiler parks weights in AGPRs and copies them
+// back: ~22 cycles per MFMA), 1 -> 8 waves x 192 registers (two waves per SIMD, no AGPR copies; default)
+template <int NN>
+__global__ __launch_bounds__(512 / NN, 1) void seanet_down64x3_kernel(Down64Args a) {
+    constexpr int NTHR = 512 / NN;
+    constexpr int DX_PRE = (DX_CHUNKS + NTHR - 1) / NTHR;   // 16-byte chunks of the input tile per thread: 9 or 5
+    constexpr int SJ = NN == 2 ? 3 : 6;                     // K steps between two chunks of side work
+    constexpr int DX_AHEAD = NN == 2 ? 18 : 12;             // K steps between a chunk's global load and its split into LDS (chunks in flight: 5 / 2)
+    extern __shared__ __attribute__((aligned(16))) __bf16 Xp[];   // [2 buffers][3 pieces][4 planes][40][72]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int L = a.L, Lo = L / 4;
@@ -43,12 +53,12 @@ __global__ __launch_bounds__(256, 1) void seanet_down64x3_kernel(Down64Args a) {
     const int total_tiles = a.B * tiles_per_clip;   // < 2^31: checked by the launcher
 
     // ---- weights -> 3 bf16 pieces in registers, once: wr[p][n][ks] = split(W[32w + 16n + r16][32 ks + 8 q .. +7]) ------------------
-    bf16x8 wr[3][2][16];
+    bf16x8 wr[3][NN][16];
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NN; ++n)
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            const float* src = a.w + (wave * 32 + n * 16 + r16) * 512 + ks * 32 + q * 8;
+            const float* src = a.w + (wave * 16 * NN + n * 16 + r16) * 512 + ks * 32 + q * 8;
             const f4 lo = *reinterpret_cast<const f4*>(src), hi = *reinterpret_cast<const f4*>(src + 4);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void seanet_down64x3_kernel(Down64Args a) {
     f4 pre[DX_PRE];
     // chunk j of a tile: 16-byte piece c = tid + 256 j of its 132 x 64 input rows
     auto load_chunk = [&](int j, const float* xb, int u0) {
-        int c = tid + 256 * j;
+        int c = tid + NTHR * j;
         c = c < DX_CHUNKS ? c : DX_CHUNKS - 1;
         int tau = 4 * u0 - 4 + (c >> 4);
         tau = tau < 0 ? -tau : tau;            // causal reflect padding at the clip start
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(256, 1) void seanet_down64x3_kernel(Down64Args a) {
     };
     // split chunk j into the three bf16 pieces of LDS buffer X
     auto stage_chunk = [&](int j, __bf16* X) {
-        const int c = tid + 256 * j;
+        const int c = tid + NTHR * j;
         {   // chunks past the tile (tid >= 64 of the last j) land in the pad rows: no branch, so the work can sit between MFMAs
             const int row = c >> 4, c4 = c & 15;          // 4 channels 4 c4 .. 4 c4 + 3 = half of the 8-channel chunk c4 >> 1
             bf16x4 p1, p2, p3;
@@ -83,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void seanet_down64x3_kernel(Down64Args a) {
                 const __bf16 x2 = (__bf16)r1;
                 p1[k] = x1; p2[k] = x2; p3[k] = (__bf16)(r1 - (float)x2);
             }
-            __bf16* d = X + dx_row(row) * 64 + ((((c4 >> 1) ^ ((row >> 2) & 7)) << 3) | ((c4 & 1) << 2));
+            __bf16* d = X + dx_off(row) + c4 * 4;
             *reinterpret_cast<bf16x4*>(d) = p1;
             *reinterpret_cast<bf16x4*>(d + DX_PIECE) = p2;
             *reinterpret_cast<bf16x4*>(d + 2 * DX_PIECE) = p3;
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void seanet_down64x3_kernel(Down64Args a) {
         xb = clip_base(t1 < total_tiles ? t1 : total_tiles - 1, u0);
 #pragma unroll
         for (int j = 0; j < DX_PRE; ++j)
-            if (3 * j + 2 - DX_AHEAD < 0) load_chunk(j, xb, u0);   // what the previous iteration would have issued
+            if (SJ * j + 2 - DX_AHEAD < 0) load_chunk(j, xb, u0);   // what the previous iteration would have issued
     }
     __syncthreads();
 
@@ -128,54 +138,67 @@ __global__ __launch_bounds__(256, 1) void seanet_down64x3_kernel(Down64Args a) {
         // (a 16x16x32 bf16 MFMA holds vector issue for 8 of its 16 cycles) instead of in a phase of its own.
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            f4 acc[NN];
+#pragma unroll
+            for (int n = 0; n < NN; ++n) acc[n] = f4{0.f, 0.f, 0.f, 0.f};
             auto xread = [&](int ks, bf16x8 (&xf)[3]) {
                 const int tap = ks >> 1, ch = (ks & 1) * 4 + q;    // 8-channel chunk of this lane's K slice
                 const int row = 4 * (16 * m + r16) + tap;
-                const __bf16* src = X + dx_row(row) * 64 + ((ch ^ ((row >> 2) & 7)) << 3);
+                const __bf16* src = X + dx_off(row) + ch * 8;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(src + p * DX_PIECE);
             };
             auto side_work = [&](int step) {   // step = 16 m + ks
 #ifndef DX_PROBE_NO_STAGE
-                if (step % 3 == 2 && step / 3 < DX_PRE) stage_chunk(step / 3, Xn);
+                if (step % SJ == 2 && step / SJ < DX_PRE) stage_chunk(step / SJ, Xn);
 #endif
 #ifndef DX_PROBE_NO_PREFETCH
                 // chunk j is loaded DX_AHEAD = 18 steps before it is split (about 5 of the 9 chunks are in flight at a time: the
                 // whole tile in registers does not fit beside 384 weight registers): in this iteration for j >= 6, else in the previous
 #pragma unroll
                 for (int j = 0; j < DX_PRE; ++j) {
-                    if (3 * j + 2 - DX_AHEAD >= 0 && step == 3 * j + 2 - DX_AHEAD) load_chunk(j, xb1, u1);
-                    if (3 * j + 2 - DX_AHEAD < 0 && step == 3 * j + 2 - DX_AHEAD + 32) load_chunk(j, xb2, u2);
+                    if (SJ * j + 2 - DX_AHEAD >= 0 && step == SJ * j + 2 - DX_AHEAD) load_chunk(j, xb1, u1);
+                    if (SJ * j + 2 - DX_AHEAD < 0 && step == SJ * j + 2 - DX_AHEAD + 32) load_chunk(j, xb2, u2);
                 }
 #endif
             };
             bf16x8 xa[3], xb[3];
-            xread(0, xa);
+            auto mfmas = [&](int ks, bf16x8 (&xf)[3]) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int n = 0; n < NN; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[PW[t]][n][ks], xf[PX[t]], acc[n], 0, 0, 0);
+            };
+            if constexpr (NN == 1) {
+                // two waves per SIMD: the partner wave covers the LDS latency, one fragment set (12 registers) is enough
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    xread(ks, xa);
+                    mfmas(ks, xa);
+                    side_work(16 * m + ks);
+                    dx_interleave<6>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                xread(0, xa);
 #ifdef DX_PROBE_KS
-            for (int ks = 0; ks < DX_PROBE_KS; ks += 2) {
+                for (int ks = 0; ks < DX_PROBE_KS; ks += 2) {
 #else
 #pragma unroll
-            for (int ks = 0; ks < 16; ks += 2) {
+                for (int ks = 0; ks < 16; ks += 2) {
 #endif
-                xread(ks + 1, xb);
-                __builtin_amdgcn_sched_barrier(0);   // keep the reads one step ahead of their MFMAs
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[PW[t]][n][ks], xa[PX[t]], acc[n], 0, 0, 0);
-                side_work(16 * m + ks);
-                dx_interleave();
-                if (ks + 2 < 16) xread(ks + 2, xa);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[PW[t]][n][ks + 1], xb[PX[t]], acc[n], 0, 0, 0);
-                side_work(16 * m + ks + 1);
-                dx_interleave();
+                    xread(ks + 1, xb);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the reads one step ahead of their MFMAs
+                    mfmas(ks, xa);
+                    side_work(16 * m + ks);
+                    dx_interleave<12>();
+                    if (ks + 2 < 16) xread(ks + 2, xa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(ks + 1, xb);
+                    side_work(16 * m + ks + 1);
+                    dx_interleave<12>();
+                }
             }
             const int u = u0 + m * 16 + r16;
 #ifdef DX_PROBE_NO_STORE
@@ -183,9 +206,9 @@ __global__ __launch_bounds__(256, 1) void seanet_down64x3_kernel(Down64Args a) {
 #else
             if (u < Lo) {
 #endif
-                float* dst = a.out + ((long long)b * Lo + u) * 128 + wave * 32 + q * 4;
+                float* dst = a.out + ((long long)b * Lo + u) * 128 + wave * 16 * NN + q * 4;
 #pragma unroll
-                for (int n = 0; n < 2; ++n) *reinterpret_cast<f4*>(dst + n * 16) = acc[n] + *reinterpret_cast<const f4*>(a.b + wave * 32 + n * 16 + q * 4);
+                for (int n = 0; n < NN; ++n) *reinterpret_cast<f4*>(dst + n * 16) = acc[n] + *reinterpret_cast<const f4*>(a.b + wave * 16 * NN + n * 16 + q * 4);
             }
         }
         __syncthreads();   // buffer buf ^ 1 is complete, buffer buf is free
@@ -197,13 +220,16 @@ int launch_seanet_down64x3(const Down64Args& a, hipStream_t stream) {
     const size_t lds = (size_t)2 * 3 * DX_PIECE * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_down64x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_down64x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_down64x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const long long tiles = (long long)a.B * ((a.L / 4 + DX_TU - 1) / DX_TU);
     AT_REQUIRE(tiles < (1LL << 30) && (long long)a.L * 64 < (1LL << 30), "tile / offset arithmetic is 32-bit");
     const int grid = (int)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(seanet_down64x3_kernel, dim3(grid), dim3(256), lds, stream, a);
+    static const int waves8 = std::getenv("AUDIOTOKEN_DOWN64_WAVES8") ? std::atoi(std::getenv("AUDIOTOKEN_DOWN64_WAVES8")) : 1;
+    if (waves8) hipLaunchKernelGGL(seanet_down64x3_kernel<1>, dim3(grid), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL(seanet_down64x3_kernel<2>, dim3(grid), dim3(256), lds, stream, a);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
