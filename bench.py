@@ -15,6 +15,10 @@ workload (configs[1]); with --workload both (default) the same line carries a "s
 per-GPU share: 64 clips x 30 s @16 kHz, 19 conformer layers, VQ 2048) with its own value / roofline / cpu_baseline and
 a "combined" figure = audio-seconds of both / (t_acoustic + t_semantic_m).
 
+Multi-GPU: `python bench.py --gpus N` with no WORLD_SIZE in the environment starts N FRESH child ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py ...`, before this process has touched the GPU) and relays rank 0's
+JSON line; under an external `torch.distributed.run` (WORLD_SIZE set) it is simply one of the ranks.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   "roofline":     dominant kernel group's achieved rate vs the gfx950 peak, timed with HIP events on the launch stream
   "cpu_baseline": the CPU oracle (a port of the reference's CPU path) timed on this host on a bounded sample.
@@ -45,6 +49,81 @@ BF16X3_ACOUSTIC = os.environ.get("AUDIOTOKEN_BF16X3_ACOUSTIC", "1") != "0"
 _X3_MASK = int(os.environ.get("AUDIOTOKEN_X3_KERNELS", "511"))
 ACOUSTIC_X3_GROUPS = tuple(g for bit, g in enumerate(("down1", "res2", "res1", "stage0_fused", "down2", "down3", "res3", "lstm_rec", "rvq"))
                            if BF16X3_ACOUSTIC and (_X3_MASK >> bit) & 1) + (("lstm_ih",) if BF16X3_ACOUSTIC else ())
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_children(n: int, argv, script: str = None, extra_env=None, timeout: float = None):
+    """Start `n` fresh ranks of this script (one process per GPU) with torch.distributed.run on 127.0.0.1 and relay their output.
+    Called BEFORE the parent has initialised the GPU; the parent never re-execs, it waits for the children and returns
+    (exit code, last JSON line printed by rank 0 or None)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.update(extra_env or {})
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    return proc.returncode, line
+
+
+def init_ranks(backend: str, dev):
+    """(rank, world, dist-or-None) from the torch.distributed.run environment; backend "nccl" is RCCL on ROCm."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return rank, world, None
+    import torch.distributed as dist_mod
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist_mod.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, dist_mod
+
+
+def rank_report(rank: int, per_rank_ms: float, dev, dist):
+    """All-gather (rank id, ms per step) so the JSON line shows that N ranks really ran: {"rccl_ranks": [...], "per_rank_ms": [...]}."""
+    from audiotoken_amd.distributed import gather_scalars
+    rows = gather_scalars([float(rank), float(per_rank_ms)], dev, dist)
+    return {"rccl_ranks": [int(r[0]) for r in rows], "per_rank_ms": [round(r[1], 3) for r in rows]}
+
+
+def run_selftest(args, rank, world, dev, dist):
+    """Launcher / collective plumbing only (no encoder, runs on CPU with gloo): weight broadcast, barrier-bracketed timed region,
+    max over ranks, rank all-gather. Used by tests/test_bench_launcher_cpu.py; never part of a reported number."""
+    from audiotoken_amd.distributed import broadcast_weights, shard_indices
+    w = {"a": np.arange(12, dtype=np.float32).reshape(3, 4), "b": np.ones(5, dtype=np.float32)} if rank == 0 else None
+    t0 = time.perf_counter()
+    w = broadcast_weights(w, dev, dist)
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+    assert float(w["a"].sum()) == 66.0 and w["b"].shape == (5,)
+    mine = shard_indices(args.batch, rank, world)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    acc = 0
+    for _ in range(args.steps):
+        acc += sum(mine)
+    elapsed = max(time.perf_counter() - t0, 1e-6)
+    if dist is not None:
+        dist.barrier()
+    ms = elapsed / args.steps * 1e3
+    elapsed = max_over_ranks(elapsed, dev, dist)
+    res = {"value": round(world * len(mine) * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 6),
+           "config": {"workload": "selftest (launcher and collectives only)", "items_per_rank": len(mine)},
+           "roofline": None, "breakdown": {}, "token_checksum": int(acc), "broadcast_ms": round(bcast_ms, 3), "rank_ms": ms}
+    return res
 
 
 def acoustic_flops_per_clip(N: int, n_q: int):
@@ -209,25 +288,21 @@ def run_hubert(args, rank, world, dev, dist):
     wav = torch.from_numpy(host).to(dev).repeat((B + gen_B - 1) // gen_B, 1)[:B].contiguous()
     mask = torch.ones_like(wav)
     enc(wav, mask)
-    for _ in range(max(0, args.warmup - 1)):
-        enc(wav, mask)
-    enc.enable_profile(True)
-    elapsed, toks = timed_steps(lambda: enc(wav, mask), args.steps, 0, dist)
-    prof = enc.read_profile()
     enc.enable_profile(False)
+    elapsed, toks, per_step = timed_steps(lambda: enc(wav, mask), args.steps, max(0, args.warmup - 1), dist)
     elapsed = max_over_ranks(elapsed, dev, dist)
+    prof = tapped_breakdown(enc, lambda: enc(wav, mask), min(args.steps, 2))
     flops, T = hubert_flops_per_clip(N, nl)
     breakdown = {}
-    for k, (ms, launches) in prof.items():
-        per = ms / args.steps
-        breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches // args.steps,
+    for k, (per, launches) in prof.items():
+        breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches,
                         "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None, "gbs": None}
     res = {
         "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "dtype": "f32 (linear layers: exact bf16x3 splits, fp32 accumulate)" if BF16X3 else "f32",
         "config": {"workload": f"Tokenizers.semantic_s encode, {B} clips x {secs:g} s @16 kHz per GPU, mHuBERT-base 11 layers, k-means 1000",
                    "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0"},
-        "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if BF16X3 else ()), "breakdown": breakdown,
+        "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if BF16X3 else (), "semantic_s"), "breakdown": breakdown,
         "token_checksum": int(toks.to(torch.int64).sum().item()),
         "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
     }
@@ -237,20 +312,77 @@ def run_hubert(args, rank, world, dev, dist):
 
 
 def timed_steps(enc_call, steps, warmup, dist):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides (the contract's timed
+    region). Also returns the per-step device times from HIP events on the launch stream (for the median)."""
     for _ in range(warmup):
         out = enc_call()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    evs[0].record()
+    for i in range(steps):
         out = enc_call()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-    return elapsed, out
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    return elapsed, out, per_step
+
+
+def tapped_breakdown(enc, enc_call, steps: int):
+    """A second, short loop with the library's HIP-event taps on (they are OFF in the timed region): ms per kernel group."""
+    enc.enable_profile(True)
+    for _ in range(steps):
+        enc_call()
+    torch.cuda.synchronize()
+    prof = enc.read_profile()
+    enc.enable_profile(False)
+    return {k: (ms / steps, launches // steps) for k, (ms, launches) in prof.items()}
+
+
+def pipelined_pcie(enc_call, host_in: torch.Tensor, dev, iters: int):
+    """SURVEY.md §8(d) wall definition: pinned host waveforms -> H2D -> encode -> D2H tokens, pipelined the way
+    AudioToken.encode_batch_files runs it (core.py): the copy of batch i+1 flies on a copy stream during the encode of batch i,
+    tokens come back on the compute stream. Returns the median and mean time per batch over `iters` batches in steady state."""
+    copy_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    bufs = [torch.empty_like(host_in, device=dev) for _ in range(2)]
+    ready = [torch.cuda.Event() for _ in range(2)]
+    free = [torch.cuda.Event() for _ in range(2)]
+    out_host = None
+    done = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+
+    def upload(i):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(free[i % 2])
+            bufs[i % 2].copy_(host_in, non_blocking=True)
+            ready[i % 2].record(copy_stream)
+
+    for f in free:
+        f.record(main)
+    upload(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done[0].record(main)
+    for i in range(iters):
+        main.wait_event(ready[i % 2])
+        if i + 1 < iters:
+            upload(i + 1)
+        toks = enc_call(bufs[i % 2])
+        free[i % 2].record(main)
+        if out_host is None:
+            out_host = torch.empty(toks.shape, dtype=toks.dtype).pin_memory()
+        out_host.copy_(toks, non_blocking=True)
+        done[i + 1].record(main)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    per = sorted(done[i].elapsed_time(done[i + 1]) for i in range(iters))
+    return {"median_ms": per[len(per) // 2], "mean_ms": wall / iters * 1e3, "iters": iters}
 
 
 def max_over_ranks(x: float, dev, dist) -> float:
@@ -261,37 +393,54 @@ def max_over_ranks(x: float, dev, dist) -> float:
     return float(t.item())
 
 
-def measured_traffic(group: str):
-    """HBM bytes per launch of a kernel group from the committed rocprofv3 PMC passes (profiles/r01_traffic.json); None if
-    that group was not profiled. PMC collection needs rocprofv3, so it cannot run inside the timed benchmark."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return json.load(f)["kernels"][group]["traffic_bytes_per_launch"]
-    except Exception:
-        return None
+def measured_traffic(group: str, workload: str = "acoustic"):
+    """HBM bytes per launch of a kernel group from the committed rocprofv3 PMC passes (profiles/r02_traffic.json, falling back to
+    round 1's); None if that group was not profiled. PMC collection needs rocprofv3, so it cannot run inside the timed benchmark."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                doc = json.load(f)
+            k = doc.get(workload, doc).get("kernels", doc.get("kernels", {}))
+            if group in k:
+                return k[group]["traffic_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
-def roofline_of(breakdown, flops, nbytes, B, split_groups=()):
+def roofline_of(breakdown, flops, nbytes, B, split_groups=(), workload: str = "acoustic", products: int = 6):
+    """Roofline of the dominant kernel group. `achieved` is ALGORITHMIC work (SURVEY.md §8(d) FLOPs or bytes per clip x clips per
+    launch) / the group's measured time. For groups that run as exact operand splits on the bf16/fp16 matrix cores the same
+    object also carries the EXECUTED rate (`products` MFMA products per multiply-add): that one is pipe utilisation, not work."""
     dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
     d = breakdown[dom]
+    launches = max(1, d["launches_per_step"])
+    common = {"kernel": dom, "launches_per_step": launches, "avg_launch_ms": round(d["ms_per_step"] / launches, 4),
+              "traffic": measured_traffic(dom, workload)}
     if dom in split_groups:
-        # executed arithmetic: six bf16 MFMAs per fp32-equivalent multiply-add, priced against the dense bf16 MFMA peak
-        ach = round(6.0 * d["tflops"], 2)
-        return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                "kernel": dom, "launches_per_step": max(1, d["launches_per_step"]),
-                "avg_launch_ms": round(d["ms_per_step"] / max(1, d["launches_per_step"]), 4), "traffic": measured_traffic(dom),
-                "note": f"bf16 MFMA executing exact 3-way operand splits: {d['tflops']} fp32-equivalent TFLOP/s x 6 products"}
+        alg = d["tflops"]
+        ex = round(products * alg, 2)
+        roof = {"bound": "mfma", "achieved": alg, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(alg / BF16_MFMA_PEAK_TFLOPS, 4),
+                "achieved_algorithmic": alg, "achieved_executed": ex, "products_per_mac": products,
+                "frac_executed": round(ex / BF16_MFMA_PEAK_TFLOPS, 4), "frac_algorithmic_vs_f32_mfma_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 4),
+                "note": f"fp32-grade contraction as exact operand splits on the 16-bit matrix cores: {products} MFMA products per multiply-add; "
+                        "`achieved`/`frac` count the algorithmic FLOPs against the dense bf16 peak, `*_executed` the issued MFMA FLOPs"}
+        roof.update(common)
+        return roof
     t_mfma = flops[dom] * B / (F32_MFMA_PEAK_TFLOPS * 1e12)
     t_hbm = (nbytes[dom] * B / (HBM_PEAK_GBS * 1e9)) if nbytes is not None else 0.0
-    launches = max(1, d["launches_per_step"])
     if t_hbm >= t_mfma:
         roof = {"bound": "hbm", "achieved": d["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["gbs"] / HBM_PEAK_GBS, 4)}
     else:
         roof = {"bound": "mfma", "achieved": d["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(d["tflops"] / F32_MFMA_PEAK_TFLOPS, 4)}
-    roof.update({"kernel": dom, "launches_per_step": launches, "avg_launch_ms": round(d["ms_per_step"] / launches, 4),
-                 "traffic": measured_traffic(dom)})
+                "frac": round(d["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "achieved_algorithmic": d["tflops"], "achieved_executed": d["tflops"]}
+    roof.update(common)
     return roof
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
 
 
 def run_acoustic(args, rank, world, dev, dist):
@@ -304,7 +453,9 @@ def run_acoustic(args, rank, world, dev, dist):
     B, N = args.batch, int(round(args.seconds * 24000))
     # weights: rank 0 generates, RCCL broadcast over xGMI to the other ranks
     weights = W.synth_encodec_weights(seed=0, with_decoder=False) if rank == 0 else None
+    t0 = time.perf_counter()
     weights = broadcast_weights(weights, dev, dist)
+    bcast_ms = (time.perf_counter() - t0) * 1e3
     enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=num_codebooks_to_bandwidth(n_q)), device=str(dev), weights=weights)
     # synthetic clips: rank r owns clips [r*B, (r+1)*B) of the global batch
     gen_B = min(B, 16)
@@ -314,46 +465,41 @@ def run_acoustic(args, rank, world, dev, dist):
         wav = (wav * torch.linspace(0.5, 1.0, B, device=dev).unsqueeze(1)).contiguous()
     mask = torch.ones_like(wav)
     enc(wav, mask)  # allocate workspace outside the timed region
-    enc.enable_profile(False)
-    # warm-up untimed, then the timed region with the HIP-event taps on
-    for _ in range(args.warmup):
-        enc(wav, mask)
-    enc.enable_profile(True)
-    elapsed, codes = timed_steps(lambda: enc(wav, mask), args.steps, 0, dist)
-    prof = enc.read_profile()
-    enc.enable_profile(False)
+    enc.enable_profile(False)   # no event taps inside the timed region
+    elapsed, codes, per_step = timed_steps(lambda: enc(wav, mask), args.steps, args.warmup, dist)
+    status = enc.last_status()
+    assert status == 0, f"persistent LSTM hand-off status {status}: the timed run is invalid"
+    rank_ms = elapsed / args.steps * 1e3
     elapsed = max_over_ranks(elapsed, dev, dist)
     checksum = int(codes.to(torch.int64).sum().item())
+    prof = tapped_breakdown(enc, lambda: enc(wav, mask), min(args.steps, 3))
     flops, T = acoustic_flops_per_clip(N, n_q)
     nbytes = acoustic_bytes_per_clip(N, n_q)
     breakdown = {}
-    for k, (ms, launches) in prof.items():
-        per = ms / args.steps
-        breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches // args.steps,
+    for k, (per, launches) in prof.items():
+        breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches,
                         "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None,
                         "gbs": round(nbytes[k] * B / (per * 1e-3) / 1e9, 1) if per > 0 else None}
     res = {
         "value": round(world * B * args.seconds * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "elapsed": elapsed, "audio_s_per_step": world * B * args.seconds,
+        "median_ms_per_step": round(median(per_step), 3),
+        "elapsed": elapsed, "audio_s_per_step": world * B * args.seconds, "rank_ms": rank_ms, "broadcast_ms": round(bcast_ms, 1),
         "config": {"workload": f"Tokenizers.acoustic encode, {B} clips x {args.seconds:g} s @24 kHz per GPU, num_codebooks={n_q}",
                    "clips_per_gpu": B, "samples_per_clip": N, "frames_per_clip": T, "weights": "synthetic seed 0",
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
-        "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS), "breakdown": breakdown, "token_checksum": checksum,
+        "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS, "acoustic"), "breakdown": breakdown,
+        "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)", "token_checksum": checksum,
+        "lstm_handoff_status": status,
     }
-    # PCIe-inclusive rate (host waveforms in pinned memory -> H2D -> encode -> D2H tokens), reported beside `value`, never as it
+    # SURVEY.md §8(d) wall (first H2D enqueue -> last token D2H), pipelined as encode_batch_files runs it. Reported beside `value`
+    # (which, by the bench contract, is the rate with inputs resident in HBM), never as it.
     try:
         host = wav.cpu().pin_memory()
-        out_host = torch.empty(codes.shape, dtype=codes.dtype).pin_memory()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            d = host.to(dev, non_blocking=True)
-            out_host.copy_(enc(d, None), non_blocking=True)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 2
-        res["pcie_inclusive"] = {"value": round(world * B * args.seconds / dt, 2), "unit": "audio-s/s", "ms_per_step": round(dt * 1e3, 3),
-                                 "note": "pinned host waveforms -> H2D -> encode -> D2H tokens, serialized on one stream"}
-        del host, out_host, d
+        pp = pipelined_pcie(lambda d: enc(d, None), host, dev, max(10, args.steps))
+        res["pcie_inclusive"] = {"value": round(world * B * args.seconds / (pp["median_ms"] * 1e-3), 2), "unit": "audio-s/s",
+                                 "median_ms_per_step": round(pp["median_ms"], 3), "mean_ms_per_step": round(pp["mean_ms"], 3), "iters": pp["iters"],
+                                 "note": "pinned host waveforms -> H2D on a copy stream during the previous encode -> encode -> D2H tokens; median over batches"}
+        del host
     except Exception as e:  # pragma: no cover - informational only
         res["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
     del enc
@@ -375,7 +521,9 @@ def run_decode(args, rank, world, dev, dist):
     g = torch.Generator().manual_seed(1234 + rank)
     codes = torch.randint(0, 1024, (B, args.num_codebooks, T), generator=g, dtype=torch.long).to(dev)
     dec(codes)
-    elapsed, out = timed_steps(lambda: dec(codes), args.steps, args.warmup, dist)
+    elapsed, out, _ = timed_steps(lambda: dec(codes), args.steps, args.warmup, dist)
+    if hasattr(dec, "last_status"):
+        assert dec.last_status() == 0, "persistent LSTM hand-off status non-zero: the timed decode is invalid"
     elapsed = max_over_ranks(elapsed, dev, dist)
     res = {"value": round(world * B * args.seconds * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
            "config": {"workload": f"Tokenizers.acoustic decode, {B} clips x {args.seconds:g} s, num_codebooks={args.num_codebooks}"},
@@ -405,29 +553,28 @@ def run_semantic(args, rank, world, dev, dist):
         wav = (wav * torch.linspace(0.5, 1.0, B, device=dev).unsqueeze(1)).contiguous()
     mask = torch.ones_like(wav)
     enc(wav, mask)
-    for _ in range(max(0, args.warmup - 1)):
-        enc(wav, mask)
-    enc.enable_profile(True)
-    elapsed, toks = timed_steps(lambda: enc(wav, mask), args.steps, 0, dist)
-    prof = enc.read_profile()
     enc.enable_profile(False)
+    elapsed, toks, per_step = timed_steps(lambda: enc(wav, mask), args.steps, max(0, args.warmup - 1), dist)
+    rank_ms = elapsed / args.steps * 1e3
     elapsed = max_over_ranks(elapsed, dev, dist)
+    prof = tapped_breakdown(enc, lambda: enc(wav, mask), min(args.steps, 2))
     T = toks.shape[-1]
     F = 1 + (N - 400) // 160
     flops = semantic_flops_per_clip(T, nl, F)
     breakdown = {}
-    for k, (ms, launches) in prof.items():
-        per = ms / args.steps
-        breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches // args.steps,
+    for k, (per, launches) in prof.items():
+        breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches,
                         "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None, "gbs": None}
     res = {
         "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "elapsed": elapsed, "audio_s_per_step": world * B * secs,
+        "median_ms_per_step": round(median(per_step), 3), "elapsed": elapsed, "audio_s_per_step": world * B * secs, "rank_ms": rank_ms,
         "dtype": "f32 (linear layers: exact bf16x3 splits, fp32 accumulate)" if BF16X3 else "f32",
         "config": {"workload": f"Tokenizers.semantic_m encode, {B} clips x {secs:g} s @16 kHz per GPU, {nl} conformer layers, VQ 2048x1024",
                    "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0",
-                   "parallelism": f"clip-sharded x{world}, no data-path collective"},
-        "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if BF16X3 else ()), "breakdown": breakdown,
+                   "parallelism": f"clip-sharded x{world}, no data-path collective",
+                   "note": "BASELINE configs[3] is 512 clips over 8 GPUs = 64 per GPU; at N=1 one step is one such 64-clip micro-batch"},
+        "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if BF16X3 else (), "semantic_m"), "breakdown": breakdown,
+        "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)",
         "token_checksum": int(toks.to(torch.int64).sum().item()),
         "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
     }
@@ -436,12 +583,12 @@ def run_semantic(args, rank, world, dev, dist):
     return res
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="all", choices=["all", "both", "acoustic", "semantic_m", "semantic_s"])
+    ap.add_argument("--workload", default="all", choices=["all", "both", "acoustic", "semantic_m", "semantic_s", "selftest"])
     ap.add_argument("--hub-batch", type=int, default=128, help="semantic_s clips per GPU per step (BASELINE configs[2]: 128)")
     ap.add_argument("--batch", type=int, default=256, help="acoustic clips per GPU per step (BASELINE configs[1]: 256)")
     ap.add_argument("--seconds", type=float, default=10.0)
@@ -450,25 +597,39 @@ def main():
     ap.add_argument("--sem-seconds", type=float, default=30.0)
     ap.add_argument("--sem-layers", type=int, default=19)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --workload selftest run on CPU (tests)")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: N fresh child processes, one per GPU; this parent has not touched the GPU and only relays the result
+        if args.backend == "nccl":
+            n_dev = torch.cuda.device_count()   # counting devices does not initialise the GPU
+            if n_dev < args.gpus:
+                print(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} device(s)", file=sys.stderr)
+                return 2
+        rc, line = launch_children(args.gpus, sys.argv[1:] if argv is None else list(argv))
+        if line is not None:
+            print(line, flush=True)
+        return rc if rc != 0 or line is not None else 1
+
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        dist = dist_mod
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    if args.workload == "selftest" and args.backend == "gloo":
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a HIP device"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    rank, world, dist = init_ranks(args.backend, dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     ac = sem = None
     sem_err = None
     hub = hub_err = None
+    if args.workload == "selftest":
+        ac = run_selftest(args, rank, world, dev, dist)
     if args.workload in ("all", "both", "acoustic"):
         ac = run_acoustic(args, rank, world, dev, dist)
     dec = None
@@ -492,8 +653,9 @@ def main():
                 raise
             sem_err = f"{type(e).__name__}: {e}"
 
+    primary = ac if ac is not None else (sem if sem is not None else hub)
+    ranks = rank_report(rank, primary.get("rank_ms", primary["ms_per_step"]), dev, dist)   # collective: every rank calls it
     if rank == 0:
-        primary = ac if ac is not None else (sem if sem is not None else hub)
         out = {
             "metric": "audio-sec tokenized / wall-sec", "value": primary["value"], "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
@@ -501,17 +663,25 @@ def main():
             "dtype": "f32 (convs, LSTM, RVQ dot products: exact bf16x3 splits, fp32 accumulate)" if ACOUSTIC_X3_GROUPS else "f32", "data": "synthetic",
             "config": primary["config"], "roofline": primary["roofline"], "breakdown": primary["breakdown"],
             "token_checksum": primary["token_checksum"],
+            "rccl_ranks": ranks["rccl_ranks"], "per_rank_ms": ranks["per_rank_ms"],
+            "backend": args.backend if world > 1 else None,
         }
-        if "pcie_inclusive" in primary:
-            out["pcie_inclusive"] = primary["pcie_inclusive"]
-        if not args.no_cpu_baseline and world == 1:
+        for k in ("median_ms_per_step", "pcie_inclusive", "broadcast_ms", "breakdown_note", "lstm_handoff_status"):
+            if k in primary:
+                out[k] = primary[k]
+        want_cpu = not args.no_cpu_baseline and world == 1 and args.workload != "selftest"
+        if not want_cpu:
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = ("skipped: --no-cpu-baseline" if args.no_cpu_baseline else
+                                        "skipped at N>1: the CPU oracle is timed on rank 0 at N=1 only")
+        else:
             if ac is not None:
                 out["cpu_baseline"] = cpu_baseline_acoustic(args.num_codebooks)
             elif sem is not None:
                 out["cpu_baseline"] = cpu_baseline_semantic(args.sem_layers)
         if ac is not None and sem is not None:
-            s = {k: v for k, v in sem.items() if k not in ("elapsed", "audio_s_per_step")}
-            if not args.no_cpu_baseline and world == 1:
+            s = {k: v for k, v in sem.items() if k not in ("elapsed", "audio_s_per_step", "rank_ms")}
+            if want_cpu:
                 s["cpu_baseline"] = cpu_baseline_semantic(args.sem_layers)
             out["semantic_m"] = s
             tot_audio = (ac["audio_s_per_step"] + sem["audio_s_per_step"]) * args.steps
@@ -528,7 +698,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
