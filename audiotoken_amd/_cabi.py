@@ -53,6 +53,8 @@ SIGNATURES = {
     "at_encodec_decode_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "at_encodec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.c_void_p]),
+    "at_encodec_decode_checked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_size_t, C.c_void_p, C.c_void_p]),
     "at_w2vbert_create": (C.c_void_p, [C.c_int]),
     "at_w2vbert_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "at_w2vbert_finalize": (C.c_int, [C.c_void_p]),
@@ -62,6 +64,10 @@ SIGNATURES = {
     "at_w2vbert_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "at_w2vbert_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "at_w2vbert_encode_checked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "at_w2vbert_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "at_w2vbert_get_option": (C.c_int, [C.c_void_p, C.c_char_p]),
     "at_w2vbert_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "at_w2vbert_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "at_hubert_create": (C.c_void_p, [C.c_int]),

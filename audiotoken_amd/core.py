@@ -115,7 +115,12 @@ class AudioToken:
         input_batch = audio.to(self.device)
         attention_mask = torch.ones_like(input_batch, device=self.device)
         toks = self.encoder(input_batch, attention_mask)
-        return toks.cpu()
+        out = toks.cpu()                      # the reference's synchronisation point
+        if hasattr(self.encoder, "verified"):  # device status of that call (LSTM hand-off / fp16 range): repeat on the safe path if set
+            checked = self.encoder.verified(toks, input_batch, attention_mask)
+            if checked is not toks:
+                out = checked.cpu()
+        return out
 
     def _chunk_stream(self, files, chunk_size: int, num_workers: int = 0):
         """File -> streamed ``chunk_size``-second chunks -> segments (reference datasets.py:107-139). Decoding and resampling
@@ -190,6 +195,8 @@ class AudioToken:
             encoded_audio = self.encoder(input_ids, attention_masks)      # asynchronous on the device
             nxt = next(batches, None)
             staged = upload(nxt) if nxt is not None else None             # next batch's copy flies during this encode
+            if hasattr(self.encoder, "verified"):   # the saves below synchronise anyway: check the call's device status first
+                encoded_audio = self.encoder.verified(encoded_audio, input_ids, attention_masks)
             for tokens_batch, file_pointer in zip(encoded_audio, file_pointers):
                 if audio_files is not None:
                     save_audio_tokens(tokens_batch, file_pointer, str(outdir))
@@ -229,4 +236,9 @@ class AudioToken:
         """core.py:355-359."""
         input_batch = tokens.to(dtype=torch.long)
         toks = self.decoder(input_batch)
-        return toks.cpu()
+        out = toks.cpu()
+        if hasattr(self.decoder, "verified"):
+            checked = self.decoder.verified(toks, input_batch)
+            if checked is not toks:
+                out = checked.cpu()
+        return out

@@ -26,6 +26,31 @@ void set_error(const std::string& msg);
         }                                                                                       \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: a process that opens handles on several
+// devices (the C ABI takes a device index) must set it on each. `flag` is a function-local static array indexed by device.
+constexpr int kMaxDevices = 64;
+struct LdsAttrFlags { bool set[kMaxDevices] = {}; };
+template <typename K>
+inline int set_max_dynamic_lds(LdsAttrFlags& f, K kernel, size_t bytes) {
+    int dev = 0;
+    AT_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices || !f.set[dev]) {
+        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        if (dev >= 0 && dev < kMaxDevices) f.set[dev] = true;
+    }
+    return 0;
+}
+// RAII: make `device` current for the duration of a C-ABI call and restore the caller's device afterwards
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; ok = false; return; }
+        if (prev != device && hipSetDevice(device) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 // ---- the one dense contraction every layer maps onto ----------------------------------------
 // out[b][m][n] = epi( alpha * ( sum_kk A(b,m,kk) * W[n][kk] + bias[n] ) ) (+ R[b][m][n])
 // where A(b,m,kk) = pro( X[b][ row(m, kk / Cin) ][ kk % Cin ] ),  row(m,tap) = m*stride + tap - pad_left,

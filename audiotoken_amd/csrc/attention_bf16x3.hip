@@ -276,11 +276,7 @@ int launch_relpos_attention_x3(const float* qkv, const float* amask, const float
     AT_REQUIRE(B >= 1 && T >= 1 && heads >= 1 && heads <= 64, "relpos_attention_x3: bad shape");
     AT_REQUIRE((long long)T * 3 * heads * 64 * 4 < (1ll << 31), "relpos_attention_x3: one clip's qkv rows exceed the buffer-descriptor range");
     dim3 grid((T + AX_QB - 1) / AX_QB, heads, B);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AX_LDS_BYTES));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, relpos_attention_x3_kernel, AX_LDS_BYTES)) return rc; }
     hipLaunchKernelGGL(relpos_attention_x3_kernel, grid, dim3(256), AX_LDS_BYTES, stream, qkv, amask, dist_emb, ctx, T, heads * 64);
     AT_CHECK_HIP(hipGetLastError());
     return 0;

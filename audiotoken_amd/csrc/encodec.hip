@@ -143,6 +143,7 @@ struct at_encodec {
     std::vector<void*> extra_allocs;
     int sub_batch = at::sub_batch();   // clips per pass through the conv stack: bounds the workspace (option "subbatch")
     bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
+    unsigned lstm_spin_limit = 1u << 18;   // option "lstm_spin_limit": flag polls before a persistent-LSTM workgroup gives up
 };
 
 namespace {
@@ -299,7 +300,7 @@ int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L
 int lstm_skip(const float* const wih[2], const float* const whh[2], const float* const bih[2], const float* const bhh[2],
               const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream,
               Profiler& prof, unsigned* sync, bool persistent, int y_elu, const __bf16* const* wih_s = nullptr, __bf16* xs = nullptr,
-              bool rec_x3 = false) {
+              bool rec_x3 = false, unsigned spin_limit = 1u << 18) {
     for (int layer = 0; layer < 2; ++layer) {
         const float* in = layer == 0 ? x : h0;
         float* hout = layer == 0 ? h0 : h1;
@@ -328,7 +329,7 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
                 const long long ro = (long long)c0 * T;
                 q.xg = xg + ro * 4 * kH; q.w_hh = whh[layer]; q.b_hh = bhh[layer]; q.h_out = hout + ro * kH;
                 q.y_out = layer == 1 ? y + ro * kH : nullptr; q.skip = x + ro * kH; q.sync = sync;
-                q.B = (B - c0) < maxc ? (B - c0) : maxc; q.T = T; q.n_groups = 0; q.h_bytes = 0; q.y_elu = y_elu;
+                q.B = (B - c0) < maxc ? (B - c0) : maxc; q.T = T; q.n_groups = 0; q.h_bytes = 0; q.y_elu = y_elu; q.spin_limit = spin_limit;
                 if (int rc = rec_x3 ? launch_lstm_seq_x3(q, stream) : launch_lstm_seq(q, stream)) return rc;
             }
             prof.end(stream);
@@ -472,7 +473,8 @@ int at_encodec_set_tensor(at_encodec_t* h, const char* name, const float* host_d
 
 int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
     AT_REQUIRE(h && !h->finalized, "bad handle");
-    AT_CHECK_HIP(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
     Packer p;
     struct Off { size_t w, b; };
     Off o_conv0, o_res[4][3], o_down[4], o_fin;
@@ -644,7 +646,7 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
 
 void at_encodec_destroy(at_encodec_t* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);   // restores the caller's current device (destroy runs from garbage collection in Python)
     if (h->blob) (void)hipFree(h->blob);
     for (void* p : h->extra_allocs) (void)hipFree(p);
     delete h;
@@ -661,6 +663,8 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                                float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream_, unsigned* status_out) {
     (void)mask;  // the reference's AcousticEncoder.forward ignores attention_mask (audiotoken/encoder.py:44-52)
     AT_REQUIRE(h && h->finalized, "model not finalized");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
     AT_REQUIRE(wav && codes && workspace, "null pointer");
     AT_REQUIRE(B >= 1 && N >= 10, "need B >= 1 and N >= 10 samples");
     AT_REQUIRE(n_q >= 1 && n_q <= h->n_codebooks, "n_q out of range for the loaded codebooks");
@@ -789,7 +793,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
     AT_CHECK_HIP(hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), stream));
     if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
-                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3))
+                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit))
         return rc;
     if (status_out) AT_CHECK_HIP(hipMemcpyAsync(status_out, sync + 63, sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     float* emb = emb_out ? emb_out : ws + p.off_emb;
@@ -831,6 +835,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "res64_x3") { h->res64_x3 = value != 0; return 0; }
     if (std::string(name) == "res128_x3") { h->res128_x3 = value != 0; return 0; }
     if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }
+    if (std::string(name) == "lstm_spin_limit") { AT_REQUIRE(value >= 0, "lstm_spin_limit must be >= 0"); h->lstm_spin_limit = (unsigned)value; return 0; }
     if (std::string(name) == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
     set_error(std::string("unknown option ") + name);
     return -1;
@@ -868,7 +873,14 @@ size_t at_encodec_decode_workspace_bytes(const at_encodec_t* h, int B, int T) {
 
 int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T, float* wav, void* workspace,
                       size_t workspace_bytes, at_stream_t stream_) {
+    return at_encodec_decode_checked(h, codes, B, K, T, wav, workspace, workspace_bytes, stream_, nullptr);
+}
+
+int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int K, int T, float* wav, void* workspace,
+                              size_t workspace_bytes, at_stream_t stream_, uint32_t* status_dev) {
     AT_REQUIRE(h && h->finalized && h->has_decoder, "model not finalized with a decoder");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
     AT_REQUIRE(codes && wav && workspace, "null pointer");
     AT_REQUIRE(B >= 1 && T >= 7 && K >= 1 && K <= h->n_codebooks, "bad B/T/K");
     hipStream_t stream = (hipStream_t)stream_;
@@ -886,8 +898,9 @@ int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T
     // every activation that is only consumed through ELU is stored already ELU'd (once per element, in the producer's
     // epilogue) so the transposed convs run the plain-linear GEMM path: y (LSTM + skip) and the block outputs of stages 0-2
     if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,
-                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3))
+                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit))
         return rc;
+    if (status_dev) AT_CHECK_HIP(hipMemcpyAsync(status_dev, sync + 63, sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
     const int Lout = p.L[4];
     for (int b0 = 0; b0 < B; b0 += p.G) {
         const int g = (B - b0) < p.G ? (B - b0) : p.G;

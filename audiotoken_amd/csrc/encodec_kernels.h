@@ -28,6 +28,7 @@ struct LstmSeqArgs {
     int y_elu;           // y_out = ELU(h + skip)
     int n_groups;        // filled by the launcher
     long long h_bytes;   // filled by the launcher
+    unsigned spin_limit = 1u << 18;   // polls of a hand-off flag before a workgroup gives up (~0.1-0.3 s; normal waits are microseconds)
 };
 int launch_lstm_seq(const LstmSeqArgs& a, hipStream_t stream);
 int lstm_seq_max_clips();

@@ -4,6 +4,24 @@
 
 namespace at {
 
+// Operand schemes. Both write an fp32 operand as a sum of 16-bit pieces and accumulate the leading cross products on the 16-bit
+// matrix cores into fp32:
+//   XB_SCHEME_BF16X3  a = a1 + a2 + a3 (bf16, 8 + 8 + 8 bits, exact), six products, any magnitude (bf16 has the fp32 exponent range);
+//   XB_SCHEME_F16X2   a * s = hi + lo (fp16, 11 + 11 bits + the sign of lo), three products hi.lo + lo.hi + hi.hi; the operand is
+//                     pre-scaled by a power of two s so that lo stays in fp16's range (weights: per tensor, max |w s| in [2^14, 2^15);
+//                     activations: XB_F16_ACT_SCALE) and the accumulator is multiplied by acc_scale = 1 / (s_a s_w) — all exact.
+//                     Measured against float64 (tools/f16x2_gemm.hip): rms error 1.10e-7 (K = 1024) / 1.39e-6 (K = 4096) vs 1.51e-7 /
+//                     1.96e-6 for bf16x3 and 1.78e-7 / 2.25e-6 for the k-ordered fp32 FMA chain, at half the MFMAs of bf16x3.
+//                     Values with |x s| > 65504 do not fit: the split writers raise bit XB_STATUS_F16_OVERFLOW in *status.
+enum { XB_SCHEME_BF16X3 = 0, XB_SCHEME_F16X2 = 1 };
+constexpr float XB_F16_ACT_SCALE = 16.0f;
+constexpr int XB_STATUS_F16_OVERFLOW = 2;
+// 16-bit storage of one operand piece (bf16 bits or fp16 bits, by scheme)
+typedef __bf16 piece_t;
+inline int xb_pieces(int scheme) { return scheme == XB_SCHEME_F16X2 ? 2 : 3; }
+// power-of-two scale that puts max |w| into [2^14, 2^15) (1 for an all-zero tensor)
+float xb_weight_scale(float max_abs);
+
 enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2, XB_EPI_GELU_SPLIT = 3, XB_EPI_GELU = 4, XB_EPI_ELU_SPLIT = 5, XB_EPI_RAW_ELU_SPLIT2 = 6 };
 
 struct Bf16x3Args {
@@ -12,6 +30,10 @@ struct Bf16x3Args {
     const float* bias = nullptr;
     int M = 0, N = 0, K = 0, Mpad = 0;
     int epi = XB_EPI_LINEAR;
+    int scheme = XB_SCHEME_BF16X3;
+    float acc_scale = 1.0f;     // multiplies the accumulator before bias / activation (XB_SCHEME_F16X2: 1 / (s_a s_w))
+    float split_scale = 1.0f;   // multiplies values before they are split into S / S2 (XB_SCHEME_F16X2: XB_F16_ACT_SCALE)
+    int* status = nullptr;      // device word, OR-ed with XB_STATUS_F16_OVERFLOW when a split output does not fit fp16 (nullable)
     // XB_EPI_LINEAR: C = alpha * (acc + bias) + R, fp32 row-major
     // XB_EPI_GLU: weight rows interleaved (a_c, b_c): C[m][c] = a_c * sigmoid(b_c), N/2 output columns, fp32 row-major
     float* C = nullptr; int ldc = 0;
@@ -42,8 +64,9 @@ struct Bf16x3Args {
 // i % phases at index i / phases) become copies of padded row 2 * pad - i
 int launch_reflect_front(__bf16* S, int B, int blocks, int phases, int Lp, int pad, hipStream_t stream);
 
-// fp32 row-major [rows][ld] (first K columns) -> 3 K-blocked bf16 pieces [3][K/16][rows_pad][16]; rows >= `rows` are zero-filled
-int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream);
+// fp32 row-major [rows][ld] (first K columns) * scale -> K-blocked pieces [pieces][K/16][rows_pad][16]; rows >= `rows` are zero-filled
+int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream,
+                         int scheme = XB_SCHEME_BF16X3, float scale = 1.0f, int* status = nullptr);
 // fp32 [B][L][C] -> the windowed-mode pieces of a causal strided conv with kernel = 2 * stride (reflect front padding included)
 int launch_split_phase_major(const float* x, int B, int L, int C, int stride, int Lp, __bf16* out, hipStream_t stream);
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream);

@@ -13,10 +13,17 @@
 // Tiles: 256 x 128 per workgroup (4 waves, each 64 x 128 = 2 x 4 MFMA tiles of 32 x 32, two workgroups per CU), 256 x 256
 // (8 waves) or 128 x 128 for small launches; K tile 16; register-staged double-buffered LDS; operands swapped (weights as MFMA A) so a lane owns 4 consecutive output channels.
 // Used for the conformer feed-forward layers (w2vbert.hip); everything that has a bit-identical fused twin stays on the fp32 MFMA.
+//
+// Round 2: the same kernel also runs the TWO-piece fp16 scheme (XB_SCHEME_F16X2, gemm_bf16x3.h): a s = hi + lo in fp16, three
+// products (hi.lo, lo.hi, hi.hi) on v_mfma_f32_32x32x16_f16, operands pre-scaled by powers of two, accumulator rescaled in the
+// epilogue. Half the MFMAs and 4 instead of 6 operand bytes per element at a float64 error below the bf16x3 scheme's
+// (tools/f16x2_gemm.hip); used where activations are normalised (the two semantic tokenizers); the scheme is a template
+// parameter, the tile shapes, staging and epilogues are shared.
 #include "at_common.h"
 #include "gemm_bf16x3.h"
 #include <type_traits>
 #include <cstdlib>
+#include <cmath>
 
 namespace at {
 
@@ -25,6 +32,56 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// The two operand schemes (gemm_bf16x3.h). `prod_a/prod_w` list the cross products in the order they are accumulated, smallest first.
+struct SchemeBf16x3 {
+    typedef __bf16 T; typedef bf16x8 V8; typedef bf16x4 V4;
+    static constexpr int NP = 3, NPROD = 6;
+    static constexpr bool RANGE_CHECK = false;
+    __device__ static constexpr int prod_a(int t) { constexpr int v[6] = {0, 2, 1, 0, 1, 0}; return v[t]; }
+    __device__ static constexpr int prod_w(int t) { constexpr int v[6] = {2, 0, 1, 1, 0, 0}; return v[t]; }
+    __device__ static __forceinline__ f16v mfma(V8 w, V8 a, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0); }
+};
+struct SchemeF16x2 {
+    typedef _Float16 T; typedef f16x8 V8; typedef f16x4 V4;
+    static constexpr int NP = 2, NPROD = 3;
+    static constexpr bool RANGE_CHECK = true;
+    __device__ static constexpr int prod_a(int t) { constexpr int v[3] = {0, 1, 0}; return v[t]; }
+    __device__ static constexpr int prod_w(int t) { constexpr int v[3] = {1, 0, 0}; return v[t]; }
+    __device__ static __forceinline__ f16v mfma(V8 w, V8 a, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, c, 0, 0, 0); }
+};
+
+// a -> NP pieces: p[0] = round(a), p[1] = round(a - p[0]), ... (every subtraction is exact)
+template <class SC>
+__device__ __forceinline__ void split_n(float a, typename SC::T (&p)[SC::NP]) {
+#pragma unroll
+    for (int i = 0; i < SC::NP; ++i) {
+        p[i] = (typename SC::T)a;
+        a -= (float)p[i];
+    }
+}
+// four values * scale -> NP pieces of four; returns true when a value does not fit the scheme's range
+template <class SC>
+__device__ __forceinline__ bool split4(const f4& v, float scale, typename SC::V4 (&p)[SC::NP]) {
+    bool over = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x = v[k] * scale;
+        if constexpr (SC::RANGE_CHECK) over |= !(fabsf(x) <= 65504.0f);
+        typename SC::T q[SC::NP];
+        split_n<SC>(x, q);
+#pragma unroll
+        for (int i = 0; i < SC::NP; ++i) p[i][k] = q[i];
+    }
+    return over;
+}
+
+float xb_weight_scale(float max_abs) {
+    if (!(max_abs > 0.f) || !std::isfinite(max_abs)) return 1.0f;
+    return std::exp2(std::floor(std::log2(32767.0f / max_abs)));
+}
 
 constexpr int XB_K = 16;
 // Two tile shapes with IDENTICAL per-element arithmetic (the k order and the order of the six products do not depend on the
@@ -34,7 +91,7 @@ template <int WM, int WN, int TI, int TJ>
 struct XbCfg {
     static constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, NT = WM * WN * 64;
     static constexpr int PA = BM * XB_K, PW = BN * XB_K;            // bf16 elements of one piece of the A / W tile
-    static constexpr int STAGE = 3 * (PA + PW);                      // bf16 elements per LDS stage
+    template <int NP> static constexpr int stage() { return NP * (PA + PW); }   // 16-bit elements per LDS stage
 };
 
 __device__ __forceinline__ void split3(float a, __bf16& p1, __bf16& p2, __bf16& p3) {
@@ -45,10 +102,11 @@ __device__ __forceinline__ void split3(float a, __bf16& p1, __bf16& p2, __bf16& 
     p3 = (__bf16)r2;
 }
 
-// fp32 row-major [rows][ld] (first K columns) -> three K-blocked bf16 pieces. Workgroup = 64 rows x 64 k through LDS so that both
+// fp32 row-major [rows][ld] (first K columns) * scale -> NP K-blocked pieces. Workgroup = 64 rows x 64 k through LDS so that both
 // the reads (256 B per row) and the writes (64 rows x 32 B = 2 KB per k-block) are contiguous.
+template <class SC>
 __global__ __launch_bounds__(256) void split_blocked_kernel(const float* __restrict__ x, int ld, long long rows, long long rows_pad, int K,
-                                                            __bf16* __restrict__ out) {
+                                                            typename SC::T* __restrict__ out, float scale, int* __restrict__ status) {
     __shared__ float tile[64][65];
     const long long r0 = (long long)blockIdx.x * 64;
     const int k0 = blockIdx.y * 64;
@@ -60,23 +118,21 @@ __global__ __launch_bounds__(256) void split_blocked_kernel(const float* __restr
     }
     __syncthreads();
     const long long ps = rows_pad * (long long)K;
+    bool over = false;
     // thread -> (k-block kb of 4, row r, quarter qd of the 16 k): 4 values = 8 bytes per piece
     for (int e = threadIdx.x; e < 4 * 64 * 4; e += 256) {
         const int qd = e & 3, r = (e >> 2) & 63, kb = e >> 8;
-        bf16x4 p1, p2, p3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __bf16 a, b, c;
-            split3(tile[r][kb * 16 + qd * 4 + i], a, b, c);
-            p1[i] = a; p2[i] = b; p3[i] = c;
-        }
+        typename SC::V4 p[SC::NP];
+        const f4 v = {tile[r][kb * 16 + qd * 4], tile[r][kb * 16 + qd * 4 + 1], tile[r][kb * 16 + qd * 4 + 2], tile[r][kb * 16 + qd * 4 + 3]};
+        over |= split4<SC>(v, scale, p);
         const long long o = ((long long)(k0 / 16 + kb) * rows_pad + r0 + r) * 16 + qd * 4;
         if (r0 + r < rows_pad) {
-            *reinterpret_cast<bf16x4*>(out + o) = p1;
-            *reinterpret_cast<bf16x4*>(out + ps + o) = p2;
-            *reinterpret_cast<bf16x4*>(out + 2 * ps + o) = p3;
+#pragma unroll
+            for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(out + i * ps + o) = p[i];
         }
     }
+    if constexpr (SC::RANGE_CHECK)
+        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
 }
 
 // fp32 [B][L][C] -> the pieces a causal strided conv (kernel = 2 x stride, left reflect padding of `stride` rows) reads as a windowed
@@ -143,20 +199,28 @@ int launch_split_phase_major(const float* x, int B, int L, int C, int stride, in
     return 0;
 }
 
-int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream) {
+int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream, int scheme, float scale,
+                         int* status) {
     AT_REQUIRE(K % 64 == 0 && ld % 4 == 0 && rows_pad >= rows && rows_pad % 64 == 0, "split_blocked: K % 64, ld % 4, rows_pad % 64");
     dim3 grid((unsigned)(rows_pad / 64), K / 64);
-    hipLaunchKernelGGL(split_blocked_kernel, grid, dim3(256), 0, stream, x, ld, rows, rows_pad, K, out);
+    if (scheme == XB_SCHEME_F16X2)
+        hipLaunchKernelGGL(split_blocked_kernel<SchemeF16x2>, grid, dim3(256), 0, stream, x, ld, rows, rows_pad, K, reinterpret_cast<_Float16*>(out), scale, status);
+    else
+        hipLaunchKernelGGL(split_blocked_kernel<SchemeBf16x3>, grid, dim3(256), 0, stream, x, ld, rows, rows_pad, K, out, scale, status);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 // DUAL: the XB_EPI_RAW_ELU_SPLIT2 epilogue as its own instantiation (in the general kernel its two split writers spilled)
-template <int WM, int WN, int TI, int TJ, bool DUAL = false>
+template <class SC, int WM, int WN, int TI, int TJ, bool DUAL = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf16x3_kernel(Bf16x3Args a) {
     using Cfg = XbCfg<WM, WN, TI, TJ>;
+    typedef typename SC::T PT;
+    typedef typename SC::V8 V8;
+    constexpr int NP = SC::NP, STAGE = Cfg::template stage<NP>();
     constexpr int XB_M = Cfg::BM, XB_N = Cfg::BN, NT = Cfg::NT;
-    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];   // [2 stages][A: 3 x 256 x 16 | W: 3 x 256 x 16]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];   // [2 stages][A: NP x rows x 16 | W: NP x rows x 16]
+    PT* lds = reinterpret_cast<PT*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ntn = a.N / XB_N, ntm = a.Mpad / XB_M;
@@ -168,31 +232,32 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
     const long long a_clip = (long long)cblocks * a.stride * Lp * 16;   // elements of one clip of one piece
     const long long psA = a_clip * a.batch, psW = (long long)a.N * a.K;
     const int nk = a.K / XB_K;
-    const __bf16* Ab = a.A + clip * a_clip + (long long)m0 * 16;
+    const PT* Ab = reinterpret_cast<const PT*>(a.A) + clip * a_clip + (long long)m0 * 16;
+    const PT* Wb = reinterpret_cast<const PT*>(a.W);
     // staging: one piece of an operand tile is rows x 32 B = 2 * rows chunks of 16 B, contiguous in the K-blocked layout
     constexpr int CA = (2 * XB_M) / NT, CW = (2 * XB_N) / NT;   // chunks per thread per piece
     static_assert((2 * XB_M) % NT == 0 && (2 * XB_N) % NT == 0, "tile rows must be a multiple of half the thread count");
-    u4 sa[3][CA], sw[3][CW];
+    u4 sa[NP][CA], sw[NP][CW];
     auto load = [&](int kt) {
         const int tapk = kt / cblocks, cbk = kt - tapk * cblocks;   // K tile -> (tap, channel block) -> (phase plane, row offset)
         const int offk = tapk / a.stride, planek = tapk - offk * a.stride;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int c = 0; c < CA; ++c)
                 sa[p][c] = *reinterpret_cast<const u4*>(Ab + p * psA + (((long long)cbk * a.stride + planek) * Lp + offk) * 16 + (tid + c * NT) * 8);
 #pragma unroll
-            for (int c = 0; c < CW; ++c) sw[p][c] = *reinterpret_cast<const u4*>(a.W + p * psW + ((long long)kt * a.N + n0) * 16 + (tid + c * NT) * 8);
+            for (int c = 0; c < CW; ++c) sw[p][c] = *reinterpret_cast<const u4*>(Wb + p * psW + ((long long)kt * a.N + n0) * 16 + (tid + c * NT) * 8);
         }
     };
     auto store = [&](int buf) {
-        __bf16* s = lds + buf * Cfg::STAGE;
+        PT* s = lds + buf * STAGE;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int c = 0; c < CA; ++c) *reinterpret_cast<u4*>(s + p * Cfg::PA + (tid + c * NT) * 8) = sa[p][c];
 #pragma unroll
-            for (int c = 0; c < CW; ++c) *reinterpret_cast<u4*>(s + 3 * Cfg::PA + p * Cfg::PW + (tid + c * NT) * 8) = sw[p][c];
+            for (int c = 0; c < CW; ++c) *reinterpret_cast<u4*>(s + NP * Cfg::PA + p * Cfg::PW + (tid + c * NT) * 8) = sw[p][c];
         }
     };
     f16v acc[TI][TJ];
@@ -207,46 +272,41 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
     __syncthreads();
     const int frow = lane & 31, fhalf = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
-        const __bf16* s = lds + (kt & 1) * Cfg::STAGE;
-        bf16x8 xa[3][TI], wb[3][TJ];
+        const PT* s = lds + (kt & 1) * STAGE;
+        V8 xa[NP][TI], wb[NP][TJ];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int i = 0; i < TI; ++i) xa[p][i] = *reinterpret_cast<const bf16x8*>(s + p * Cfg::PA + (wm * TI * 32 + i * 32 + frow) * 16 + fhalf * 8);
+            for (int i = 0; i < TI; ++i) xa[p][i] = *reinterpret_cast<const V8*>(s + p * Cfg::PA + (wm * TI * 32 + i * 32 + frow) * 16 + fhalf * 8);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) wb[p][j] = *reinterpret_cast<const bf16x8*>(s + 3 * Cfg::PA + p * Cfg::PW + (wn * TJ * 32 + j * 32 + frow) * 16 + fhalf * 8);
+            for (int j = 0; j < TJ; ++j) wb[p][j] = *reinterpret_cast<const V8*>(s + NP * Cfg::PA + p * Cfg::PW + (wn * TJ * 32 + j * 32 + frow) * 16 + fhalf * 8);
         }
         if (kt + 1 < nk) load(kt + 1);
-        // the six leading cross products, smallest first
-        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PW[6] = {2, 0, 1, 1, 0, 0};
+        // the leading cross products, smallest first
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[PW[t]][j], xa[PA[t]][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SC::mfma(wb[SC::prod_w(t)][j], xa[SC::prod_a(t)][i], acc[i][j]);
         if (kt + 1 < nk) store((kt + 1) & 1);
         __syncthreads();
     }
     // lane holds output row m = frow of its 32-row tile and, per register group g, 4 consecutive columns n = 8g + 4 fhalf ..
     // split outputs: [3][batch][blocks][phases][pad][16]; output row m lives in plane m % phases at index m / phases + front
-    auto write_split = [&](__bf16* S, int pad, int phases, int front, int blocks, int block0, int m, int n, const f4& v) {
+    bool over = false;
+    auto write_split = [&](__bf16* S_, int pad, int phases, int front, int blocks, int block0, int m, int n, const f4& v) {
+        PT* S = reinterpret_cast<PT*>(S_);
         const int nb = blocks > 0 ? blocks : a.N / 16;
         const long long s_clip = (long long)pad * phases * nb * 16;   // elements of one clip of one piece
         const long long psS = s_clip * a.batch;
-        bf16x4 p1, p2, p3;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            __bf16 x1, x2, x3;
-            split3(v[k], x1, x2, x3);
-            p1[k] = x1; p2[k] = x2; p3[k] = x3;
-        }
+        typename SC::V4 p[NP];
+        over |= split4<SC>(v, a.split_scale, p);
         const int sq = m / phases, sp = m - sq * phases;
-        __bf16* d = S + clip * s_clip + (((long long)(block0 + (n >> 4)) * phases + sp) * pad + sq + front) * 16 + (n & 15);
-        *reinterpret_cast<bf16x4*>(d) = p1;
-        *reinterpret_cast<bf16x4*>(d + psS) = p2;
-        *reinterpret_cast<bf16x4*>(d + 2 * psS) = p3;
+        PT* d = S + clip * s_clip + (((long long)(block0 + (n >> 4)) * phases + sp) * pad + sq + front) * 16 + (n & 15);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) *reinterpret_cast<typename SC::V4*>(d + i * psS) = p[i];
     };
     float* Cb = a.C ? a.C + (long long)clip * a.M * a.ldc : nullptr;
     const float* Rb = a.R ? a.R + (long long)clip * a.M * a.ldr : nullptr;
@@ -264,6 +324,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
                 for (int g = 0; g < 4; ++g) {
                     const int n = n0 + wn * TJ * 32 + j * 32 + 8 * g + 4 * fhalf;
                     f4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    if constexpr (SC::RANGE_CHECK) v *= a.acc_scale;   // exact: a power of two (1 for the bf16 scheme)
                     if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
                     if constexpr (E == XB_EPI_RAW_ELU_SPLIT2) {
                         write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, v);
@@ -303,21 +364,33 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
             default: epilogue(std::integral_constant<int, XB_EPI_LINEAR>{}); break;
         }
     }
+    if constexpr (SC::RANGE_CHECK)
+        if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
 }
 
-template <int WM, int WN, int TI, int TJ, bool DUAL = false>
+template <class SC, int WM, int WN, int TI, int TJ, bool DUAL = false>
 static int launch_xb(const Bf16x3Args& a, hipStream_t stream) {
     using Cfg = XbCfg<WM, WN, TI, TJ>;
-    const size_t ldsb = 2 * Cfg::STAGE * sizeof(__bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<WM, WN, TI, TJ, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-        attr_set = true;
-    }
+    const size_t ldsb = 2 * (size_t)Cfg::template stage<SC::NP>() * 2;
+    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_bf16x3_kernel<SC, WM, WN, TI, TJ, DUAL>, ldsb)) return rc; }
     const dim3 grid((unsigned)((long long)a.batch * (a.Mpad / Cfg::BM) * (a.N / Cfg::BN)));
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TI, TJ, DUAL>), grid, dim3(Cfg::NT), ldsb, stream, a);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<SC, WM, WN, TI, TJ, DUAL>), grid, dim3(Cfg::NT), ldsb, stream, a);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+template <class SC>
+static int launch_scheme(const Bf16x3Args& a, hipStream_t stream) {
+    const long long tiles256 = (long long)a.batch * (a.Mpad / 256) * ((a.N + 255) / 256);
+    if constexpr (!SC::RANGE_CHECK) {
+        if (a.epi == XB_EPI_RAW_ELU_SPLIT2) return launch_xb<SC, 4, 1, 2, 4, true>(a, stream);
+    }
+    if (tiles256 < 256 || a.N % 256 != 0) return launch_xb<SC, 2, 2, 2, 2>(a, stream);   // 4x as many 128 x 128 tiles: same arithmetic, fills the chip
+    // large launches: 256 x 128 tiles, 4 waves, TWO workgroups per CU (one loads while the other multiplies) measured 1-2 % ahead of
+    // 256 x 256 with 8 waves and one workgroup per CU (less operand traffic, no overlap); $AUDIOTOKEN_XB_TILE=0 selects the latter.
+    static const int big = std::getenv("AUDIOTOKEN_XB_TILE") ? std::atoi(std::getenv("AUDIOTOKEN_XB_TILE")) : 1;
+    if (big == 1) return launch_xb<SC, 4, 1, 2, 4>(a, stream);
+    return launch_xb<SC, 4, 2, 2, 4>(a, stream);
 }
 
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
@@ -328,15 +401,9 @@ int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
     AT_REQUIRE(a.epi != XB_EPI_RAW_ELU_SPLIT2 || (a.S2 != nullptr && a.S2phases >= 1 && (long long)a.S2pad * a.S2phases >= a.M + (long long)a.S2front * a.S2phases), "gemm_bf16x3: bad second output");
     AT_REQUIRE(a.batch >= 1 && a.stride >= 1 && (a.cblocks == 0 || (a.K / XB_K) % a.cblocks == 0), "gemm_bf16x3: bad window description");
     AT_REQUIRE((a.Lp > 0 ? a.Lp : a.Mpad) >= a.Mpad + ((a.cblocks > 0 ? (a.K / XB_K) / a.cblocks : 1) - 1) / a.stride, "gemm_bf16x3: Lp too small for the last tile");
-    const long long tiles256 = (long long)a.batch * (a.Mpad / 256) * ((a.N + 255) / 256);
-    if (a.epi == XB_EPI_RAW_ELU_SPLIT2) return launch_xb<4, 1, 2, 4, true>(a, stream);
-    if (tiles256 < 256 || a.N % 256 != 0) return launch_xb<2, 2, 2, 2>(a, stream);   // 4x as many 128 x 128 tiles: same arithmetic, fills the chip
-    // large launches: 256 x 128 tiles, 4 waves, TWO workgroups per CU (one loads while the other multiplies) measured 1-2 % ahead of
-    // 256 x 256 with 8 waves and one workgroup per CU (less operand traffic, no overlap); $AUDIOTOKEN_XB_TILE=0 selects the latter.
-    // The kernel is bound by the L2 -> LDS operand stream: time = 1.67 ms + 0.41 ms per product on the FFN shape (tools/bf16x3_gemm.hip).
-    static const int big = std::getenv("AUDIOTOKEN_XB_TILE") ? std::atoi(std::getenv("AUDIOTOKEN_XB_TILE")) : 1;
-    if (big == 1) return launch_xb<4, 1, 2, 4>(a, stream);
-    return launch_xb<4, 2, 2, 4>(a, stream);
+    AT_REQUIRE(a.scheme == XB_SCHEME_BF16X3 || (a.scheme == XB_SCHEME_F16X2 && a.epi != XB_EPI_RAW_ELU_SPLIT2), "gemm_bf16x3: unknown scheme / dual split output needs the bf16 scheme");
+    if (a.scheme == XB_SCHEME_F16X2) return launch_scheme<SchemeF16x2>(a, stream);
+    return launch_scheme<SchemeBf16x3>(a, stream);
 }
 
 }  // namespace at

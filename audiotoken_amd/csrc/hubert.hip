@@ -168,7 +168,8 @@ int at_hubert_set_tensor(at_hubert_t* h, const char* name, const float* host_dat
 
 int at_hubert_finalize(at_hubert_t* h) {
     AT_REQUIRE(h && !h->finalized, "bad handle");
-    AT_CHECK_HIP(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
     bool ok = true;
     for (int i = 0; i < 7; ++i) {
         const std::string key = "feature_extractor.conv_layers." + std::to_string(i) + ".conv.weight";
@@ -287,7 +288,7 @@ int at_hubert_finalize(at_hubert_t* h) {
 
 void at_hubert_destroy(at_hubert_t* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);   // restores the caller's current device
     for (float* p : h->allocs) (void)hipFree(p);
     delete h;
 }

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_kernel(LstmSeqArgs a) {
                     const unsigned f = __hip_atomic_load(flags + (lane & (LS_SLICES - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__builtin_amdgcn_ballot_w64(f < target) == 0ull) break;
                     ++spins;
-                    if (spins > LS_SPIN_LIMIT) { give_up = 1; break; }
+                    if (spins > a.spin_limit) { give_up = 1; break; }
                     if ((spins & 1023u) == 0u &&
                         __hip_atomic_load(a.sync + LS_STATUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { give_up = 1; break; }
                 }
@@ -195,11 +195,7 @@ int launch_lstm_seq(const LstmSeqArgs& a_in, hipStream_t stream) {
     a.h_bytes = (long long)a.B * a.T * LS_H * 4;
     AT_REQUIRE(a.h_bytes < (1ll << 31), "lstm_seq: h buffer exceeds the 2 GB buffer-descriptor range");
     const size_t lds = (size_t)LS_H_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, lstm_seq_kernel, lds)) return rc; }
     AT_CHECK_HIP(hipMemsetAsync(a.sync + LS_FLAGS, 0, LS_MAX_GROUPS * LS_SLICES * sizeof(unsigned), stream));   // flags, every launch
     hipLaunchKernelGGL(lstm_seq_kernel, dim3(a.n_groups * LS_SLICES), dim3(256), lds, stream, a);
     AT_CHECK_HIP(hipGetLastError());

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512 / NJ, 1) void lstm_seq_x3_kernel(LstmSeqArgs a)
                     const unsigned f = __hip_atomic_load(flags + (lane & (LX_SLICES - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__builtin_amdgcn_ballot_w64(f < target) == 0ull) break;
                     ++spins;
-                    if (spins > LX_SPIN_LIMIT) { give_up = 1; break; }
+                    if (spins > a.spin_limit) { give_up = 1; break; }
                     if ((spins & 1023u) == 0u &&
                         __hip_atomic_load(a.sync + LX_STATUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { give_up = 1; break; }
                 }
@@ -221,12 +221,8 @@ int launch_lstm_seq_x3(const LstmSeqArgs& a_in, hipStream_t stream) {
     a.h_bytes = (long long)a.B * a.T * LX_H * 4;
     AT_REQUIRE(a.h_bytes < (1ll << 31), "lstm_seq_x3: h buffer exceeds the 2 GB buffer-descriptor range");
     const size_t lds = (size_t)3 * LX_HP * sizeof(__bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, lstm_seq_x3_kernel<1>, lds)) return rc; }
+    { static LdsAttrFlags lds_attr_1; if (int rc = set_max_dynamic_lds(lds_attr_1, lstm_seq_x3_kernel<2>, lds)) return rc; }
     static const int waves8 = std::getenv("AUDIOTOKEN_LSTM_X3_WAVES8") ? std::atoi(std::getenv("AUDIOTOKEN_LSTM_X3_WAVES8")) : 1;
     AT_CHECK_HIP(hipMemsetAsync(a.sync + LX_FLAGS, 0, LX_MAX_GROUPS * LX_FLAG_STRIDE * sizeof(unsigned), stream));   // flags, every launch
     if (waves8) hipLaunchKernelGGL(lstm_seq_x3_kernel<1>, dim3(a.n_groups * LX_SLICES), dim3(512), lds, stream, a);

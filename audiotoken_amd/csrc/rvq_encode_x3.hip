@@ -186,11 +186,7 @@ int launch_rvq_encode_x3(const float* x, long long rows, int T, const float* cod
     if (rows <= 0) return 0;
     const long long blocks = (rows + QX_ROWS - 1) / QX_ROWS;
     const size_t lds = (size_t)2 * QX_TILE * sizeof(__bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rvq_encode_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, rvq_encode_x3_kernel, lds)) return rc; }
     hipLaunchKernelGGL(rvq_encode_x3_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, x, rows, T, codebooks, cb_s, cb_piece, e2, n_q, codes);
     AT_CHECK_HIP(hipGetLastError());
     return 0;

@@ -217,11 +217,7 @@ __global__ __launch_bounds__(256, 2) void seanet_dectail_kernel(DecTailArgs a) {
 int launch_seanet_dectail(const DecTailArgs& a, hipStream_t stream) {
     AT_REQUIRE(a.L >= 8 && a.B >= 1, "fused decoder tail needs at least 8 input rows");
     const size_t lds = (size_t)DT_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_dectail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_dectail_kernel, lds)) return rc; }
     const long long tiles = (long long)a.B * ((2 * a.L + DT_TO - 1) / DT_TO);
     const int grid = (int)(tiles < 512 ? tiles : 512);   // two resident workgroups per CU
     hipLaunchKernelGGL(seanet_dectail_kernel, dim3(grid), dim3(256), lds, stream, a);

@@ -116,11 +116,7 @@ __global__ __launch_bounds__(256, 1) void seanet_down64_kernel(Down64Args a) {
 int launch_seanet_down64(const Down64Args& a, hipStream_t stream) {
     AT_REQUIRE(a.L >= 8 && a.L % 4 == 0 && a.B >= 1, "register-stationary stride-4 conv needs L % 4 == 0");
     const size_t lds = (size_t)D64_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_down64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_down64_kernel, lds)) return rc; }
     const long long tiles = (long long)a.B * ((a.L / 4 + D64_TU - 1) / D64_TU);
     const int grid = (int)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(seanet_down64_kernel, dim3(grid), dim3(256), lds, stream, a);

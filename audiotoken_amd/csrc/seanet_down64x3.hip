@@ -218,12 +218,8 @@ __global__ __launch_bounds__(512 / NN, 1) void seanet_down64x3_kernel(Down64Args
 int launch_seanet_down64x3(const Down64Args& a, hipStream_t stream) {
     AT_REQUIRE(a.L >= 8 && a.L % 4 == 0 && a.B >= 1, "register-stationary stride-4 conv needs L % 4 == 0");
     const size_t lds = (size_t)2 * 3 * DX_PIECE * sizeof(__bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_down64x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_down64x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_down64x3_kernel<1>, lds)) return rc; }
+    { static LdsAttrFlags lds_attr_1; if (int rc = set_max_dynamic_lds(lds_attr_1, seanet_down64x3_kernel<2>, lds)) return rc; }
     const long long tiles = (long long)a.B * ((a.L / 4 + DX_TU - 1) / DX_TU);
     AT_REQUIRE(tiles < (1LL << 30) && (long long)a.L * 64 < (1LL << 30), "tile / offset arithmetic is 32-bit");
     const int grid = (int)(tiles < 256 ? tiles : 256);

@@ -266,11 +266,7 @@ int launch_seanet_res128x3(const Res64Args& a, hipStream_t stream) {
     const long long tiles = (long long)a.B * ((a.L + RX_TT - 1) / RX_TT);
     AT_REQUIRE(tiles < (1LL << 30) && (long long)a.L * 128 < (1LL << 30), "tile / offset arithmetic is 32-bit");
     const size_t lds = (size_t)(6 * RX_XP + 3 * RX_HP) * sizeof(__bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_res128x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_res128x3_kernel, lds)) return rc; }
     const int grid = (int)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(seanet_res128x3_kernel, dim3(grid), dim3(256), lds, stream, a);
     AT_CHECK_HIP(hipGetLastError());

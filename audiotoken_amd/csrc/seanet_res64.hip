@@ -141,11 +141,7 @@ __global__ __launch_bounds__(256, 3) void seanet_res64_kernel(Res64Args a) {
 int launch_seanet_res64(const Res64Args& a, hipStream_t stream) {
     AT_REQUIRE(a.L >= 4 && a.B >= 1, "fused resblock needs at least 4 rows");
     const size_t lds = (size_t)R64_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_res64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_res64_kernel, lds)) return rc; }
     const long long tiles = (long long)a.B * ((a.L + R64_TT - 1) / R64_TT);
     const int grid = (int)(tiles < 768 ? tiles : 768);   // three resident workgroups per CU
     hipLaunchKernelGGL(seanet_res64_kernel, dim3(grid), dim3(256), lds, stream, a);

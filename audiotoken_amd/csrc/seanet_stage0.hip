@@ -214,11 +214,7 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0_kernel(Stage0Args a) {
 int launch_seanet_stage0(const Stage0Args& a, hipStream_t stream) {
     AT_REQUIRE(a.N % 2 == 0 && a.N >= 16 && a.B >= 1, "fused stage 0 needs an even sample count");
     const size_t lds = (size_t)S0_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_stage0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_stage0_kernel, lds)) return rc; }
     const long long tiles = (long long)a.B * ((a.N + S0_ADV - 1) / S0_ADV);
     const int grid = (int)(tiles < 512 ? tiles : 512);   // two resident workgroups per CU
     hipLaunchKernelGGL(seanet_stage0_kernel, dim3(grid), dim3(256), lds, stream, a);

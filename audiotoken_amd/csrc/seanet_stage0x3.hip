@@ -243,11 +243,7 @@ int launch_seanet_stage0x3(const Stage0Args& a, hipStream_t stream) {
     AT_REQUIRE(a.N % 2 == 0 && a.N >= 16 && a.B >= 1, "fused stage 0 needs an even sample count");
     const long long tiles = (long long)a.B * ((a.N + SX_ADV - 1) / SX_ADV);
     AT_REQUIRE(tiles < (1LL << 30), "tile arithmetic is 32-bit");
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seanet_stage0x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SX_LDS_BYTES));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_stage0x3_kernel, SX_LDS_BYTES)) return rc; }
     const int grid = (int)(tiles < 512 ? tiles : 512);   // two resident workgroups per CU
     hipLaunchKernelGGL(seanet_stage0x3_kernel, dim3(grid), dim3(256), SX_LDS_BYTES, stream, a);
     AT_CHECK_HIP(hipGetLastError());

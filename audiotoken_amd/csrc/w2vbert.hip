@@ -47,9 +47,14 @@ struct LayerW {
     const float *ln_conv_g, *ln_conv_b, *pw1, *dw, *ln_dw_g, *ln_dw_b, *pw2;
     const float *ln_ffn2_g, *ln_ffn2_b, *w2a, *b2a, *w2b, *b2b;
     const float *ln_fin_g, *ln_fin_b;
-    // split-bf16 weights of the linear layers (gemm_bf16x3.hip)
-    const __bf16 *w1a_s = nullptr, *w1b_s = nullptr, *w2a_s = nullptr, *w2b_s = nullptr, *wqkv_s = nullptr, *wo_s = nullptr, *pw1_s = nullptr, *pw2_s = nullptr;
+    // the eight linear layers as 16-bit operand pieces (gemm_bf16x3.hip), per scheme [XB_SCHEME_*][W_*]; split lazily per scheme.
+    // wscale: the power of two the fp16 scheme multiplied that weight by (max |w s| in [2^14, 2^15))
+    const piece_t* ws[2][8] = {};
+    float wscale[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
 };
+enum { W_1A = 0, W_1B, W_2A, W_2B, W_QKV, W_O, W_PW1, W_PW2 };
+// arithmetic of the linear layers: the fp32 MFMA, or operand splits on the 16-bit matrix cores (gemm_bf16x3.h)
+enum { ARITH_F32 = 0, ARITH_BF16X3 = 1, ARITH_F16X2 = 2 };
 }  // namespace
 
 struct at_w2vbert {
@@ -62,13 +67,13 @@ struct at_w2vbert {
     const float *fp_ln_g = nullptr, *fp_ln_b = nullptr, *fp_w = nullptr, *fp_b = nullptr;
     std::vector<LayerW> layers;
     const float *codebook = nullptr, *e2 = nullptr;
-    bool bf16x3_ffn = false;   // feed-forward layers on the bf16 matrix cores with exact 3-way operand splits ($AUDIOTOKEN_BF16X3)
+    int arith = ARITH_F16X2;   // linear layers: ARITH_* ($AUDIOTOKEN_SEMANTIC_ARITH = f32 | bf16x3 | f16x2; option "arith")
+    bool split_done[2] = {false, false};
+    std::map<const float*, float> wmax;   // max |w| of every uploaded tensor (the fp16 scheme's weight scales)
     Profiler prof;
 };
 
 namespace {
-
-constexpr bool kBf16x3Default = true;
 
 const HostTensor* find(const at_w2vbert* h, const std::string& name) {
     auto it = h->staged.find(name);
@@ -82,6 +87,9 @@ const float* upload(at_w2vbert* h, const std::vector<float>& v) {
     if (hipMalloc((void**)&d, n * sizeof(float)) != hipSuccess) return nullptr;
     if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     h->allocs.push_back(d);
+    float mx = 0.f;
+    for (float x : v) mx = std::fmax(mx, std::fabs(x));
+    h->wmax[d] = mx;
     return d;
 }
 
@@ -142,29 +150,63 @@ int linear(const float* X, int K, const float* W, const float* bias, float* C, i
     return launch_gemm(a, stream);
 }
 
-// x += 0.5 * (swish(t1 . W1^T + b1) . W2^T + b2) on the bf16 matrix cores: t1 is split into 3 bf16 pieces, the hidden activation is
-// written split by the first GEMM's epilogue, the second GEMM adds the residual in fp32 (gemm_bf16x3.hip)
-int ffn_bf16x3(const float* t1, const __bf16* w1s, const float* b1, const __bf16* w2s, const float* b2, float* x, __bf16* t1s, __bf16* bigs,
-               long long M, long long Mpad, hipStream_t stream) {
-    if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream)) return rc;
-    Bf16x3Args a;
-    a.A = t1s; a.W = w1s; a.bias = b1; a.M = (int)M; a.N = kFfn; a.K = kHid; a.Mpad = (int)Mpad;
-    a.epi = XB_EPI_SWISH_SPLIT; a.S = bigs; a.Spad = (int)Mpad;
-    if (int rc = launch_gemm_bf16x3(a, stream)) return rc;
-    Bf16x3Args b;
-    b.A = bigs; b.W = w2s; b.bias = b2; b.M = (int)M; b.N = kHid; b.K = kFfn; b.Mpad = (int)Mpad;
-    b.epi = XB_EPI_LINEAR; b.C = x; b.ldc = kHid; b.R = x; b.ldr = kHid; b.alpha = 0.5f;
-    return launch_gemm_bf16x3(b, stream);
+// Split the eight linear layers of every conformer layer into the 16-bit pieces of `scheme` (once per scheme)
+int split_weights(at_w2vbert* h, int scheme) {
+    if (h->split_done[scheme]) return 0;
+    const int np = xb_pieces(scheme);
+    for (LayerW& L : h->layers) {
+        const float* src[8] = {L.w1a, L.w1b, L.w2a, L.w2b, L.wqkv, L.wo, L.pw1, L.pw2};
+        const int ns[8] = {kFfn, kHid, kFfn, kHid, 3 * kHid, kHid, 2 * kHid, kHid}, ks[8] = {kHid, kFfn, kHid, kFfn, kHid, kHid, kHid, kHid};
+        for (int j = 0; j < 8; ++j) {
+            const int n = ns[j], k = ks[j];
+            piece_t* d = nullptr;
+            AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)np * n * k * sizeof(piece_t)));
+            h->allocs.push_back(reinterpret_cast<float*>(d));
+            float sc = 1.0f;
+            if (scheme == XB_SCHEME_F16X2) {
+                auto it = h->wmax.find(src[j]);
+                AT_REQUIRE(it != h->wmax.end(), "weight maximum not recorded");
+                sc = xb_weight_scale(it->second);
+                L.wscale[j] = sc;
+            }
+            if (int rc = launch_split_blocked(src[j], k, n, n, k, d, nullptr, scheme, sc, nullptr)) return rc;
+            L.ws[scheme][j] = d;
+        }
+    }
+    AT_CHECK_HIP(hipDeviceSynchronize());
+    h->split_done[scheme] = true;
+    return 0;
 }
 
-// C = epi(X . W^T): fp32 row-major X [M][1024] is split into 3 bf16 pieces (t1s), then the split-bf16 GEMM
-int linear_x3(const float* X, const __bf16* Ws, const float* bias, float* C, int N, long long M, long long Mpad, int epi, float alpha,
-              const float* R, int ldc, __bf16* t1s, hipStream_t stream) {
-    if (int rc = launch_split_blocked(X, kHid, M, Mpad, kHid, t1s, stream)) return rc;
+// One split-operand GEMM of the conformer: C / S = epi(A . W^T) with A given as pieces (gemm_bf16x3.hip)
+struct SplitCtx {
+    int scheme; int* status;
+    float act_scale() const { return scheme == XB_SCHEME_F16X2 ? XB_F16_ACT_SCALE : 1.0f; }
+};
+int gemm_split(const SplitCtx& c, const piece_t* A, const LayerW& L, int w, const float* bias, int N, int K, long long M, long long Mpad, int epi,
+               float alpha, float* C, const float* R, int ldc, piece_t* S, hipStream_t stream) {
     Bf16x3Args a;
-    a.A = t1s; a.W = Ws; a.bias = bias; a.M = (int)M; a.N = N; a.K = kHid; a.Mpad = (int)Mpad;
-    a.epi = epi; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc; a.alpha = alpha;
+    a.A = A; a.W = L.ws[c.scheme][w]; a.bias = bias; a.M = (int)M; a.N = N; a.K = K; a.Mpad = (int)Mpad;
+    a.epi = epi; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc; a.alpha = alpha; a.S = S; a.Spad = (int)Mpad;
+    a.scheme = c.scheme; a.status = c.status;
+    if (c.scheme == XB_SCHEME_F16X2) { a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[w]); a.split_scale = XB_F16_ACT_SCALE; }
     return launch_gemm_bf16x3(a, stream);
+}
+
+// x += 0.5 * (swish(t1 . W1^T + b1) . W2^T + b2): t1 is split into pieces, the hidden activation is written split by the first GEMM's
+// epilogue, the second GEMM adds the residual in fp32
+int ffn_split(const SplitCtx& c, const float* t1, const LayerW& L, int w1, const float* b1, int w2, const float* b2, float* x, piece_t* t1s, piece_t* bigs,
+              long long M, long long Mpad, hipStream_t stream) {
+    if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream, c.scheme, c.act_scale(), c.status)) return rc;
+    if (int rc = gemm_split(c, t1s, L, w1, b1, kFfn, kHid, M, Mpad, XB_EPI_SWISH_SPLIT, 1.f, nullptr, nullptr, kFfn, bigs, stream)) return rc;
+    return gemm_split(c, bigs, L, w2, b2, kHid, kFfn, M, Mpad, XB_EPI_LINEAR, 0.5f, x, x, kHid, nullptr, stream);
+}
+
+// C = epi(X . W^T): fp32 row-major X [M][1024] is split into pieces (t1s), then the split GEMM
+int linear_split(const SplitCtx& c, const float* X, const LayerW& L, int w, const float* bias, float* C, int N, long long M, long long Mpad, int epi, float alpha,
+                 const float* R, int ldc, piece_t* t1s, hipStream_t stream) {
+    if (int rc = launch_split_blocked(X, kHid, M, Mpad, kHid, t1s, stream, c.scheme, c.act_scale(), c.status)) return rc;
+    return gemm_split(c, t1s, L, w, bias, N, kHid, M, Mpad, epi, alpha, C, R, ldc, nullptr, stream);
 }
 
 }  // namespace
@@ -195,7 +237,8 @@ int at_w2vbert_set_tensor(at_w2vbert_t* h, const char* name, const float* host_d
 
 int at_w2vbert_finalize(at_w2vbert_t* h) {
     AT_REQUIRE(h && !h->finalized, "bad handle");
-    AT_CHECK_HIP(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
     bool ok = true;
     // ---- front-end tables --------------------------------------------------------------------
     h->window = take(h, "frontend.window", {kFrame}, ok);
@@ -321,32 +364,23 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
     }
     h->staged.clear();
     {
-        const char* e = std::getenv("AUDIOTOKEN_BF16X3");
-        h->bf16x3_ffn = e ? std::atoi(e) != 0 : kBf16x3Default;
-    }
-    if (h->bf16x3_ffn) {
-        for (LayerW& L : h->layers) {
-            const float* src[8] = {L.w1a, L.w1b, L.w2a, L.w2b, L.wqkv, L.wo, L.pw1, L.pw2};
-            const __bf16** dst[8] = {&L.w1a_s, &L.w1b_s, &L.w2a_s, &L.w2b_s, &L.wqkv_s, &L.wo_s, &L.pw1_s, &L.pw2_s};
-            const int ns[8] = {kFfn, kHid, kFfn, kHid, 3 * kHid, kHid, 2 * kHid, kHid}, ks[8] = {kHid, kFfn, kHid, kFfn, kHid, kHid, kHid, kHid};
-            for (int j = 0; j < 8; ++j) {
-                const int n = ns[j], k = ks[j];
-                __bf16* d = nullptr;
-                AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * n * k * sizeof(__bf16)));
-                h->allocs.push_back(reinterpret_cast<float*>(d));
-                if (int rc = launch_split_blocked(src[j], k, n, n, k, d, nullptr)) return rc;
-                *dst[j] = d;
-            }
+        h->arith = ARITH_F16X2;
+        if (const char* e = std::getenv("AUDIOTOKEN_BF16X3")) if (std::atoi(e) == 0) h->arith = ARITH_F32;   // round-1 switch, kept
+        if (const char* e = std::getenv("AUDIOTOKEN_SEMANTIC_ARITH")) {
+            const std::string v(e);
+            AT_REQUIRE(v == "f32" || v == "bf16x3" || v == "f16x2", "AUDIOTOKEN_SEMANTIC_ARITH must be f32, bf16x3 or f16x2");
+            h->arith = v == "f32" ? ARITH_F32 : v == "bf16x3" ? ARITH_BF16X3 : ARITH_F16X2;
         }
-        AT_CHECK_HIP(hipDeviceSynchronize());
     }
+    if (h->arith != ARITH_F32)
+        if (int rc = split_weights(h, h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
     h->finalized = true;
     return 0;
 }
 
 void at_w2vbert_destroy(at_w2vbert_t* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);   // restores the caller's current device (destroy runs from garbage collection in Python)
     for (float* p : h->allocs) (void)hipFree(p);
     if (h->dft64) (void)hipFree(h->dft64);
     delete h;
@@ -386,10 +420,41 @@ int at_w2vbert_profile_read(at_w2vbert_t* h, char* names, size_t names_cap, floa
     return n;
 }
 
+int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value) {
+    AT_REQUIRE(h && h->finalized && name, "bad handle");
+    const std::string n(name);
+    if (n == "arith") {
+        AT_REQUIRE(value == ARITH_F32 || value == ARITH_BF16X3 || value == ARITH_F16X2, "arith: 0 = f32 MFMA, 1 = bf16x3, 2 = f16x2");
+        DeviceGuard guard(h->device);
+        AT_REQUIRE(guard.ok, "cannot select the handle's device");
+        if (value != ARITH_F32)
+            if (int rc = split_weights(h, value == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
+        h->arith = value;
+        return 0;
+    }
+    set_error("at_w2vbert_set_option: unknown option " + n);
+    return -1;
+}
+
+int at_w2vbert_get_option(const at_w2vbert_t* h, const char* name) {
+    if (!h || !name) return -1;
+    if (std::string(name) == "arith") return h->arith;
+    return -1;
+}
+
 int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int B, int N, int pad_to_multiple_of, int n_layers,
                       int16_t* tokens, int* T_out, float* features_out, float* attn_mask_out, float* hidden_out, void* workspace,
                       size_t workspace_bytes, at_stream_t stream_) {
+    return at_w2vbert_encode_checked(h, wav, mask, B, N, pad_to_multiple_of, n_layers, tokens, T_out, features_out, attn_mask_out, hidden_out,
+                                     workspace, workspace_bytes, stream_, nullptr);
+}
+
+int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* mask, int B, int N, int pad_to_multiple_of, int n_layers,
+                              int16_t* tokens, int* T_out, float* features_out, float* attn_mask_out, float* hidden_out, void* workspace,
+                              size_t workspace_bytes, at_stream_t stream_, int32_t* status_dev) {
     AT_REQUIRE(h && h->finalized, "model not finalized");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
     AT_REQUIRE(wav && workspace, "null pointer");
     AT_REQUIRE(B >= 1 && N >= kFrame + kHop, "need B >= 1 and at least two frames (N >= 560 samples)");
     AT_REQUIRE(n_layers >= 0 && n_layers <= (int)h->layers.size(), "n_layers exceeds the loaded layers");
@@ -403,6 +468,9 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
     const long long M = (long long)B * T, BF = (long long)B * F;
     if (T_out) *T_out = T;
     Profiler& prof = h->prof;
+    if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
+    const bool split = h->arith != ARITH_F32;
+    const SplitCtx sc{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, reinterpret_cast<int*>(status_dev)};
 
     // ---- log-mel front-end (reference processors.py) -------------------------------------------
     double* frames = reinterpret_cast<double*>(ws + p.off_frames);
@@ -427,8 +495,8 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
     float* x = ws + p.off_x;
     float* t1 = ws + p.off_t1;
     float* big = ws + p.off_big;
-    __bf16* t1s = reinterpret_cast<__bf16*>(ws + p.off_t1s);
-    __bf16* bigs = reinterpret_cast<__bf16*>(ws + p.off_bigs);
+    piece_t* t1s = reinterpret_cast<piece_t*>(ws + p.off_t1s);
+    piece_t* bigs = reinterpret_cast<piece_t*>(ws + p.off_bigs);
     prof.begin("feature_projection", 2, stream);
     if (int rc = launch_layernorm(feats, h->fp_ln_g, h->fp_ln_b, nullptr, t1, M, kFeat, stream)) return rc;
     if (int rc = linear(t1, kFeat, h->fp_w, h->fp_b, x, kHid, M, EPI_NONE, 1.f, nullptr, amask, kHid, stream)) return rc;
@@ -438,8 +506,8 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
         const LayerW& L = h->layers[li];
         prof.begin("ffn", 3, stream);
         if (int rc = launch_layernorm(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, t1, M, kHid, stream)) return rc;
-        if (h->bf16x3_ffn) {
-            if (int rc = ffn_bf16x3(t1, L.w1a_s, L.b1a, L.w1b_s, L.b1b, x, t1s, bigs, M, (long long)p.Mpad, stream)) return rc;
+        if (split) {
+            if (int rc = ffn_split(sc, t1, L, W_1A, L.b1a, W_1B, L.b1b, x, t1s, bigs, M, (long long)p.Mpad, stream)) return rc;
         } else {
             if (int rc = linear(t1, kHid, L.w1a, L.b1a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
             if (int rc = linear(big, kFfn, L.w1b, L.b1b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
@@ -448,8 +516,8 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
 
         prof.begin("attn_proj", 3, stream);
         if (int rc = launch_layernorm(x, L.ln_att_g, L.ln_att_b, nullptr, t1, M, kHid, stream)) return rc;
-        if (h->bf16x3_ffn) {
-            if (int rc = linear_x3(t1, L.wqkv_s, L.bqkv, big, 3 * kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, nullptr, 3 * kHid, t1s, stream)) return rc;
+        if (split) {
+            if (int rc = linear_split(sc, t1, L, W_QKV, L.bqkv, big, 3 * kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, nullptr, 3 * kHid, t1s, stream)) return rc;
         } else if (int rc = linear(t1, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, 1.f, nullptr, nullptr, 3 * kHid, stream)) {
             return rc;
         }
@@ -458,8 +526,8 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
         if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
-        if (h->bf16x3_ffn) {
-            if (int rc = linear_x3(t1, L.wo_s, L.bo, x, kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, x, kHid, t1s, stream)) return rc;
+        if (split) {
+            if (int rc = linear_split(sc, t1, L, W_O, L.bo, x, kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, x, kHid, t1s, stream)) return rc;
         } else if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) {
             return rc;
         }
@@ -467,14 +535,14 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
 
         prof.begin("conv_module", 4, stream);
         if (int rc = launch_layernorm(x, L.ln_conv_g, L.ln_conv_b, amask, t1, M, kHid, stream)) return rc;
-        if (h->bf16x3_ffn) {
-            if (int rc = linear_x3(t1, L.pw1_s, nullptr, big, 2 * kHid, M, (long long)p.Mpad, XB_EPI_GLU, 1.f, nullptr, kHid, t1s, stream)) return rc;
+        if (split) {
+            if (int rc = linear_split(sc, t1, L, W_PW1, nullptr, big, 2 * kHid, M, (long long)p.Mpad, XB_EPI_GLU, 1.f, nullptr, kHid, t1s, stream)) return rc;
         } else if (int rc = linear(t1, kHid, L.pw1, nullptr, big, 2 * kHid, M, EPI_GLU, 1.f, nullptr, nullptr, kHid, stream)) {
             return rc;
         }
         if (int rc = launch_dwconv_ln_swish(big, L.dw, L.ln_dw_g, L.ln_dw_b, t1, B, T, stream)) return rc;
-        if (h->bf16x3_ffn) {
-            if (int rc = linear_x3(t1, L.pw2_s, nullptr, x, kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, x, kHid, t1s, stream)) return rc;
+        if (split) {
+            if (int rc = linear_split(sc, t1, L, W_PW2, nullptr, x, kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, x, kHid, t1s, stream)) return rc;
         } else if (int rc = linear(t1, kHid, L.pw2, nullptr, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) {
             return rc;
         }
@@ -482,8 +550,8 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
 
         prof.begin("ffn", 4, stream);
         if (int rc = launch_layernorm(x, L.ln_ffn2_g, L.ln_ffn2_b, nullptr, t1, M, kHid, stream)) return rc;
-        if (h->bf16x3_ffn) {
-            if (int rc = ffn_bf16x3(t1, L.w2a_s, L.b2a, L.w2b_s, L.b2b, x, t1s, bigs, M, (long long)p.Mpad, stream)) return rc;
+        if (split) {
+            if (int rc = ffn_split(sc, t1, L, W_2A, L.b2a, W_2B, L.b2b, x, t1s, bigs, M, (long long)p.Mpad, stream)) return rc;
         } else {
             if (int rc = linear(t1, kHid, L.w2a, L.b2a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
             if (int rc = linear(big, kFfn, L.w2b, L.b2b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;

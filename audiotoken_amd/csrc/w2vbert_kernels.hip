@@ -550,12 +550,7 @@ int launch_relpos_attention(const float* qkv, const float* amask, const float* d
     if (x3) return launch_relpos_attention_x3(qkv, amask, dist_emb, ctx, B, T, stream, heads);
     dim3 grid((T + ATT_QB - 1) / ATT_QB, heads, B);
     const size_t lds = ATT_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, relpos_attention_kernel, lds)) return rc; }
     hipLaunchKernelGGL(relpos_attention_kernel, grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T, heads * 64);
     AT_CHECK_HIP(hipGetLastError());
     return 0;

@@ -28,6 +28,24 @@ class AcousticDecoder(torch.nn.Module):
         self._h = _EncodecHandle(device, weights if weights is not None else config.weights, with_decoder=True)
         self.device = self._h.device
         self._ws: Optional[torch.Tensor] = None
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def last_status(self) -> int:
+        """0 = ok, 1 = a bounded wait inside the persistent LSTM kernel gave up (synchronises the device)."""
+        return int(self._status.item())
+
+    def verified(self, wav: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
+        """As AcousticEncoder.verified: on an LSTM hand-off time-out repeat the decode with per-step LSTM launches."""
+        status = self.last_status()
+        if status == 0:
+            return wav
+        logger.error(f"persistent LSTM hand-off timed out in the decoder (status {status}): waveform discarded; "
+                     "decoding again with per-step LSTM launches (option persistent_lstm=0) from now on")
+        self.set_option("persistent_lstm", 0)
+        wav = self.forward(tokens)
+        if self.last_status() != 0:
+            raise _cabi.HipLibraryError("acoustic decode failed twice (LSTM status non-zero with per-step launches)")
+        return wav
 
     def set_option(self, name: str, value: int) -> None:
         """Kernel-selection switches of the library (results are bit-identical either way; used by the parity tests)."""
@@ -45,7 +63,7 @@ class AcousticDecoder(torch.nn.Module):
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            rc = lib.at_encodec_decode(self._h.handle, codes.data_ptr(), B, K, T, out.data_ptr(), self._ws.data_ptr(), nbytes,
-                                       _cabi.current_stream_handle(self.device))
-        _cabi.check(rc, "at_encodec_decode")
+            rc = lib.at_encodec_decode_checked(self._h.handle, codes.data_ptr(), B, K, T, out.data_ptr(), self._ws.data_ptr(), nbytes,
+                                               _cabi.current_stream_handle(self.device), self._status.data_ptr())
+        _cabi.check(rc, "at_encodec_decode_checked")
         return out

@@ -138,6 +138,21 @@ class AcousticEncoder(torch.nn.Module):
         """0 = ok, 1 = a bounded wait inside the persistent LSTM kernel gave up (synchronises the device)."""
         return int(self._status.item())
 
+    def verified(self, codes: torch.Tensor, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Product-path guard, called where the caller synchronises anyway (tokens leaving the device): if the persistent LSTM
+        reported a hand-off time-out for the call that produced `codes` (another process on the GPU, a partitioned device: not all
+        256 workgroups resident), log it and repeat the batch with the per-step LSTM launches, which need no co-residency."""
+        status = self.last_status()
+        if status == 0:
+            return codes
+        logger.error(f"persistent LSTM hand-off timed out (status {status}): the tokens of this batch were discarded; "
+                     "re-encoding with per-step LSTM launches (option persistent_lstm=0) from now on")
+        self.set_option("persistent_lstm", 0)
+        codes = self.forward(input_batch, attention_mask)
+        if self.last_status() != 0:
+            raise _cabi.HipLibraryError("acoustic encode failed twice (LSTM status non-zero with per-step launches)")
+        return codes
+
     @torch.no_grad()
     def forward(self, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 return_embeddings: bool = False):
@@ -251,11 +266,41 @@ class Wav2VecBertEncoder(torch.nn.Module):
         if self.n_layers < self.output_layer:
             raise ValueError(f"checkpoint has {self.n_layers} conformer layers, output_layer={self.output_layer} needs that many")
         self._ws: Optional[torch.Tensor] = None
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def __del__(self):
         h = self.__dict__.pop("handle", None)
         if h:
             self.lib.at_w2vbert_destroy(h)
+
+    ARITH = {"f32": 0, "bf16x3": 1, "f16x2": 2}
+
+    def set_option(self, name: str, value) -> None:
+        """"arith": "f32" | "bf16x3" | "f16x2" (or 0/1/2) — arithmetic of the linear layers (include/audiotoken_hip.h)."""
+        if isinstance(value, str):
+            value = self.ARITH[value]
+        _cabi.check(self.lib.at_w2vbert_set_option(self.handle, name.encode(), int(value)), f"at_w2vbert_set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        return int(self.lib.at_w2vbert_get_option(self.handle, name.encode()))
+
+    def last_status(self) -> int:
+        """0 = ok; bit 1 (2) = an activation overflowed the fp16 range of the f16x2 arithmetic (synchronises the device)."""
+        return int(self._status.item())
+
+    def verified(self, tokens: torch.Tensor, input_batch: torch.Tensor, mask: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
+        """Product-path guard, called where the caller synchronises anyway: if the call that produced `tokens` reported an fp16
+        range overflow, log it, switch the linear layers to the bf16x3 arithmetic (full fp32 exponent range) and repeat the batch."""
+        status = self.last_status()
+        if status == 0:
+            return tokens
+        logger.error(f"semantic_m encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
+                     "the tokens of this batch were discarded; re-encoding with arith=bf16x3 from now on")
+        self.set_option("arith", "bf16x3")
+        tokens = self.forward(input_batch, mask, **kw)
+        if self.last_status() != 0:
+            raise _cabi.HipLibraryError("semantic_m encode failed twice (status non-zero with bf16x3 arithmetic)")
+        return tokens
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes:
@@ -286,10 +331,11 @@ class Wav2VecBertEncoder(torch.nn.Module):
         ws = self._workspace(nbytes)
         t_out = C.c_int(0)
         with torch.cuda.device(self.device):
-            rc = self.lib.at_w2vbert_encode(self.handle, x.data_ptr(), _cabi.ptr(m), B, N, pad_to_multiple_of, nl,
-                                            _cabi.ptr(tokens), C.byref(t_out), _cabi.ptr(feats), _cabi.ptr(amask),
-                                            _cabi.ptr(hidden), ws.data_ptr(), nbytes, _cabi.current_stream_handle(self.device))
-        _cabi.check(rc, "at_w2vbert_encode")
+            rc = self.lib.at_w2vbert_encode_checked(self.handle, x.data_ptr(), _cabi.ptr(m), B, N, pad_to_multiple_of, nl,
+                                                    _cabi.ptr(tokens), C.byref(t_out), _cabi.ptr(feats), _cabi.ptr(amask),
+                                                    _cabi.ptr(hidden), ws.data_ptr(), nbytes, _cabi.current_stream_handle(self.device),
+                                                    self._status.data_ptr())
+        _cabi.check(rc, "at_w2vbert_encode_checked")
         assert t_out.value == T
         if return_taps:
             return tokens, {"input_features": feats, "attention_mask": amask, "hidden": hidden}

@@ -80,6 +80,8 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
  *   stage-2 / stage-3 convs + 256-channel block (as chained GEMMs) the LSTM recurrence and the RVQ search on the bf16 matrix cores with exact 3-way bf16 splits of every
  *   operand (default on; $AUDIOTOKEN_X3_KERNELS bit mask, bits 3, 2, 1, 0, 4, 5, 6, 7, 8 in that order; 0 = the fp32-MFMA kernels:
  *   same tokens, embeddings differ in the last bits);
+ *   "lstm_spin_limit" n >= 0 — polls of a hand-off flag before a workgroup of the persistent LSTM gives up and the status word of the
+ *   *_checked entry points becomes 1 (default 2^18, i.e. 0.1-0.3 s; 0 makes the first unready poll give up — used by the tests);
  *   "subbatch" n >= 1 — clips per pass through the conv stack (default 256 or $AUDIOTOKEN_SUBBATCH): bounds
  *   at_encodec_workspace_bytes / at_encodec_decode_workspace_bytes, which must be re-queried after changing it. */
 int at_encodec_set_option(at_encodec_t* h, const char* name, int value);
@@ -97,6 +99,9 @@ size_t at_encodec_decode_workspace_bytes(const at_encodec_t* h, int B, int T);
  * wav device float32 [B*320*T] (the reference's [1, B*320*T] row). */
 int at_encodec_decode(at_encodec_t* h, const int64_t* codes, int B, int K, int T, float* wav, void* workspace,
                       size_t workspace_bytes, at_stream_t stream);
+/* Same, plus the device status word of at_encodec_encode_checked (the decoder runs the same persistent LSTM). */
+int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int K, int T, float* wav, void* workspace,
+                              size_t workspace_bytes, at_stream_t stream, uint32_t* status_dev);
 
 /* ---- semantic_m tokenizer: log-mel front-end + Wav2Vec2-BERT conformer + LayerNorm + VQ ------------------
  * Replaces reference Wav2VecBertEncoder (audiotoken/encoder.py:111-186): ctor = Wav2VecBertProcessor +
@@ -130,6 +135,18 @@ size_t at_w2vbert_workspace_bytes(const at_w2vbert_t* h, int B, int N, int pad_t
 int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int B, int N, int pad_to_multiple_of, int n_layers,
                       int16_t* tokens, int* T_out, float* features_out, float* attn_mask_out, float* hidden_out, void* workspace,
                       size_t workspace_bytes, at_stream_t stream);
+/* Same as at_w2vbert_encode, plus a device int32 status word (stream-ordered: zeroed at the start of the call, final when the call's work
+ * has completed): bit 1 (value 2) = an activation did not fit the fp16 range of the "f16x2" arithmetic (|x| > 65504 / 16) — the
+ * tokens are then invalid and the caller should repeat the batch after at_w2vbert_set_option(h, "arith", 1). */
+int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* mask, int B, int N, int pad_to_multiple_of, int n_layers,
+                              int16_t* tokens, int* T_out, float* features_out, float* attn_mask_out, float* hidden_out, void* workspace,
+                              size_t workspace_bytes, at_stream_t stream, int32_t* status_dev);
+/* Options. "arith": arithmetic of the eight linear layers per conformer layer — 0 = f32-input MFMA; 1 = "bf16x3": exact 3-way bf16
+ * operand splits, six products on the bf16 matrix cores; 2 = "f16x2" (default, also $AUDIOTOKEN_SEMANTIC_ARITH=f32|bf16x3|f16x2): two fp16
+ * pieces per operand, three products, operands pre-scaled by powers of two (fp32-class accuracy: csrc/gemm_bf16x3.h). Weights are split
+ * for a scheme the first time it is selected. at_w2vbert_get_option returns the current value (or -1). */
+int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value);
+int at_w2vbert_get_option(const at_w2vbert_t* h, const char* name);
 int at_w2vbert_profile(at_w2vbert_t* h, int enable);
 int at_w2vbert_profile_read(at_w2vbert_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups);
 
