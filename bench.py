@@ -561,6 +561,9 @@ def run_semantic(args, rank, world, dev, dist):
     T = toks.shape[-1]
     F = 1 + (N - 400) // 160
     flops = semantic_flops_per_clip(T, nl, F)
+    arith = enc.get_option("arith")                    # 0 f32 MFMA, 1 bf16x3 (six products), 2 f16x2 (three products)
+    products = {0: 1, 1: 6, 2: 3}[arith]
+    assert enc.last_status() == 0, "semantic_m status word non-zero (fp16 range overflow): the timed run is invalid"
     breakdown = {}
     for k, (per, launches) in prof.items():
         breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches,
@@ -568,12 +571,13 @@ def run_semantic(args, rank, world, dev, dist):
     res = {
         "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "median_ms_per_step": round(median(per_step), 3), "elapsed": elapsed, "audio_s_per_step": world * B * secs, "rank_ms": rank_ms,
-        "dtype": "f32 (linear layers: exact bf16x3 splits, fp32 accumulate)" if BF16X3 else "f32",
+        "dtype": {0: "f32", 1: "f32 (linear layers: three bf16 pieces per operand, six MFMA products, fp32 accumulate)",
+                  2: "f32 (linear layers: two fp16 pieces per operand, three MFMA products, fp32 accumulate)"}[arith],
         "config": {"workload": f"Tokenizers.semantic_m encode, {B} clips x {secs:g} s @16 kHz per GPU, {nl} conformer layers, VQ 2048x1024",
                    "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0",
                    "parallelism": f"clip-sharded x{world}, no data-path collective",
                    "note": "BASELINE configs[3] is 512 clips over 8 GPUs = 64 per GPU; at N=1 one step is one such 64-clip micro-batch"},
-        "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if BF16X3 else (), "semantic_m"), "breakdown": breakdown,
+        "roofline": roofline_of(breakdown, flops, None, B, ("ffn", "attn_proj", "conv_module") if arith else (), "semantic_m", products), "breakdown": breakdown,
         "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)",
         "token_checksum": int(toks.to(torch.int64).sum().item()),
         "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),

@@ -166,9 +166,13 @@ def rvq_encode(w, emb: torch.Tensor, n_q: int, return_margins: bool = False):
     return (codes, torch.stack(margins)) if return_margins else codes
 
 
-def acoustic_encode(w, wav: torch.Tensor, n_q: int) -> torch.Tensor:
-    """Reference AcousticEncoder.forward (audiotoken/encoder.py:44-57): int16 [B, n_q, T]."""
+def acoustic_encode(w, wav: torch.Tensor, n_q: int, return_margins: bool = False):
+    """Reference AcousticEncoder.forward (audiotoken/encoder.py:44-57): int16 [B, n_q, T]. With return_margins also the
+    oracle's own top-2 distance margin of every choice, [B, n_q, T] (what a differing id is explained by, or not)."""
     emb = seanet_encode(w, wav)
+    if return_margins:
+        codes, margins = rvq_encode(w, emb, n_q, return_margins=True)
+        return codes.transpose(0, 1).to(torch.int16), margins.transpose(0, 1)
     codes = rvq_encode(w, emb, n_q)
     return codes.transpose(0, 1).to(torch.int16)
 

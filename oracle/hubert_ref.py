@@ -118,10 +118,13 @@ def kmeans_assign(e: torch.Tensor, centers: torch.Tensor, return_margin: bool = 
     return idx
 
 
-def semantic_s_encode(w, wave: torch.Tensor, mask: torch.Tensor, n_layers: int = 11) -> torch.Tensor:
+def semantic_s_encode(w, wave: torch.Tensor, mask: torch.Tensor, n_layers: int = 11, return_margins: bool = False):
     """Reference HubertEncoder.__call__ (audiotoken/encoder.py:87-108): int16 [B, 1, T]. `wave` is already normalised
     by hubert_processor (the reference applies it as transform_func before batching)."""
     h = hidden_states(w, wave, mask, n_layers)
     e = F.layer_norm(h, (HIDDEN,))
+    if return_margins:   # also the oracle's own top-2 distance margin per token, [B, 1, T]
+        idx, margin = kmeans_assign(e, _t(w, "kmeans.cluster_centers_"), return_margin=True)
+        return idx.unsqueeze(-1).transpose(1, 2).to(torch.int16), margin.unsqueeze(-1).transpose(1, 2)
     idx = kmeans_assign(e, _t(w, "kmeans.cluster_centers_"))
     return idx.unsqueeze(-1).transpose(1, 2).to(torch.int16)

@@ -222,11 +222,15 @@ def vq_assign(x: torch.Tensor, embed: torch.Tensor, return_margin: bool = False)
     return idx
 
 
-def semantic_m_encode(w, wave: torch.Tensor, mask: torch.Tensor, pad_to_multiple_of: int = 2, n_layers: int = 19) -> torch.Tensor:
-    """Reference Wav2VecBertEncoder.forward with quantize=True (audiotoken/encoder.py:163-184): int16 [B, 1, T']."""
+def semantic_m_encode(w, wave: torch.Tensor, mask: torch.Tensor, pad_to_multiple_of: int = 2, n_layers: int = 19, return_margins: bool = False):
+    """Reference Wav2VecBertEncoder.forward with quantize=True (audiotoken/encoder.py:163-184): int16 [B, 1, T'].
+    With return_margins also the oracle's own top-2 distance margin per token, [B, 1, T']."""
     feats, am = processor(wave, mask, pad_to_multiple_of)
     h = encoder_hidden_state(w, feats, am, n_layers)
     e = layer_norm(h, w, None, HIDDEN)
     embed = _t(w, "vq._codebook.embed")
+    if return_margins:
+        clusters, margin = vq_assign(e, embed.reshape(-1, embed.shape[-1]), return_margin=True)
+        return clusters.unsqueeze(-1).transpose(1, 2).to(torch.int16), margin.unsqueeze(-1).transpose(1, 2)
     clusters = vq_assign(e, embed.reshape(-1, embed.shape[-1]))
     return clusters.unsqueeze(-1).transpose(1, 2).to(torch.int16)

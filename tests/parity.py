@@ -1,0 +1,51 @@
+"""The parity bar for token ids: equal to the oracle's, or EXPLAINED — the oracle's own top-2 distance margin at the (first) differing
+choice is below a near-tie bound, i.e. the two candidates are closer than the fp32 rounding noise of the embedding that any two fp32
+implementations (two BLAS builds of the reference included) differ by. Nothing else is accepted; the counts are printed."""
+import torch
+
+# near-tie bounds, in the units of the oracle's distance: EnCodec's -(|x|^2 - 2 x.e + |e|^2) at embedding scale ~10 (squared distances
+# ~100-400), cdist (Euclidean) at ~40 for the two semantic tokenizers. 1e-3 is the contract's tolerance for float intermediates.
+RVQ_TIE = 1e-3
+VQ_TIE = 1e-3
+
+
+def explain_token_mismatches(got: torch.Tensor, ref: torch.Tensor, margins: torch.Tensor, tie: float, valid: torch.Tensor = None):
+    """got / ref / margins [B, 1, T] (one choice per position). Returns (n_differing, n_unexplained, largest margin among mismatches)."""
+    got, ref = got.cpu().long(), ref.cpu().long()
+    mism = got != ref
+    if valid is not None:
+        mism = mism & valid.cpu().bool()
+    n = int(mism.sum())
+    if n == 0:
+        return 0, 0, 0.0
+    m = margins.cpu()[mism]
+    return n, int((m >= tie).sum()), float(m.max())
+
+
+def explain_rvq_mismatches(got: torch.Tensor, ref: torch.Tensor, margins: torch.Tensor, tie: float):
+    """got / ref / margins [B, n_q, T]: residual VQ — once a stage differs the later stages quantise a different residual, so a
+    frame is explained by the margin at its FIRST differing stage. Returns (differing ids, differing frames, unexplained frames)."""
+    got, ref = got.cpu().long(), ref.cpu().long()
+    mism = got != ref
+    frames = mism.any(dim=1)                                   # [B, T]
+    if not bool(frames.any()):
+        return 0, 0, 0
+    first = mism.float().argmax(dim=1)                         # first differing stage per frame
+    m0 = margins.cpu().gather(1, first.unsqueeze(1)).squeeze(1)
+    unexplained = frames & (m0 >= tie)
+    return int(mism.sum()), int(frames.sum()), int(unexplained.sum())
+
+
+def assert_tokens_equal_or_explained(got, ref, margins, tie, what, valid=None):
+    n, bad, worst = explain_token_mismatches(got, ref, margins, tie, valid)
+    total = int(valid.sum()) if valid is not None else got.numel()
+    print(f"{what}: {n} of {total} ids differ from the oracle, {bad} not explained by an oracle top-2 margin < {tie:g} (largest margin among them {worst:.2e})")
+    assert bad == 0, f"{what}: {bad} token ids differ from the oracle without a near-tie"
+    return n
+
+
+def assert_rvq_equal_or_explained(got, ref, margins, tie, what):
+    n_ids, n_frames, bad = explain_rvq_mismatches(got, ref, margins, tie)
+    print(f"{what}: {n_ids} of {got.numel()} ids differ ({n_frames} frames), {bad} frames not explained by an oracle top-2 margin < {tie:g} at the first differing stage")
+    assert bad == 0, f"{what}: {bad} frames differ from the oracle without a near-tie"
+    return n_ids
