@@ -79,6 +79,10 @@ SIGNATURES = {
     "at_hubert_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "at_hubert_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "at_hubert_encode_checked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "at_hubert_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "at_hubert_get_option": (C.c_int, [C.c_void_p, C.c_char_p]),
     "at_hubert_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "at_hubert_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "at_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),

@@ -21,63 +21,14 @@
 // parameter, the tile shapes, staging and epilogues are shared.
 #include "at_common.h"
 #include "gemm_bf16x3.h"
+#include "split_scheme.h"
 #include <type_traits>
 #include <cstdlib>
 #include <cmath>
 
 namespace at {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-// The two operand schemes (gemm_bf16x3.h). `prod_a/prod_w` list the cross products in the order they are accumulated, smallest first.
-struct SchemeBf16x3 {
-    typedef __bf16 T; typedef bf16x8 V8; typedef bf16x4 V4;
-    static constexpr int NP = 3, NPROD = 6;
-    static constexpr bool RANGE_CHECK = false;
-    __device__ static constexpr int prod_a(int t) { constexpr int v[6] = {0, 2, 1, 0, 1, 0}; return v[t]; }
-    __device__ static constexpr int prod_w(int t) { constexpr int v[6] = {2, 0, 1, 1, 0, 0}; return v[t]; }
-    __device__ static __forceinline__ f16v mfma(V8 w, V8 a, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0); }
-};
-struct SchemeF16x2 {
-    typedef _Float16 T; typedef f16x8 V8; typedef f16x4 V4;
-    static constexpr int NP = 2, NPROD = 3;
-    static constexpr bool RANGE_CHECK = true;
-    __device__ static constexpr int prod_a(int t) { constexpr int v[3] = {0, 1, 0}; return v[t]; }
-    __device__ static constexpr int prod_w(int t) { constexpr int v[3] = {1, 0, 0}; return v[t]; }
-    __device__ static __forceinline__ f16v mfma(V8 w, V8 a, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, c, 0, 0, 0); }
-};
-
-// a -> NP pieces: p[0] = round(a), p[1] = round(a - p[0]), ... (every subtraction is exact)
-template <class SC>
-__device__ __forceinline__ void split_n(float a, typename SC::T (&p)[SC::NP]) {
-#pragma unroll
-    for (int i = 0; i < SC::NP; ++i) {
-        p[i] = (typename SC::T)a;
-        a -= (float)p[i];
-    }
-}
-// four values * scale -> NP pieces of four; returns true when a value does not fit the scheme's range
-template <class SC>
-__device__ __forceinline__ bool split4(const f4& v, float scale, typename SC::V4 (&p)[SC::NP]) {
-    bool over = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float x = v[k] * scale;
-        if constexpr (SC::RANGE_CHECK) over |= !(fabsf(x) <= 65504.0f);
-        typename SC::T q[SC::NP];
-        split_n<SC>(x, q);
-#pragma unroll
-        for (int i = 0; i < SC::NP; ++i) p[i][k] = q[i];
-    }
-    return over;
-}
-
 float xb_weight_scale(float max_abs) {
     if (!(max_abs > 0.f) || !std::isfinite(max_abs)) return 1.0f;
     return std::exp2(std::floor(std::log2(32767.0f / max_abs)));

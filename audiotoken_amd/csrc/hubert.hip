@@ -31,8 +31,12 @@ struct HostTensor {
 };
 struct LayerW {
     const float *wqkv, *bqkv, *wo, *bo, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
-    const __bf16 *wqkv_s = nullptr, *wo_s = nullptr, *w1_s = nullptr, *w2_s = nullptr;   // split-bf16 weights (gemm_bf16x3.hip)
+    // the four linear layers as 16-bit operand pieces per scheme [XB_SCHEME_*][HW_*] (gemm_bf16x3.h); wscale: the fp16 scheme's weight scales
+    const piece_t* ws[2][4] = {};
+    float wscale[4] = {1.f, 1.f, 1.f, 1.f};
 };
+enum { HW_QKV = 0, HW_O, HW_1, HW_2 };
+enum { ARITH_F32 = 0, ARITH_BF16X3 = 1, ARITH_F16X2 = 2 };
 }  // namespace
 
 struct at_hubert {
@@ -45,8 +49,11 @@ struct at_hubert {
     const float *pos_w = nullptr, *pos_b = nullptr, *enc_ln_g = nullptr, *enc_ln_b = nullptr;
     std::vector<LayerW> layers;
     const float *centers = nullptr, *c2 = nullptr;
-    const __bf16* conv_ws[7] = {};   // split-bf16 conv weights (layers 1..6)
-    bool bf16x3 = false;   // transformer linear layers on the bf16 matrix cores with exact 3-way operand splits ($AUDIOTOKEN_BF16X3, default on)
+    const piece_t* conv_ws[2][7] = {};   // conv weights of layers 1..6 as operand pieces, per scheme
+    float conv_wscale[7] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    int arith = ARITH_F16X2;   // linear layers + conv chain: ARITH_* ($AUDIOTOKEN_SEMANTIC_ARITH = f32 | bf16x3 | f16x2; option "arith")
+    bool split_done[2] = {false, false};
+    std::map<const float*, float> wmax;   // max |w| of every uploaded tensor
     Profiler prof;
 };
 
@@ -62,6 +69,9 @@ const float* upload(at_hubert* h, const std::vector<float>& v) {
     if (hipMalloc((void**)&d, n * sizeof(float)) != hipSuccess) return nullptr;
     if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
     h->allocs.push_back(d);
+    float mx = 0.f;
+    for (float x : v) mx = std::fmax(mx, std::fabs(x));
+    h->wmax[d] = mx;
     return d;
 }
 const float* take(at_hubert* h, const std::string& name, std::vector<int64_t> shape, bool& ok) {
@@ -118,16 +128,55 @@ Plan make_plan(int B, int N) {
     return p;
 }
 
-// C = epi(X . W^T) through the split-bf16 GEMM: X fp32 row-major [M][K] is split into xs first (unless it already is: X == nullptr)
-int linear_x3(const float* X, int K, const __bf16* xs, __bf16* xs_w, const __bf16* Ws, const float* bias, float* C, int N, long long M, long long Mpad,
-              int epi, const float* R, int ldc, __bf16* S, hipStream_t stream) {
+struct SplitCtx {
+    int scheme; int* status;
+    float act_scale() const { return scheme == XB_SCHEME_F16X2 ? XB_F16_ACT_SCALE : 1.0f; }
+};
+
+// Split the conv chain's and the transformer's weights into the 16-bit pieces of `scheme` (once per scheme)
+int split_weights(at_hubert* h, int scheme) {
+    if (h->split_done[scheme]) return 0;
+    const int np = xb_pieces(scheme);
+    auto one = [&](const float* src, int n, int k, const piece_t** dst, float* scale_out) -> int {
+        piece_t* d = nullptr;
+        AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)np * n * k * sizeof(piece_t)));
+        h->allocs.push_back(reinterpret_cast<float*>(d));
+        float sc = 1.0f;
+        if (scheme == XB_SCHEME_F16X2) {
+            auto it = h->wmax.find(src);
+            AT_REQUIRE(it != h->wmax.end(), "weight maximum not recorded");
+            sc = xb_weight_scale(it->second);
+            *scale_out = sc;
+        }
+        if (int rc = launch_split_blocked(src, k, n, n, k, d, nullptr, scheme, sc, nullptr)) return rc;
+        *dst = d;
+        return 0;
+    };
+    for (int i = 1; i < 7; ++i)
+        if (int rc = one(h->conv_w[i], kCd, kKs[i] * kCd, &h->conv_ws[scheme][i], &h->conv_wscale[i])) return rc;
+    for (LayerW& L : h->layers) {
+        const float* src[4] = {L.wqkv, L.wo, L.w1, L.w2};
+        const int ns[4] = {3 * kHid, kHid, kFfn, kHid}, ks[4] = {kHid, kHid, kHid, kFfn};
+        for (int j = 0; j < 4; ++j)
+            if (int rc = one(src[j], ns[j], ks[j], &L.ws[scheme][j], &L.wscale[j])) return rc;
+    }
+    AT_CHECK_HIP(hipDeviceSynchronize());
+    h->split_done[scheme] = true;
+    return 0;
+}
+
+// C = epi(X . W^T) through the split GEMM: X fp32 row-major [M][K] is split into xs first (unless it already is: X == nullptr)
+int linear_split(const SplitCtx& c, const float* X, int K, const piece_t* xs, piece_t* xs_w, const LayerW& L, int w, const float* bias, float* C, int N,
+                 long long M, long long Mpad, int epi, const float* R, int ldc, piece_t* S, hipStream_t stream) {
     if (X) {
-        if (int rc = launch_split_blocked(X, K, M, Mpad, K, xs_w, stream)) return rc;
+        if (int rc = launch_split_blocked(X, K, M, Mpad, K, xs_w, stream, c.scheme, c.act_scale(), c.status)) return rc;
         xs = xs_w;
     }
     Bf16x3Args a;
-    a.A = xs; a.W = Ws; a.bias = bias; a.M = (int)M; a.N = N; a.K = K; a.Mpad = (int)Mpad;
+    a.A = xs; a.W = L.ws[c.scheme][w]; a.bias = bias; a.M = (int)M; a.N = N; a.K = K; a.Mpad = (int)Mpad;
     a.epi = epi; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc; a.alpha = 1.0f; a.S = S; a.Spad = (int)Mpad;
+    a.scheme = c.scheme; a.status = c.status;
+    if (c.scheme == XB_SCHEME_F16X2) { a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[w]); a.split_scale = XB_F16_ACT_SCALE; }
     return launch_gemm_bf16x3(a, stream);
 }
 
@@ -256,32 +305,16 @@ int at_hubert_finalize(at_hubert_t* h) {
     }
     h->staged.clear();
     {
-        const char* e = std::getenv("AUDIOTOKEN_BF16X3");
-        h->bf16x3 = e ? std::atoi(e) != 0 : true;
-    }
-    if (h->bf16x3) {
-        for (int i = 1; i < 7; ++i) {
-            const int k = kKs[i] * kCd;
-            __bf16* d = nullptr;
-            AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * kCd * k * sizeof(__bf16)));
-            h->allocs.push_back(reinterpret_cast<float*>(d));
-            if (int rc = launch_split_blocked(h->conv_w[i], k, kCd, kCd, k, d, nullptr)) return rc;
-            h->conv_ws[i] = d;
+        h->arith = ARITH_F16X2;
+        if (const char* e = std::getenv("AUDIOTOKEN_BF16X3")) if (std::atoi(e) == 0) h->arith = ARITH_F32;   // round-1 switch, kept
+        if (const char* e = std::getenv("AUDIOTOKEN_SEMANTIC_ARITH")) {
+            const std::string v(e);
+            AT_REQUIRE(v == "f32" || v == "bf16x3" || v == "f16x2", "AUDIOTOKEN_SEMANTIC_ARITH must be f32, bf16x3 or f16x2");
+            h->arith = v == "f32" ? ARITH_F32 : v == "bf16x3" ? ARITH_BF16X3 : ARITH_F16X2;
         }
-        for (LayerW& L : h->layers) {
-            const float* src[4] = {L.wqkv, L.wo, L.w1, L.w2};
-            const __bf16** dst[4] = {&L.wqkv_s, &L.wo_s, &L.w1_s, &L.w2_s};
-            const int ns[4] = {3 * kHid, kHid, kFfn, kHid}, ks[4] = {kHid, kHid, kHid, kFfn};
-            for (int j = 0; j < 4; ++j) {
-                __bf16* d = nullptr;
-                AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * ns[j] * ks[j] * sizeof(__bf16)));
-                h->allocs.push_back(reinterpret_cast<float*>(d));
-                if (int rc = launch_split_blocked(src[j], ks[j], ns[j], ns[j], ks[j], d, nullptr)) return rc;
-                *dst[j] = d;
-            }
-        }
-        AT_CHECK_HIP(hipDeviceSynchronize());
     }
+    if (h->arith != ARITH_F32)
+        if (int rc = split_weights(h, h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
     h->finalized = true;
     return 0;
 }
@@ -307,9 +340,38 @@ size_t at_hubert_workspace_bytes(const at_hubert_t* h, int B, int N) {
     return make_plan(B, N).total_floats * sizeof(float);
 }
 
+int at_hubert_set_option(at_hubert_t* h, const char* name, int value) {
+    AT_REQUIRE(h && h->finalized && name, "bad handle");
+    const std::string n(name);
+    if (n == "arith") {
+        AT_REQUIRE(value == ARITH_F32 || value == ARITH_BF16X3 || value == ARITH_F16X2, "arith: 0 = f32 MFMA, 1 = bf16x3, 2 = f16x2");
+        DeviceGuard guard(h->device);
+        AT_REQUIRE(guard.ok, "cannot select the handle's device");
+        if (value != ARITH_F32)
+            if (int rc = split_weights(h, value == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
+        h->arith = value;
+        return 0;
+    }
+    set_error("at_hubert_set_option: unknown option " + n);
+    return -1;
+}
+
+int at_hubert_get_option(const at_hubert_t* h, const char* name) {
+    if (!h || !name) return -1;
+    if (std::string(name) == "arith") return h->arith;
+    return -1;
+}
+
 int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B, int N, int n_layers, int16_t* tokens, int* T_out,
                      float* hidden_out, void* workspace, size_t workspace_bytes, at_stream_t stream_) {
+    return at_hubert_encode_checked(h, wav, mask, B, N, n_layers, tokens, T_out, hidden_out, workspace, workspace_bytes, stream_, nullptr);
+}
+
+int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask, int B, int N, int n_layers, int16_t* tokens, int* T_out,
+                             float* hidden_out, void* workspace, size_t workspace_bytes, at_stream_t stream_, int32_t* status_dev) {
     AT_REQUIRE(h && h->finalized, "model not finalized");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
     AT_REQUIRE(wav && workspace, "null pointer");
     AT_REQUIRE(n_layers >= 0 && n_layers <= (int)h->layers.size(), "n_layers exceeds the loaded layers");
     AT_REQUIRE(tokens == nullptr || h->centers != nullptr, "tokens requested but no k-means centres loaded");
@@ -322,22 +384,27 @@ int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B,
     const long long M = (long long)B * T;
     if (T_out) *T_out = T;
     Profiler& prof = h->prof;
+    if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), (hipStream_t)stream_));
+    const bool split = h->arith != ARITH_F32;
+    const SplitCtx sc{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, reinterpret_cast<int*>(status_dev)};
 
     // ---- conv feature encoder (7 valid strided convs, GroupNorm after the first, GELU) ----------------------
     float* bufs[2] = {ws + p.off_a, ws + p.off_b};
     prof.begin("feature_extractor", 9, stream);
     // conv0 + GroupNorm + GELU: statistics from float64 waveform moments, one pass over the output (hubert_kernels.hip)
-    if (h->bf16x3) {
+    if (split) {
         // the six 512 -> 512 convs as windowed split-bf16 GEMMs (gemm_bf16x3.hip): conv0 writes the K-blocked bf16 pieces of its
         // output, every conv's GELU epilogue writes the next conv's input the same way, the last one writes fp32 features
-        __bf16* sb[2] = {reinterpret_cast<__bf16*>(ws + p.off_sb), reinterpret_cast<__bf16*>(ws + p.off_sa)};   // [i & 1]
+        piece_t* sb[2] = {reinterpret_cast<piece_t*>(ws + p.off_sb), reinterpret_cast<piece_t*>(ws + p.off_sa)};   // [i & 1]
         if (int rc = launch_hub_conv0_gn_gelu(wav, h->conv_w[0], h->gn_g, h->gn_b, ws + p.off_part, ws + p.off_ss, nullptr, B, N, p.L[1], stream,
-                                              sb[1], p.Lp[1]))
+                                              sb[1], p.Lp[1], sc.scheme, sc.act_scale(), sc.status))
             return rc;
         for (int i = 1; i < 7; ++i) {
             Bf16x3Args a;
-            a.A = sb[i & 1]; a.W = h->conv_ws[i]; a.M = p.L[i + 1]; a.Mpad = p.Mp[i]; a.N = kCd; a.K = kKs[i] * kCd;
+            a.A = sb[i & 1]; a.W = h->conv_ws[sc.scheme][i]; a.M = p.L[i + 1]; a.Mpad = p.Mp[i]; a.N = kCd; a.K = kKs[i] * kCd;
             a.batch = B; a.stride = kSt[i]; a.cblocks = kCd / 16; a.Lp = p.Lp[i];
+            a.scheme = sc.scheme; a.status = sc.status;
+            if (sc.scheme == XB_SCHEME_F16X2) { a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->conv_wscale[i]); a.split_scale = XB_F16_ACT_SCALE; }
             if (i < 6) { a.epi = XB_EPI_GELU_SPLIT; a.S = sb[(i + 1) & 1]; a.Spad = p.Lp[i + 1]; a.Sphases = kSt[i + 1]; }
             else { a.epi = XB_EPI_GELU; a.C = bufs[6 & 1]; a.ldc = kCd; }
             if (int rc = launch_gemm_bf16x3(a, stream)) return rc;
@@ -363,8 +430,8 @@ int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B,
     float* x = ws + p.off_x;
     float* t1 = ws + p.off_t1;
     float* pos = ws + p.off_pos;
-    __bf16* xs = reinterpret_cast<__bf16*>(ws + p.off_xs);
-    __bf16* bigs = reinterpret_cast<__bf16*>(ws + p.off_bigs);
+    piece_t* xs = reinterpret_cast<piece_t*>(ws + p.off_xs);
+    piece_t* bigs = reinterpret_cast<piece_t*>(ws + p.off_bigs);
     const long long Mpad = (long long)p.Mpad;
     float* big = ws + p.off_big;
     prof.begin("projection_posconv", 20, stream);
@@ -387,8 +454,8 @@ int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B,
     for (int li = 0; li < n_layers; ++li) {
         const LayerW& L = h->layers[li];
         prof.begin("attn_proj", 3, stream);
-        if (h->bf16x3) {
-            if (int rc = linear_x3(x, kHid, nullptr, xs, L.wqkv_s, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream)) return rc;
+        if (split) {
+            if (int rc = linear_split(sc, x, kHid, nullptr, xs, L, HW_QKV, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream)) return rc;
         } else if (int rc = linear(x, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, nullptr, nullptr, 3 * kHid, stream)) {
             return rc;
         }
@@ -397,17 +464,17 @@ int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B,
         if (int rc = launch_relpos_attention(big, fmask, nullptr, t1, B, T, stream, kHeads)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
-        if (h->bf16x3) {
-            if (int rc = linear_x3(t1, kHid, nullptr, xs, L.wo_s, L.bo, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
+        if (split) {
+            if (int rc = linear_split(sc, t1, kHid, nullptr, xs, L, HW_O, L.bo, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
         } else if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) {
             return rc;
         }
         if (int rc = launch_layernorm(x, L.ln1_g, L.ln1_b, nullptr, x, M, kHid, stream)) return rc;
         prof.end(stream);
         prof.begin("ffn", 3, stream);
-        if (h->bf16x3) {   // hidden activation written split by the first GEMM's epilogue
-            if (int rc = linear_x3(x, kHid, nullptr, xs, L.w1_s, L.b1, nullptr, kFfn, M, Mpad, XB_EPI_GELU_SPLIT, nullptr, kFfn, bigs, stream)) return rc;
-            if (int rc = linear_x3(nullptr, kFfn, bigs, nullptr, L.w2_s, L.b2, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
+        if (split) {   // hidden activation written split by the first GEMM's epilogue
+            if (int rc = linear_split(sc, x, kHid, nullptr, xs, L, HW_1, L.b1, nullptr, kFfn, M, Mpad, XB_EPI_GELU_SPLIT, nullptr, kFfn, bigs, stream)) return rc;
+            if (int rc = linear_split(sc, nullptr, kFfn, bigs, nullptr, L, HW_2, L.b2, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
         } else {
             if (int rc = linear(x, kHid, L.w1, L.b1, big, kFfn, M, EPI_GELU, nullptr, nullptr, kFfn, stream)) return rc;
             if (int rc = linear(big, kFfn, L.w2, L.b2, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) return rc;

@@ -8,6 +8,7 @@ int hub_ws_nchunk(int T0);
 // split != nullptr: instead of out, write the clip-major K-blocked, phase-major bf16 pieces [3][B][512/16][2][Lp][16] the split-bf16
 // conv GEMM reads (frame t in plane t & 1 at index t >> 1)
 int launch_hub_conv0_gn_gelu(const float* wav, const float* w, const float* gamma, const float* beta, float* part, float* ss, float* out,
-                             int B, int N, int T0, hipStream_t stream, __bf16* split = nullptr, int Lp = 0);
+                             int B, int N, int T0, hipStream_t stream, __bf16* split = nullptr, int Lp = 0, int scheme = 0, float split_scale = 1.0f,
+                             int* status = nullptr);
 int launch_hub_frame_mask(const float* smask, float* fmask, int B, int N, int T, hipStream_t stream);
 }  // namespace at

@@ -3,6 +3,7 @@
 // grouped positional conv, Linear, attention, LayerNorm, k-means assignment) reuses the shared kernels.
 #include "gemm_core.h"
 #include "hubert_kernels.h"
+#include "split_scheme.h"
 
 namespace at {
 
@@ -95,9 +96,10 @@ __global__ __launch_bounds__(512) void hub_gn_coeff_kernel(const double* __restr
 // ran at 1.3 TB/s). The waveform segment (325 samples) goes through LDS; 128 threads write one 2-KB output row.
 constexpr int C0_FRAMES = 64;
 
+template <class SC>
 __global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __restrict__ wav, const float* __restrict__ w /*[512][10]*/,
                                                                 const float* __restrict__ ss, float* __restrict__ out, int N, int T0,
-                                                                __bf16* __restrict__ split, int Lp) {
+                                                                typename SC::T* __restrict__ split, int Lp, float split_scale, int* __restrict__ status) {
     __shared__ float xs[C0_FRAMES * 5 + 8];
     const int b = blockIdx.y, t0 = blockIdx.x * C0_FRAMES;
     const int cg = threadIdx.x & 127, sub = threadIdx.x >> 7;
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __r
     __syncthreads();
     const int nf = T0 - t0 < C0_FRAMES ? T0 - t0 : C0_FRAMES;
     float* orow = out + ((long long)b * T0 + t0) * 512 + cg * 4;
+    bool over = false;
     for (int f = sub; f < nf; f += 2) {
         float xv[10];
 #pragma unroll
@@ -130,39 +133,37 @@ __global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __r
             o[c] = gelu_erf(fmaf(acc, sc[c], sh[c]));
         }
         if (split) {
-            // the next conv runs on the split-bf16 GEMM: write the three K-blocked pieces [3][B][512/16][2][Lp][16] of this clip
+            // the next conv runs on the split GEMM: write the K-blocked pieces [NP][B][512/16][2][Lp][16] of this clip
             // (channels 4cg..4cg+3 = channel block cg/4, quarter cg%4)
-            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-            bf16x4 p1, p2, p3;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const __bf16 a1 = (__bf16)o[k];
-                const float r1 = o[k] - (float)a1;
-                const __bf16 a2 = (__bf16)r1;
-                p1[k] = a1; p2[k] = a2; p3[k] = (__bf16)(r1 - (float)a2);
-            }
+            typename SC::V4 p[SC::NP];
+            over |= split4<SC>(o, split_scale, p);
             // phase-major time axis for the stride-2 conv that follows: frame t -> plane t & 1, index t >> 1 (Lp rows per plane)
             const int t = t0 + f;
             const long long off = ((((long long)b * 32 + (cg >> 2)) * 2 + (t & 1)) * Lp + (t >> 1)) * 16 + (cg & 3) * 4;
             const long long ps = (long long)gridDim.y * 32 * 2 * Lp * 16;
-            *reinterpret_cast<bf16x4*>(split + off) = p1;
-            *reinterpret_cast<bf16x4*>(split + ps + off) = p2;
-            *reinterpret_cast<bf16x4*>(split + 2 * ps + off) = p3;
+#pragma unroll
+            for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(split + i * ps + off) = p[i];
         } else {
             *reinterpret_cast<f4*>(orow + (long long)f * 512) = o;
         }
     }
+    if constexpr (SC::RANGE_CHECK)
+        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
 }
 
 int launch_hub_conv0_gn_gelu(const float* wav, const float* w, const float* gamma, const float* beta, float* part, float* ss, float* out,
-                             int B, int N, int T0, hipStream_t stream, __bf16* split, int Lp) {
+                             int B, int N, int T0, hipStream_t stream, __bf16* split, int Lp, int scheme, float split_scale, int* status) {
     const int nchunk = hub_ws_nchunk(T0);
     double* dpart = reinterpret_cast<double*>(part);   // workspace slices are 256-byte aligned
     hipLaunchKernelGGL(hub_wavstats_kernel, dim3(nchunk, B), dim3(256), 0, stream, wav, dpart, N, T0, nchunk);
     AT_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(hub_gn_coeff_kernel, dim3(B), dim3(512), 0, stream, dpart, w, gamma, beta, ss, T0, nchunk);
     AT_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(hub_conv0_gn_gelu_kernel, dim3((T0 + C0_FRAMES - 1) / C0_FRAMES, B), dim3(256), 0, stream, wav, w, ss, out, N, T0, split, Lp);
+    const dim3 grid((T0 + C0_FRAMES - 1) / C0_FRAMES, B);
+    if (scheme == XB_SCHEME_F16X2)
+        hipLaunchKernelGGL(hub_conv0_gn_gelu_kernel<SchemeF16x2>, grid, dim3(256), 0, stream, wav, w, ss, out, N, T0, reinterpret_cast<_Float16*>(split), Lp, split_scale, status);
+    else
+        hipLaunchKernelGGL(hub_conv0_gn_gelu_kernel<SchemeBf16x3>, grid, dim3(256), 0, stream, wav, w, ss, out, N, T0, split, Lp, split_scale, status);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -94,11 +94,40 @@ class HubertEncoder(torch.nn.Module):
         if self.lib.at_hubert_num_layers(self.handle) < self.output_layer:
             raise ValueError(f"checkpoint has too few transformer layers for output_layer={self.output_layer}")
         self._ws: Optional[torch.Tensor] = None
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def __del__(self):
         h = self.__dict__.pop("handle", None)
         if h:
             self.lib.at_hubert_destroy(h)
+
+    ARITH = {"f32": 0, "bf16x3": 1, "f16x2": 2}
+
+    def set_option(self, name: str, value) -> None:
+        """"arith": "f32" | "bf16x3" | "f16x2" (or 0/1/2) — arithmetic of the linear layers and the 512->512 convs."""
+        if isinstance(value, str):
+            value = self.ARITH[value]
+        _cabi.check(self.lib.at_hubert_set_option(self.handle, name.encode(), int(value)), f"at_hubert_set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        return int(self.lib.at_hubert_get_option(self.handle, name.encode()))
+
+    def last_status(self) -> int:
+        """0 = ok; bit 1 (2) = an activation overflowed the fp16 range of the f16x2 arithmetic (synchronises the device)."""
+        return int(self._status.item())
+
+    def verified(self, tokens: torch.Tensor, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Product-path guard (see Wav2VecBertEncoder.verified): on an fp16 range overflow repeat the batch with arith=bf16x3."""
+        status = self.last_status()
+        if status == 0:
+            return tokens
+        logger.error(f"semantic_s encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
+                     "the tokens of this batch were discarded; re-encoding with arith=bf16x3 from now on")
+        self.set_option("arith", "bf16x3")
+        tokens = self.forward(input_batch, attention_mask)
+        if self.last_status() != 0:
+            raise _cabi.HipLibraryError("semantic_s encode failed twice (status non-zero with bf16x3 arithmetic)")
+        return tokens
 
     @torch.no_grad()
     def forward(self, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, n_layers: Optional[int] = None,
@@ -118,9 +147,10 @@ class HubertEncoder(torch.nn.Module):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         t_out = C.c_int(0)
         with torch.cuda.device(self.device):
-            rc = self.lib.at_hubert_encode(self.handle, x.data_ptr(), _cabi.ptr(m), B, N, nl, _cabi.ptr(tokens), C.byref(t_out),
-                                           _cabi.ptr(hidden), self._ws.data_ptr(), nbytes, _cabi.current_stream_handle(self.device))
-        _cabi.check(rc, "at_hubert_encode")
+            rc = self.lib.at_hubert_encode_checked(self.handle, x.data_ptr(), _cabi.ptr(m), B, N, nl, _cabi.ptr(tokens), C.byref(t_out),
+                                                   _cabi.ptr(hidden), self._ws.data_ptr(), nbytes, _cabi.current_stream_handle(self.device),
+                                                   self._status.data_ptr())
+        _cabi.check(rc, "at_hubert_encode_checked")
         assert t_out.value == T
         if return_hidden:
             return tokens, hidden

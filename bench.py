@@ -293,16 +293,20 @@ def run_hubert(args, rank, world, dev, dist):
     elapsed = max_over_ranks(elapsed, dev, dist)
     prof = tapped_breakdown(enc, lambda: enc(wav, mask), min(args.steps, 2))
     flops, T = hubert_flops_per_clip(N, nl)
+    arith = enc.get_option("arith")
+    products = {0: 1, 1: 6, 2: 3}[arith]
+    assert enc.last_status() == 0, "semantic_s status word non-zero (fp16 range overflow): the timed run is invalid"
     breakdown = {}
     for k, (per, launches) in prof.items():
         breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches,
                         "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None, "gbs": None}
     res = {
         "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "dtype": "f32 (linear layers: exact bf16x3 splits, fp32 accumulate)" if BF16X3 else "f32",
+        "dtype": {0: "f32", 1: "f32 (linear layers and convs: three bf16 pieces per operand, six MFMA products, fp32 accumulate)",
+                  2: "f32 (linear layers and convs: two fp16 pieces per operand, three MFMA products, fp32 accumulate)"}[arith],
         "config": {"workload": f"Tokenizers.semantic_s encode, {B} clips x {secs:g} s @16 kHz per GPU, mHuBERT-base 11 layers, k-means 1000",
                    "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0"},
-        "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if BF16X3 else (), "semantic_s"), "breakdown": breakdown,
+        "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if arith else (), "semantic_s", products), "breakdown": breakdown,
         "token_checksum": int(toks.to(torch.int64).sum().item()),
         "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
     }

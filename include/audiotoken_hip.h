@@ -170,6 +170,12 @@ size_t at_hubert_workspace_bytes(const at_hubert_t* h, int B, int N);
  * tokens device int16 [B][1][T] or NULL; hidden_out optional device float32 [B][T][768] = hidden_states[n_layers]. */
 int at_hubert_encode(at_hubert_t* h, const float* wav, const float* mask, int B, int N, int n_layers, int16_t* tokens, int* T_out,
                      float* hidden_out, void* workspace, size_t workspace_bytes, at_stream_t stream);
+/* As at_w2vbert_encode_checked / at_w2vbert_set_option / at_w2vbert_get_option: device status word (bit 1 = fp16 range overflow of the
+ * "f16x2" arithmetic) and the "arith" option (0 f32 MFMA, 1 bf16x3, 2 f16x2 = default; also covers the six 512->512 feature-extractor convs). */
+int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask, int B, int N, int n_layers, int16_t* tokens, int* T_out,
+                             float* hidden_out, void* workspace, size_t workspace_bytes, at_stream_t stream, int32_t* status_dev);
+int at_hubert_set_option(at_hubert_t* h, const char* name, int value);
+int at_hubert_get_option(const at_hubert_t* h, const char* name);
 int at_hubert_profile(at_hubert_t* h, int enable);
 int at_hubert_profile_read(at_hubert_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups);
 
