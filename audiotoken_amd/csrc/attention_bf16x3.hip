@@ -8,15 +8,16 @@
 // K/V tiles of 32 keys: K as [3 pieces][32 keys][64 d], V transposed [3 pieces][64 d][32 keys] with the keys of a 16-group
 // permuted so that the 8 keys a lane's P registers hold for one MFMA k-step are contiguous (one ds_read_b128 per fragment).
 // 71 KB of LDS: two workgroups per CU. Also serves HuBERT (12 heads, no rel-pos bias).
+//
+// Round 2: the kernel is templated on the operand scheme (split_scheme.h). With the two-piece fp16 scheme q, k, v are scaled by
+// XB_F16_ACT_SCALE and the probabilities by 2^10 before they are split (all exact; undone in the softmax scale and the final 1 / l),
+// three products per step instead of six, 61 KB of LDS; values beyond the fp16 range raise XB_STATUS_F16_OVERFLOW.
 #include "at_common.h"
 #include "w2vbert_kernels.h"
+#include "split_scheme.h"
 
 namespace at {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 constexpr int AX_QB = 128, AX_KB = 32;
@@ -24,21 +25,27 @@ constexpr int AX_KLD = 72;    // bf16 per K row (64 d + 8 pad: 144-byte stride, 
 constexpr int AX_VLD = 40;    // bf16 per V^T row (32 keys + 8 pad)
 constexpr int AX_QE_LD = 81;
 constexpr float AX_SCALE2 = 0.125f * 1.4426950408889634f;
-constexpr int AX_K_ELEMS = 3 * AX_KB * AX_KLD, AX_V_ELEMS = 3 * 64 * AX_VLD;
-constexpr size_t AX_LDS_BYTES = (size_t)(AX_K_ELEMS + AX_V_ELEMS) * 2 + (size_t)(AX_QB * AX_QE_LD + AX_KB + 4) * 4;
+constexpr float AX_P_SCALE = 1024.0f;   // fp16 scheme: probabilities (<= 1) are split as p * 2^10
+template <int NP> constexpr int ax_k_elems() { return NP * AX_KB * AX_KLD; }
+template <int NP> constexpr int ax_v_elems() { return NP * 64 * AX_VLD; }
+template <int NP> constexpr size_t ax_lds_bytes() { return (size_t)(ax_k_elems<NP>() + ax_v_elems<NP>()) * 2 + (size_t)(AX_QB * AX_QE_LD + AX_KB + 4) * 4; }
 
-__device__ __forceinline__ void ax_split(float a, __bf16& p1, __bf16& p2, __bf16& p3) {
-    p1 = (__bf16)a;
-    const float r1 = a - (float)p1;
-    p2 = (__bf16)r1;
-    p3 = (__bf16)(r1 - (float)p2);
-}
-
+template <class SC>
 __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ amask,
-                                                                     const float* __restrict__ dist_emb, float* __restrict__ ctx, int T, int hid) {
+                                                                     const float* __restrict__ dist_emb, float* __restrict__ ctx, int T, int hid,
+                                                                     int* __restrict__ status) {
+    typedef typename SC::T PT;
+    typedef typename SC::V8 V8;
+    typedef typename SC::V4 V4;
+    constexpr int NP = SC::NP;
+    constexpr int AX_K_ELEMS = ax_k_elems<NP>(), AX_V_ELEMS = ax_v_elems<NP>();
+    // operand scales (1 for the bf16 scheme): q, k, v * XS; p * PS. S = acc / XS^2, O = acc / (PS XS)
+    constexpr float XS = SC::RANGE_CHECK ? XB_F16_ACT_SCALE : 1.0f, PS = SC::RANGE_CHECK ? AX_P_SCALE : 1.0f;
+    constexpr float S_SCALE2 = AX_SCALE2 / (XS * XS);
+    bool over = false;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* Ks = reinterpret_cast<__bf16*>(smem_raw);            // [3][32 keys][72]
-    __bf16* Vt = Ks + AX_K_ELEMS;                                // [3][64 d][40], keys permuted inside each 16-group
+    PT* Ks = reinterpret_cast<PT*>(smem_raw);                    // [NP][32 keys][72]
+    PT* Vt = Ks + AX_K_ELEMS;                                    // [NP][64 d][40], keys permuted inside each 16-group
     float* QE = reinterpret_cast<float*>(Vt + AX_V_ELEMS);       // [128 queries][81]: log2(e)/8 * q.E[bucket]
     float* kb = QE + AX_QB * AX_QE_LD;                           // [32] additive key bias: 0 / finfo.min (padded) / -inf (beyond T)
     int* kb_any = reinterpret_cast<int*>(kb + AX_KB);
@@ -84,19 +91,20 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
     }
     // ---- this lane's query (column l32 of the wave's tile): 3 bf16 pieces of q[lq][dstep*16 + 8*hh .. +7] -------------------
     const int lq = l0 + wave * 32 + l32;
-    bf16x8 qpc[3][4];
+    V8 qpc[NP][4];
     {
         const int lc = lq < T ? lq : T - 1;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
             const f4 a = *reinterpret_cast<const f4*>(qp + (rowbase + lc) * LD + ds * 16 + 8 * hh);
             const f4 c = *reinterpret_cast<const f4*>(qp + (rowbase + lc) * LD + ds * 16 + 8 * hh + 4);
+            V4 pa[NP], pc[NP];
+            over |= split4<SC>(a, XS, pa);
+            over |= split4<SC>(c, XS, pc);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                __bf16 x1, x2, x3;
-                ax_split(a[k], x1, x2, x3); qpc[0][ds][k] = x1; qpc[1][ds][k] = x2; qpc[2][ds][k] = x3;
-                ax_split(c[k], x1, x2, x3); qpc[0][ds][4 + k] = x1; qpc[1][ds][4 + k] = x2; qpc[2][ds][4 + k] = x3;
-            }
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { qpc[i][ds][k] = pa[i][k]; qpc[i][ds][4 + k] = pc[i][k]; }
         }
     }
     f16v oacc[2];
@@ -135,31 +143,29 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
         const int r0 = kt * AX_KB;
         __syncthreads();   // previous tile fully consumed (also orders the QE stores before first use)
         {
-            bf16x8 k1, k2, k3;
+            V8 kpc[NP];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                __bf16 x1, x2, x3;
-                ax_split(__uint_as_float(kreg[e >> 2][e & 3]), x1, x2, x3);
-                k1[e] = x1; k2[e] = x2; k3[e] = x3;
+            for (int u = 0; u < 2; ++u) {
+                const f4 kv = {__uint_as_float(kreg[u][0]), __uint_as_float(kreg[u][1]), __uint_as_float(kreg[u][2]), __uint_as_float(kreg[u][3])};
+                V4 p4[NP];
+                over |= split4<SC>(kv, XS, p4);
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) kpc[i][4 * u + k] = p4[i][k];
             }
-            __bf16* kd = Ks + sk_key * AX_KLD + sk_d;
-            *reinterpret_cast<bf16x8*>(kd) = k1;
-            *reinterpret_cast<bf16x8*>(kd + AX_KB * AX_KLD) = k2;
-            *reinterpret_cast<bf16x8*>(kd + 2 * AX_KB * AX_KLD) = k3;
+            PT* kd = Ks + sk_key * AX_KLD + sk_d;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) *reinterpret_cast<V8*>(kd + i * AX_KB * AX_KLD) = kpc[i];
             // V^T: keys 8*sv_g + e -> 16-group g = sv_g >> 1, position 8*((e >> 2)) + 4*(sv_g & 1) + (e & 3) inside it
-            bf16x4 v1[2], v2[2], v3[2];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                __bf16 x1, x2, x3;
-                ax_split(__uint_as_float(vreg[e]), x1, x2, x3);
-                v1[e >> 2][e & 3] = x1; v2[e >> 2][e & 3] = x2; v3[e >> 2][e & 3] = x3;
-            }
-            __bf16* vd = Vt + sv_d * AX_VLD + (sv_g >> 1) * 16 + 4 * (sv_g & 1);
+            PT* vd = Vt + sv_d * AX_VLD + (sv_g >> 1) * 16 + 4 * (sv_g & 1);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {   // u = e >> 2 selects the half hh whose lanes read this key quartet
-                *reinterpret_cast<bf16x4*>(vd + 8 * u) = v1[u];
-                *reinterpret_cast<bf16x4*>(vd + 8 * u + 64 * AX_VLD) = v2[u];
-                *reinterpret_cast<bf16x4*>(vd + 8 * u + 2 * 64 * AX_VLD) = v3[u];
+                const f4 vv = {__uint_as_float(vreg[4 * u]), __uint_as_float(vreg[4 * u + 1]), __uint_as_float(vreg[4 * u + 2]), __uint_as_float(vreg[4 * u + 3])};
+                V4 p4[NP];
+                over |= split4<SC>(vv, XS, p4);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(vd + 8 * u + i * 64 * AX_VLD) = p4[i];
             }
             if (tid < AX_KB) {
                 const int rr = r0 + tid;
@@ -175,14 +181,13 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
         f16v s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
-            bf16x8 kf[3];
+            V8 kf[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8*>(Ks + p * AX_KB * AX_KLD + l32 * AX_KLD + ds * 16 + 8 * hh);
+            for (int p = 0; p < NP; ++p) kf[p] = *reinterpret_cast<const V8*>(Ks + p * AX_KB * AX_KLD + l32 * AX_KLD + ds * 16 + 8 * hh);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[t]], qpc[PB[t]][ds], s, 0, 0, 0);
+            for (int t = 0; t < SC::NPROD; ++t) s = SC::mfma(kf[SC::prod_a(t)], qpc[SC::prod_w(t)][ds], s);
         }
         // ---- bias + mask, online softmax in the exp2 domain ------------------------------------------------------------------------
         const bool far_left = (r0 + AX_KB - 1) - wl_min <= -64;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
         if (plain && !masked) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float sc = fmaf(AX_SCALE2, s[r], c_far);
+                const float sc = fmaf(S_SCALE2, s[r], c_far);
                 s[r] = sc;
                 mx = fmaxf(mx, sc);
             }
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
                     dd = dd < -64 ? -64 : (dd > 8 ? 8 : dd);
                     bias = qe[dd + 64];
                 }
-                const float sc = fmaf(AX_SCALE2, s[r], bias + kb[key]);
+                const float sc = fmaf(S_SCALE2, s[r], bias + kb[key]);
                 s[r] = sc;
                 mx = fmaxf(mx, sc);
             }
@@ -238,30 +243,31 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
             lrun += rs;
         }
         // ---- P pieces (B operand of P.V: k-step ks uses registers 8ks .. 8ks+7 = keys 16ks + {0..3, 8..11} + 4hh) -----------------
-        bf16x8 pp[3][2];
+        V8 pp[NP][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                __bf16 x1, x2, x3;
-                ax_split(s[8 * ks + j], x1, x2, x3);
-                pp[0][ks][j] = x1; pp[1][ks][j] = x2; pp[2][ks][j] = x3;
+                PT q[NP];
+                split_n<SC>(s[8 * ks + j] * PS, q);   // p <= 1: p * 2^10 always fits
+#pragma unroll
+                for (int i = 0; i < NP; ++i) pp[i][ks][j] = q[i];
             }
         // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------------------------
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 vf[3];
+                V8 vf[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const bf16x8*>(Vt + p * 64 * AX_VLD + (dt * 32 + l32) * AX_VLD + ks * 16 + 8 * hh);
+                for (int p = 0; p < NP; ++p) vf[p] = *reinterpret_cast<const V8*>(Vt + p * 64 * AX_VLD + (dt * 32 + l32) * AX_VLD + ks * 16 + 8 * hh);
 #pragma unroll
-                for (int t = 0; t < 6; ++t) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[t]], pp[PB[t]][ks], oacc[dt], 0, 0, 0);
+                for (int t = 0; t < SC::NPROD; ++t) oacc[dt] = SC::mfma(vf[SC::prod_a(t)], pp[SC::prod_w(t)][ks], oacc[dt]);
             }
     }
     // lane holds O[lq][dv = 32 dt + 8*(r/4) + 4 hh + r%4]
     if (lq < T) {
-        const float inv = 1.0f / lrun;
+        const float inv = (1.0f / lrun) * (1.0f / (PS * XS));
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -270,16 +276,26 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
                 *reinterpret_cast<f4*>(ctx + (rowbase + lq) * hid + h * 64 + dt * 32 + 8 * g + 4 * hh) = v;
             }
     }
+    if constexpr (SC::RANGE_CHECK)
+        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
 }
 
-int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads) {
-    AT_REQUIRE(B >= 1 && T >= 1 && heads >= 1 && heads <= 64, "relpos_attention_x3: bad shape");
-    AT_REQUIRE((long long)T * 3 * heads * 64 * 4 < (1ll << 31), "relpos_attention_x3: one clip's qkv rows exceed the buffer-descriptor range");
+template <class SC>
+static int launch_ax(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads, int* status) {
     dim3 grid((T + AX_QB - 1) / AX_QB, heads, B);
-    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, relpos_attention_x3_kernel, AX_LDS_BYTES)) return rc; }
-    hipLaunchKernelGGL(relpos_attention_x3_kernel, grid, dim3(256), AX_LDS_BYTES, stream, qkv, amask, dist_emb, ctx, T, heads * 64);
+    constexpr size_t lds = ax_lds_bytes<SC::NP>();
+    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, relpos_attention_x3_kernel<SC>, lds)) return rc; }
+    hipLaunchKernelGGL(relpos_attention_x3_kernel<SC>, grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T, heads * 64, status);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
+                               int scheme, int* status) {
+    AT_REQUIRE(B >= 1 && T >= 1 && heads >= 1 && heads <= 64, "relpos_attention_x3: bad shape");
+    AT_REQUIRE((long long)T * 3 * heads * 64 * 4 < (1ll << 31), "relpos_attention_x3: one clip's qkv rows exceed the buffer-descriptor range");
+    if (scheme == XB_SCHEME_F16X2) return launch_ax<SchemeF16x2>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status);
+    return launch_ax<SchemeBf16x3>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status);
 }
 
 }  // namespace at

@@ -70,5 +70,9 @@ int launch_split_blocked(const float* x, int ld, long long rows, long long rows_
 // fp32 [B][L][C] -> the windowed-mode pieces of a causal strided conv with kernel = 2 * stride (reflect front padding included)
 int launch_split_phase_major(const float* x, int B, int L, int C, int stride, int Lp, __bf16* out, hipStream_t stream);
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream);
+// the fp16 scheme's kernel for launches that fill the chip (gemm_f16x2_tg.hip); launch_gemm_bf16x3 dispatches to it
+// ($AUDIOTOKEN_F16X2_TG=0 keeps the register-staged kernel)
+bool gemm_f16x2_tg_eligible(const Bf16x3Args& a);
+int launch_gemm_f16x2_tg(const Bf16x3Args& a, hipStream_t stream);
 
 }  // namespace at

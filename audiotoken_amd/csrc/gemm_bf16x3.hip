@@ -22,6 +22,8 @@
 #include "at_common.h"
 #include "gemm_bf16x3.h"
 #include "split_scheme.h"
+#include "split_epilogue.h"
+#include "../../include/audiotoken_hip.h"
 #include <type_traits>
 #include <cstdlib>
 #include <cmath>
@@ -245,24 +247,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
         __syncthreads();
     }
     // lane holds output row m = frow of its 32-row tile and, per register group g, 4 consecutive columns n = 8g + 4 fhalf ..
-    // split outputs: [3][batch][blocks][phases][pad][16]; output row m lives in plane m % phases at index m / phases + front
-    bool over = false;
-    auto write_split = [&](__bf16* S_, int pad, int phases, int front, int blocks, int block0, int m, int n, const f4& v) {
-        PT* S = reinterpret_cast<PT*>(S_);
-        const int nb = blocks > 0 ? blocks : a.N / 16;
-        const long long s_clip = (long long)pad * phases * nb * 16;   // elements of one clip of one piece
-        const long long psS = s_clip * a.batch;
-        typename SC::V4 p[NP];
-        over |= split4<SC>(v, a.split_scale, p);
-        const int sq = m / phases, sp = m - sq * phases;
-        PT* d = S + clip * s_clip + (((long long)(block0 + (n >> 4)) * phases + sp) * pad + sq + front) * 16 + (n & 15);
-#pragma unroll
-        for (int i = 0; i < NP; ++i) *reinterpret_cast<typename SC::V4*>(d + i * psS) = p[i];
-    };
-    float* Cb = a.C ? a.C + (long long)clip * a.M * a.ldc : nullptr;
-    const float* Rb = a.R ? a.R + (long long)clip * a.M * a.ldr : nullptr;
     // one specialised copy of the epilogue per mode (a uniform switch): with the mode tested per element the compiler evaluated
     // every activation and selected (+5 % on the FFN GEMMs)
+    XbEpilogue<SC> ep(a, clip);
     auto epilogue = [&](auto mode) {
         constexpr int E = decltype(mode)::value;
 #pragma unroll
@@ -274,32 +261,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = n0 + wn * TJ * 32 + j * 32 + 8 * g + 4 * fhalf;
-                    f4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    if constexpr (SC::RANGE_CHECK) v *= a.acc_scale;   // exact: a power of two (1 for the bf16 scheme)
-                    if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
-                    if constexpr (E == XB_EPI_RAW_ELU_SPLIT2) {
-                        write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, v);
-                        const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
-                        write_split(a.S2, a.S2pad, a.S2phases, a.S2front, a.S2blocks, a.S2block0, m, n, e);
-                    } else if constexpr (E == XB_EPI_SWISH_SPLIT || E == XB_EPI_GELU_SPLIT || E == XB_EPI_ELU_SPLIT) {
-                        f4 w;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            w[k] = E == XB_EPI_GELU_SPLIT ? gelu_erf(v[k])
-                                 : E == XB_EPI_ELU_SPLIT ? elu1(v[k])
-                                                         : v[k] * __frcp_rn(1.0f + __expf(-v[k]));   // as the fp32 GEMM's epilogues
-                        write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
-                    } else if constexpr (E == XB_EPI_GLU) {
-                        float2 o;
-                        o.x = v.x * sigmoidf_(v.y);
-                        o.y = v.z * sigmoidf_(v.w);
-                        *reinterpret_cast<float2*>(Cb + (long long)m * a.ldc + (n >> 1)) = o;
-                    } else {
-                        if constexpr (E == XB_EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-                        v *= a.alpha;
-                        if (Rb) v += *reinterpret_cast<const f4*>(Rb + (long long)m * a.ldr + n);
-                        *reinterpret_cast<f4*>(Cb + (long long)m * a.ldc + n) = v;
-                    }
+                    const f4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    ep.template apply<E>(m, n, v);
                 }
         }
     };
@@ -315,8 +278,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
             default: epilogue(std::integral_constant<int, XB_EPI_LINEAR>{}); break;
         }
     }
-    if constexpr (SC::RANGE_CHECK)
-        if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
+    ep.finish();
 }
 
 template <class SC, int WM, int WN, int TI, int TJ, bool DUAL = false>
@@ -353,8 +315,40 @@ int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
     AT_REQUIRE(a.batch >= 1 && a.stride >= 1 && (a.cblocks == 0 || (a.K / XB_K) % a.cblocks == 0), "gemm_bf16x3: bad window description");
     AT_REQUIRE((a.Lp > 0 ? a.Lp : a.Mpad) >= a.Mpad + ((a.cblocks > 0 ? (a.K / XB_K) / a.cblocks : 1) - 1) / a.stride, "gemm_bf16x3: Lp too small for the last tile");
     AT_REQUIRE(a.scheme == XB_SCHEME_BF16X3 || (a.scheme == XB_SCHEME_F16X2 && a.epi != XB_EPI_RAW_ELU_SPLIT2), "gemm_bf16x3: unknown scheme / dual split output needs the bf16 scheme");
+    static const bool tg = std::getenv("AUDIOTOKEN_F16X2_TG") ? std::atoi(std::getenv("AUDIOTOKEN_F16X2_TG")) != 0 : true;
+    if (tg && gemm_f16x2_tg_eligible(a)) return launch_gemm_f16x2_tg(a, stream);
     if (a.scheme == XB_SCHEME_F16X2) return launch_scheme<SchemeF16x2>(a, stream);
     return launch_scheme<SchemeBf16x3>(a, stream);
 }
 
 }  // namespace at
+
+// ---- operator-level entry point for the parity tests ------------------------------------------------------------------------------
+extern "C" int at_op_gemm_split(const float* X, const float* W, const float* bias, float* C, int M, int N, int K, int scheme, float w_max_abs,
+                                int kernel, void* workspace, size_t workspace_bytes, int32_t* status_dev, at_stream_t stream_) {
+    using namespace at;
+    AT_REQUIRE(X && W && C && workspace && M >= 1 && N % 128 == 0 && K % 64 == 0, "at_op_gemm_split: bad arguments (N % 128, K % 64)");
+    AT_REQUIRE(scheme == XB_SCHEME_BF16X3 || scheme == XB_SCHEME_F16X2, "at_op_gemm_split: scheme 0 (bf16x3) or 1 (f16x2)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long Mpad = ((long long)M + 255) / 256 * 256;
+    const int np = xb_pieces(scheme);
+    const size_t need = ((size_t)Mpad * K + (size_t)N * K) * np * sizeof(piece_t);
+    AT_REQUIRE(workspace_bytes >= need, "at_op_gemm_split: workspace too small");
+    piece_t* xs = reinterpret_cast<piece_t*>(workspace);
+    piece_t* wsp = xs + (size_t)Mpad * K * np;
+    const float sa = scheme == XB_SCHEME_F16X2 ? XB_F16_ACT_SCALE : 1.0f, sw = scheme == XB_SCHEME_F16X2 ? xb_weight_scale(w_max_abs) : 1.0f;
+    if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
+    if (int rc = launch_split_blocked(X, K, M, Mpad, K, xs, stream, scheme, sa, reinterpret_cast<int*>(status_dev))) return rc;
+    if (int rc = launch_split_blocked(W, K, N, N, K, wsp, stream, scheme, sw, reinterpret_cast<int*>(status_dev))) return rc;
+    Bf16x3Args a;
+    a.A = xs; a.W = wsp; a.bias = bias; a.M = M; a.N = N; a.K = K; a.Mpad = (int)Mpad; a.epi = XB_EPI_LINEAR; a.C = C; a.ldc = N;
+    a.scheme = scheme; a.acc_scale = 1.0f / (sa * sw); a.split_scale = sa; a.status = reinterpret_cast<int*>(status_dev);
+    if (kernel == 1) {   // force the two-group kernel (gemm_f16x2_tg.hip) whatever the launch size
+        AT_REQUIRE(scheme == XB_SCHEME_F16X2 && N % 256 == 0 && K % 32 == 0, "at_op_gemm_split: the two-group kernel needs f16x2, N % 256, K % 32");
+        return launch_gemm_f16x2_tg(a, stream);
+    }
+    if (kernel == 2) {   // force the register-staged kernel
+        return a.scheme == XB_SCHEME_F16X2 ? launch_scheme<SchemeF16x2>(a, stream) : launch_scheme<SchemeBf16x3>(a, stream);
+    }
+    return launch_gemm_bf16x3(a, stream);
+}

@@ -1,0 +1,163 @@
+// The two-piece fp16 split GEMM (gemm_bf16x3.h, XB_SCHEME_F16X2) for launches that fill the chip: C = epi(A . W^T) with both operands as
+// hi + lo fp16 pieces in the K-blocked layout [piece][K/16][rows][16], three products per multiply-add on v_mfma_f32_16x16x32_f16.
+//
+// Structure ("two groups", measured against the alternatives in tools/f16x2_gemm.hip: 431-468 fp32-equivalent TFLOP/s on the conformer
+// shapes = 1.3-1.4 PFLOP/s of issued MFMA on random data, against 295-347 for the register-staged 2-barrier kernel in gemm_bf16x3.hip):
+//   * tile 256 x 256, 8 waves (4 x 2, each 64 x 128 = 4 x 8 MFMA tiles of 16 x 16, 128 accumulator registers), one workgroup per CU:
+//     waves w and w + 4 share a SIMD;
+//   * operands by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write): one ring slot = one 16-wide k-block of all four
+//     pieces (32 KB, the global chunks are contiguous 8 KB runs); a K step is 32 = two slots; ring of two pairs (128 KB);
+//   * every K step has two segments per wave — L: read the step's fragments (24 ds_read_b128, conflict-free in the linear [rows][16]
+//     image: a lane's fragment is k-block lane >> 5, half (lane >> 4) & 1 of row lane & 15) and issue the DMA of the next step;
+//     C: 96 MFMAs under s_setprio 1 — each closed by a workgroup barrier, and waves 4-7 run ONE BARRIER BEHIND waves 0-3: while one
+//     group multiplies, its SIMD partners load. The matrix pipe alternates between the two waves of a SIMD instead of being fought
+//     over and then left idle (MI355X_MICROARCH.md, two waves per SIMD);
+//   * the 16x16x32 MFMA shape: same cycles per FLOP as 32x32x16, but the chip holds a higher clock on it under load (+12-20 % here);
+//   * hazards: the slot pair of step s + 1 is refilled only after the barrier that closed the trailing group's reads of step s - 1 (every
+//     read retires behind s_waitcnt lgkmcnt(0) before its barrier), and every wave waits for its own share of the DMA (vmcnt(0)) before
+//     the barrier that opens the leading group's reads of step s + 1 — which puts the two groups' issue / wait points in different
+//     segments (see the loop).
+// Windowed (conv1d) mode, epilogues and the fp16 range check are those of gemm_bf16x3.hip (split_epilogue.h).
+#include "at_common.h"
+#include "gemm_bf16x3.h"
+#include "split_scheme.h"
+#include "split_epilogue.h"
+#include <type_traits>
+#include <cstdlib>
+
+namespace at {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int TG_PIECE = 256 * 16;                 // 16-bit elements of one (piece, k-block) chunk of 256 rows
+constexpr int TG_SLOT = 4 * TG_PIECE;              // A hi, A lo, W hi, W lo of one k-block (32 KB)
+constexpr size_t TG_LDS_BYTES = (size_t)4 * TG_SLOT * 2;
+
+__global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a) {
+    typedef SchemeF16x2 SC;
+    typedef _Float16 PT;
+    typedef f16x8 V8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    PT* lds = reinterpret_cast<PT*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);     // 0: leading group, 1: trailing group
+    const int wm = wave & 3, wn = wave >> 2;                       // SIMD partners own the two column halves of the same 64 rows
+    const int ntn = a.N / 256, ntm = a.Mpad / 256;
+    const int n0 = (blockIdx.x % ntn) * 256;   // n fastest: the activation tile is fetched once per row of blocks
+    const int mt = blockIdx.x / ntn;
+    const int clip = mt / ntm, m0 = (mt - clip * ntm) * 256;
+    const int cblocks = a.cblocks > 0 ? a.cblocks : a.K / 16;
+    const int Lp = a.Lp > 0 ? a.Lp : a.Mpad;
+    const long long a_clip = (long long)cblocks * a.stride * Lp * 16;   // elements of one clip of one piece
+    const long long psA = a_clip * a.batch, psW = (long long)a.N * a.K;
+    const int nk2 = a.K / 32;
+    // DMA: a chunk (one piece of one operand, 256 rows x 32 B) = 8 pieces of 1 KB; wave w moves rows 32 w .. 32 w + 31 of all four chunks
+    const int srow = wave * 32 + (lane >> 1), shalf = lane & 1;
+    const PT* gA = reinterpret_cast<const PT*>(a.A) + clip * a_clip + ((long long)m0 + srow) * 16 + shalf * 8;
+    const PT* gW = reinterpret_cast<const PT*>(a.W) + ((long long)n0 + srow) * 16 + shalf * 8;
+    auto issue = [&](int kp, int pair) {             // K step kp = k-blocks 2 kp, 2 kp + 1 -> ring slots 2 pair, 2 pair + 1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kt = 2 * kp + h;
+            const int tapk = kt / cblocks, cbk = kt - tapk * cblocks;   // k-block -> (tap, channel block) -> (phase plane, row offset)
+            const int offk = tapk / a.stride, planek = tapk - offk * a.stride;
+            const long long ka = (((long long)cbk * a.stride + planek) * Lp + offk) * 16, kw = (long long)kt * a.N * 16;
+            PT* s = lds + (2 * pair + h) * TG_SLOT + wave * 512;        // wave-uniform; the hardware adds lane * 16 B
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + ka), (lds_void*)(s + p * TG_PIECE), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(gW + p * psW + kw), (lds_void*)(s + (2 + p) * TG_PIECE), 16, 0, 0);
+            }
+        }
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    const int foff = (fq >> 1) * TG_SLOT + fr * 16 + (fq & 1) * 8;      // k-block, row, half
+    f4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) {                                  // the trailing group starts one barrier late, with its share of step 1 in flight
+        if (nk2 > 1) issue(1, 1);
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int kp = 0; kp < nk2; ++kp) {
+        // ---- L -------------------------------------------------------------------------------------------------------------
+        const PT* s = lds + (kp & 1) * 2 * TG_SLOT + foff;
+        V8 xa[2][4], wb[2][8];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xa[p][i] = *reinterpret_cast<const V8*>(s + p * TG_PIECE + (wm * 64 + i * 16) * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wb[p][j] = *reinterpret_cast<const V8*>(s + (2 + p) * TG_PIECE + (wn * 128 + j * 16) * 16);
+        }
+        // DMA of the NEXT step: its slot pair is free once the barrier that closed the trailing group's segment L of step kp - 1 has
+        // passed, and it must have landed before the barrier that opens the leading group's segment L of step kp + 1. Between those two
+        // barriers the leading group runs L(kp) + C(kp) and the trailing group C(kp - 1) + L(kp): each group issues its share at the START
+        // of that window and waits for it at the END (issue in L / wait after C for the leaders, issue in C / wait in L for the trailers).
+        if (grp == 0) { if (kp + 1 < nk2) issue(kp + 1, (kp + 1) & 1); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- C: hi.lo, lo.hi, hi.hi (smallest first) -------------------------------------------------------------------------
+        if (grp == 1 && kp + 2 < nk2) issue(kp + 2, kp & 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[SC::prod_w(t)][j], xa[SC::prod_a(t)][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the leaders' share of step kp + 1 has landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();      // pairs the trailing group's last barrier
+    // lane holds, per 16 x 16 tile (i, j): output row m = .. + lane & 15 and the 4 consecutive columns n = .. + 4 (lane >> 4) ..
+    XbEpilogue<SC> ep(a, clip);
+    auto epilogue = [&](auto mode) {
+        constexpr int E = decltype(mode)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + fr;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ep.template apply<E>(m, n0 + wn * 128 + j * 16 + 4 * fq, acc[i][j]);
+        }
+    };
+    switch (a.epi) {
+        case XB_EPI_SWISH_SPLIT: epilogue(std::integral_constant<int, XB_EPI_SWISH_SPLIT>{}); break;
+        case XB_EPI_GELU_SPLIT: epilogue(std::integral_constant<int, XB_EPI_GELU_SPLIT>{}); break;
+        case XB_EPI_ELU_SPLIT: epilogue(std::integral_constant<int, XB_EPI_ELU_SPLIT>{}); break;
+        case XB_EPI_GLU: epilogue(std::integral_constant<int, XB_EPI_GLU>{}); break;
+        case XB_EPI_GELU: epilogue(std::integral_constant<int, XB_EPI_GELU>{}); break;
+        default: epilogue(std::integral_constant<int, XB_EPI_LINEAR>{}); break;
+    }
+    ep.finish();
+}
+
+// eligibility: the fp16 scheme, whole 256-column tiles, K steps of 32, enough tiles to fill the chip, no dual split output
+bool gemm_f16x2_tg_eligible(const Bf16x3Args& a) {
+    if (a.scheme != XB_SCHEME_F16X2 || a.epi == XB_EPI_RAW_ELU_SPLIT2) return false;
+    if (a.N % 256 != 0 || a.K % 32 != 0 || a.Mpad % 256 != 0) return false;
+    static const long long min_tiles = std::getenv("AUDIOTOKEN_F16X2_TG_MIN_TILES") ? std::atoll(std::getenv("AUDIOTOKEN_F16X2_TG_MIN_TILES")) : 256;
+    return (long long)a.batch * (a.Mpad / 256) * (a.N / 256) >= min_tiles;
+}
+
+int launch_gemm_f16x2_tg(const Bf16x3Args& a, hipStream_t stream) {
+    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel, TG_LDS_BYTES)) return rc; }
+    const dim3 grid((unsigned)((long long)a.batch * (a.Mpad / 256) * (a.N / 256)));
+    hipLaunchKernelGGL(gemm_f16x2_tg_kernel, grid, dim3(512), TG_LDS_BYTES, stream, a);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace at

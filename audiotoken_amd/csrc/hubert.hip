@@ -461,7 +461,7 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         }
         prof.end(stream);
         prof.begin("attention", 1, stream);
-        if (int rc = launch_relpos_attention(big, fmask, nullptr, t1, B, T, stream, kHeads)) return rc;
+        if (int rc = launch_relpos_attention(big, fmask, nullptr, t1, B, T, stream, kHeads, (std::getenv("AUDIOTOKEN_ATTN_X3") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_X3")) == 0) ? 0 : h->arith, sc.status)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
         if (split) {

@@ -1,0 +1,71 @@
+// Epilogues of the split GEMMs (gemm_bf16x3.hip, gemm_f16x2_tg.hip): what happens to four consecutive output columns n .. n + 3 of
+// output row m once their accumulators are final. One object per thread; `apply<E>` is instantiated per epilogue mode.
+#pragma once
+#include "split_scheme.h"
+
+namespace at {
+
+template <class SC>
+struct XbEpilogue {
+    typedef typename SC::T PT;
+    const Bf16x3Args& a;
+    const int clip;
+    float* Cb;
+    const float* Rb;
+    bool over = false;
+
+    __device__ XbEpilogue(const Bf16x3Args& args, int clip_) : a(args), clip(clip_) {
+        Cb = a.C ? a.C + (long long)clip * a.M * a.ldc : nullptr;
+        Rb = a.R ? a.R + (long long)clip * a.M * a.ldr : nullptr;
+    }
+
+    // split outputs: [pieces][batch][blocks][phases][pad][16]; output row m lives in plane m % phases at index m / phases + front
+    __device__ __forceinline__ void write_split(__bf16* S_, int pad, int phases, int front, int blocks, int block0, int m, int n, const f4& v) {
+        PT* S = reinterpret_cast<PT*>(S_);
+        const int nb = blocks > 0 ? blocks : a.N / 16;
+        const long long s_clip = (long long)pad * phases * nb * 16;   // elements of one clip of one piece
+        const long long psS = s_clip * a.batch;
+        typename SC::V4 p[SC::NP];
+        over |= split4<SC>(v, a.split_scale, p);
+        const int sq = m / phases, sp = m - sq * phases;
+        PT* d = S + clip * s_clip + (((long long)(block0 + (n >> 4)) * phases + sp) * pad + sq + front) * 16 + (n & 15);
+#pragma unroll
+        for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(d + i * psS) = p[i];
+    }
+
+    template <int E>
+    __device__ __forceinline__ void apply(int m, int n, f4 v) {
+        if constexpr (SC::RANGE_CHECK) v *= a.acc_scale;   // exact: a power of two (1 for the bf16 scheme)
+        if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + n);
+        if constexpr (E == XB_EPI_RAW_ELU_SPLIT2) {
+            write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, v);
+            const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
+            write_split(a.S2, a.S2pad, a.S2phases, a.S2front, a.S2blocks, a.S2block0, m, n, e);
+        } else if constexpr (E == XB_EPI_SWISH_SPLIT || E == XB_EPI_GELU_SPLIT || E == XB_EPI_ELU_SPLIT) {
+            f4 w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                w[k] = E == XB_EPI_GELU_SPLIT ? gelu_erf(v[k])
+                     : E == XB_EPI_ELU_SPLIT ? elu1(v[k])
+                                             : v[k] * __frcp_rn(1.0f + __expf(-v[k]));   // as the fp32 GEMM's epilogues
+            write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
+        } else if constexpr (E == XB_EPI_GLU) {
+            float2 o;
+            o.x = v.x * sigmoidf_(v.y);
+            o.y = v.z * sigmoidf_(v.w);
+            *reinterpret_cast<float2*>(Cb + (long long)m * a.ldc + (n >> 1)) = o;
+        } else {
+            if constexpr (E == XB_EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+            v *= a.alpha;
+            if (Rb) v += *reinterpret_cast<const f4*>(Rb + (long long)m * a.ldr + n);
+            *reinterpret_cast<f4*>(Cb + (long long)m * a.ldc + n) = v;
+        }
+    }
+
+    __device__ __forceinline__ void finish() {
+        if constexpr (SC::RANGE_CHECK)
+            if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
+    }
+};
+
+}  // namespace at

@@ -523,7 +523,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
         }
         prof.end(stream);
         prof.begin("attention", 1, stream);
-        if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream)) return rc;
+        if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, (std::getenv("AUDIOTOKEN_ATTN_X3") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_X3")) == 0) ? 0 : h->arith, sc.status)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
         if (split) {

@@ -11,10 +11,13 @@ int launch_fbank_normalize(const float* logmel, const float* fmask, float* stats
                            hipStream_t stream);
 int launch_layernorm(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, long long rows, int D,
                      hipStream_t stream);
+// arith: 0 = fp32-MFMA kernel, 1 = bf16x3, 2 = f16x2 (attention_bf16x3.hip), -1 = the default ($AUDIOTOKEN_ATTN_X3=0 -> 0, else
+// $AUDIOTOKEN_SEMANTIC_ARITH, else f16x2); status: device word for the fp16 range check (nullable)
 int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
-                            hipStream_t stream, int heads = 16);
-// the same attention with both products as exact 3-way bf16 splits on the bf16 matrix cores (attention_bf16x3.hip)
-int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads);
+                            hipStream_t stream, int heads = 16, int arith = -1, int* status = nullptr);
+// the same attention with both products as operand splits on the 16-bit matrix cores (attention_bf16x3.hip); scheme = XB_SCHEME_*
+int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
+                               int scheme, int* status);
 int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,
                            hipStream_t stream);
 int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,

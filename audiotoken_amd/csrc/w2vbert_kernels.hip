@@ -544,10 +544,20 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_kernel(const float* _
     }
 }
 
+static int default_attention_arith() {
+    if (const char* e = std::getenv("AUDIOTOKEN_ATTN_X3")) if (std::atoi(e) == 0) return 0;
+    if (const char* e = std::getenv("AUDIOTOKEN_SEMANTIC_ARITH")) {
+        const std::string v(e);
+        return v == "f32" ? 0 : v == "bf16x3" ? 1 : 2;
+    }
+    return kAttnX3Default ? 2 : 0;
+}
+
 int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
-                            hipStream_t stream, int heads) {
-    static const bool x3 = std::getenv("AUDIOTOKEN_ATTN_X3") ? std::atoi(std::getenv("AUDIOTOKEN_ATTN_X3")) != 0 : kAttnX3Default;
-    if (x3) return launch_relpos_attention_x3(qkv, amask, dist_emb, ctx, B, T, stream, heads);
+                            hipStream_t stream, int heads, int arith, int* status) {
+    static const int dflt = default_attention_arith();
+    if (arith < 0) arith = dflt;
+    if (arith > 0) return launch_relpos_attention_x3(qkv, amask, dist_emb, ctx, B, T, stream, heads, arith == 2 ? 1 : 0, status);
     dim3 grid((T + ATT_QB - 1) / ATT_QB, heads, B);
     const size_t lds = ATT_LDS_FLOATS * sizeof(float);
     { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, relpos_attention_kernel, lds)) return rc; }

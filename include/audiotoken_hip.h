@@ -202,6 +202,12 @@ int at_op_gemm(const at_gemm_desc* d, at_stream_t stream);
 /* Residual VQ search (ref: encodec ResidualVectorQuantizer.encode; formula SURVEY.md Appendix A.1):
  * x device float32 [rows][128]; codebooks device [n_q][1024][128]; e2 device [n_q][1024];
  * codes int16 written at codes[(row / T)*n_q*T + q*T + row % T]. */
+/* The split-operand GEMM of the semantic tokenizers (csrc/gemm_bf16x3.h), for the parity tests: C[M][N] = X[M][K] . W[N][K]^T + bias with both
+ * fp32 operands written as 16-bit pieces — scheme 0 = three bf16 pieces / six products, 1 = two fp16 pieces / three products (w_max_abs = max |W|
+ * sets the weight scale). kernel: 0 = as the product dispatches, 1 = the two-group kernel (gemm_f16x2_tg.hip), 2 = the register-staged kernel.
+ * workspace >= (round_up(M, 256) + N) * K * pieces * 2 bytes. status_dev: nullable device word (bit 1 = fp16 range overflow). */
+int at_op_gemm_split(const float* X, const float* W, const float* bias, float* C, int M, int N, int K, int scheme, float w_max_abs,
+                     int kernel, void* workspace, size_t workspace_bytes, int32_t* status_dev, at_stream_t stream);
 int at_op_rvq_encode(const float* x, int64_t rows, int T, const float* codebooks, const float* e2, int n_q,
                      int16_t* codes, at_stream_t stream);
 

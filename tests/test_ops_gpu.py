@@ -131,3 +131,32 @@ def test_rvq_encode(cuda_device, rows, T, n_q):
     print(f"rvq rows={rows} n_q={n_q}: {int(mism.sum())} differing ids, {bad} not explained by a near-tie; min margin {margins.min().item():.2e}")
     assert bad == 0
     assert int(mism.sum()) == 0, "ids differ from the oracle (near-ties only, but the bar is bit-exact)"
+
+
+@pytest.mark.parametrize("kernel,scheme", [(2, 0), (2, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(200, 256, 1024), (303, 512, 1024), (1500, 1024, 4096), (3000, 4096, 1024)])
+def test_split_gemm_vs_float64(cuda_device, M, N, K, kernel, scheme):
+    """The split-operand GEMM (bf16x3: kernel 2 / scheme 0; f16x2: register-staged kernel 2 and two-group kernel 1) against numpy float64:
+    error not above the k-ordered fp32 FMA chain's scale (a few 1e-7 of the row scale), on ragged M (row padding, several M tiles)."""
+    lib = _cabi.load()
+    x = prng.irwin_hall(f"sg.x{M}", (M, K), 1.0, 3)
+    w = prng.irwin_hall(f"sg.w{N}", (N, K), 0.05, 3)
+    b = prng.irwin_hall("sg.b", (N,), 0.5, 3)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b.astype(np.float64)
+    dev = cuda_device
+    xd, wd, bd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    np_ = 3 if scheme == 0 else 2
+    nbytes = ((M + 255) // 256 * 256 + N) * K * np_ * 2
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    _cabi.check(lib.at_op_gemm_split(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), M, N, K, scheme, float(np.abs(w).max()), kernel,
+                                     ws.data_ptr(), nbytes, status.data_ptr(), _cabi.current_stream_handle(dev)), "at_op_gemm_split")
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    got = out.cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref)
+    chain = np.abs((torch.from_numpy(x) @ torch.from_numpy(w).t() + torch.from_numpy(b)).numpy().astype(np.float64) - ref).max()
+    print(f"split gemm M={M} N={N} K={K} scheme={scheme} kernel={kernel}: max err {err.max():.2e} (torch fp32 on CPU: {chain:.2e}), ref rms {np.sqrt((ref ** 2).mean()):.2f}")
+    assert np.isfinite(got).all()
+    assert err.max() <= 1.5e-5 * np.sqrt(K / 1024.0) * max(1.0, np.sqrt((ref ** 2).mean()))

@@ -131,6 +131,323 @@ __global__ __launch_bounds__(512, 1) void gemm_split(const T* __restrict__ A, co
         }
 }
 
+
+// ---- variant P: one wave per SIMD, software-pipelined -------------------------------------------------------------------------
+// 256 x 256 tile, 4 waves (2 x 2), each 128 x 128 = 4 x 4 MFMA tiles of 32 x 32 (256 accumulator registers); K stage = 16 (one
+// k-block of every piece: 4 chunks of 8 KB); operands by LDS-DMA (global_load_lds_dwordx4, no staging registers) into a 3-slot ring,
+// two stages in flight behind a counted vmcnt; the fragments of K tile j + 1 are read into a second register set WHILE the MFMAs of
+// tile j run, so a wave's MFMA stream only stops at the one barrier per K tile. XOR of the 16-byte half with bit 3 of the row
+// (on the DMA source and on the fragment read) removes the 2-way ds_read_b128 bank conflict of the linear [rows][16] image.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+template <typename T, int SCHED, int XCDMAP>
+__global__ __launch_bounds__(256, 1) void gemm_pipe(const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, int M, int N, int K, float out_scale) {
+    typedef typename Vec8<T>::type V8;
+    constexpr int NP = 2, PIECE = 256 * 16;               // elements of one (piece, k-block) chunk of 256 rows
+    constexpr int STAGE = 2 * NP * PIECE;                 // A hi, A lo, B hi, B lo
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = N / 256, mtn = M / 256;
+    int mt, nt;
+    if (XCDMAP) {
+        // blocks b and b + 8 share an XCD (round-robin dispatch; speed only): give every XCD whole rows of tiles, walked in groups of
+        // GA m-tiles x all n-tiles, so an activation tile is fetched into ONE L2 and the weight tiles are re-used GA times there
+        constexpr int GA = 4;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int lo = (int)((long long)mtn * xcd / 8), hi = (int)((long long)mtn * (xcd + 1) / 8);
+        const int g = slot / (GA * ntn), base = lo + g * GA;
+        const int ga = min(GA, hi - base);
+        if (ga <= 0) return;
+        const int r = slot - g * GA * ntn;
+        if (r >= ga * ntn) return;
+        nt = r / ga; mt = base + (r - nt * ga);
+    } else {
+        mt = blockIdx.x / ntn; nt = blockIdx.x % ntn;
+    }
+    const int m0 = mt * 256, n0 = nt * 256;
+    const long long psA = (long long)M * K, psB = (long long)N * K;
+    const int nk = K / 16;
+    // DMA: chunk c (0 A hi, 1 A lo, 2 B hi, 3 B lo) = 8 pieces of 1 KB; wave w moves pieces 2w and 2w + 1 of every chunk. Lane l of a piece
+    // writes LDS bytes [16 l, 16 l + 16) = row 32 j + l / 2, half l & 1; it fetches the half (l & 1) ^ ((l >> 4) & 1) of that row.
+    const int srow = wave * 64 + (lane >> 1), shalf = (lane & 1) ^ ((lane >> 4) & 1);
+    const T* gA = A + ((long long)m0 + srow) * 16 + shalf * 8;
+    const T* gB = B + ((long long)n0 + srow) * 16 + shalf * 8;
+    auto issue = [&](int kt, int slot) {
+        T* s = lds + slot * STAGE + wave * 1024;                     // wave-uniform; the hardware adds lane * 16 B
+        const long long ka = (long long)kt * M * 16, kb = (long long)kt * N * 16;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + ka + j * 512), (lds_void*)(s + p * PIECE + j * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(gB + p * psB + kb + j * 512), (lds_void*)(s + (NP + p) * PIECE + j * 512), 16, 0, 0);
+            }
+        }
+    };
+    const int frow = lane & 31, fhalf = (lane >> 5) ^ ((frow >> 3) & 1);
+    auto read_frags = [&](int slot, V8 (&a)[NP][4], V8 (&b)[NP][4]) {
+        const T* s = lds + slot * STAGE;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[p][i] = *reinterpret_cast<const V8*>(s + p * PIECE + (wm * 128 + i * 32 + frow) * 16 + fhalf * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[p][j] = *reinterpret_cast<const V8*>(s + (NP + p) * PIECE + (wn * 128 + j * 32 + frow) * 16 + fhalf * 8);
+        }
+    };
+    f16v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mfmas = [&](V8 (&a)[NP][4], V8 (&b)[NP][4]) {
+        constexpr int PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#ifdef PIPE_ASM_MFMA
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(b[PB2[t]][j]), "v"(a[PA2[t]][i]));
+#else
+                    acc[i][j] = mfma32(b[PB2[t]][j], a[PA2[t]][i], acc[i][j]);
+#endif
+                }
+    };
+    // prologue: stages 0, 1, 2 in flight; stages 0 and 1 landed and visible; fragments of tile 0 in set 0
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    V8 a0[NP][4], b0[NP][4], a1[NP][4], b1[NP][4];
+    read_frags(0, a0, b0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    auto step = [&](int kt, V8 (&ac)[NP][4], V8 (&bc)[NP][4], V8 (&an)[NP][4], V8 (&bn)[NP][4]) {
+        // slot of tile kt is free (its fragments are in registers): refill it with tile kt + 3
+        if (kt + 3 < nk) issue(kt + 3, kt % 3);
+        if (kt + 1 < nk) read_frags((kt + 1) % 3, an, bn);
+        mfmas(ac, bc);
+        if (SCHED) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // 3 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS read
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (LDS-DMA)
+            }
+        }
+        // tile kt + 2 (this wave's part; issued one iteration ago) has landed; kt + 3 may still be in flight
+        if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, a0, b0, a1, b1);
+        if (kt + 1 < nk) step(kt + 1, a1, b1, a0, b0);
+    }
+#ifdef PIPE_ASM_MFMA
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU reads: the hazard is not visible to the compiler through inline asm
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* dst = C + (long long)(m0 + wm * 128 + i * 32 + frow) * N + n0 + wn * 128 + j * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = {acc[i][j][4 * g] * out_scale, acc[i][j][4 * g + 1] * out_scale, acc[i][j][4 * g + 2] * out_scale, acc[i][j][4 * g + 3] * out_scale};
+                *reinterpret_cast<float4*>(dst + 8 * g) = v;
+            }
+        }
+}
+
+
+// ---- variant Q: 8 waves in two groups one barrier apart ---------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves (4 x 2, each 64 x 128), one workgroup per CU: waves w and w + 4 share a SIMD. Every K tile has two
+// segments per wave — L: read this tile's fragments from LDS and issue the LDS-DMA of tile t + 2; C: the 24 MFMAs — each closed by a
+// workgroup barrier, and waves 4-7 run one barrier behind waves 0-3: while one group multiplies, its SIMD partners load, so the
+// matrix pipe alternates between two waves instead of being fought over and then left idle. 3-slot ring, counted vmcnt.
+template <typename T, int SWZ, int PRIO>
+__global__ __launch_bounds__(512, 1) void gemm_two_groups(const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, int M, int N, int K, float out_scale) {
+    typedef typename Vec8<T>::type V8;
+    constexpr int NP = 2, PIECE = 256 * 16;
+    constexpr int STAGE = 2 * NP * PIECE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2;                       // 0: leading group, 1: trailing group
+    const int wm = wave & 3, wn = grp;               // SIMD partners (w, w + 4) own the two column halves of the same 64 rows
+    const int ntn = N / 256;
+    const int m0 = (blockIdx.x / ntn) * 256, n0 = (blockIdx.x % ntn) * 256;
+    const long long psA = (long long)M * K, psB = (long long)N * K;
+    const int nk = K / 16;
+    // DMA: chunk c (A hi, A lo, B hi, B lo) = 8 pieces of 1 KB, wave w moves piece w of every chunk (rows 32 w .. 32 w + 31)
+    const int srow = wave * 32 + (lane >> 1), shalf = SWZ ? ((lane & 1) ^ ((lane >> 4) & 1)) : (lane & 1);
+    const T* gA = A + ((long long)m0 + srow) * 16 + shalf * 8;
+    const T* gB = B + ((long long)n0 + srow) * 16 + shalf * 8;
+    auto issue = [&](int kt, int slot) {
+        T* s = lds + slot * STAGE + wave * 512;
+        const long long ka = (long long)kt * M * 16, kb = (long long)kt * N * 16;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + ka), (lds_void*)(s + p * PIECE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(gB + p * psB + kb), (lds_void*)(s + (NP + p) * PIECE), 16, 0, 0);
+        }
+    };
+    const int frow = lane & 31, fhalf = SWZ ? ((lane >> 5) ^ ((frow >> 3) & 1)) : (lane >> 5);
+    f16v acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // prologue: tiles 0 and 1 in flight, tile 0 landed and visible
+    issue(0, 0);
+    if (nk > 1) { issue(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();      // the trailing group starts one barrier late
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- L: fragments of tile kt, DMA of tile kt + 2 (its slot held tile kt - 1: every read of it retired before the last barrier)
+        const T* s = lds + (kt % 3) * STAGE;
+        V8 a[NP][2], b[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[p][i] = *reinterpret_cast<const V8*>(s + p * PIECE + (wm * 64 + i * 32 + frow) * 16 + fhalf * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[p][j] = *reinterpret_cast<const V8*>(s + (NP + p) * PIECE + (wn * 128 + j * 32 + frow) * 16 + fhalf * 8);
+        }
+        if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+        // tile kt + 1 (this wave's share, issued one tile ago) has landed; tile kt + 2 may still be in flight
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- C
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        constexpr int PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(b[PB2[t]][j], a[PA2[t]][i], acc[i][j]);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();      // pair the trailing group's last barrier
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* dst = C + (long long)(m0 + wm * 64 + i * 32 + frow) * N + n0 + wn * 128 + j * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = {acc[i][j][4 * g] * out_scale, acc[i][j][4 * g + 1] * out_scale, acc[i][j][4 * g + 2] * out_scale, acc[i][j][4 * g + 3] * out_scale};
+                *reinterpret_cast<float4*>(dst + 8 * g) = v;
+            }
+        }
+}
+
+
+// ---- variant R: variant Q with v_mfma_f32_16x16x32_f16 (the shape this chip holds a higher clock on) ------------------------------
+// A segment covers a K step of 32 = two 16-wide k-blocks (two ring slots of 32 KB; ring of 4 slots = two pairs); a lane's fragment
+// is 8 consecutive k of one row: k-block (lane >> 5), half (lane >> 4) & 1 — conflict-free in the linear [rows][16] image.
+template <typename T, int PRIO>
+__global__ __launch_bounds__(512, 1) void gemm_two_groups16(const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, int M, int N, int K, float out_scale) {
+    typedef typename Vec8<T>::type V8;
+    constexpr int NP = 2, PIECE = 256 * 16;
+    constexpr int STAGE = 2 * NP * PIECE;            // one k-block of every piece of both operands (32 KB)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int ntn = N / 256;
+    const int m0 = (blockIdx.x / ntn) * 256, n0 = (blockIdx.x % ntn) * 256;
+    const long long psA = (long long)M * K, psB = (long long)N * K;
+    const int nk2 = K / 32;
+    const int srow = wave * 32 + (lane >> 1), shalf = lane & 1;
+    const T* gA = A + ((long long)m0 + srow) * 16 + shalf * 8;
+    const T* gB = B + ((long long)n0 + srow) * 16 + shalf * 8;
+    auto issue = [&](int kp, int pair) {             // K pair kp = k-blocks 2 kp, 2 kp + 1 -> ring slots 2 pair, 2 pair + 1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            T* s = lds + (2 * pair + h) * STAGE + wave * 512;
+            const long long ka = (long long)(2 * kp + h) * M * 16, kb = (long long)(2 * kp + h) * N * 16;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + ka), (lds_void*)(s + p * PIECE), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(gB + p * psB + kb), (lds_void*)(s + (NP + p) * PIECE), 16, 0, 0);
+            }
+        }
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    const int foff = (fq >> 1) * STAGE + fr * 16 + (fq & 1) * 8;    // k-block, row, half
+    f4v acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) {
+        if (nk2 > 1) issue(1, 1);
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int kp = 0; kp < nk2; ++kp) {
+        const T* s = lds + (kp & 1) * 2 * STAGE + foff;
+        V8 a[NP][4], b[NP][8];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[p][i] = *reinterpret_cast<const V8*>(s + p * PIECE + (wm * 64 + i * 16) * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[p][j] = *reinterpret_cast<const V8*>(s + (NP + p) * PIECE + (wn * 128 + j * 16) * 16);
+        }
+        // the other pair of slots held K pair kp - 1: every read of it retired before the barrier that closed the trailing group's L(kp - 1).
+        // Leaders issue the next pair here and wait after C; trailers issued it at the start of their previous C and wait here
+        // (see csrc/gemm_f16x2_tg.hip for the window argument).
+        if (grp == 0) { if (kp + 1 < nk2) issue(kp + 1, (kp + 1) & 1); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1 && kp + 2 < nk2) issue(kp + 2, kp & 1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        constexpr int PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(b[PB2[t]][j], a[PA2[t]][i], acc[i][j]);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float* dst = C + (long long)(m0 + wm * 64 + i * 16 + fr) * N + n0 + wn * 128 + j * 16 + 4 * fq;
+            float4 v = {acc[i][j][0] * out_scale, acc[i][j][1] * out_scale, acc[i][j][2] * out_scale, acc[i][j][3] * out_scale};
+            *reinterpret_cast<float4*>(dst) = v;
+        }
+}
+
 // ---- hardware questions -------------------------------------------------------------------------------------------------
 // (1) subnormal fp16 inputs of the MFMA: a = 2^-20 (subnormal), b = 2^10 -> 2^-10 per product if they are kept, 0 if flushed
 __global__ void denorm_probe(float* out) {
@@ -226,6 +543,92 @@ static int run(const char* name, int M, int N, int K, bool check, float sa, floa
     return 0;
 }
 
+template <typename T, int SCHED, int XCDMAP>
+static int run_pipe(const char* name, int M, int N, int K, bool check, float sa, float sb, const std::vector<float>& hA, const std::vector<float>& hB,
+                    float* dA, float* dB, float* dC) {
+    constexpr int NP = 2;
+    T *pA, *pB;
+    CK(hipMalloc(&pA, (size_t)M * K * 2 * NP)); CK(hipMalloc(&pB, (size_t)N * K * 2 * NP));
+    hipLaunchKernelGGL((split_kernel<T, NP>), dim3((unsigned)(((long long)M * K + 255) / 256)), dim3(256), 0, 0, dA, pA, (long long)M, K, sa);
+    hipLaunchKernelGGL((split_kernel<T, NP>), dim3((unsigned)(((long long)N * K + 255) / 256)), dim3(256), 0, 0, dB, pB, (long long)N, K, sb);
+    const size_t ldsb = 3 * (size_t)2 * NP * 256 * 16 * 2;
+    auto kern = gemm_pipe<T, SCHED, XCDMAP>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const int mtn = M / 256, ntn = N / 256;
+    const int per_xcd = ((mtn + 7) / 8 + 3) / 4 * 4 * ntn;     // upper bound of tiles on one XCD incl. group padding
+    const dim3 grid(XCDMAP ? 8 * per_xcd : mtn * ntn);
+    const float os = 1.0f / (sa * sb);
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, 0, pA, pB, dC, M, N, K, os);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int reps = check ? 1 : 5;
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, 0, pA, pB, dC, M, N, K, os);
+    hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("{\"scheme\": \"%s\", \"sched\": %d, \"xcdmap\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"ms\": %.3f, \"fp32_equiv_tflops\": %.1f", name, SCHED, XCDMAP, M, N, K, ms, 2.0 * M * N * K / ms * 1e-9);
+    if (check) {
+        std::vector<float> hC((size_t)M * N);
+        CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+        double e_mx = 0, e_sq = 0, ref_sq = 0;
+        long long cnt = 0;
+        for (int m = 0; m < M; m += 3)
+            for (int n = 0; n < N; n += 5) {
+                double ref = 0;
+                for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)m * K + k] * hB[(size_t)n * K + k];
+                const double e = fabs(hC[(size_t)m * N + n] - ref);
+                e_mx = fmax(e_mx, e); e_sq += e * e; ref_sq += ref * ref; ++cnt;
+            }
+        printf(", \"max_abs_err\": %.3e, \"rms_err\": %.3e, \"ref_rms\": %.3e", e_mx, sqrt(e_sq / cnt), sqrt(ref_sq / cnt));
+    }
+    printf("}\n");
+    hipFree(pA); hipFree(pB);
+    return 0;
+}
+
+template <typename T, int SWZ, int PRIO, int SHAPE16 = 0>
+static int run_two(const char* name, int M, int N, int K, bool check, float sa, float sb, const std::vector<float>& hA, const std::vector<float>& hB,
+                   float* dA, float* dB, float* dC) {
+    constexpr int NP = 2;
+    T *pA, *pB;
+    CK(hipMalloc(&pA, (size_t)M * K * 2 * NP)); CK(hipMalloc(&pB, (size_t)N * K * 2 * NP));
+    hipLaunchKernelGGL((split_kernel<T, NP>), dim3((unsigned)(((long long)M * K + 255) / 256)), dim3(256), 0, 0, dA, pA, (long long)M, K, sa);
+    hipLaunchKernelGGL((split_kernel<T, NP>), dim3((unsigned)(((long long)N * K + 255) / 256)), dim3(256), 0, 0, dB, pB, (long long)N, K, sb);
+    const size_t ldsb = (SHAPE16 ? 4 : 3) * (size_t)2 * NP * 256 * 16 * 2;
+    auto kern = SHAPE16 ? gemm_two_groups16<T, PRIO> : gemm_two_groups<T, SWZ, PRIO>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const dim3 grid((M / 256) * (N / 256));
+    const float os = 1.0f / (sa * sb);
+    CK(hipMemset(dC, 0, (size_t)M * N * 4));
+    hipLaunchKernelGGL(kern, grid, dim3(512), ldsb, 0, pA, pB, dC, M, N, K, os);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int reps = check ? 1 : 5;
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, grid, dim3(512), ldsb, 0, pA, pB, dC, M, N, K, os);
+    hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("{\"scheme\": \"%s\", \"mfma\": \"%s\", \"swizzle\": %d, \"setprio\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"ms\": %.3f, \"fp32_equiv_tflops\": %.1f", name, SHAPE16 ? "16x16x32" : "32x32x16", SWZ, PRIO, M, N, K, ms, 2.0 * M * N * K / ms * 1e-9);
+    if (check) {
+        std::vector<float> hC((size_t)M * N);
+        CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+        double e_mx = 0, e_sq = 0, ref_sq = 0;
+        long long cnt = 0;
+        for (int m = 0; m < M; m += 3)
+            for (int n = 0; n < N; n += 5) {
+                double ref = 0;
+                for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)m * K + k] * hB[(size_t)n * K + k];
+                const double e = fabs(hC[(size_t)m * N + n] - ref);
+                e_mx = fmax(e_mx, e); e_sq += e * e; ref_sq += ref * ref; ++cnt;
+            }
+        printf(", \"max_abs_err\": %.3e, \"rms_err\": %.3e, \"ref_rms\": %.3e", e_mx, sqrt(e_sq / cnt), sqrt(ref_sq / cnt));
+    }
+    printf("}\n");
+    hipFree(pA); hipFree(pB);
+    return 0;
+}
+
 static int shape(int M, int N, int K, bool check, float wscale, float ascale_data) {
     std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
     unsigned long long s = 88172645463325252ull;
@@ -243,6 +646,16 @@ static int shape(int M, int N, int K, bool check, float wscale, float ascale_dat
     if (run<__bf16, 3, 1>("bf16x3 (6 products)", M, N, K, check, 1.f, 1.f, hA, hB, dA, dB, dC)) return 1;
     if (run<_Float16, 2, 1>("fp16x2 (3 products), scaled", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
     if (run<_Float16, 2, 2>("fp16x2 (3 products), scaled", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+#ifdef WITH_PIPE
+    if (run_pipe<_Float16, 0, 0>("fp16x2 pipelined 4-wave", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+    if (run_pipe<_Float16, 1, 1>("fp16x2 pipelined 4-wave", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+#endif
+    if (run_two<_Float16, 0, 0>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+    if (run_two<_Float16, 1, 0>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+    if (run_two<_Float16, 0, 1>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+    if (run_two<_Float16, 1, 1>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+    if (run_two<_Float16, 0, 0, 1>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+    if (run_two<_Float16, 0, 1, 1>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
     if (check) {
         if (run<_Float16, 2, 1>("fp16x2 (3 products), UNSCALED operands", M, N, K, check, 1.f, 1.f, hA, hB, dA, dB, dC)) return 1;
         if (run<_Float16, 2, 1>("fp16x2 (3 products), activations scaled 64, weights to 2^15", M, N, K, check, 64.f, sb, hA, hB, dA, dB, dC)) return 1;
@@ -267,6 +680,15 @@ static int rate(const char* name, const float* seed, float* out) {
 }
 
 int main(int argc, char** argv) {
+    const bool gemm_only = argc > 1 && argv[1][0] == 'g';
+    if (gemm_only) {
+        if (shape(768, 512, 1024, true, 0.05f, 1.0f)) return 1;
+        if (shape(96000, 4096, 1024, false, 0.05f, 1.0f)) return 1;
+        if (shape(96000, 1024, 4096, false, 0.05f, 1.0f)) return 1;
+        if (shape(96000, 1024, 1024, false, 0.05f, 1.0f)) return 1;
+        if (shape(96000, 3072, 1024, false, 0.05f, 1.0f)) return 1;
+        return 0;
+    }
     float* d; CK(hipMalloc(&d, 4096 * 4 + 256 * 256 * 4));
     hipLaunchKernelGGL(denorm_probe, dim3(1), dim3(64), 0, 0, d);
     float h[3]; CK(hipMemcpy(h, d, 12, hipMemcpyDeviceToHost));
