@@ -33,7 +33,7 @@ template <int NP> constexpr size_t ax_lds_bytes() { return (size_t)(ax_k_elems<N
 template <class SC>
 __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ amask,
                                                                      const float* __restrict__ dist_emb, float* __restrict__ ctx, int T, int hid,
-                                                                     int* __restrict__ status) {
+                                                                     int* __restrict__ status, typename SC::T* __restrict__ ctx_pieces, long long rows_pad) {
     typedef typename SC::T PT;
     typedef typename SC::V8 V8;
     typedef typename SC::V4 V4;
@@ -273,7 +273,10 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f4 v = {oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv};
-                *reinterpret_cast<f4*>(ctx + (rowbase + lq) * hid + h * 64 + dt * 32 + 8 * g + 4 * hh) = v;
+                if (ctx_pieces)   // straight to the output projection's GEMM operand (split_scheme.h): an 8-byte store per piece
+                    over |= store_pieces4<SC>(ctx_pieces, rows_pad * hid, rows_pad, rowbase + lq, h * 64 + dt * 32 + 8 * g + 4 * hh, v, XS);
+                else
+                    *reinterpret_cast<f4*>(ctx + (rowbase + lq) * hid + h * 64 + dt * 32 + 8 * g + 4 * hh) = v;
             }
     }
     if constexpr (SC::RANGE_CHECK)
@@ -281,21 +284,24 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
 }
 
 template <class SC>
-static int launch_ax(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads, int* status) {
+static int launch_ax(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads, int* status,
+                     __bf16* ctx_pieces, long long rows_pad) {
     dim3 grid((T + AX_QB - 1) / AX_QB, heads, B);
     constexpr size_t lds = ax_lds_bytes<SC::NP>();
     { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, relpos_attention_x3_kernel<SC>, lds)) return rc; }
-    hipLaunchKernelGGL(relpos_attention_x3_kernel<SC>, grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T, heads * 64, status);
+    hipLaunchKernelGGL(relpos_attention_x3_kernel<SC>, grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T, heads * 64, status,
+                       reinterpret_cast<typename SC::T*>(ctx_pieces), rows_pad);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
-                               int scheme, int* status) {
+                               int scheme, int* status, __bf16* ctx_pieces, long long rows_pad) {
     AT_REQUIRE(B >= 1 && T >= 1 && heads >= 1 && heads <= 64, "relpos_attention_x3: bad shape");
     AT_REQUIRE((long long)T * 3 * heads * 64 * 4 < (1ll << 31), "relpos_attention_x3: one clip's qkv rows exceed the buffer-descriptor range");
-    if (scheme == XB_SCHEME_F16X2) return launch_ax<SchemeF16x2>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status);
-    return launch_ax<SchemeBf16x3>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status);
+    AT_REQUIRE(ctx_pieces == nullptr || rows_pad >= (long long)B * T, "relpos_attention_x3: rows_pad too small");
+    if (scheme == XB_SCHEME_F16X2) return launch_ax<SchemeF16x2>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad);
+    return launch_ax<SchemeBf16x3>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad);
 }
 
 }  // namespace at

@@ -34,6 +34,9 @@ constexpr int TG_PIECE = 256 * 16;                 // 16-bit elements of one (pi
 constexpr int TG_SLOT = 4 * TG_PIECE;              // A hi, A lo, W hi, W lo of one k-block (32 KB)
 constexpr size_t TG_LDS_BYTES = (size_t)4 * TG_SLOT * 2;
 
+// WINDOWED = false: a plain linear layer (one tap, stride 1): the k-block -> row offset map is a multiplication; true: conv1d windows
+// (per k-block two integer divisions on the scalar unit — kept off the linear layers' instruction stream)
+template <bool WINDOWED>
 __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a) {
     typedef SchemeF16x2 SC;
     typedef _Float16 PT;
@@ -60,9 +63,15 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int kt = 2 * kp + h;
-            const int tapk = kt / cblocks, cbk = kt - tapk * cblocks;   // k-block -> (tap, channel block) -> (phase plane, row offset)
-            const int offk = tapk / a.stride, planek = tapk - offk * a.stride;
-            const long long ka = (((long long)cbk * a.stride + planek) * Lp + offk) * 16, kw = (long long)kt * a.N * 16;
+            long long ka;
+            if constexpr (WINDOWED) {
+                const int tapk = kt / cblocks, cbk = kt - tapk * cblocks;   // k-block -> (tap, channel block) -> (phase plane, row offset)
+                const int offk = tapk / a.stride, planek = tapk - offk * a.stride;
+                ka = (((long long)cbk * a.stride + planek) * Lp + offk) * 16;
+            } else {
+                ka = (long long)kt * Lp * 16;
+            }
+            const long long kw = (long long)kt * a.N * 16;
             PT* s = lds + (2 * pair + h) * TG_SLOT + wave * 512;        // wave-uniform; the hardware adds lane * 16 B
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -153,9 +162,15 @@ bool gemm_f16x2_tg_eligible(const Bf16x3Args& a) {
 }
 
 int launch_gemm_f16x2_tg(const Bf16x3Args& a, hipStream_t stream) {
-    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel, TG_LDS_BYTES)) return rc; }
     const dim3 grid((unsigned)((long long)a.batch * (a.Mpad / 256) * (a.N / 256)));
-    hipLaunchKernelGGL(gemm_f16x2_tg_kernel, grid, dim3(512), TG_LDS_BYTES, stream, a);
+    const bool windowed = a.stride != 1 || (a.cblocks > 0 && a.cblocks != a.K / 16);
+    if (windowed) {
+        { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<true>, TG_LDS_BYTES)) return rc; }
+        hipLaunchKernelGGL(gemm_f16x2_tg_kernel<true>, grid, dim3(512), TG_LDS_BYTES, stream, a);
+    } else {
+        { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<false>, TG_LDS_BYTES)) return rc; }
+        hipLaunchKernelGGL(gemm_f16x2_tg_kernel<false>, grid, dim3(512), TG_LDS_BYTES, stream, a);
+    }
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -42,7 +42,6 @@ constexpr int LS_SLICES = 32;      // workgroups per group
 constexpr int LS_ROWS = 64;        // gate rows per workgroup = 16 hidden units x 4 gates
 constexpr int LS_KG = LS_H / 16;   // 32 k-groups of 16
 constexpr int LS_H_FLOATS = LS_CLIPS * LS_H;   // 8192 floats = 32 KB
-constexpr unsigned LS_SPIN_LIMIT = 1u << 18;   // ~0.1-0.3 s of polling; normal waits are microseconds
 constexpr int LS_STATUS = 63;                  // word of a.sync that reports a timed-out wait (sticky for the encode call)
 constexpr int LS_FLAGS = 128;                  // word offset of flags[16 groups][32 slices] in a.sync (1024 words)
 constexpr int LS_MAX_GROUPS = 16;

@@ -23,7 +23,6 @@ constexpr int LX_CLIPS = 16;       // clips per group = one MFMA row tile
 constexpr int LX_SLICES = 16;      // workgroups per group: 32 hidden units each
 constexpr int LX_LDH = LX_H + 8;   // LDS row stride (bf16)
 constexpr int LX_HP = LX_CLIPS * LX_LDH;       // elements of one piece
-constexpr unsigned LX_SPIN_LIMIT = 1u << 18;
 constexpr int LX_STATUS = 63;      // as lstm_seq.hip
 constexpr int LX_FLAGS = 128;      // flags[16 groups][32 words] (16 used)
 constexpr int LX_FLAG_STRIDE = 32;

@@ -56,4 +56,16 @@ __device__ __forceinline__ bool split4(const f4& v, float scale, typename SC::V4
     return over;
 }
 
+// pieces of the 4 consecutive columns col .. col + 3 (col % 4 == 0) of row `row`, into K-blocked pieces [NP][K/16][rows_pad][16]
+// (piece_stride = rows_pad * K elements); one 8-byte store per piece. Returns true when a value does not fit the scheme's range.
+template <class SC>
+__device__ __forceinline__ bool store_pieces4(typename SC::T* out, long long piece_stride, long long rows_pad, long long row, int col, const f4& v, float scale) {
+    typename SC::V4 p[SC::NP];
+    const bool over = split4<SC>(v, scale, p);
+    typename SC::T* d = out + ((long long)(col >> 4) * rows_pad + row) * 16 + (col & 15);
+#pragma unroll
+    for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(d + i * piece_stride) = p[i];
+    return over;
+}
+
 }  // namespace at

@@ -193,22 +193,6 @@ int gemm_split(const SplitCtx& c, const piece_t* A, const LayerW& L, int w, cons
     return launch_gemm_bf16x3(a, stream);
 }
 
-// x += 0.5 * (swish(t1 . W1^T + b1) . W2^T + b2): t1 is split into pieces, the hidden activation is written split by the first GEMM's
-// epilogue, the second GEMM adds the residual in fp32
-int ffn_split(const SplitCtx& c, const float* t1, const LayerW& L, int w1, const float* b1, int w2, const float* b2, float* x, piece_t* t1s, piece_t* bigs,
-              long long M, long long Mpad, hipStream_t stream) {
-    if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream, c.scheme, c.act_scale(), c.status)) return rc;
-    if (int rc = gemm_split(c, t1s, L, w1, b1, kFfn, kHid, M, Mpad, XB_EPI_SWISH_SPLIT, 1.f, nullptr, nullptr, kFfn, bigs, stream)) return rc;
-    return gemm_split(c, bigs, L, w2, b2, kHid, kFfn, M, Mpad, XB_EPI_LINEAR, 0.5f, x, x, kHid, nullptr, stream);
-}
-
-// C = epi(X . W^T): fp32 row-major X [M][1024] is split into pieces (t1s), then the split GEMM
-int linear_split(const SplitCtx& c, const float* X, const LayerW& L, int w, const float* bias, float* C, int N, long long M, long long Mpad, int epi, float alpha,
-                 const float* R, int ldc, piece_t* t1s, hipStream_t stream) {
-    if (int rc = launch_split_blocked(X, kHid, M, Mpad, kHid, t1s, stream, c.scheme, c.act_scale(), c.status)) return rc;
-    return gemm_split(c, t1s, L, w, bias, N, kHid, M, Mpad, epi, alpha, C, R, ldc, nullptr, stream);
-}
-
 }  // namespace
 
 extern "C" {
@@ -471,6 +455,8 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
     const bool split = h->arith != ARITH_F32;
     const SplitCtx sc{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, reinterpret_cast<int*>(status_dev)};
+    // attention follows the linear layers' arithmetic; $AUDIOTOKEN_ATTN_X3=0 keeps the fp32-MFMA attention kernel
+    const int attn_arith = (std::getenv("AUDIOTOKEN_ATTN_X3") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_X3")) == 0) ? 0 : h->arith;
 
     // ---- log-mel front-end (reference processors.py) -------------------------------------------
     double* frames = reinterpret_cast<double*>(ws + p.off_frames);
@@ -502,60 +488,77 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     if (int rc = linear(t1, kFeat, h->fp_w, h->fp_b, x, kHid, M, EPI_NONE, 1.f, nullptr, amask, kHid, stream)) return rc;
     prof.end(stream);
 
+    const long long Mpad = (long long)p.Mpad;
     for (int li = 0; li < n_layers; ++li) {
         const LayerW& L = h->layers[li];
+        if (split) {
+            // Split arithmetic: every GEMM operand is produced directly as K-blocked pieces — LayerNorm (launch_layernorm_split), the first
+            // FFN GEMM's swish epilogue, the attention kernel's context and the depthwise-conv kernel's output — so no fp32 activation is
+            // written only to be re-read by a split pass.
+            const float as = sc.act_scale();
+            prof.begin("ffn", 3, stream);
+            if (int rc = launch_layernorm_split(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            if (int rc = gemm_split(sc, t1s, L, W_1A, L.b1a, kFfn, kHid, M, Mpad, XB_EPI_SWISH_SPLIT, 1.f, nullptr, nullptr, kFfn, bigs, stream)) return rc;
+            if (int rc = gemm_split(sc, bigs, L, W_1B, L.b1b, kHid, kFfn, M, Mpad, XB_EPI_LINEAR, 0.5f, x, x, kHid, nullptr, stream)) return rc;
+            prof.end(stream);
+
+            prof.begin("attn_proj", 2, stream);
+            if (int rc = launch_layernorm_split(x, L.ln_att_g, L.ln_att_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            if (int rc = gemm_split(sc, t1s, L, W_QKV, L.bqkv, 3 * kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, big, nullptr, 3 * kHid, nullptr, stream)) return rc;
+            prof.end(stream);
+            prof.begin("attention", 1, stream);
+            if (attn_arith > 0) {
+                if (int rc = launch_relpos_attention(big, amask, L.dist, nullptr, B, T, stream, 16, attn_arith, sc.status, t1s, Mpad)) return rc;
+            } else {
+                if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, 0, nullptr)) return rc;
+                if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream, sc.scheme, as, sc.status)) return rc;
+            }
+            prof.end(stream);
+            prof.begin("attn_proj", 1, stream);
+            if (int rc = gemm_split(sc, t1s, L, W_O, L.bo, kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, x, x, kHid, nullptr, stream)) return rc;
+            prof.end(stream);
+
+            prof.begin("conv_module", 4, stream);
+            if (int rc = launch_layernorm_split(x, L.ln_conv_g, L.ln_conv_b, amask, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            if (int rc = gemm_split(sc, t1s, L, W_PW1, nullptr, 2 * kHid, kHid, M, Mpad, XB_EPI_GLU, 1.f, big, nullptr, kHid, nullptr, stream)) return rc;
+            if (int rc = launch_dwconv_ln_swish(big, L.dw, L.ln_dw_g, L.ln_dw_b, nullptr, B, T, stream, t1s, Mpad, sc.scheme, as, sc.status)) return rc;
+            if (int rc = gemm_split(sc, t1s, L, W_PW2, nullptr, kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, x, x, kHid, nullptr, stream)) return rc;
+            prof.end(stream);
+
+            prof.begin("ffn", 4, stream);
+            if (int rc = launch_layernorm_split(x, L.ln_ffn2_g, L.ln_ffn2_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            if (int rc = gemm_split(sc, t1s, L, W_2A, L.b2a, kFfn, kHid, M, Mpad, XB_EPI_SWISH_SPLIT, 1.f, nullptr, nullptr, kFfn, bigs, stream)) return rc;
+            if (int rc = gemm_split(sc, bigs, L, W_2B, L.b2b, kHid, kFfn, M, Mpad, XB_EPI_LINEAR, 0.5f, x, x, kHid, nullptr, stream)) return rc;
+            if (int rc = launch_layernorm(x, L.ln_fin_g, L.ln_fin_b, nullptr, x, M, kHid, stream)) return rc;
+            prof.end(stream);
+            continue;
+        }
+        // ---- fp32 MFMA path --------------------------------------------------------------------------------------------------
         prof.begin("ffn", 3, stream);
         if (int rc = launch_layernorm(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, t1, M, kHid, stream)) return rc;
-        if (split) {
-            if (int rc = ffn_split(sc, t1, L, W_1A, L.b1a, W_1B, L.b1b, x, t1s, bigs, M, (long long)p.Mpad, stream)) return rc;
-        } else {
-            if (int rc = linear(t1, kHid, L.w1a, L.b1a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
-            if (int rc = linear(big, kFfn, L.w1b, L.b1b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
-        }
+        if (int rc = linear(t1, kHid, L.w1a, L.b1a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
+        if (int rc = linear(big, kFfn, L.w1b, L.b1b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
         prof.end(stream);
-
         prof.begin("attn_proj", 3, stream);
         if (int rc = launch_layernorm(x, L.ln_att_g, L.ln_att_b, nullptr, t1, M, kHid, stream)) return rc;
-        if (split) {
-            if (int rc = linear_split(sc, t1, L, W_QKV, L.bqkv, big, 3 * kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, nullptr, 3 * kHid, t1s, stream)) return rc;
-        } else if (int rc = linear(t1, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, 1.f, nullptr, nullptr, 3 * kHid, stream)) {
-            return rc;
-        }
+        if (int rc = linear(t1, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, 1.f, nullptr, nullptr, 3 * kHid, stream)) return rc;
         prof.end(stream);
         prof.begin("attention", 1, stream);
-        if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, (std::getenv("AUDIOTOKEN_ATTN_X3") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_X3")) == 0) ? 0 : h->arith, sc.status)) return rc;
+        if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, attn_arith, sc.status)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
-        if (split) {
-            if (int rc = linear_split(sc, t1, L, W_O, L.bo, x, kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, x, kHid, t1s, stream)) return rc;
-        } else if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) {
-            return rc;
-        }
+        if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) return rc;
         prof.end(stream);
-
         prof.begin("conv_module", 4, stream);
         if (int rc = launch_layernorm(x, L.ln_conv_g, L.ln_conv_b, amask, t1, M, kHid, stream)) return rc;
-        if (split) {
-            if (int rc = linear_split(sc, t1, L, W_PW1, nullptr, big, 2 * kHid, M, (long long)p.Mpad, XB_EPI_GLU, 1.f, nullptr, kHid, t1s, stream)) return rc;
-        } else if (int rc = linear(t1, kHid, L.pw1, nullptr, big, 2 * kHid, M, EPI_GLU, 1.f, nullptr, nullptr, kHid, stream)) {
-            return rc;
-        }
+        if (int rc = linear(t1, kHid, L.pw1, nullptr, big, 2 * kHid, M, EPI_GLU, 1.f, nullptr, nullptr, kHid, stream)) return rc;
         if (int rc = launch_dwconv_ln_swish(big, L.dw, L.ln_dw_g, L.ln_dw_b, t1, B, T, stream)) return rc;
-        if (split) {
-            if (int rc = linear_split(sc, t1, L, W_PW2, nullptr, x, kHid, M, (long long)p.Mpad, XB_EPI_LINEAR, 1.f, x, kHid, t1s, stream)) return rc;
-        } else if (int rc = linear(t1, kHid, L.pw2, nullptr, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) {
-            return rc;
-        }
+        if (int rc = linear(t1, kHid, L.pw2, nullptr, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) return rc;
         prof.end(stream);
-
         prof.begin("ffn", 4, stream);
         if (int rc = launch_layernorm(x, L.ln_ffn2_g, L.ln_ffn2_b, nullptr, t1, M, kHid, stream)) return rc;
-        if (split) {
-            if (int rc = ffn_split(sc, t1, L, W_2A, L.b2a, W_2B, L.b2b, x, t1s, bigs, M, (long long)p.Mpad, stream)) return rc;
-        } else {
-            if (int rc = linear(t1, kHid, L.w2a, L.b2a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
-            if (int rc = linear(big, kFfn, L.w2b, L.b2b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
-        }
+        if (int rc = linear(t1, kHid, L.w2a, L.b2a, big, kFfn, M, EPI_SWISH, 1.f, nullptr, nullptr, kFfn, stream)) return rc;
+        if (int rc = linear(big, kFfn, L.w2b, L.b2b, x, kHid, M, EPI_NONE, 0.5f, x, nullptr, kHid, stream)) return rc;
         if (int rc = launch_layernorm(x, L.ln_fin_g, L.ln_fin_b, nullptr, x, M, kHid, stream)) return rc;
         prof.end(stream);
     }

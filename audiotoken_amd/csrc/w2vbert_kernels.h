@@ -13,13 +13,18 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, cons
                      hipStream_t stream);
 // arith: 0 = fp32-MFMA kernel, 1 = bf16x3, 2 = f16x2 (attention_bf16x3.hip), -1 = the default ($AUDIOTOKEN_ATTN_X3=0 -> 0, else
 // $AUDIOTOKEN_SEMANTIC_ARITH, else f16x2); status: device word for the fp16 range check (nullable)
+// ctx_pieces != nullptr (split arithmetic only): the context is written as operand pieces [NP][hid/16][rows_pad][16] instead of fp32 ctx
 int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
-                            hipStream_t stream, int heads = 16, int arith = -1, int* status = nullptr);
+                            hipStream_t stream, int heads = 16, int arith = -1, int* status = nullptr, __bf16* ctx_pieces = nullptr, long long rows_pad = 0);
 // the same attention with both products as operand splits on the 16-bit matrix cores (attention_bf16x3.hip); scheme = XB_SCHEME_*
 int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
-                               int scheme, int* status);
+                               int scheme, int* status, __bf16* ctx_pieces = nullptr, long long rows_pad = 0);
+// pieces != nullptr: the output is written as the K-blocked operand pieces [NP][64][rows_pad][16] of `scheme` (times `scale`) instead of fp32
 int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,
-                           hipStream_t stream);
+                           hipStream_t stream, __bf16* pieces = nullptr, long long rows_pad = 0, int scheme = 0, float scale = 1.0f, int* status = nullptr);
+// LayerNorm(1024) written as operand pieces [NP][64][rows_pad][16] of `scheme` (times `scale`); y != nullptr: also as fp32 [rows][1024]
+int launch_layernorm_split(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, __bf16* out, long long rows, long long rows_pad,
+                           int D, int scheme, float scale, int* status, hipStream_t stream);
 int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,
                      hipStream_t stream);
 

@@ -3,7 +3,9 @@
 // GEMM-shaped work (DFT, mel projection, all Linear layers) goes through gemm_core.h.
 #include "gemm_core.h"
 #include "w2vbert_kernels.h"
+#include "split_scheme.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace at {
 
@@ -302,6 +304,108 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, cons
 }
 
 // ------------------------------------------------------------------------------------------------------
+// LayerNorm(1024) whose output goes straight to a split GEMM: the normalised row is written as the K-blocked operand pieces
+// [NP][64][rows_pad][16] (gemm_bf16x3.h) instead of (or, for the post-LN HuBERT layers, besides) fp32 — the separate split pass
+// and one fp32 round trip of the activation disappear (16 -> 8 bytes of HBM traffic per element). Same arithmetic as layernorm_kernel.
+// Workgroup = 16 consecutive rows (4 waves x 4 rows); the pieces go through LDS so that every (piece, k-block) is written as one
+// contiguous 512-byte run (16 rows x 32 B) — a wave writing its own row directly scatters 32-byte segments (measured slower in round 1).
+// ------------------------------------------------------------------------------------------------------
+constexpr int LNS_ROWS = 16, LNS_D = 1024;
+
+template <class SC, bool WRITE_Y>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ row_mask, float* __restrict__ y, typename SC::T* __restrict__ out,
+                                                              long long rows, long long rows_pad, float scale, int* __restrict__ status) {
+    typedef typename SC::T PT;
+    typedef typename SC::V4 V4;
+    constexpr int NP = SC::NP;
+    __shared__ __attribute__((aligned(16))) PT tile[NP][LNS_D / 16][LNS_ROWS][16];   // 64 KB (two pieces) / 96 KB (three)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.x * LNS_ROWS;
+    bool over = false;
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+        const int lr = wave * 4 + rr;
+        const long long row = r0 + lr;
+        f4 v[4];
+        if (row < rows) {
+            const f4* xr = reinterpret_cast<const f4*>(x + row * LNS_D);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = xr[lane + 64 * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        const float mean = s / (float)LNS_D;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f4 d = v[j] - mean;
+            q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+        const float rstd = 1.0f / sqrtf(q / (float)LNS_D + 1e-5f);
+        const float shift = -rstd * mean;
+        const bool zero = row >= rows || (row_mask && row_mask[row] == 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane + 64 * j;           // float4 index: columns 4c .. 4c + 3 = k-block c / 4, quarter c % 4
+            f4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaf(v[j][k], rstd, shift);
+            if (gamma) {
+                const f4 g = reinterpret_cast<const f4*>(gamma)[c];
+                const f4 bb = reinterpret_cast<const f4*>(beta)[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = fmaf(o[k], g[k], bb[k]);
+            }
+            if (zero) o = f4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (WRITE_Y)
+                if (row < rows) reinterpret_cast<f4*>(y + row * LNS_D)[c] = o;
+            V4 p[NP];
+            over |= split4<SC>(o, scale, p);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(&tile[i][c >> 2][lr][(c & 3) * 4]) = p[i];
+        }
+    }
+    __syncthreads();
+    // (piece, k-block) = 16 rows x 32 B = 512 contiguous bytes = 32 chunks of 16 B: thread -> chunk
+    typedef unsigned int u4_ __attribute__((ext_vector_type(4)));
+    const long long ps = rows_pad * (long long)LNS_D;
+    for (int e = threadIdx.x; e < NP * (LNS_D / 16) * 32; e += 256) {
+        const int ch = e & 31, kb = (e >> 5) & 63, pi = e >> 11;
+        const int lr = ch >> 1;
+        if (r0 + lr < rows_pad)
+            *reinterpret_cast<u4_*>(out + pi * ps + ((long long)kb * rows_pad + r0 + lr) * 16 + (ch & 1) * 8) =
+                *reinterpret_cast<const u4_*>(&tile[pi][kb][lr][(ch & 1) * 8]);
+    }
+    if constexpr (SC::RANGE_CHECK)
+        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
+}
+
+int launch_layernorm_split(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, __bf16* out, long long rows, long long rows_pad,
+                           int D, int scheme, float scale, int* status, hipStream_t stream) {
+    AT_REQUIRE(D == LNS_D && rows_pad >= rows && rows_pad % LNS_ROWS == 0 && out, "layernorm_split: D must be 1024, rows_pad a multiple of 16");
+    const unsigned blocks = (unsigned)(rows_pad / LNS_ROWS);
+    if (scheme == XB_SCHEME_F16X2) {
+        _Float16* o = reinterpret_cast<_Float16*>(out);
+        if (y) hipLaunchKernelGGL((layernorm_split_kernel<SchemeF16x2, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, o, rows, rows_pad, scale, status);
+        else hipLaunchKernelGGL((layernorm_split_kernel<SchemeF16x2, false>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, o, rows, rows_pad, scale, status);
+    } else {
+        if (y) hipLaunchKernelGGL((layernorm_split_kernel<SchemeBf16x3, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, out, rows, rows_pad, scale, status);
+        else hipLaunchKernelGGL((layernorm_split_kernel<SchemeBf16x3, false>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, out, rows, rows_pad, scale, status);
+    }
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Relative-position self-attention (reference audiotoken/modeling_wav2vec2_bert.py:46-73), flash style, fp32 MFMA.
 //   scores[l][r] = q_l.k_r / 8 + (q_l . E[clamp(r-l,-64,8)+64]) / 8 + (key r padded ? finfo.min : 0);  softmax;  . v
 // The reference materialises the [B,16,T,T] bias with an einsum; here q.E^T (73 buckets) is formed once per query
@@ -554,10 +658,11 @@ static int default_attention_arith() {
 }
 
 int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
-                            hipStream_t stream, int heads, int arith, int* status) {
+                            hipStream_t stream, int heads, int arith, int* status, __bf16* ctx_pieces, long long rows_pad) {
     static const int dflt = default_attention_arith();
     if (arith < 0) arith = dflt;
-    if (arith > 0) return launch_relpos_attention_x3(qkv, amask, dist_emb, ctx, B, T, stream, heads, arith == 2 ? 1 : 0, status);
+    if (arith > 0) return launch_relpos_attention_x3(qkv, amask, dist_emb, ctx, B, T, stream, heads, arith == 2 ? 1 : 0, status, ctx_pieces, rows_pad);
+    AT_REQUIRE(ctx_pieces == nullptr, "relpos_attention: piece output needs the split kernels");
     dim3 grid((T + ATT_QB - 1) / ATT_QB, heads, B);
     const size_t lds = ATT_LDS_FLOATS * sizeof(float);
     { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, relpos_attention_kernel, lds)) return rc; }
@@ -574,9 +679,13 @@ int launch_relpos_attention(const float* qkv, const float* amask, const float* d
 // ------------------------------------------------------------------------------------------------------
 constexpr int DW_TT = 8, DW_K = 31;
 
+// SC = void: fp32 output [B*T][1024]; SC = an operand scheme: the output goes straight to the pointwise-conv-2 GEMM as K-blocked pieces
+// [NP][64][rows_pad][16] (thread = 4 channels = one quarter of a k-block row: an 8-byte store per piece)
+template <class SC>
 __global__ __launch_bounds__(256) void dwconv_ln_swish_kernel(const float* __restrict__ g, const float* __restrict__ w /*[31][1024]*/,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float* __restrict__ out, int T) {
+                                                              float* __restrict__ out, int T, void* __restrict__ pieces, long long rows_pad, float scale,
+                                                              int* __restrict__ status) {
     __shared__ float red[2][4][DW_TT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
@@ -626,6 +735,8 @@ __global__ __launch_bounds__(256) void dwconv_ln_swish_kernel(const float* __res
     __syncthreads();
     const f4 gm = reinterpret_cast<const f4*>(gamma)[tid];
     const f4 bt = reinterpret_cast<const f4*>(beta)[tid];
+    bool over = false;
+    (void)over;
 #pragma unroll
     for (int i = 0; i < DW_TT; ++i) {
         const int t = t0 + i;
@@ -636,14 +747,26 @@ __global__ __launch_bounds__(256) void dwconv_ln_swish_kernel(const float* __res
         f4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = swishf_(fmaf(fmaf(acc[i][k], rstd, shift), gm[k], bt[k]));
-        reinterpret_cast<f4*>(out + (base + t) * 1024)[tid] = o;
+        if constexpr (std::is_void<SC>::value) {
+            reinterpret_cast<f4*>(out + (base + t) * 1024)[tid] = o;
+        } else {
+            over |= store_pieces4<SC>(reinterpret_cast<typename SC::T*>(pieces), rows_pad * 1024, rows_pad, base + t, tid * 4, o, scale);
+        }
     }
+    if constexpr (!std::is_void<SC>::value)
+        if constexpr (SC::RANGE_CHECK)
+            if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
 }
 
 int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,
-                           hipStream_t stream) {
+                           hipStream_t stream, __bf16* pieces, long long rows_pad, int scheme, float scale, int* status) {
     dim3 grid((T + DW_TT - 1) / DW_TT, B);
-    hipLaunchKernelGGL(dwconv_ln_swish_kernel, grid, dim3(256), 0, stream, g, w, gamma, beta, out, T);
+    if (pieces && scheme == XB_SCHEME_F16X2)
+        hipLaunchKernelGGL(dwconv_ln_swish_kernel<SchemeF16x2>, grid, dim3(256), 0, stream, g, w, gamma, beta, out, T, (void*)pieces, rows_pad, scale, status);
+    else if (pieces)
+        hipLaunchKernelGGL(dwconv_ln_swish_kernel<SchemeBf16x3>, grid, dim3(256), 0, stream, g, w, gamma, beta, out, T, (void*)pieces, rows_pad, scale, status);
+    else
+        hipLaunchKernelGGL(dwconv_ln_swish_kernel<void>, grid, dim3(256), 0, stream, g, w, gamma, beta, out, T, nullptr, 0, 1.0f, nullptr);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
