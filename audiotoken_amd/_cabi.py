@@ -90,6 +90,7 @@ SIGNATURES = {
     "at_op_dwconv_ln_swish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "at_op_vq_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "at_op_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "at_required_tensors": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "at_op_gemm_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "at_op_rvq_encode": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -123,6 +124,22 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def required_tensors(model: str, n: int, with_extras: bool = True):
+    """{name: shape} of the host tensors `model`'s finalize() needs (include/audiotoken_hip.h: at_required_tensors)."""
+    lib = load()
+    need = -lib.at_required_tensors(model.encode(), n, 1 if with_extras else 0, None, 0)
+    if need <= 1:   # -1 = error (a real list always needs more than one byte)
+        raise HipLibraryError(f"at_required_tensors({model}) failed: {last_error()}")
+    buf = C.create_string_buffer(need)
+    cnt = lib.at_required_tensors(model.encode(), n, 1 if with_extras else 0, buf, need)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        parts = line.split()
+        out[parts[0]] = tuple(int(x) for x in parts[1:])
+    assert len(out) == cnt
+    return out
 
 
 def last_error() -> str:

@@ -14,9 +14,10 @@
 //     over and then left idle (MI355X_MICROARCH.md, two waves per SIMD);
 //   * the 16x16x32 MFMA shape: same cycles per FLOP as 32x32x16, but the chip holds a higher clock on it under load (+12-20 % here);
 //   * hazards: the slot pair of step s + 1 is refilled only after the barrier that closed the trailing group's reads of step s - 1 (every
-//     read retires behind s_waitcnt lgkmcnt(0) before its barrier), and every wave waits for its own share of the DMA (vmcnt(0)) before
-//     the barrier that opens the leading group's reads of step s + 1 — which puts the two groups' issue / wait points in different
-//     segments (see the loop).
+//     read retires behind s_waitcnt lgkmcnt(0) before its barrier), and the issuing waves wait for their DMA (vmcnt(0)) before the barrier
+//     that opens the leading group's reads of step s + 1 (see the loop). A first version let both groups issue in their own segment L and
+//     wait after their own C: the trailing group's share then landed one barrier too late and the leaders read stale rows — found by
+//     tests/test_ops_gpu.py::test_split_gemm_vs_float64, not by the prototype's single check shape.
 // Windowed (conv1d) mode, epilogues and the fp16 range check are those of gemm_bf16x3.hip (split_epilogue.h).
 #include "at_common.h"
 #include "gemm_bf16x3.h"
@@ -55,8 +56,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a) {
     const long long a_clip = (long long)cblocks * a.stride * Lp * 16;   // elements of one clip of one piece
     const long long psA = a_clip * a.batch, psW = (long long)a.N * a.K;
     const int nk2 = a.K / 32;
-    // DMA: a chunk (one piece of one operand, 256 rows x 32 B) = 8 pieces of 1 KB; wave w moves rows 32 w .. 32 w + 31 of all four chunks
-    const int srow = wave * 32 + (lane >> 1), shalf = lane & 1;
+    // DMA: a chunk (one piece of one operand, 256 rows x 32 B) = 8 pieces of 1 KB. Only the LEADING group issues DMA (its waves move rows
+    // 64 w .. 64 w + 63 of all four chunks, 16 instructions per K step, in segment L while the trailing group multiplies): measured 2-7 %
+    // ahead of sharing the issue between the groups, whose trailing half had to sit in front of its MFMAs (tools/f16x2_gemm.hip, variant S)
+    const int srow = (wave & 3) * 64 + (lane >> 1), shalf = lane & 1;
     const PT* gA = reinterpret_cast<const PT*>(a.A) + clip * a_clip + ((long long)m0 + srow) * 16 + shalf * 8;
     const PT* gW = reinterpret_cast<const PT*>(a.W) + ((long long)n0 + srow) * 16 + shalf * 8;
     auto issue = [&](int kp, int pair) {             // K step kp = k-blocks 2 kp, 2 kp + 1 -> ring slots 2 pair, 2 pair + 1
@@ -72,12 +75,14 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a) {
                 ka = (long long)kt * Lp * 16;
             }
             const long long kw = (long long)kt * a.N * 16;
-            PT* s = lds + (2 * pair + h) * TG_SLOT + wave * 512;        // wave-uniform; the hardware adds lane * 16 B
+            PT* s = lds + (2 * pair + h) * TG_SLOT + (wave & 3) * 1024;  // wave-uniform; the hardware adds lane * 16 B
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + ka), (lds_void*)(s + p * TG_PIECE), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_void*)(gW + p * psW + kw), (lds_void*)(s + (2 + p) * TG_PIECE), 16, 0, 0);
-            }
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {                             // rows + 32 j: 512 elements further in both images
+                    __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + ka + j * 512), (lds_void*)(s + p * TG_PIECE + j * 512), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_void*)(gW + p * psW + kw + j * 512), (lds_void*)(s + (2 + p) * TG_PIECE + j * 512), 16, 0, 0);
+                }
         }
     };
     const int fr = lane & 15, fq = lane >> 4;
@@ -87,13 +92,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    issue(0, 0);
+    if (grp == 0) issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (grp == 1) {                                  // the trailing group starts one barrier late, with its share of step 1 in flight
-        if (nk2 > 1) issue(1, 1);
-        __builtin_amdgcn_s_barrier();
-    }
+    if (grp == 1) __builtin_amdgcn_s_barrier();      // the trailing group starts one barrier late
     for (int kp = 0; kp < nk2; ++kp) {
         // ---- L -------------------------------------------------------------------------------------------------------------
         const PT* s = lds + (kp & 1) * 2 * TG_SLOT + foff;
@@ -106,16 +108,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a) {
             for (int j = 0; j < 8; ++j) wb[p][j] = *reinterpret_cast<const V8*>(s + (2 + p) * TG_PIECE + (wn * 128 + j * 16) * 16);
         }
         // DMA of the NEXT step: its slot pair is free once the barrier that closed the trailing group's segment L of step kp - 1 has
-        // passed, and it must have landed before the barrier that opens the leading group's segment L of step kp + 1. Between those two
-        // barriers the leading group runs L(kp) + C(kp) and the trailing group C(kp - 1) + L(kp): each group issues its share at the START
-        // of that window and waits for it at the END (issue in L / wait after C for the leaders, issue in C / wait in L for the trailers).
-        if (grp == 0) { if (kp + 1 < nk2) issue(kp + 1, (kp + 1) & 1); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // passed (= the barrier in front of this segment, for the leaders), and it must have landed before the barrier that opens the
+        // leading group's segment L of step kp + 1 (= the one that closes their C(kp): they wait there).
+        if (grp == 0 && kp + 1 < nk2) issue(kp + 1, (kp + 1) & 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- C: hi.lo, lo.hi, hi.hi (smallest first) -------------------------------------------------------------------------
-        if (grp == 1 && kp + 2 < nk2) issue(kp + 2, kp & 1);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t = 0; t < 3; ++t)

@@ -212,14 +212,21 @@ def frontend_tables() -> Dict[str, np.ndarray]:
     return {"frontend.mel_filters": fb.numpy(), "frontend.window": window.numpy()}
 
 
+W2VBERT_ARCH = {"hidden_size": 1024, "intermediate_size": 4096, "num_attention_heads": 16, "feature_projection_input_dim": 160,
+                "position_embeddings_type": "relative_key", "left_max_position_embeddings": 64, "right_max_position_embeddings": 8,
+                "conv_depthwise_kernel_size": 31, "hidden_act": "swish"}
+
+
 def load_w2vbert_checkpoint(model_dir: str, quantizer_path: Optional[str]) -> Dict[str, np.ndarray]:
-    """HF ``model.safetensors`` of the trimmed w2v-bert-2.0 (+ the VQ ``.pkl`` state dict) -> numpy dict
-    (reference audiotoken/encoder.py:132,156-161; audiotoken/configs.py:114-134)."""
-    import os
-    from safetensors.numpy import load_file
-    w = {k: v.astype(np.float32) for k, v in load_file(os.path.join(model_dir, "model.safetensors")).items()}
+    """The reference's ``Wav2Vec2BertModel.from_pretrained(config.model_id)`` directory (``w2vbert2_l21/``: config.json +
+    model.safetensors, possibly sharded, 21 conformer layers of which 19 are used) + the VQ ``.pkl`` state dict it ``torch.load``s
+    (reference audiotoken/encoder.py:132,156-161; audiotoken/configs.py:114-134; audiotoken/utils.py:331-339) -> numpy dict."""
+    W.check_hf_config(model_dir, W2VBERT_ARCH, "semantic_m checkpoint")
+    w = W.read_hf_state_dict(model_dir, strip_prefixes=("wav2vec2_bert.",))
     if quantizer_path:
         sd = torch.load(quantizer_path, map_location="cpu", weights_only=True)
+        if "_codebook.embed" not in sd:
+            raise ValueError(f"{quantizer_path}: no '_codebook.embed' (expected a vector_quantize_pytorch VectorQuantize state dict)")
         w["vq._codebook.embed"] = sd["_codebook.embed"].float().numpy()
     return w
 

@@ -48,17 +48,16 @@ def fold_hubert_weights(w: Dict[str, np.ndarray], n_layers: int) -> Dict[str, np
     return out
 
 
+HUBERT_ARCH = {"hidden_size": 768, "intermediate_size": 3072, "num_attention_heads": 12, "conv_dim": [512] * 7, "conv_kernel": [10, 3, 3, 3, 3, 2, 2],
+               "conv_stride": [5, 2, 2, 2, 2, 2, 2], "conv_bias": False, "feat_extract_norm": "group", "do_stable_layer_norm": False,
+               "num_conv_pos_embeddings": 128, "num_conv_pos_embedding_groups": 16, "hidden_act": "gelu"}
+
+
 def load_hubert_checkpoint(model_dir: str, quantizer_path: Optional[str]) -> Dict[str, np.ndarray]:
-    """HF checkpoint directory (``model.safetensors`` or ``pytorch_model.bin``) + the joblib k-means pickle
-    (reference encoder.py:72, 84-85)."""
-    import os
-    st = os.path.join(model_dir, "model.safetensors")
-    if os.path.exists(st):
-        from safetensors.numpy import load_file
-        sd = {k: v.astype(np.float32) for k, v in load_file(st).items()}
-    else:
-        sd = {k: v.float().numpy() for k, v in torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu", weights_only=True).items()}
-    sd = {(k[len("hubert."):] if k.startswith("hubert.") else k): v for k, v in sd.items()}
+    """The reference's ``HubertModel.from_pretrained`` directory (config.json + model.safetensors / pytorch_model.bin, possibly sharded,
+    keys possibly under ``hubert.``) + the joblib k-means pickle whose ``cluster_centers_`` it reads (reference encoder.py:72, 84-85)."""
+    sd = W.read_hf_state_dict(model_dir, strip_prefixes=("hubert.",))
+    W.check_hf_config(model_dir, HUBERT_ARCH, "semantic_s checkpoint")
     if quantizer_path:
         import joblib
         sd["kmeans.cluster_centers_"] = np.asarray(joblib.load(quantizer_path).cluster_centers_, dtype=np.float32)

@@ -18,7 +18,7 @@ generators below (counter-based PRNG, bit-reproducible everywhere — see ``prng
 """
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+from typing import Dict, Optional, List, Tuple
 
 import numpy as np
 
@@ -262,3 +262,79 @@ def synth_hubert_weights(n_layers: int = HUB_LAYERS_USED, seed: int = 0, with_km
         # sklearn KMeans.cluster_centers_ [1000, 768] (reference audiotoken/encoder.py:84-85)
         w["kmeans.cluster_centers_"] = prng.irwin_hall("kmeans.cluster_centers_", (HUB_CENTROIDS, H), 1.0, seed)
     return w
+
+
+# ======================================================================================================
+# HF checkpoint directories (save_pretrained layout) -> numpy state dict
+# ======================================================================================================
+def read_hf_state_dict(model_dir: str, strip_prefixes=()) -> Dict[str, np.ndarray]:
+    """A HF ``save_pretrained`` directory -> {name: float32 array}. Understands ``model.safetensors``, the sharded form
+    (``model.safetensors.index.json`` + ``model-0000i-of-0000n.safetensors``) and the legacy ``pytorch_model.bin`` (+ its sharded index).
+    Task-head prefixes such as ``"wav2vec2_bert."`` / ``"hubert."`` are removed."""
+    import json
+    import os
+    sd: Dict[str, np.ndarray] = {}
+
+    def add_safetensors(path):
+        from safetensors import safe_open
+        with safe_open(path, framework="pt", device="cpu") as f:      # "pt": also reads bf16 / fp16 checkpoints
+            for k in f.keys():
+                sd[k] = f.get_tensor(k).float().numpy()
+
+    def add_bin(path):
+        import torch
+        for k, v in torch.load(path, map_location="cpu", weights_only=True).items():
+            sd[k] = v.float().numpy()
+
+    st, st_idx = os.path.join(model_dir, "model.safetensors"), os.path.join(model_dir, "model.safetensors.index.json")
+    pt, pt_idx = os.path.join(model_dir, "pytorch_model.bin"), os.path.join(model_dir, "pytorch_model.bin.index.json")
+    if os.path.exists(st):
+        add_safetensors(st)
+    elif os.path.exists(st_idx):
+        with open(st_idx) as fh:
+            for shard in sorted(set(json.load(fh)["weight_map"].values())):
+                add_safetensors(os.path.join(model_dir, shard))
+    elif os.path.exists(pt):
+        add_bin(pt)
+    elif os.path.exists(pt_idx):
+        with open(pt_idx) as fh:
+            for shard in sorted(set(json.load(fh)["weight_map"].values())):
+                add_bin(os.path.join(model_dir, shard))
+    else:
+        raise FileNotFoundError(f"{model_dir}: no model.safetensors / model.safetensors.index.json / pytorch_model.bin")
+    out = {}
+    for k, v in sd.items():
+        for pre in strip_prefixes:
+            if k.startswith(pre):
+                k = k[len(pre):]
+                break
+        out[k] = v
+    return out
+
+
+def check_hf_config(model_dir: str, expected: Dict[str, object], what: str) -> Optional[dict]:
+    """If the directory has a config.json, the architecture fields the HIP kernels are built for must match; returns the config."""
+    import json
+    import os
+    path = os.path.join(model_dir, "config.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        cfg = json.load(fh)
+    bad = {k: (cfg.get(k), v) for k, v in expected.items() if k in cfg and cfg[k] != v}
+    if bad:
+        raise ValueError(f"{what}: {path} describes a different architecture than the kernels implement: "
+                         + ", ".join(f"{k}={got!r} (need {want!r})" for k, (got, want) in bad.items()))
+    return cfg
+
+
+def missing_tensors(model: str, n: int, with_extras: bool, have: Dict[str, np.ndarray]):
+    """Names (or shape mismatches) that the library's finalize() for `model` needs and `have` does not provide."""
+    from . import _cabi
+    out = []
+    for name, shape in _cabi.required_tensors(model, n, with_extras).items():
+        if name not in have:
+            out.append(name)
+        elif tuple(have[name].shape) != shape:
+            out.append(f"{name}: shape {tuple(have[name].shape)} != {shape}")
+    return out

@@ -202,6 +202,12 @@ int at_op_gemm(const at_gemm_desc* d, at_stream_t stream);
 /* Residual VQ search (ref: encodec ResidualVectorQuantizer.encode; formula SURVEY.md Appendix A.1):
  * x device float32 [rows][128]; codebooks device [n_q][1024][128]; e2 device [n_q][1024];
  * codes int16 written at codes[(row / T)*n_q*T + q*T + row % T]. */
+/* The named host tensors (float32, weight-norm already folded) a model's finalize() needs, one per line as "name d0 d1 ...":
+ * model "encodec" (n = number of codebooks, with_extras = decoder too), "w2vbert" (n = conformer layers, with_extras = VQ codebook),
+ * "hubert" (n = transformer layers, with_extras = k-means centres). Returns the number of entries, or -(bytes needed) when buf is NULL or
+ * too small. A checkpoint loader can validate its output against this list without a device. */
+int at_required_tensors(const char* model, int n, int with_extras, char* buf, size_t cap);
+
 /* The split-operand GEMM of the semantic tokenizers (csrc/gemm_bf16x3.h), for the parity tests: C[M][N] = X[M][K] . W[N][K]^T + bias with both
  * fp32 operands written as 16-bit pieces — scheme 0 = three bf16 pieces / six products, 1 = two fp16 pieces / three products (w_max_abs = max |W|
  * sets the weight scale). kernel: 0 = as the product dispatches, 1 = the two-group kernel (gemm_f16x2_tg.hip), 2 = the register-staged kernel.

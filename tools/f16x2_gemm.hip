@@ -448,6 +448,114 @@ __global__ __launch_bounds__(512, 1) void gemm_two_groups16(const T* __restrict_
         }
 }
 
+// ---- variant S: variant R with other placements of the LDS-DMA issue (DMAMODE 1: none = timing bound; 2: leaders issue both shares in L;
+// 3: every wave spreads its share through its C segment) ----
+// A segment covers a K step of 32 = two 16-wide k-blocks (two ring slots of 32 KB; ring of 4 slots = two pairs); a lane's fragment
+// is 8 consecutive k of one row: k-block (lane >> 5), half (lane >> 4) & 1 — conflict-free in the linear [rows][16] image.
+template <typename T, int DMAMODE>
+__global__ __launch_bounds__(512, 1) void gemm_two_groups16s(const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, int M, int N, int K, float out_scale) {
+    typedef typename Vec8<T>::type V8;
+    constexpr int NP = 2, PIECE = 256 * 16;
+    constexpr int STAGE = 2 * NP * PIECE;            // one k-block of every piece of both operands (32 KB)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int ntn = N / 256;
+    const int m0 = (blockIdx.x / ntn) * 256, n0 = (blockIdx.x % ntn) * 256;
+    const long long psA = (long long)M * K, psB = (long long)N * K;
+    const int nk2 = K / 32;
+    const int srow = (DMAMODE == 2 ? (wave & 3) * 64 : wave * 32) + (lane >> 1), shalf = lane & 1;
+    const T* gA = A + ((long long)m0 + srow) * 16 + shalf * 8;
+    const T* gB = B + ((long long)n0 + srow) * 16 + shalf * 8;
+    auto issue = [&](int kp, int pair) {             // K pair kp = k-blocks 2 kp, 2 kp + 1 -> ring slots 2 pair, 2 pair + 1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            T* s = lds + (2 * pair + h) * STAGE + (DMAMODE == 2 ? (wave & 3) * 1024 : wave * 512);
+            const long long ka = (long long)(2 * kp + h) * M * 16, kb = (long long)(2 * kp + h) * N * 16;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + ka), (lds_void*)(s + p * PIECE), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(gB + p * psB + kb), (lds_void*)(s + (NP + p) * PIECE), 16, 0, 0);
+                if (DMAMODE == 2) {
+                    __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + ka + 512), (lds_void*)(s + p * PIECE + 512), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_void*)(gB + p * psB + kb + 512), (lds_void*)(s + (NP + p) * PIECE + 512), 16, 0, 0);
+                }
+            }
+        }
+    };
+    auto issue1 = [&](int kp, int pair, int q) {     // one of the 8 DMAs of a wave's share: q = (h, p, operand)
+        const int h = q >> 2, p = (q >> 1) & 1, op = q & 1;
+        T* s = lds + (2 * pair + h) * STAGE + wave * 512;
+        if (op == 0) __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + (long long)(2 * kp + h) * M * 16), (lds_void*)(s + p * PIECE), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((glb_void*)(gB + p * psB + (long long)(2 * kp + h) * N * 16), (lds_void*)(s + (NP + p) * PIECE), 16, 0, 0);
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    const int foff = (fq >> 1) * STAGE + fr * 16 + (fq & 1) * 8;    // k-block, row, half
+    f4v acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) {
+        if (DMAMODE == 0 && nk2 > 1) issue(1, 1);
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int kp = 0; kp < nk2; ++kp) {
+        const T* s = lds + (kp & 1) * 2 * STAGE + foff;
+        V8 a[NP][4], b[NP][8];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[p][i] = *reinterpret_cast<const V8*>(s + p * PIECE + (wm * 64 + i * 16) * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[p][j] = *reinterpret_cast<const V8*>(s + (NP + p) * PIECE + (wn * 128 + j * 16) * 16);
+        }
+        // the other pair of slots held K pair kp - 1: every read of it retired before the barrier that closed the trailing group's L(kp - 1).
+        // Leaders issue the next pair here and wait after C; trailers issued it at the start of their previous C and wait here
+        // (see csrc/gemm_f16x2_tg.hip for the window argument).
+        if (DMAMODE == 0) {
+            if (grp == 0) { if (kp + 1 < nk2) issue(kp + 1, (kp + 1) & 1); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (DMAMODE == 2) {
+            if (grp == 0 && kp + 1 < nk2) issue(kp + 1, (kp + 1) & 1);
+        } else if (DMAMODE == 3) {
+            // every wave issued its share of step kp + 1 during its previous C segment (leaders: C(kp - 1) is too early -> they issue in C(kp)
+            // and the step must have landed one barrier later: see below) -- timing experiment only for the leaders' half
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (DMAMODE == 0 && grp == 1 && kp + 2 < nk2) issue(kp + 2, kp & 1);
+        constexpr int PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (DMAMODE == 3 && (t * 4 + i) < 8 && kp + 2 < nk2) issue1(kp + 2, kp & 1, t * 4 + i);   // one DMA per 8 MFMAs
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(b[PB2[t]][j], a[PA2[t]][i], acc[i][j]);
+            }
+        if ((DMAMODE == 0 || DMAMODE == 2) && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float* dst = C + (long long)(m0 + wm * 64 + i * 16 + fr) * N + n0 + wn * 128 + j * 16 + 4 * fq;
+            float4 v = {acc[i][j][0] * out_scale, acc[i][j][1] * out_scale, acc[i][j][2] * out_scale, acc[i][j][3] * out_scale};
+            *reinterpret_cast<float4*>(dst) = v;
+        }
+}
+
 // ---- hardware questions -------------------------------------------------------------------------------------------------
 // (1) subnormal fp16 inputs of the MFMA: a = 2^-20 (subnormal), b = 2^10 -> 2^-10 per product if they are kept, 0 if flushed
 __global__ void denorm_probe(float* out) {
@@ -596,7 +704,7 @@ static int run_two(const char* name, int M, int N, int K, bool check, float sa, 
     hipLaunchKernelGGL((split_kernel<T, NP>), dim3((unsigned)(((long long)M * K + 255) / 256)), dim3(256), 0, 0, dA, pA, (long long)M, K, sa);
     hipLaunchKernelGGL((split_kernel<T, NP>), dim3((unsigned)(((long long)N * K + 255) / 256)), dim3(256), 0, 0, dB, pB, (long long)N, K, sb);
     const size_t ldsb = (SHAPE16 ? 4 : 3) * (size_t)2 * NP * 256 * 16 * 2;
-    auto kern = SHAPE16 ? gemm_two_groups16<T, PRIO> : gemm_two_groups<T, SWZ, PRIO>;
+    auto kern = SHAPE16 == 2 ? gemm_two_groups16s<T, PRIO> : SHAPE16 ? gemm_two_groups16<T, PRIO> : gemm_two_groups<T, SWZ, PRIO>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     const dim3 grid((M / 256) * (N / 256));
     const float os = 1.0f / (sa * sb);
@@ -609,7 +717,7 @@ static int run_two(const char* name, int M, int N, int K, bool check, float sa, 
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, grid, dim3(512), ldsb, 0, pA, pB, dC, M, N, K, os);
     hipEventRecord(e1, 0); CK(hipEventSynchronize(e1));
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
-    printf("{\"scheme\": \"%s\", \"mfma\": \"%s\", \"swizzle\": %d, \"setprio\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"ms\": %.3f, \"fp32_equiv_tflops\": %.1f", name, SHAPE16 ? "16x16x32" : "32x32x16", SWZ, PRIO, M, N, K, ms, 2.0 * M * N * K / ms * 1e-9);
+    printf("{\"scheme\": \"%s\", \"mfma\": \"%s\", \"swizzle\": %d, \"setprio\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"ms\": %.3f, \"fp32_equiv_tflops\": %.1f", name, SHAPE16 == 2 ? "16x16x32 dma-mode = setprio field" : SHAPE16 ? "16x16x32" : "32x32x16", SWZ, PRIO, M, N, K, ms, 2.0 * M * N * K / ms * 1e-9);
     if (check) {
         std::vector<float> hC((size_t)M * N);
         CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
@@ -656,6 +764,10 @@ static int shape(int M, int N, int K, bool check, float wscale, float ascale_dat
     if (run_two<_Float16, 1, 1>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
     if (run_two<_Float16, 0, 0, 1>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
     if (run_two<_Float16, 0, 1, 1>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+    if (run_two<_Float16, 0, 0, 2>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+    if (run_two<_Float16, 0, 1, 2>("fp16x2 two wave groups (no DMA: timing bound, wrong results)", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+    if (run_two<_Float16, 0, 2, 2>("fp16x2 two wave groups", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
+    if (run_two<_Float16, 0, 3, 2>("fp16x2 two wave groups (DMA spread through C: timing only)", M, N, K, check, sa, sb, hA, hB, dA, dB, dC)) return 1;
     if (check) {
         if (run<_Float16, 2, 1>("fp16x2 (3 products), UNSCALED operands", M, N, K, check, 1.f, 1.f, hA, hB, dA, dB, dC)) return 1;
         if (run<_Float16, 2, 1>("fp16x2 (3 products), activations scaled 64, weights to 2^15", M, N, K, check, 64.f, sb, hA, hB, dA, dB, dC)) return 1;
