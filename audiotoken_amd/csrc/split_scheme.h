@@ -40,14 +40,18 @@ __device__ __forceinline__ void split_n(float a, typename SC::T (&p)[SC::NP]) {
         a -= (float)p[i];
     }
 }
-// four values * scale -> NP pieces of four; returns true when a value does not fit the scheme's range
+// four values * scale -> NP pieces of four; returns true when a value does not fit the scheme's range (two v_max3 and one compare per
+// call; an infinity fails it — a NaN can only descend from one, or from a NaN in the caller's input)
 template <class SC>
 __device__ __forceinline__ bool split4(const f4& v, float scale, typename SC::V4 (&p)[SC::NP]) {
     bool over = false;
+    if constexpr (SC::RANGE_CHECK) {
+        const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * scale;
+        over = !(m <= 65504.0f);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float x = v[k] * scale;
-        if constexpr (SC::RANGE_CHECK) over |= !(fabsf(x) <= 65504.0f);
         typename SC::T q[SC::NP];
         split_n<SC>(x, q);
 #pragma unroll
