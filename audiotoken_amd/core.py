@@ -130,9 +130,15 @@ class AudioToken:
         sr = self.model_config.model_sample_rate
 
         def load(file_path: str):
-            """One unit of host work: plain audio files are decoded completely; archives return a streaming source."""
+            """One unit of host work: plain audio files are decoded completely; archives return a streaming source. A file that
+            cannot be decoded (a codec this build does not ship, stereo, a truncated header) is logged and skipped, like the
+            unsupported extensions below — it must not abort a run whose earlier files have already been appended to."""
             if file_path.endswith(AUDIO_EXTS):
-                return list(process_audio_chunks(file_path, sr, chunk_size))
+                try:
+                    return list(process_audio_chunks(file_path, sr, chunk_size))
+                except Exception as e:
+                    logger.error(f"Skipping {file_path}: {type(e).__name__}: {e}")
+                    return []
             if file_path.endswith(TAR_EXTS):
                 return background(lambda: iterate_tar(file_path, sr, chunk_size)) if num_workers > 0 else iterate_tar(file_path, sr, chunk_size)
             if file_path.endswith(ZIP_EXTS):

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <string>
 #include <vector>
+#include <cstdlib>
 
 namespace at {
 
@@ -40,12 +41,18 @@ inline int set_max_dynamic_lds(LdsAttrFlags& f, K kernel, size_t bytes) {
     }
     return 0;
 }
+// $AUDIOTOKEN_HOST_ONLY_TEST=1: the sanitizer build's CPU test (tests/test_asan_cpu.py) runs tensor staging and the host-side packing of
+// finalize() on a machine without a device; handles can then be created and the first real device call fails with an error code as usual
+inline bool host_only_test() {
+    const char* e = std::getenv("AUDIOTOKEN_HOST_ONLY_TEST");
+    return e && e[0] == '1';
+}
 // RAII: make `device` current for the duration of a C-ABI call and restore the caller's device afterwards
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
     explicit DeviceGuard(int device) {
-        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; ok = false; return; }
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; ok = host_only_test(); return; }
         if (prev != device && hipSetDevice(device) != hipSuccess) ok = false;
     }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }

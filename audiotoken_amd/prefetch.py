@@ -41,38 +41,60 @@ def ordered_map(fn: Callable[[T], R], items: Iterable[T], num_workers: int) -> I
                 f.cancel()
 
 
-def background(gen_fn: Callable[[], Iterable[T]], depth: int = 8) -> Iterator[T]:
-    """Run a generator in one background thread, handing its items over through a bounded queue (order preserved)."""
-    q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
-    stop = threading.Event()
+class background(Iterator[T]):
+    """Run a generator in one background thread, handing its items over through a bounded queue (order preserved).
 
-    def run():
+    An iterator OBJECT, not a generator function: the thread starts when the object is made (so an archive streams ahead while
+    earlier files are still being consumed), and ``close()`` / garbage collection / an exception in the consumer stops the producer —
+    every ``put`` of the producer, including the final sentinel and a forwarded exception, gives up once ``stop`` is set, so the thread
+    (and the tar / zip handle it holds) never outlives an abandoned consumer."""
+
+    def __init__(self, gen_fn: Callable[[], Iterable[T]], depth: int = 8):
+        self._q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self._stop = threading.Event()
+        self._done = False
+        self._thread = threading.Thread(target=self._run, args=(gen_fn,), name="audiotoken-io-stream", daemon=True)
+        self._thread.start()
+
+    def _put(self, x) -> bool:
+        while not self._stop.is_set():
+            try:
+                self._q.put(x, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _run(self, gen_fn):
         try:
             for x in gen_fn():
-                while not stop.is_set():
-                    try:
-                        q.put(x, timeout=0.1)
-                        break
-                    except queue.Full:
-                        continue
-                if stop.is_set():
+                if not self._put(x):
                     return
-            q.put(_END)
+            self._put(_END)
         except BaseException as e:  # delivered to the consumer
-            q.put(e)
+            self._put(e)
 
-    t = threading.Thread(target=run, name="audiotoken-io-stream", daemon=True)
-    t.start()
-    try:
-        while True:
-            x = q.get()
-            if x is _END:
-                return
-            if isinstance(x, BaseException):
-                raise x
-            yield x
-    finally:
-        stop.set()
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> T:
+        if self._done:
+            raise StopIteration
+        x = self._q.get()
+        if x is _END:
+            self.close()
+            raise StopIteration
+        if isinstance(x, BaseException):
+            self.close()
+            raise x
+        return x
+
+    def close(self) -> None:
+        self._done = True
+        self._stop.set()
+
+    def __del__(self):
+        self._stop.set()
 
 
 def chunks_of_files(files: List[str], load_chunks: Callable[[str], list], num_workers: int) -> Iterator:

@@ -87,3 +87,42 @@ def test_batch_files_same_output_with_workers(tmp_path):
     assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 7
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_background_starts_eagerly_and_stops_when_abandoned():
+    """The producer thread starts with the object (decode-ahead) and ends when the consumer goes away with the queue full."""
+    import threading
+    import time
+    from audiotoken_amd.prefetch import background
+    started = threading.Event()
+    produced = []
+
+    def gen():
+        started.set()
+        for i in range(1000):
+            produced.append(i)
+            yield i
+
+    it = background(gen, depth=2)
+    assert started.wait(2.0), "the producer must start before the first next()"
+    assert next(it) == 0 and next(it) == 1
+    t = it._thread
+    it.close()                       # consumer stops early: queue full, producer blocked in put()
+    t.join(2.0)
+    assert not t.is_alive(), "an abandoned producer must not stay blocked"
+    assert len(produced) < 1000
+
+
+def test_background_forwards_exceptions_and_end():
+    from audiotoken_amd.prefetch import background
+
+    def gen():
+        yield 1
+        raise RuntimeError("boom")
+
+    it = background(gen)
+    assert next(it) == 1
+    import pytest
+    with pytest.raises(RuntimeError, match="boom"):
+        next(it)
+    assert list(background(lambda: iter([1, 2, 3]))) == [1, 2, 3]
