@@ -140,6 +140,11 @@ struct at_encodec {
     bool bf16x3 = false;            // plain linear layers (LSTM input projections) on the split-bf16 GEMM ($AUDIOTOKEN_BF16X3_ACOUSTIC)
     const __bf16* wih_s[2] = {nullptr, nullptr};
     const __bf16* dwih_s[2] = {nullptr, nullptr};
+    // the LSTM input projections also as two-piece fp16 operands (gemm_bf16x3.h, XB_SCHEME_F16X2): weights + their power-of-two scales
+    const piece_t* wih_f[2] = {nullptr, nullptr};
+    const piece_t* dwih_f[2] = {nullptr, nullptr};
+    float wih_fs[2] = {1.f, 1.f}, dwih_fs[2] = {1.f, 1.f};
+    bool ih_f16x2 = true;   // option "ih_f16x2" / $AUDIOTOKEN_IH_F16X2: LSTM input projections on the fp16 scheme (three MFMA products instead of six)
     std::vector<void*> extra_allocs;
     int sub_batch = at::sub_batch();   // clips per pass through the conv stack: bounds the workspace (option "subbatch")
     bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
@@ -297,10 +302,19 @@ int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L
 }
 
 // 2-layer LSTM + skip over [B][T][512]; xg/c/h0 are scratch. y = lstm(x) + x.
+// status word of the *_checked entry points: bit 0 = an LSTM hand-off wait gave up (sync[63]), bit 1 = fp16 range overflow (sync[62])
+__global__ void status_combine_kernel(const unsigned* sync, unsigned* out) { out[0] = (sync[63] ? 1u : 0u) | (sync[62] & 2u); }
+int launch_status_combine(const unsigned* sync, unsigned* out, hipStream_t stream) {
+    hipLaunchKernelGGL(status_combine_kernel, dim3(1), dim3(1), 0, stream, sync, out);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int lstm_skip(const float* const wih[2], const float* const whh[2], const float* const bih[2], const float* const bhh[2],
               const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream,
               Profiler& prof, unsigned* sync, bool persistent, int y_elu, const __bf16* const* wih_s = nullptr, __bf16* xs = nullptr,
-              bool rec_x3 = false, unsigned spin_limit = 1u << 18) {
+              bool rec_x3 = false, unsigned spin_limit = 1u << 18, const piece_t* const* wih_f = nullptr, const float* wih_fs = nullptr,
+              int* range_status = nullptr) {
     for (int layer = 0; layer < 2; ++layer) {
         const float* in = layer == 0 ? x : h0;
         float* hout = layer == 0 ? h0 : h1;
@@ -309,7 +323,15 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
         g.W = wih[layer]; g.bias = bih[layer];
         g.C = xg; g.ldc = 4 * kH; g.M = B * T; g.N = 4 * kH; g.K = kH; g.batch = 1;
         prof.begin("lstm_ih", 1, stream);
-        if (wih_s && wih_s[layer] && xs) {   // split-bf16 GEMM (gemm_bf16x3.hip): x -> 3 bf16 pieces, then 6 bf16 MFMAs per step
+        if (wih_f && wih_f[layer] && xs) {   // two fp16 pieces per operand, three MFMA products (gemm_f16x2_tg.hip for full batches)
+            const long long M = (long long)B * T, Mpad = (M + 255) / 256 * 256;
+            if (int rc = launch_split_blocked(in, kH, M, Mpad, kH, xs, stream, XB_SCHEME_F16X2, XB_F16_ACT_SCALE, range_status)) return rc;
+            Bf16x3Args a;
+            a.A = xs; a.W = wih_f[layer]; a.bias = bih[layer]; a.M = (int)M; a.N = 4 * kH; a.K = kH; a.Mpad = (int)Mpad;
+            a.epi = XB_EPI_LINEAR; a.C = xg; a.ldc = 4 * kH; a.alpha = 1.0f;
+            a.scheme = XB_SCHEME_F16X2; a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * wih_fs[layer]); a.split_scale = XB_F16_ACT_SCALE; a.status = range_status;
+            if (int rc = launch_gemm_bf16x3(a, stream)) return rc;
+        } else if (wih_s && wih_s[layer] && xs) {   // split-bf16 GEMM (gemm_bf16x3.hip): x -> 3 bf16 pieces, then 6 bf16 MFMAs per step
             const long long M = (long long)B * T, Mpad = (M + 255) / 256 * 256;
             if (int rc = launch_split_blocked(in, kH, M, Mpad, kH, xs, stream)) return rc;
             Bf16x3Args a;
@@ -599,6 +621,7 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
         h->rvq_x3 = (mask & 256) != 0;
     }
     if (h->bf16x3) {
+        if (const char* e = std::getenv("AUDIOTOKEN_IH_F16X2")) h->ih_f16x2 = std::atoi(e) != 0;
         for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
             for (int l = 0; l < 2; ++l) {
                 __bf16* d = nullptr;
@@ -606,6 +629,17 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
                 h->extra_allocs.push_back(d);
                 if (int rc = launch_split_blocked(dec ? h->dwih[l] : h->wih[l], kH, 4 * kH, 4 * kH, kH, d, nullptr)) return rc;
                 (dec ? h->dwih_s : h->wih_s)[l] = d;
+                // the same weights as two fp16 pieces, scaled by a power of two into [2^14, 2^15)
+                const size_t off = dec ? d_lstm[l][0] : o_lstm[l][0];
+                float mx = 0.f;
+                for (size_t i = 0; i < (size_t)4 * kH * kH; ++i) mx = std::fmax(mx, std::fabs(p.host[off + i]));
+                const float sc = xb_weight_scale(mx);
+                piece_t* f = nullptr;
+                AT_CHECK_HIP(hipMalloc((void**)&f, (size_t)2 * 4 * kH * kH * sizeof(piece_t)));
+                h->extra_allocs.push_back(f);
+                if (int rc = launch_split_blocked(dec ? h->dwih[l] : h->wih[l], kH, 4 * kH, 4 * kH, kH, f, nullptr, XB_SCHEME_F16X2, sc, nullptr)) return rc;
+                (dec ? h->dwih_f : h->wih_f)[l] = f;
+                (dec ? h->dwih_fs : h->wih_fs)[l] = sc;
             }
         {   // codebooks as plain (row-major) bf16 pieces for the RVQ search
             __bf16* d = nullptr;
@@ -793,9 +827,10 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
     AT_CHECK_HIP(hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), stream));
     if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
-                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit))
+                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
+                           (h->bf16x3 && h->ih_f16x2) ? h->wih_f : nullptr, h->wih_fs, reinterpret_cast<int*>(sync + 62)))
         return rc;
-    if (status_out) AT_CHECK_HIP(hipMemcpyAsync(status_out, sync + 63, sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
+    if (status_out) if (int rc = launch_status_combine(sync, status_out, stream)) return rc;
     float* emb = emb_out ? emb_out : ws + p.off_emb;
     prof.begin("final_conv", 1, stream);
     if (int rc = conv_gemm(h->fin, y, (long long)T * kH, T, emb, (long long)T * kDim, T, B, PRO_NONE, nullptr, 0, stream)) return rc;  // y holds ELU(lstm + skip)
@@ -835,6 +870,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "res64_x3") { h->res64_x3 = value != 0; return 0; }
     if (std::string(name) == "res128_x3") { h->res128_x3 = value != 0; return 0; }
     if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }
+    if (std::string(name) == "ih_f16x2") { h->ih_f16x2 = value != 0; return 0; }
     if (std::string(name) == "lstm_spin_limit") { AT_REQUIRE(value >= 0, "lstm_spin_limit must be >= 0"); h->lstm_spin_limit = (unsigned)value; return 0; }
     if (std::string(name) == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
     set_error(std::string("unknown option ") + name);
@@ -898,9 +934,10 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
     // every activation that is only consumed through ELU is stored already ELU'd (once per element, in the producer's
     // epilogue) so the transposed convs run the plain-linear GEMM path: y (LSTM + skip) and the block outputs of stages 0-2
     if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,
-                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit))
+                           sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
+                           (h->bf16x3 && h->ih_f16x2) ? h->dwih_f : nullptr, h->dwih_fs, reinterpret_cast<int*>(sync + 62)))
         return rc;
-    if (status_dev) AT_CHECK_HIP(hipMemcpyAsync(status_dev, sync + 63, sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
+    if (status_dev) if (int rc = launch_status_combine(sync, status_dev, stream)) return rc;
     const int Lout = p.L[4];
     for (int b0 = 0; b0 < B; b0 += p.G) {
         const int g = (B - b0) < p.G ? (B - b0) : p.G;

@@ -344,7 +344,7 @@ extern "C" int at_op_gemm_split(const float* X, const float* W, const float* bia
     a.A = xs; a.W = wsp; a.bias = bias; a.M = M; a.N = N; a.K = K; a.Mpad = (int)Mpad; a.epi = XB_EPI_LINEAR; a.C = C; a.ldc = N;
     a.scheme = scheme; a.acc_scale = 1.0f / (sa * sw); a.split_scale = sa; a.status = reinterpret_cast<int*>(status_dev);
     if (kernel == 1) {   // force the two-group kernel (gemm_f16x2_tg.hip) whatever the launch size
-        AT_REQUIRE(scheme == XB_SCHEME_F16X2 && N % 256 == 0 && K % 32 == 0, "at_op_gemm_split: the two-group kernel needs f16x2, N % 256, K % 32");
+        AT_REQUIRE(gemm_f16x2_tg_eligible(a), "at_op_gemm_split: the two-group kernel needs f16x2, N % 128, K % 32");
         return launch_gemm_f16x2_tg(a, stream);
     }
     if (kernel == 2) {   // force the register-staged kernel

@@ -31,9 +31,18 @@ namespace at {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-constexpr int TG_PIECE = 256 * 16;                 // 16-bit elements of one (piece, k-block) chunk of 256 rows
-constexpr int TG_SLOT = 4 * TG_PIECE;              // A hi, A lo, W hi, W lo of one k-block (32 KB)
-constexpr size_t TG_LDS_BYTES = (size_t)4 * TG_SLOT * 2;
+// Two tile shapes with IDENTICAL per-element arithmetic (the same MFMA instruction, k order and product order), so a result does not
+// depend on the batch size that picked the shape: TI x TJ = 4 x 8 tiles of 16 x 16 per wave = 256 x 256 per workgroup (128 KB of LDS, one
+// workgroup per CU) for launches that fill the chip, 2 x 4 = 128 x 128 (64 KB, two per CU) for small ones (single clips).
+template <int TI, int TJ>
+struct TgCfg {
+    static constexpr int BM = 4 * TI * 16, BN = 2 * TJ * 16;
+    static_assert(BM == BN, "square tiles: one chunk size for both operands");
+    static constexpr int PIECE = BM * 16;              // 16-bit elements of one (piece, k-block) chunk of BM rows
+    static constexpr int SLOT = 4 * PIECE;             // A hi, A lo, W hi, W lo of one k-block
+    static constexpr size_t LDS_BYTES = (size_t)4 * SLOT * 2;
+    static constexpr int DMA_PER_CHUNK = BM / 128;     // 1-KB pieces (32 rows) of a chunk per leading wave
+};
 
 // WINDOWED = false: a plain linear layer (one tap, stride 1): the k-block -> row offset map is a multiplication; true: conv1d windows
 // (per k-block two integer divisions on the scalar unit — kept off the linear layers' instruction stream)
@@ -41,8 +50,10 @@ constexpr size_t TG_LDS_BYTES = (size_t)4 * TG_SLOT * 2;
 // contiguous range of m-tiles and walks it in groups of `ga` m-tiles x all n-tiles, m fastest — the ~32 tiles an XCD runs at a time then
 // share `ga` activation tiles and 32 / ga weight tiles in ITS L2, and an activation tile is fetched into one L2 instead of all eight
 // (n-fastest order: 8 x the activation bytes leave the Infinity Cache; the K = 4096 GEMM moved 12.6 GB per launch that way).
-template <bool WINDOWED>
-__global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a, int ga) {
+template <bool WINDOWED, int TI, int TJ>
+__global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_kernel(Bf16x3Args a, int ga) {
+    using Cfg = TgCfg<TI, TJ>;
+    constexpr int BM = Cfg::BM, TG_PIECE = Cfg::PIECE, TG_SLOT = Cfg::SLOT;
     typedef SchemeF16x2 SC;
     typedef _Float16 PT;
     typedef f16x8 V8;
@@ -51,7 +62,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);     // 0: leading group, 1: trailing group
     const int wm = wave & 3, wn = wave >> 2;                       // SIMD partners own the two column halves of the same 64 rows
-    const int ntn = a.N / 256, ntm = a.Mpad / 256;
+    const int ntn = a.N / BM, ntm = a.Mpad / BM;
     int mt, nt;
     if (ga > 0) {
         const int mtn = ntm * a.batch;
@@ -67,8 +78,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a, int
         nt = blockIdx.x % ntn;   // n fastest: the activation tile is fetched once per row of blocks
         mt = blockIdx.x / ntn;
     }
-    const int n0 = nt * 256;
-    const int clip = mt / ntm, m0 = (mt - clip * ntm) * 256;
+    const int n0 = nt * BM;
+    const int clip = mt / ntm, m0 = (mt - clip * ntm) * BM;
     const int cblocks = a.cblocks > 0 ? a.cblocks : a.K / 16;
     const int Lp = a.Lp > 0 ? a.Lp : a.Mpad;
     const long long a_clip = (long long)cblocks * a.stride * Lp * 16;   // elements of one clip of one piece
@@ -77,7 +88,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a, int
     // DMA: a chunk (one piece of one operand, 256 rows x 32 B) = 8 pieces of 1 KB. Only the LEADING group issues DMA (its waves move rows
     // 64 w .. 64 w + 63 of all four chunks, 16 instructions per K step, in segment L while the trailing group multiplies): measured 2-7 %
     // ahead of sharing the issue between the groups, whose trailing half had to sit in front of its MFMAs (tools/f16x2_gemm.hip, variant S)
-    const int srow = (wave & 3) * 64 + (lane >> 1), shalf = lane & 1;
+    const int srow = (wave & 3) * (BM / 4) + (lane >> 1), shalf = lane & 1;
     const PT* gA = reinterpret_cast<const PT*>(a.A) + clip * a_clip + ((long long)m0 + srow) * 16 + shalf * 8;
     const PT* gW = reinterpret_cast<const PT*>(a.W) + ((long long)n0 + srow) * 16 + shalf * 8;
     auto issue = [&](int kp, int pair) {             // K step kp = k-blocks 2 kp, 2 kp + 1 -> ring slots 2 pair, 2 pair + 1
@@ -93,11 +104,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a, int
                 ka = (long long)kt * Lp * 16;
             }
             const long long kw = (long long)kt * a.N * 16;
-            PT* s = lds + (2 * pair + h) * TG_SLOT + (wave & 3) * 1024;  // wave-uniform; the hardware adds lane * 16 B
+            PT* s = lds + (2 * pair + h) * TG_SLOT + (wave & 3) * (BM / 4) * 16;  // wave-uniform; the hardware adds lane * 16 B
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {                             // rows + 32 j: 512 elements further in both images
+                for (int j = 0; j < Cfg::DMA_PER_CHUNK; ++j) {            // rows + 32 j: 512 elements further in both images
                     __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + ka + j * 512), (lds_void*)(s + p * TG_PIECE + j * 512), 16, 0, 0);
                     __builtin_amdgcn_global_load_lds((glb_void*)(gW + p * psW + kw + j * 512), (lds_void*)(s + (2 + p) * TG_PIECE + j * 512), 16, 0, 0);
                 }
@@ -105,11 +116,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a, int
     };
     const int fr = lane & 15, fq = lane >> 4;
     const int foff = (fq >> 1) * TG_SLOT + fr * 16 + (fq & 1) * 8;      // k-block, row, half
-    f4 acc[4][8];
+    f4 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     if (grp == 0) issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -117,13 +128,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a, int
     for (int kp = 0; kp < nk2; ++kp) {
         // ---- L -------------------------------------------------------------------------------------------------------------
         const PT* s = lds + (kp & 1) * 2 * TG_SLOT + foff;
-        V8 xa[2][4], wb[2][8];
+        V8 xa[2][TI], wb[2][TJ];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xa[p][i] = *reinterpret_cast<const V8*>(s + p * TG_PIECE + (wm * 64 + i * 16) * 16);
+            for (int i = 0; i < TI; ++i) xa[p][i] = *reinterpret_cast<const V8*>(s + p * TG_PIECE + (wm * TI * 16 + i * 16) * 16);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wb[p][j] = *reinterpret_cast<const V8*>(s + (2 + p) * TG_PIECE + (wn * 128 + j * 16) * 16);
+            for (int j = 0; j < TJ; ++j) wb[p][j] = *reinterpret_cast<const V8*>(s + (2 + p) * TG_PIECE + (wn * TJ * 16 + j * 16) * 16);
         }
         // DMA of the NEXT step: its slot pair is free once the barrier that closed the trailing group's segment L of step kp - 1 has
         // passed (= the barrier in front of this segment, for the leaders), and it must have landed before the barrier that opens the
@@ -137,9 +148,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a, int
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[SC::prod_w(t)][j], xa[SC::prod_a(t)][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the leaders' share of step kp + 1 has landed
@@ -152,11 +163,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a, int
     auto epilogue = [&](auto mode) {
         constexpr int E = decltype(mode)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + fr;
+        for (int i = 0; i < TI; ++i) {
+            const int m = m0 + wm * TI * 16 + i * 16 + fr;
             if (m >= a.M) continue;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ep.template apply<E>(m, n0 + wn * 128 + j * 16 + 4 * fq, acc[i][j]);
+            for (int j = 0; j < TJ; ++j) ep.template apply<E>(m, n0 + wn * TJ * 16 + j * 16 + 4 * fq, acc[i][j]);
         }
     };
     switch (a.epi) {
@@ -170,34 +181,38 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_tg_kernel(Bf16x3Args a, int
     ep.finish();
 }
 
-// eligibility: the fp16 scheme, whole 256-column tiles, K steps of 32, enough tiles to fill the chip, no dual split output
+// eligibility: the fp16 scheme, whole 128-column tiles, K steps of 32, row padding of 256, no dual split output
 bool gemm_f16x2_tg_eligible(const Bf16x3Args& a) {
     if (a.scheme != XB_SCHEME_F16X2 || a.epi == XB_EPI_RAW_ELU_SPLIT2) return false;
-    if (a.N % 256 != 0 || a.K % 32 != 0 || a.Mpad % 256 != 0) return false;
-    static const long long min_tiles = std::getenv("AUDIOTOKEN_F16X2_TG_MIN_TILES") ? std::atoll(std::getenv("AUDIOTOKEN_F16X2_TG_MIN_TILES")) : 256;
-    return (long long)a.batch * (a.Mpad / 256) * (a.N / 256) >= min_tiles;
+    return a.N % 128 == 0 && a.K % 32 == 0 && a.Mpad % 256 == 0;
+}
+
+template <bool WINDOWED, int TI, int TJ>
+static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream) {
+    using Cfg = TgCfg<TI, TJ>;
+    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<WINDOWED, TI, TJ>, Cfg::LDS_BYTES)) return rc; }
+    hipLaunchKernelGGL((gemm_f16x2_tg_kernel<WINDOWED, TI, TJ>), grid, dim3(512), Cfg::LDS_BYTES, stream, a, ga);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_gemm_f16x2_tg(const Bf16x3Args& a, hipStream_t stream) {
-    const int ntn = a.N / 256, mtn = a.batch * (a.Mpad / 256);
+    // 256 x 256 tiles when they fill the chip, else 128 x 128 (4 x as many workgroups, two per CU): same arithmetic per element
+    static const long long min_tiles = std::getenv("AUDIOTOKEN_F16X2_TG_MIN_TILES") ? std::atoll(std::getenv("AUDIOTOKEN_F16X2_TG_MIN_TILES")) : 256;
+    const bool big = a.N % 256 == 0 && (long long)a.batch * (a.Mpad / 256) * (a.N / 256) >= min_tiles;
+    const int bm = big ? 256 : 128;
+    const int ntn = a.N / bm, mtn = a.batch * (a.Mpad / bm);
     static const int xcdmap = std::getenv("AUDIOTOKEN_XB_XCDMAP") ? std::atoi(std::getenv("AUDIOTOKEN_XB_XCDMAP")) : 1;
     int ga = 0;
     dim3 grid((unsigned)((long long)mtn * ntn));
-    if (xcdmap && mtn >= 64) {
+    if (xcdmap && big && mtn >= 64) {
         ga = ntn >= 8 ? 4 : (32 / ntn > 16 ? 16 : 32 / ntn);
         const int per_xcd = ((mtn + 7) / 8 + ga - 1) / ga * ga * ntn;   // upper bound of one XCD's slots incl. the padding of its last group
         grid = dim3((unsigned)(8 * per_xcd));
     }
     const bool windowed = a.stride != 1 || (a.cblocks > 0 && a.cblocks != a.K / 16);
-    if (windowed) {
-        { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<true>, TG_LDS_BYTES)) return rc; }
-        hipLaunchKernelGGL(gemm_f16x2_tg_kernel<true>, grid, dim3(512), TG_LDS_BYTES, stream, a, ga);
-    } else {
-        { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<false>, TG_LDS_BYTES)) return rc; }
-        hipLaunchKernelGGL(gemm_f16x2_tg_kernel<false>, grid, dim3(512), TG_LDS_BYTES, stream, a, ga);
-    }
-    AT_CHECK_HIP(hipGetLastError());
-    return 0;
+    if (big) return windowed ? launch_tg<true, 4, 8>(a, ga, grid, stream) : launch_tg<false, 4, 8>(a, ga, grid, stream);
+    return windowed ? launch_tg<true, 2, 4>(a, ga, grid, stream) : launch_tg<false, 2, 4>(a, ga, grid, stream);
 }
 
 }  // namespace at

@@ -39,9 +39,14 @@ class AcousticDecoder(torch.nn.Module):
         status = self.last_status()
         if status == 0:
             return wav
-        logger.error(f"persistent LSTM hand-off timed out in the decoder (status {status}): waveform discarded; "
-                     "decoding again with per-step LSTM launches (option persistent_lstm=0) from now on")
-        self.set_option("persistent_lstm", 0)
+        if status & 1:
+            logger.error(f"persistent LSTM hand-off timed out in the decoder (status {status}): waveform discarded; "
+                         "decoding again with per-step LSTM launches (option persistent_lstm=0) from now on")
+            self.set_option("persistent_lstm", 0)
+        if status & 2:
+            logger.error(f"fp16 range overflow in the decoder's f16x2 LSTM input projection (status {status}): waveform discarded; "
+                         "decoding again with the bf16x3 projection (option ih_f16x2=0) from now on")
+            self.set_option("ih_f16x2", 0)
         wav = self.forward(tokens)
         if self.last_status() != 0:
             raise _cabi.HipLibraryError("acoustic decode failed twice (LSTM status non-zero with per-step launches)")
