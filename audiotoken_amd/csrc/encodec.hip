@@ -144,6 +144,10 @@ struct at_encodec {
     const piece_t* wih_f[2] = {nullptr, nullptr};
     const piece_t* dwih_f[2] = {nullptr, nullptr};
     float wih_fs[2] = {1.f, 1.f}, dwih_fs[2] = {1.f, 1.f};
+    // the stage 2-3 GEMM chain's weights as two fp16 pieces (+ scales): down2, res3 conv3, res3 tail, down3 (option "chain_f16x2")
+    const piece_t* chain_f[4] = {nullptr, nullptr, nullptr, nullptr};
+    float chain_fs[4] = {1.f, 1.f, 1.f, 1.f};
+    bool chain_f16x2 = true;
     bool ih_f16x2 = true;   // option "ih_f16x2" / $AUDIOTOKEN_IH_F16X2: LSTM input projections on the fp16 scheme (three MFMA products instead of six)
     std::vector<void*> extra_allocs;
     int sub_batch = at::sub_batch();   // clips per pass through the conv stack: bounds the workspace (option "subbatch")
@@ -672,6 +676,23 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             if (int rc = launch_split_blocked(h->res[3][1].w, 384, 256, 256, 384, d1, nullptr)) return rc;
             h->res3c_s = d0; h->res3t_s = d1;
         }
+        {   // the same four weights as two fp16 pieces, each scaled by a power of two into [2^14, 2^15) (gemm_bf16x3.h, XB_SCHEME_F16X2)
+            if (const char* e = std::getenv("AUDIOTOKEN_CHAIN_F16X2")) h->chain_f16x2 = std::atoi(e) != 0;
+            const float* src[4] = {h->down[2].w, h->res[3][0].w, h->res[3][1].w, h->down[3].w};
+            const size_t off[4] = {o_down[2].w, o_res[3][0].w, o_res[3][1].w, o_down[3].w};
+            const int ns[4] = {256, 128, 256, 512}, ks[4] = {1280, 768, 384, 4096};
+            for (int j = 0; j < 4; ++j) {
+                float mx = 0.f;
+                for (size_t i = 0; i < (size_t)ns[j] * ks[j]; ++i) mx = std::fmax(mx, std::fabs(p.host[off[j] + i]));
+                const float sc = xb_weight_scale(mx);
+                piece_t* f = nullptr;
+                AT_CHECK_HIP(hipMalloc((void**)&f, (size_t)2 * ns[j] * ks[j] * sizeof(piece_t)));
+                h->extra_allocs.push_back(f);
+                if (int rc = launch_split_blocked(src[j], ks[j], ns[j], ns[j], ks[j], f, nullptr, XB_SCHEME_F16X2, sc, nullptr)) return rc;
+                h->chain_f[j] = f;
+                h->chain_fs[j] = sc;
+            }
+        }
         AT_CHECK_HIP(hipDeviceSynchronize());
     }
     h->finalized = true;
@@ -711,6 +732,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     if (T_out) *T_out = T;
 
     float* x4 = ws + p.off_x4;
+    AT_CHECK_HIP(hipMemsetAsync(ws + p.off_sync, 0, 1024 * sizeof(unsigned), stream));   // LSTM flags + the two status words
     for (int b0 = 0; b0 < B; b0 += p.G) {
         const int g = (B - b0) < p.G ? (B - b0) : p.G;
         static const char* kRes[4] = {"res0", "res1", "res2", "res3"};
@@ -732,7 +754,19 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             if (int rc = launch_conv0(wav + (long long)b0 * N, h->conv0.w, h->conv0.b, ws + p.off_x[0], g, N, stream)) return rc;
             prof.end(stream);
         }
-        bool chain3 = false;   // stage-2 strided conv -> 256-channel block -> stage-3 strided conv as chained split-bf16 GEMMs (no fp32 in between)
+        bool chain3 = false;   // stage-2 strided conv -> 256-channel block -> stage-3 strided conv as chained split GEMMs (no fp32 in between)
+        // operand scheme of that chain: two fp16 pieces / three products (default) or three bf16 pieces / six products
+        const bool cf = h->chain_f16x2 && h->chain_f[0] != nullptr;
+        const int cnp = cf ? 2 : 3;
+        int* range_status = reinterpret_cast<int*>(reinterpret_cast<unsigned*>(ws + p.off_sync) + 62);
+        auto chain_cfg = [&](Bf16x3Args& a, int j, const __bf16* w_bf16) {
+            if (cf) {
+                a.W = h->chain_f[j]; a.scheme = XB_SCHEME_F16X2; a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->chain_fs[j]);
+                a.split_scale = XB_F16_ACT_SCALE; a.status = range_status;
+            } else {
+                a.W = w_bf16;
+            }
+        };
         for (int s = fused0 ? 1 : 0; s < 4; ++s) {
             const int C = 32 << s, L = p.L[s], Lo = p.L[s + 1];
             float* x = ws + p.off_x[s];
@@ -753,11 +787,14 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 ra.B = g; ra.L = L;
                 // with the strided conv as a split-bf16 GEMM the block writes that GEMM's operand pieces instead of fp32 rows
                 down2_gemm = h->down128_x3 && h->res128_x3 && h->bf16x3 && h->down2_s && L % 5 == 0 && L >= 10;
-                if (down2_gemm) { ra.S = reinterpret_cast<__bf16*>(r); ra.Lp = p.Lp2; }
+                if (down2_gemm) {
+                    ra.S = reinterpret_cast<__bf16*>(r); ra.Lp = p.Lp2;
+                    if (cf) { ra.S_scheme = XB_SCHEME_F16X2; ra.S_scale = XB_F16_ACT_SCALE; ra.status = range_status; }
+                }
                 prof.begin("res2", down2_gemm ? 2 : 1, stream);
                 if (int rc = (h->res128_x3 && h->bf16x3) ? launch_seanet_res128x3(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
                 if (down2_gemm)
-                    if (int rc = launch_reflect_front5(ra.S, g, 8, p.Lp2, stream)) return rc;
+                    if (int rc = launch_reflect_front5(ra.S, g, 8, p.Lp2, stream, cnp)) return rc;
                 prof.end(stream);
             } else if (s == 3 && chain3) {
                 // conv3 (k3, 256 -> 128) on the ELU pieces the stage-2 GEMM wrote; its ELU_SPLIT epilogue fills K-blocks 0..7 of the tail's
@@ -767,16 +804,16 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 __bf16* s3 = reinterpret_cast<__bf16*>(ws + p.off_s3);
                 prof.begin(kRes[s], 3, stream);
                 Bf16x3Args ca;
-                ca.A = ac3; ca.W = h->res3c_s; ca.bias = h->res[3][0].b; ca.M = L; ca.Mpad = p.Mpc; ca.N = 128; ca.K = 768;
+                ca.A = ac3; chain_cfg(ca, 1, h->res3c_s); ca.bias = h->res[3][0].b; ca.M = L; ca.Mpad = p.Mpc; ca.N = 128; ca.K = 768;
                 ca.batch = g; ca.stride = 1; ca.cblocks = 16; ca.Lp = p.Lpc;
                 ca.epi = XB_EPI_ELU_SPLIT; ca.S = at3; ca.Spad = p.Mpc; ca.Sphases = 1; ca.Sfront = 0; ca.Sblocks = 24; ca.Sblock0 = 0;
                 if (int rc = launch_gemm_bf16x3(ca, stream)) return rc;
                 Bf16x3Args ta;
-                ta.A = at3; ta.W = h->res3t_s; ta.bias = h->res[3][1].b; ta.M = L; ta.Mpad = p.Mpc; ta.N = 256; ta.K = 384;
+                ta.A = at3; chain_cfg(ta, 2, h->res3t_s); ta.bias = h->res[3][1].b; ta.M = L; ta.Mpad = p.Mpc; ta.N = 256; ta.K = 384;
                 ta.batch = g; ta.stride = 1; ta.cblocks = 24; ta.Lp = p.Mpc;
                 ta.epi = XB_EPI_ELU_SPLIT; ta.S = s3; ta.Spad = p.Lp3; ta.Sphases = 8; ta.Sfront = 1;
                 if (int rc = launch_gemm_bf16x3(ta, stream)) return rc;
-                if (int rc = launch_reflect_front(s3, g, 16, 8, p.Lp3, 8, stream)) return rc;
+                if (int rc = launch_reflect_front(s3, g, 16, 8, p.Lp3, 8, stream, cnp)) return rc;
                 prof.end(stream);
             } else {
                 prof.begin(kRes[s], 2, stream);
@@ -792,7 +829,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 if (int rc = (h->down64_x3 && h->bf16x3) ? launch_seanet_down64x3(da, stream) : launch_seanet_down64(da, stream)) return rc;
             } else if (s == 2 && down2_gemm) {
                 Bf16x3Args ga;
-                ga.A = reinterpret_cast<const __bf16*>(r); ga.W = h->down2_s; ga.bias = h->down[2].b;
+                ga.A = reinterpret_cast<const __bf16*>(r); chain_cfg(ga, 0, h->down2_s); ga.bias = h->down[2].b;
                 ga.M = Lo; ga.Mpad = p.Mp2; ga.N = 256; ga.K = 1280;
                 ga.batch = g; ga.stride = 5; ga.cblocks = 8; ga.Lp = p.Lp2;
                 chain3 = h->res256_x3 && h->down256_x3 && h->res3c_s && h->down3_s && Lo % 8 == 0 && Lo >= 16;
@@ -805,13 +842,14 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 }
                 if (int rc = launch_gemm_bf16x3(ga, stream)) return rc;
                 if (chain3)
-                    if (int rc = launch_reflect_front(ga.S2, g, 16, 1, p.Lpc, 2, stream)) return rc;
+                    if (int rc = launch_reflect_front(ga.S2, g, 16, 1, p.Lpc, 2, stream, cnp)) return rc;
             } else if (s == 3 && h->down256_x3 && h->bf16x3 && h->down3_s && L % 8 == 0 && L >= 16) {
                 __bf16* s3 = reinterpret_cast<__bf16*>(ws + p.off_s3);
                 if (!chain3)
                     if (int rc = launch_split_phase_major(r, g, L, 256, 8, p.Lp3, s3, stream)) return rc;
                 Bf16x3Args ga;
-                ga.A = s3; ga.W = h->down3_s; ga.bias = h->down[3].b;
+                ga.A = s3; ga.bias = h->down[3].b;
+                if (chain3) chain_cfg(ga, 3, h->down3_s); else ga.W = h->down3_s;   // the stand-alone split pass writes bf16 pieces
                 ga.M = Lo; ga.Mpad = p.Mp3; ga.N = 512; ga.K = 4096;
                 ga.batch = g; ga.stride = 8; ga.cblocks = 16; ga.Lp = p.Lp3;
                 ga.epi = XB_EPI_LINEAR; ga.C = out; ga.ldc = 512;
@@ -824,8 +862,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     }
     Profiler& prof = h->prof;
     float* y = ws + p.off_y;
-    unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
-    AT_CHECK_HIP(hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), stream));
+    unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);   // zeroed at the start of the call (the conv stack's range status lives in it)
     if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
                            sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
                            (h->bf16x3 && h->ih_f16x2) ? h->wih_f : nullptr, h->wih_fs, reinterpret_cast<int*>(sync + 62)))
@@ -871,6 +908,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "res128_x3") { h->res128_x3 = value != 0; return 0; }
     if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }
     if (std::string(name) == "ih_f16x2") { h->ih_f16x2 = value != 0; return 0; }
+    if (std::string(name) == "chain_f16x2") { h->chain_f16x2 = value != 0; return 0; }
     if (std::string(name) == "lstm_spin_limit") { AT_REQUIRE(value >= 0, "lstm_spin_limit must be >= 0"); h->lstm_spin_limit = (unsigned)value; return 0; }
     if (std::string(name) == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
     set_error(std::string("unknown option ") + name);

@@ -64,9 +64,13 @@ struct Res64Args {
     // reads (gemm_bf16x3.h: [3][B][C/16][5 planes][Lp][16], row t in plane t % 5 at index t / 5 + 1) instead of fp32 rows
     __bf16* S = nullptr;
     int Lp = 0;
+    // S_scheme = XB_SCHEME_F16X2 (gemm_bf16x3.h): two fp16 pieces of out * S_scale instead; status = device word for the fp16 range check
+    int S_scheme = 0;
+    float S_scale = 1.0f;
+    int* status = nullptr;
 };
 // fills the causal reflect padding (5 front rows = index 0 of every plane) of those pieces
-int launch_reflect_front5(__bf16* S, int B, int cblocks, int Lp, hipStream_t stream);
+int launch_reflect_front5(__bf16* S, int B, int cblocks, int Lp, hipStream_t stream, int npieces = 3);
 int launch_seanet_res64(const Res64Args& a, hipStream_t stream);
 // the 128-channel block on the bf16 matrix cores with exact 3-way bf16 splits of all operands (seanet_res128x3.hip)
 int launch_seanet_res128x3(const Res64Args& a, hipStream_t stream);

@@ -62,7 +62,7 @@ struct Bf16x3Args {
 };
 // fills the causal reflect padding of windowed-mode pieces [3][B][blocks][phases][Lp][16]: padded rows i < pad (row i lives in plane
 // i % phases at index i / phases) become copies of padded row 2 * pad - i
-int launch_reflect_front(__bf16* S, int B, int blocks, int phases, int Lp, int pad, hipStream_t stream);
+int launch_reflect_front(__bf16* S, int B, int blocks, int phases, int Lp, int pad, hipStream_t stream, int npieces = 3);
 
 // fp32 row-major [rows][ld] (first K columns) * scale -> K-blocked pieces [pieces][K/16][rows_pad][16]; rows >= `rows` are zero-filled
 int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream,

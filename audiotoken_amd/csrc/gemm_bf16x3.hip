@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256) void split_phase_major_kernel(const float* __r
     }
 }
 
-__global__ void reflect_front_kernel(__bf16* S, int B, int blocks, int phases, int Lp, int pad) {
+__global__ void reflect_front_kernel(__bf16* S, int B, int blocks, int phases, int Lp, int pad, int npieces) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;          // (piece, clip, block) x pad row x 4-channel group
-    const long long total = 3LL * B * blocks * pad * 4;
+    const long long total = (long long)npieces * B * blocks * pad * 4;
     if (gid >= total) return;
     const int c4 = (int)(gid & 3), i = (int)((gid >> 2) % pad);
     const long long rest = (gid >> 2) / pad;   // (piece * B + clip) * blocks + block
@@ -135,9 +135,9 @@ __global__ void reflect_front_kernel(__bf16* S, int B, int blocks, int phases, i
         *reinterpret_cast<const bf16x4*>(base + ((long long)(j % phases) * Lp + j / phases) * 16);
 }
 
-int launch_reflect_front(__bf16* S, int B, int blocks, int phases, int Lp, int pad, hipStream_t stream) {
-    const long long total = 3LL * B * blocks * pad * 4;
-    hipLaunchKernelGGL(reflect_front_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, S, B, blocks, phases, Lp, pad);
+int launch_reflect_front(__bf16* S, int B, int blocks, int phases, int Lp, int pad, hipStream_t stream, int npieces) {
+    const long long total = (long long)npieces * B * blocks * pad * 4;
+    hipLaunchKernelGGL(reflect_front_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, S, B, blocks, phases, Lp, pad, npieces);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -295,9 +295,7 @@ static int launch_xb(const Bf16x3Args& a, hipStream_t stream) {
 template <class SC>
 static int launch_scheme(const Bf16x3Args& a, hipStream_t stream) {
     const long long tiles256 = (long long)a.batch * (a.Mpad / 256) * ((a.N + 255) / 256);
-    if constexpr (!SC::RANGE_CHECK) {
-        if (a.epi == XB_EPI_RAW_ELU_SPLIT2) return launch_xb<SC, 4, 1, 2, 4, true>(a, stream);
-    }
+    if (a.epi == XB_EPI_RAW_ELU_SPLIT2) return launch_xb<SC, 4, 1, 2, 4, true>(a, stream);
     if (tiles256 < 256 || a.N % 256 != 0) return launch_xb<SC, 2, 2, 2, 2>(a, stream);   // 4x as many 128 x 128 tiles: same arithmetic, fills the chip
     // large launches: 256 x 128 tiles, 4 waves, TWO workgroups per CU (one loads while the other multiplies) measured 1-2 % ahead of
     // 256 x 256 with 8 waves and one workgroup per CU (less operand traffic, no overlap); $AUDIOTOKEN_XB_TILE=0 selects the latter.
@@ -314,7 +312,7 @@ int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
     AT_REQUIRE(a.epi != XB_EPI_RAW_ELU_SPLIT2 || (a.S2 != nullptr && a.S2phases >= 1 && (long long)a.S2pad * a.S2phases >= a.M + (long long)a.S2front * a.S2phases), "gemm_bf16x3: bad second output");
     AT_REQUIRE(a.batch >= 1 && a.stride >= 1 && (a.cblocks == 0 || (a.K / XB_K) % a.cblocks == 0), "gemm_bf16x3: bad window description");
     AT_REQUIRE((a.Lp > 0 ? a.Lp : a.Mpad) >= a.Mpad + ((a.cblocks > 0 ? (a.K / XB_K) / a.cblocks : 1) - 1) / a.stride, "gemm_bf16x3: Lp too small for the last tile");
-    AT_REQUIRE(a.scheme == XB_SCHEME_BF16X3 || (a.scheme == XB_SCHEME_F16X2 && a.epi != XB_EPI_RAW_ELU_SPLIT2), "gemm_bf16x3: unknown scheme / dual split output needs the bf16 scheme");
+    AT_REQUIRE(a.scheme == XB_SCHEME_BF16X3 || a.scheme == XB_SCHEME_F16X2, "gemm_bf16x3: unknown scheme");
     static const bool tg = std::getenv("AUDIOTOKEN_F16X2_TG") ? std::atoi(std::getenv("AUDIOTOKEN_F16X2_TG")) != 0 : true;
     if (tg && gemm_f16x2_tg_eligible(a)) return launch_gemm_f16x2_tg(a, stream);
     if (a.scheme == XB_SCHEME_F16X2) return launch_scheme<SchemeF16x2>(a, stream);

@@ -176,14 +176,15 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         case XB_EPI_ELU_SPLIT: epilogue(std::integral_constant<int, XB_EPI_ELU_SPLIT>{}); break;
         case XB_EPI_GLU: epilogue(std::integral_constant<int, XB_EPI_GLU>{}); break;
         case XB_EPI_GELU: epilogue(std::integral_constant<int, XB_EPI_GELU>{}); break;
+        case XB_EPI_RAW_ELU_SPLIT2: epilogue(std::integral_constant<int, XB_EPI_RAW_ELU_SPLIT2>{}); break;
         default: epilogue(std::integral_constant<int, XB_EPI_LINEAR>{}); break;
     }
     ep.finish();
 }
 
-// eligibility: the fp16 scheme, whole 128-column tiles, K steps of 32, row padding of 256, no dual split output
+// eligibility: the fp16 scheme, whole 128-column tiles, K steps of 32, row padding of 256
 bool gemm_f16x2_tg_eligible(const Bf16x3Args& a) {
-    if (a.scheme != XB_SCHEME_F16X2 || a.epi == XB_EPI_RAW_ELU_SPLIT2) return false;
+    if (a.scheme != XB_SCHEME_F16X2) return false;
     return a.N % 128 == 0 && a.K % 32 == 0 && a.Mpad % 256 == 0;
 }
 

@@ -11,6 +11,7 @@
 // (tests/test_acoustic_gpu.py::test_x3_kernels_match_fp32). (EnCodec architecture: SURVEY.md Appendix A.1.)
 #include "gemm_core.h"
 #include "encodec_kernels.h"
+#include "split_scheme.h"
 
 namespace at {
 
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
     const int L = a.L;
     const int tiles_per_clip = (L + RX_TT - 1) / RX_TT;
     const int total_tiles = a.B * tiles_per_clip;   // < 2^30: checked by the launcher
+    bool over = false;                               // fp16 range check of the f16x2 piece output
 
     // ---- weights -> 3 bf16 pieces in registers, once per workgroup (MFMA A operand: row r16, k = 32 ks + 8 q .. + 7) -------------
     bf16x8 w3p[3][12], wtp[3][2][6];
@@ -219,19 +221,28 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
                         const f4 v = acc[m][n] + *reinterpret_cast<const f4*>(a.bt + wave * 32 + n * 16 + q * 4);
                         f4 o;
                         o.x = elu1(v.x); o.y = elu1(v.y); o.z = elu1(v.z); o.w = elu1(v.w);
-                        if (a.S) {   // the consumer is the stride-5 split-bf16 GEMM: K-blocked, phase-major pieces
-                            bf16x4 s1, s2, s3;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                __bf16 x1, x2, x3;
-                                rx_split(o[k], x1, x2, x3);
-                                s1[k] = x1; s2[k] = x2; s3[k] = x3;
-                            }
+                        if (a.S) {   // the consumer is the stride-5 split GEMM: K-blocked, phase-major pieces (bf16x3 or f16x2: a.S_scheme)
                             const long long ps = (long long)a.B * 8 * 5 * a.Lp * 16;
-                            __bf16* d = a.S + ((((long long)b * 8 + wave * 2 + n) * 5 + plane) * a.Lp + idx) * 16 + q * 4;
-                            *reinterpret_cast<bf16x4*>(d) = s1;
-                            *reinterpret_cast<bf16x4*>(d + ps) = s2;
-                            *reinterpret_cast<bf16x4*>(d + 2 * ps) = s3;
+                            const long long off = ((((long long)b * 8 + wave * 2 + n) * 5 + plane) * a.Lp + idx) * 16 + q * 4;
+                            if (a.S_scheme == XB_SCHEME_F16X2) {
+                                SchemeF16x2::V4 pp[2];
+                                over |= split4<SchemeF16x2>(o, a.S_scale, pp);
+                                _Float16* d = reinterpret_cast<_Float16*>(a.S) + off;
+                                *reinterpret_cast<SchemeF16x2::V4*>(d) = pp[0];
+                                *reinterpret_cast<SchemeF16x2::V4*>(d + ps) = pp[1];
+                            } else {
+                                bf16x4 s1, s2, s3;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    __bf16 x1, x2, x3;
+                                    rx_split(o[k], x1, x2, x3);
+                                    s1[k] = x1; s2[k] = x2; s3[k] = x3;
+                                }
+                                __bf16* d = a.S + off;
+                                *reinterpret_cast<bf16x4*>(d) = s1;
+                                *reinterpret_cast<bf16x4*>(d + ps) = s2;
+                                *reinterpret_cast<bf16x4*>(d + 2 * ps) = s3;
+                            }
                         } else {
                             *reinterpret_cast<f4*>(dst + n * 16) = o;
                         }
@@ -240,12 +251,13 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
             }
         }
     }
+    if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
 }
 
 // index 0 of plane i = padded row i = time i - 5 = reflect of time 5 - i (plane (5 - i) % 5, index (5 - i) / 5 + 1)
-__global__ void reflect_front5_kernel(__bf16* S, int B, int cblocks, int Lp) {
+__global__ void reflect_front5_kernel(__bf16* S, int B, int cblocks, int Lp, int npieces) {
     const int gid = blockIdx.x * 256 + threadIdx.x;          // (piece, clip, cblock, plane, 4-channel group)
-    const int total = 3 * B * cblocks * 5 * 4;
+    const int total = npieces * B * cblocks * 5 * 4;
     if (gid >= total) return;
     const int c4 = gid & 3, i = (gid >> 2) % 5, rest = (gid >> 2) / 5;   // rest = (piece * B + clip) * cblocks + cblock
     const int t = 5 - i;
@@ -254,9 +266,9 @@ __global__ void reflect_front5_kernel(__bf16* S, int B, int cblocks, int Lp) {
         *reinterpret_cast<const bf16x4*>(base + ((long long)(t % 5) * Lp + t / 5 + 1) * 16 + c4 * 4);
 }
 
-int launch_reflect_front5(__bf16* S, int B, int cblocks, int Lp, hipStream_t stream) {
-    const int total = 3 * B * cblocks * 5 * 4;
-    hipLaunchKernelGGL(reflect_front5_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, S, B, cblocks, Lp);
+int launch_reflect_front5(__bf16* S, int B, int cblocks, int Lp, hipStream_t stream, int npieces) {
+    const int total = npieces * B * cblocks * 5 * 4;
+    hipLaunchKernelGGL(reflect_front5_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, S, B, cblocks, Lp, npieces);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -135,8 +135,8 @@ class AcousticEncoder(torch.nn.Module):
                 torch.cuda.empty_cache()
 
     def last_status(self) -> int:
-        """0 = ok; bit 0 = a bounded wait inside the persistent LSTM kernel gave up; bit 1 = fp16 range overflow in the f16x2 LSTM
-        input projection (synchronises the device)."""
+        """0 = ok; bit 0 = a bounded wait inside the persistent LSTM kernel gave up; bit 1 = fp16 range overflow in an f16x2 kernel (stage 2-3
+        convs, LSTM input projection) (synchronises the device)."""
         return int(self._status.item())
 
     def verified(self, codes: torch.Tensor, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -151,9 +151,10 @@ class AcousticEncoder(torch.nn.Module):
                          "re-encoding with per-step LSTM launches (option persistent_lstm=0) from now on")
             self.set_option("persistent_lstm", 0)
         if status & 2:
-            logger.error(f"an LSTM input exceeded the fp16 range of the f16x2 input projection (status {status}): the tokens of this batch "
-                         "were discarded; re-encoding with the bf16x3 projection (option ih_f16x2=0) from now on")
+            logger.error(f"an activation exceeded the fp16 range of the f16x2 kernels (stage 2-3 convs, LSTM input projection; status {status}): "
+                         "the tokens of this batch were discarded; re-encoding with the bf16x3 kernels (options chain_f16x2=0, ih_f16x2=0) from now on")
             self.set_option("ih_f16x2", 0)
+            self.set_option("chain_f16x2", 0)
         codes = self.forward(input_batch, attention_mask)
         if self.last_status() != 0:
             raise _cabi.HipLibraryError("acoustic encode failed twice (LSTM status non-zero with per-step launches)")

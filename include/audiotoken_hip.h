@@ -67,8 +67,8 @@ int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int 
                       int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream);
 
 /* Same as at_encodec_encode, plus a device uint32 status word (stream-ordered): 0 on success; bit 0 (1) = a bounded wait inside the
- * persistent LSTM kernel gave up (the call still terminates); bit 1 (2) = an LSTM input did not fit the fp16 range of the "ih_f16x2" input
- * projection. In both cases the codes are invalid and the caller repeats the batch on the safe path (options persistent_lstm = 0 / ih_f16x2 = 0). */
+ * persistent LSTM kernel gave up (the call still terminates); bit 1 (2) = an activation did not fit the fp16 range of an f16x2 kernel ("chain_f16x2",
+ * "ih_f16x2"). In both cases the codes are invalid and the caller repeats the batch on the safe path (options persistent_lstm = 0 / chain_f16x2 = ih_f16x2 = 0). */
 int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes,
                               int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream,
                               uint32_t* status_dev);
@@ -81,8 +81,9 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
  *   stage-2 / stage-3 convs + 256-channel block (as chained GEMMs) the LSTM recurrence and the RVQ search on the bf16 matrix cores with exact 3-way bf16 splits of every
  *   operand (default on; $AUDIOTOKEN_X3_KERNELS bit mask, bits 3, 2, 1, 0, 4, 5, 6, 7, 8 in that order; 0 = the fp32-MFMA kernels:
  *   same tokens, embeddings differ in the last bits);
- *   "ih_f16x2" 1/0 — the two LSTM input projections (encoder and decoder) as two-piece fp16 operand splits, three MFMA products (default on,
- *   $AUDIOTOKEN_IH_F16X2) or as the three-piece bf16 splits, six products; see csrc/gemm_bf16x3.h;
+ *   "ih_f16x2", "chain_f16x2" 1/0 — the two LSTM input projections (encoder and decoder) / the encoder's stage-2 strided conv, 256-channel block
+ *   and stage-3 strided conv (the GEMM chain) as two-piece fp16 operand splits, three MFMA products (default on, $AUDIOTOKEN_IH_F16X2 /
+ *   $AUDIOTOKEN_CHAIN_F16X2) or as the three-piece bf16 splits, six products; see csrc/gemm_bf16x3.h;
  *   "lstm_spin_limit" n >= 0 — polls of a hand-off flag before a workgroup of the persistent LSTM gives up and the status word of the
  *   *_checked entry points becomes 1 (default 2^18, i.e. 0.1-0.3 s; 0 makes the first unready poll give up — used by the tests);
  *   "subbatch" n >= 1 — clips per pass through the conv stack (default 256 or $AUDIOTOKEN_SUBBATCH): bounds
