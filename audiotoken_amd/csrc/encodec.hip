@@ -148,6 +148,8 @@ struct at_encodec {
     const piece_t* chain_f[4] = {nullptr, nullptr, nullptr, nullptr};
     float chain_fs[4] = {1.f, 1.f, 1.f, 1.f};
     bool chain_f16x2 = true;
+    float whh_fs[2] = {0.f, 0.f}, dwhh_fs[2] = {0.f, 0.f};   // W_hh scales of the fp16-scheme LSTM recurrence (option "lstm_f16x2")
+    bool lstm_f16x2 = true;
     bool ih_f16x2 = true;   // option "ih_f16x2" / $AUDIOTOKEN_IH_F16X2: LSTM input projections on the fp16 scheme (three MFMA products instead of six)
     std::vector<void*> extra_allocs;
     int sub_batch = at::sub_batch();   // clips per pass through the conv stack: bounds the workspace (option "subbatch")
@@ -318,7 +320,7 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
               const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream,
               Profiler& prof, unsigned* sync, bool persistent, int y_elu, const __bf16* const* wih_s = nullptr, __bf16* xs = nullptr,
               bool rec_x3 = false, unsigned spin_limit = 1u << 18, const piece_t* const* wih_f = nullptr, const float* wih_fs = nullptr,
-              int* range_status = nullptr) {
+              int* range_status = nullptr, const float* whh_fs = nullptr) {
     for (int layer = 0; layer < 2; ++layer) {
         const float* in = layer == 0 ? x : h0;
         float* hout = layer == 0 ? h0 : h1;
@@ -356,6 +358,7 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
                 q.xg = xg + ro * 4 * kH; q.w_hh = whh[layer]; q.b_hh = bhh[layer]; q.h_out = hout + ro * kH;
                 q.y_out = layer == 1 ? y + ro * kH : nullptr; q.skip = x + ro * kH; q.sync = sync;
                 q.B = (B - c0) < maxc ? (B - c0) : maxc; q.T = T; q.n_groups = 0; q.h_bytes = 0; q.y_elu = y_elu; q.spin_limit = spin_limit;
+                q.w_scale_f16 = (rec_x3 && whh_fs) ? whh_fs[layer] : 0.f;
                 if (int rc = rec_x3 ? launch_lstm_seq_x3(q, stream) : launch_lstm_seq(q, stream)) return rc;
             }
             prof.end(stream);
@@ -626,6 +629,7 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
     }
     if (h->bf16x3) {
         if (const char* e = std::getenv("AUDIOTOKEN_IH_F16X2")) h->ih_f16x2 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("AUDIOTOKEN_LSTM_F16X2")) h->lstm_f16x2 = std::atoi(e) != 0;
         for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
             for (int l = 0; l < 2; ++l) {
                 __bf16* d = nullptr;
@@ -644,6 +648,11 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
                 if (int rc = launch_split_blocked(dec ? h->dwih[l] : h->wih[l], kH, 4 * kH, 4 * kH, kH, f, nullptr, XB_SCHEME_F16X2, sc, nullptr)) return rc;
                 (dec ? h->dwih_f : h->wih_f)[l] = f;
                 (dec ? h->dwih_fs : h->wih_fs)[l] = sc;
+                // W_hh scale of the fp16-scheme recurrence (the kernel splits W_hh itself, once per launch)
+                const size_t offh = dec ? d_lstm[l][1] : o_lstm[l][1];
+                float mxh = 0.f;
+                for (size_t i = 0; i < (size_t)4 * kH * kH; ++i) mxh = std::fmax(mxh, std::fabs(p.host[offh + i]));
+                (dec ? h->dwhh_fs : h->whh_fs)[l] = xb_weight_scale(mxh);
             }
         {   // codebooks as plain (row-major) bf16 pieces for the RVQ search
             __bf16* d = nullptr;
@@ -865,7 +874,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);   // zeroed at the start of the call (the conv stack's range status lives in it)
     if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
                            sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
-                           (h->bf16x3 && h->ih_f16x2) ? h->wih_f : nullptr, h->wih_fs, reinterpret_cast<int*>(sync + 62)))
+                           (h->bf16x3 && h->ih_f16x2) ? h->wih_f : nullptr, h->wih_fs, reinterpret_cast<int*>(sync + 62), h->lstm_f16x2 ? h->whh_fs : nullptr))
         return rc;
     if (status_out) if (int rc = launch_status_combine(sync, status_out, stream)) return rc;
     float* emb = emb_out ? emb_out : ws + p.off_emb;
@@ -908,6 +917,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "res128_x3") { h->res128_x3 = value != 0; return 0; }
     if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }
     if (std::string(name) == "ih_f16x2") { h->ih_f16x2 = value != 0; return 0; }
+    if (std::string(name) == "lstm_f16x2") { h->lstm_f16x2 = value != 0; return 0; }
     if (std::string(name) == "chain_f16x2") { h->chain_f16x2 = value != 0; return 0; }
     if (std::string(name) == "lstm_spin_limit") { AT_REQUIRE(value >= 0, "lstm_spin_limit must be >= 0"); h->lstm_spin_limit = (unsigned)value; return 0; }
     if (std::string(name) == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
@@ -973,7 +983,7 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
     // epilogue) so the transposed convs run the plain-linear GEMM path: y (LSTM + skip) and the block outputs of stages 0-2
     if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,
                            sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
-                           (h->bf16x3 && h->ih_f16x2) ? h->dwih_f : nullptr, h->dwih_fs, reinterpret_cast<int*>(sync + 62)))
+                           (h->bf16x3 && h->ih_f16x2) ? h->dwih_f : nullptr, h->dwih_fs, reinterpret_cast<int*>(sync + 62), h->lstm_f16x2 ? h->dwhh_fs : nullptr))
         return rc;
     if (status_dev) if (int rc = launch_status_combine(sync, status_dev, stream)) return rc;
     const int Lout = p.L[4];

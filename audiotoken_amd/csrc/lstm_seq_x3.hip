@@ -8,15 +8,21 @@
 // ([3 pieces][16 clips][512 + 8 pad] bf16: the 16-byte pad puts the 16 clip rows of a fragment read on 16 bank groups).
 // The result differs from the fp32 chain in rounding only (both ~1e-6 of float64 per step); it is compared with the fp32
 // persistent kernel and the per-step path by tolerance and by identical tokens (tests/test_acoustic_gpu.py).
+//
+// Round 2: the kernel is templated on the operand scheme (split_scheme.h). Default is the two-piece fp16 scheme: h lies in (-1, 1), so
+// h * 2^14 always fits fp16 (no range check needed) and W_hh is scaled per layer into [2^14, 2^15); three products per K step instead of
+// six (48 MFMAs per wave and step instead of 96), 128 weight registers per lane instead of 192, two LDS piece planes instead of three.
+// The 4-wave x 384-register shape of round 1 lost its A/B (8.4 vs 7.6 ms) and is gone.
 #include "gemm_core.h"
 #include "encodec_kernels.h"
+#include "split_scheme.h"
 #include <cstdlib>
+#include <cmath>
 
 namespace at {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+constexpr float LX_H_SCALE = 16384.0f;   // fp16 scheme: h (|h| < 1) is split as h * 2^14
 
 constexpr int LX_H = 512;
 constexpr int LX_CLIPS = 16;       // clips per group = one MFMA row tile
@@ -28,18 +34,19 @@ constexpr int LX_FLAGS = 128;      // flags[16 groups][32 words] (16 used)
 constexpr int LX_FLAG_STRIDE = 32;
 constexpr int LX_MAX_GROUPS = 16;
 
-__device__ __forceinline__ void lx_split(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
-    p1 = (__bf16)v;
-    const float r1 = v - (float)p1;
-    p2 = (__bf16)r1;
-    p3 = (__bf16)(r1 - (float)p2);
-}
+__device__ __forceinline__ f4 lx_mfma(bf16x8 w, bf16x8 x, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0); }
+__device__ __forceinline__ f4 lx_mfma(f16x8 w, f16x8 x, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0); }
 
-// NJ = row tiles per wave: 2 -> 4 waves (384 weight registers, one wave per SIMD), 1 -> 8 waves (192, two waves per SIMD)
-template <int NJ>
-__global__ __launch_bounds__(512 / NJ, 1) void lstm_seq_x3_kernel(LstmSeqArgs a) {
+// 8 waves, one 16-row tile each (two waves per SIMD); SC = operand scheme; w_scale / h_scale / acc_scale: the fp16 scheme's powers of two
+template <class SC>
+__global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, float w_scale, float h_scale, float acc_scale) {
+    typedef typename SC::T PT;
+    typedef typename SC::V8 V8;
+    typedef typename SC::V4 V4;
+    constexpr int NP = SC::NP, NJ = 1;
     constexpr int NTHR = 512 / NJ, NST = 2048 / NTHR;   // threads; 16-byte staging chunks per thread
-    extern __shared__ __attribute__((aligned(16))) __bf16 Hp[];   // [3][16 clips][520]
+    extern __shared__ __attribute__((aligned(16))) unsigned char Hp_raw[];   // [NP][16 clips][520]
+    PT* Hp = reinterpret_cast<PT*>(Hp_raw);
     __shared__ int abort_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
@@ -51,7 +58,7 @@ __global__ __launch_bounds__(512 / NJ, 1) void lstm_seq_x3_kernel(LstmSeqArgs a)
     // row tile j of wave w = tile nt = 2w + j of the 8 tiles of this slice; in the weight layout of lstm_seq.hip (64-row blocks of 16 units,
     // rows = unit * 4 + gate) that is block 2*slice + (nt >> 2), rows 16*(nt & 3) ..; lane (r16, q) then owns unit .. + q, gates = acc[0..3]
     int unit[NJ];
-    bf16x8 wp[3][NJ][16];
+    V8 wp[NP][NJ][16];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int nt = NJ * wave + j;
@@ -61,12 +68,13 @@ __global__ __launch_bounds__(512 / NJ, 1) void lstm_seq_x3_kernel(LstmSeqArgs a)
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const f4 lo = *reinterpret_cast<const f4*>(wrow + ks * 32 + q * 8), hi = *reinterpret_cast<const f4*>(wrow + ks * 32 + q * 8 + 4);
+            V4 plo[NP], phi[NP];
+            split4<SchemeNoCheck<SC>>(lo, w_scale, plo);
+            split4<SchemeNoCheck<SC>>(hi, w_scale, phi);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                __bf16 x1, x2, x3;
-                lx_split(k < 4 ? lo[k] : hi[k - 4], x1, x2, x3);
-                wp[0][j][ks][k] = x1; wp[1][j][ks][k] = x2; wp[2][j][ks][k] = x3;
-            }
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { wp[i][j][ks][k] = plo[i][k]; wp[i][j][ks][4 + k] = phi[i][k]; }
         }
     }
     const int clip = b0 + r16;
@@ -89,8 +97,7 @@ __global__ __launch_bounds__(512 / NJ, 1) void lstm_seq_x3_kernel(LstmSeqArgs a)
     }
     const int l_off0 = (tid >> 7) * LX_LDH + (tid & 127) * 4;            // + (NTHR / 128) j rows
     unsigned* flags = a.sync + LX_FLAGS + group * LX_FLAG_STRIDE;
-    const __bf16* hb = Hp + r16 * LX_LDH + q * 8;                        // fragment base: + 32 ks elements, + piece
-    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+    const PT* hb = Hp + r16 * LX_LDH + q * 8;                            // fragment base: + 32 ks elements, + piece
 
     for (int t = 0; t < T; ++t) {
         // input-side gates and the skip inputs of this step: independent of the recurrence, issued before the wait
@@ -134,42 +141,39 @@ __global__ __launch_bounds__(512 / NJ, 1) void lstm_seq_x3_kernel(LstmSeqArgs a)
             for (int j = 0; j < NST; ++j) stage[j] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, g_off[j] + toff, 0, 16);   // aux 16 = sc1
 #pragma unroll
             for (int j = 0; j < NST; ++j) {
-                bf16x4 p1, p2, p3;
+                const f4 hv = {__uint_as_float(stage[j][0]), __uint_as_float(stage[j][1]), __uint_as_float(stage[j][2]), __uint_as_float(stage[j][3])};
+                V4 pp[NP];
+                split4<SchemeNoCheck<SC>>(hv, h_scale, pp);
+                PT* d = Hp + l_off0 + (NTHR / 128) * j * LX_LDH;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    __bf16 x1, x2, x3;
-                    lx_split(__uint_as_float(stage[j][k]), x1, x2, x3);
-                    p1[k] = x1; p2[k] = x2; p3[k] = x3;
-                }
-                __bf16* d = Hp + l_off0 + (NTHR / 128) * j * LX_LDH;
-                *reinterpret_cast<bf16x4*>(d) = p1;
-                *reinterpret_cast<bf16x4*>(d + LX_HP) = p2;
-                *reinterpret_cast<bf16x4*>(d + 2 * LX_HP) = p3;
+                for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(d + i * LX_HP) = pp[i];
             }
             __syncthreads();
             // ---- gates += h_{t-1} . W_slice^T: 16 K steps x 6 products x 2 row tiles = 192 MFMAs per wave; fragments one K step ahead ----
-            bf16x8 xa[3], xb[3];
+            V8 xa[NP], xb[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) xa[p] = *reinterpret_cast<const bf16x8*>(hb + p * LX_HP);
+            for (int p = 0; p < NP; ++p) xa[p] = *reinterpret_cast<const V8*>(hb + p * LX_HP);
 #pragma unroll
             for (int ks = 0; ks < 16; ks += 2) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) xb[p] = *reinterpret_cast<const bf16x8*>(hb + p * LX_HP + (ks + 1) * 32);
+                for (int p = 0; p < NP; ++p) xb[p] = *reinterpret_cast<const V8*>(hb + p * LX_HP + (ks + 1) * 32);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tt = 0; tt < 6; ++tt)
+                for (int tt = 0; tt < SC::NPROD; ++tt)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[PW[tt]][j][ks], xa[PX[tt]], acc[j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) acc[j] = lx_mfma(wp[SC::prod_w(tt)][j][ks], xa[SC::prod_a(tt)], acc[j]);
                 if (ks + 2 < 16) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) xa[p] = *reinterpret_cast<const bf16x8*>(hb + p * LX_HP + (ks + 2) * 32);
+                    for (int p = 0; p < NP; ++p) xa[p] = *reinterpret_cast<const V8*>(hb + p * LX_HP + (ks + 2) * 32);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tt = 0; tt < 6; ++tt)
+                for (int tt = 0; tt < SC::NPROD; ++tt)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp[PW[tt]][j][ks + 1], xb[PX[tt]], acc[j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) acc[j] = lx_mfma(wp[SC::prod_w(tt)][j][ks + 1], xb[SC::prod_a(tt)], acc[j]);
             }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] *= acc_scale;   // exact: a power of two (1 for the bf16 scheme)
         }
         // ---- cell update (torch CPU LSTMCell order: gates = (hW + b_hh) + igates; c = f*c + i*g unfused) -----------------------------
         float hn[NJ];
@@ -213,21 +217,24 @@ int lstm_seq_x3_max_clips() {
     return cached[dev];
 }
 
+template <class SC>
+static int launch_lx(const LstmSeqArgs& a, float w_scale, float h_scale, hipStream_t stream) {
+    const size_t lds = (size_t)SC::NP * LX_HP * 2;
+    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, lstm_seq_x3_kernel<SC>, lds)) return rc; }
+    hipLaunchKernelGGL(lstm_seq_x3_kernel<SC>, dim3(a.n_groups * LX_SLICES), dim3(512), lds, stream, a, w_scale, h_scale, 1.0f / (w_scale * h_scale));
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_lstm_seq_x3(const LstmSeqArgs& a_in, hipStream_t stream) {
     LstmSeqArgs a = a_in;
     AT_REQUIRE(a.B >= 1 && a.B <= lstm_seq_x3_max_clips() && a.T >= 1, "lstm_seq_x3: too many clips for one launch on this device");
     a.n_groups = (a.B + LX_CLIPS - 1) / LX_CLIPS;
     a.h_bytes = (long long)a.B * a.T * LX_H * 4;
     AT_REQUIRE(a.h_bytes < (1ll << 31), "lstm_seq_x3: h buffer exceeds the 2 GB buffer-descriptor range");
-    const size_t lds = (size_t)3 * LX_HP * sizeof(__bf16);
-    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, lstm_seq_x3_kernel<1>, lds)) return rc; }
-    { static LdsAttrFlags lds_attr_1; if (int rc = set_max_dynamic_lds(lds_attr_1, lstm_seq_x3_kernel<2>, lds)) return rc; }
-    static const int waves8 = std::getenv("AUDIOTOKEN_LSTM_X3_WAVES8") ? std::atoi(std::getenv("AUDIOTOKEN_LSTM_X3_WAVES8")) : 1;
     AT_CHECK_HIP(hipMemsetAsync(a.sync + LX_FLAGS, 0, LX_MAX_GROUPS * LX_FLAG_STRIDE * sizeof(unsigned), stream));   // flags, every launch
-    if (waves8) hipLaunchKernelGGL(lstm_seq_x3_kernel<1>, dim3(a.n_groups * LX_SLICES), dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL(lstm_seq_x3_kernel<2>, dim3(a.n_groups * LX_SLICES), dim3(256), lds, stream, a);
-    AT_CHECK_HIP(hipGetLastError());
-    return 0;
+    if (a.w_scale_f16 > 0.f) return launch_lx<SchemeF16x2>(a, a.w_scale_f16, LX_H_SCALE, stream);
+    return launch_lx<SchemeBf16x3>(a, 1.0f, 1.0f, stream);
 }
 
 }  // namespace at

@@ -219,13 +219,10 @@ int launch_seanet_down64x3(const Down64Args& a, hipStream_t stream) {
     AT_REQUIRE(a.L >= 8 && a.L % 4 == 0 && a.B >= 1, "register-stationary stride-4 conv needs L % 4 == 0");
     const size_t lds = (size_t)2 * 3 * DX_PIECE * sizeof(__bf16);
     { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_down64x3_kernel<1>, lds)) return rc; }
-    { static LdsAttrFlags lds_attr_1; if (int rc = set_max_dynamic_lds(lds_attr_1, seanet_down64x3_kernel<2>, lds)) return rc; }
     const long long tiles = (long long)a.B * ((a.L / 4 + DX_TU - 1) / DX_TU);
     AT_REQUIRE(tiles < (1LL << 30) && (long long)a.L * 64 < (1LL << 30), "tile / offset arithmetic is 32-bit");
     const int grid = (int)(tiles < 256 ? tiles : 256);
-    static const int waves8 = std::getenv("AUDIOTOKEN_DOWN64_WAVES8") ? std::atoi(std::getenv("AUDIOTOKEN_DOWN64_WAVES8")) : 1;
-    if (waves8) hipLaunchKernelGGL(seanet_down64x3_kernel<1>, dim3(grid), dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL(seanet_down64x3_kernel<2>, dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(seanet_down64x3_kernel<1>, dim3(grid), dim3(512), lds, stream, a);   // 8 waves x 192 weight registers (the 4-wave x 384 shape lost its A/B: 5.8 vs 5.4 ms)
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -31,6 +31,10 @@ struct SchemeF16x2 {
     __device__ static __forceinline__ f16v mfma(V8 w, V8 a, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, c, 0, 0, 0); }
 };
 
+// a scheme with its range check compiled out (operands known to fit: weights scaled on the host, LSTM states in (-1, 1))
+template <class SC>
+struct SchemeNoCheck : SC { static constexpr bool RANGE_CHECK = false; };
+
 // a -> NP pieces: p[0] = round(a), p[1] = round(a - p[0]), ... (every subtraction is exact)
 template <class SC>
 __device__ __forceinline__ void split_n(float a, typename SC::T (&p)[SC::NP]) {

@@ -496,14 +496,18 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             // FFN GEMM's swish epilogue, the attention kernel's context and the depthwise-conv kernel's output — so no fp32 activation is
             // written only to be re-read by a split pass.
             const float as = sc.act_scale();
-            prof.begin("ffn", 3, stream);
+            prof.begin("layernorm", 1, stream);
             if (int rc = launch_layernorm_split(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            prof.end(stream);
+            prof.begin("ffn", 2, stream);
             if (int rc = gemm_split(sc, t1s, L, W_1A, L.b1a, kFfn, kHid, M, Mpad, XB_EPI_SWISH_SPLIT, 1.f, nullptr, nullptr, kFfn, bigs, stream)) return rc;
             if (int rc = gemm_split(sc, bigs, L, W_1B, L.b1b, kHid, kFfn, M, Mpad, XB_EPI_LINEAR, 0.5f, x, x, kHid, nullptr, stream)) return rc;
             prof.end(stream);
 
-            prof.begin("attn_proj", 2, stream);
+            prof.begin("layernorm", 1, stream);
             if (int rc = launch_layernorm_split(x, L.ln_att_g, L.ln_att_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            prof.end(stream);
+            prof.begin("attn_proj", 1, stream);
             if (int rc = gemm_split(sc, t1s, L, W_QKV, L.bqkv, 3 * kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, big, nullptr, 3 * kHid, nullptr, stream)) return rc;
             prof.end(stream);
             prof.begin("attention", 1, stream);
@@ -518,17 +522,23 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             if (int rc = gemm_split(sc, t1s, L, W_O, L.bo, kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, x, x, kHid, nullptr, stream)) return rc;
             prof.end(stream);
 
-            prof.begin("conv_module", 4, stream);
+            prof.begin("layernorm", 1, stream);
             if (int rc = launch_layernorm_split(x, L.ln_conv_g, L.ln_conv_b, amask, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            prof.end(stream);
+            prof.begin("conv_module", 3, stream);
             if (int rc = gemm_split(sc, t1s, L, W_PW1, nullptr, 2 * kHid, kHid, M, Mpad, XB_EPI_GLU, 1.f, big, nullptr, kHid, nullptr, stream)) return rc;
             if (int rc = launch_dwconv_ln_swish(big, L.dw, L.ln_dw_g, L.ln_dw_b, nullptr, B, T, stream, t1s, Mpad, sc.scheme, as, sc.status)) return rc;
             if (int rc = gemm_split(sc, t1s, L, W_PW2, nullptr, kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, x, x, kHid, nullptr, stream)) return rc;
             prof.end(stream);
 
-            prof.begin("ffn", 4, stream);
+            prof.begin("layernorm", 1, stream);
             if (int rc = launch_layernorm_split(x, L.ln_ffn2_g, L.ln_ffn2_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            prof.end(stream);
+            prof.begin("ffn", 2, stream);
             if (int rc = gemm_split(sc, t1s, L, W_2A, L.b2a, kFfn, kHid, M, Mpad, XB_EPI_SWISH_SPLIT, 1.f, nullptr, nullptr, kFfn, bigs, stream)) return rc;
             if (int rc = gemm_split(sc, bigs, L, W_2B, L.b2b, kHid, kFfn, M, Mpad, XB_EPI_LINEAR, 0.5f, x, x, kHid, nullptr, stream)) return rc;
+            prof.end(stream);
+            prof.begin("layernorm", 1, stream);
             if (int rc = launch_layernorm(x, L.ln_fin_g, L.ln_fin_b, nullptr, x, M, kHid, stream)) return rc;
             prof.end(stream);
             continue;

@@ -49,6 +49,9 @@ BF16X3_ACOUSTIC = os.environ.get("AUDIOTOKEN_BF16X3_ACOUSTIC", "1") != "0"
 _X3_MASK = int(os.environ.get("AUDIOTOKEN_X3_KERNELS", "511"))
 ACOUSTIC_X3_GROUPS = tuple(g for bit, g in enumerate(("down1", "res2", "res1", "stage0_fused", "down2", "down3", "res3", "lstm_rec", "rvq"))
                            if BF16X3_ACOUSTIC and (_X3_MASK >> bit) & 1) + (("lstm_ih",) if BF16X3_ACOUSTIC else ())
+# groups that run on the two-piece fp16 scheme (three MFMA products per multiply-add) instead of three bf16 pieces (six)
+ACOUSTIC_F16X2_GROUPS = ((("down2", "res3", "down3") if os.environ.get("AUDIOTOKEN_CHAIN_F16X2", "1") != "0" else ())
+                         + (("lstm_ih",) if os.environ.get("AUDIOTOKEN_IH_F16X2", "1") != "0" else ())) if BF16X3_ACOUSTIC else ()
 
 
 def free_port() -> int:
@@ -491,7 +494,9 @@ def run_acoustic(args, rank, world, dev, dist):
         "config": {"workload": f"Tokenizers.acoustic encode, {B} clips x {args.seconds:g} s @24 kHz per GPU, num_codebooks={n_q}",
                    "clips_per_gpu": B, "samples_per_clip": N, "frames_per_clip": T, "weights": "synthetic seed 0",
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
-        "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS, "acoustic"), "breakdown": breakdown,
+        "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS, "acoustic",
+                                3 if max(breakdown, key=lambda k: breakdown[k]["ms_per_step"]) in ACOUSTIC_F16X2_GROUPS else 6), "breakdown": breakdown,
+        "mfma_products_per_mac": {g: (3 if g in ACOUSTIC_F16X2_GROUPS else 6) for g in ACOUSTIC_X3_GROUPS},
         "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)", "token_checksum": checksum,
         "lstm_handoff_status": status,
     }
@@ -569,9 +574,12 @@ def run_semantic(args, rank, world, dev, dist):
     products = {0: 1, 1: 6, 2: 3}[arith]
     assert enc.last_status() == 0, "semantic_m status word non-zero (fp16 range overflow): the timed run is invalid"
     breakdown = {}
+    ln_bytes = {"layernorm": 8.0 * T * 1024 * (4 * nl) + 8.0 * T * 1024 * nl}   # LayerNorm -> pieces: 4 B in + 4 B out per element; final LN 4 + 4
     for k, (per, launches) in prof.items():
         breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches,
-                        "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None, "gbs": None}
+                        "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 and k in flops else None,
+                        "gbs": round(ln_bytes[k] * B / (per * 1e-3) / 1e9, 1) if per > 0 and k in ln_bytes else None}
+    flops = dict(flops, layernorm=0.0)
     res = {
         "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "median_ms_per_step": round(median(per_step), 3), "elapsed": elapsed, "audio_s_per_step": world * B * secs, "rank_ms": rank_ms,
@@ -668,13 +676,15 @@ def main(argv=None):
             "metric": "audio-sec tokenized / wall-sec", "value": primary["value"], "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (convs, LSTM, RVQ dot products: exact bf16x3 splits, fp32 accumulate)" if ACOUSTIC_X3_GROUPS else "f32", "data": "synthetic",
+            "dtype": ("f32 (every contraction as operand splits on the 16-bit matrix cores, fp32 accumulate: three bf16 pieces / six products in the fused "
+                      "conv kernels, LSTM recurrence and RVQ search; two fp16 pieces / three products in the stage 2-3 convs and LSTM input projections)")
+                     if ACOUSTIC_X3_GROUPS else "f32", "data": "synthetic",
             "config": primary["config"], "roofline": primary["roofline"], "breakdown": primary["breakdown"],
             "token_checksum": primary["token_checksum"],
             "rccl_ranks": ranks["rccl_ranks"], "per_rank_ms": ranks["per_rank_ms"],
             "backend": args.backend if world > 1 else None,
         }
-        for k in ("median_ms_per_step", "pcie_inclusive", "broadcast_ms", "breakdown_note", "lstm_handoff_status"):
+        for k in ("median_ms_per_step", "pcie_inclusive", "broadcast_ms", "breakdown_note", "lstm_handoff_status", "mfma_products_per_mac"):
             if k in primary:
                 out[k] = primary[k]
         want_cpu = not args.no_cpu_baseline and world == 1 and args.workload != "selftest"

@@ -84,6 +84,8 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
  *   "ih_f16x2", "chain_f16x2" 1/0 — the two LSTM input projections (encoder and decoder) / the encoder's stage-2 strided conv, 256-channel block
  *   and stage-3 strided conv (the GEMM chain) as two-piece fp16 operand splits, three MFMA products (default on, $AUDIOTOKEN_IH_F16X2 /
  *   $AUDIOTOKEN_CHAIN_F16X2) or as the three-piece bf16 splits, six products; see csrc/gemm_bf16x3.h;
+ *   "lstm_f16x2" 1/0 — the persistent LSTM's recurrent product on the two-piece fp16 scheme (h in (-1, 1) always fits: no range check) or on
+ *   three bf16 pieces (default on, $AUDIOTOKEN_LSTM_F16X2; needs "lstm_x3" = 1);
  *   "lstm_spin_limit" n >= 0 — polls of a hand-off flag before a workgroup of the persistent LSTM gives up and the status word of the
  *   *_checked entry points becomes 1 (default 2^18, i.e. 0.1-0.3 s; 0 makes the first unready poll give up — used by the tests);
  *   "subbatch" n >= 1 — clips per pass through the conv stack (default 256 or $AUDIOTOKEN_SUBBATCH): bounds
