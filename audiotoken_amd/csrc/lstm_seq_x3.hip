@@ -5,7 +5,7 @@
 // its weights are 384 registers of bf16 pieces per lane (one wave per SIMD owns 512), so a group of 16 clips has 16 workgroups
 // instead of 32 and ONE workgroup sits on a CU: 192 MFMAs of 16 cycles per step and wave instead of 2 x 128 of 32 cycles for the
 // two co-resident fp32 workgroups, and half as many producers to wait for. h_{t-1} is split while it is staged into LDS
-// ([3 pieces][16 clips][512 + 8 pad] bf16: the 16-byte pad puts the 16 clip rows of a fragment read on 16 bank groups).
+// ([pieces][16 clips][512 + 16 pad]: the 32-byte pad makes the fragment reads conflict-free).
 // The result differs from the fp32 chain in rounding only (both ~1e-6 of float64 per step); it is compared with the fp32
 // persistent kernel and the per-step path by tolerance and by identical tokens (tests/test_acoustic_gpu.py).
 //
@@ -27,7 +27,7 @@ constexpr float LX_H_SCALE = 16384.0f;   // fp16 scheme: h (|h| < 1) is split as
 constexpr int LX_H = 512;
 constexpr int LX_CLIPS = 16;       // clips per group = one MFMA row tile
 constexpr int LX_SLICES = 16;      // workgroups per group: 32 hidden units each
-constexpr int LX_LDH = LX_H + 8;   // LDS row stride (bf16)
+constexpr int LX_LDH = LX_H + 16;  // LDS row stride (16-bit elements): + 32 B, conflict-free fragment reads under the real ds_read_b128 lane grouping (see seanet_res128x3.hip)
 constexpr int LX_HP = LX_CLIPS * LX_LDH;       // elements of one piece
 constexpr int LX_STATUS = 63;      // as lstm_seq.hip
 constexpr int LX_FLAGS = 128;      // flags[16 groups][32 words] (16 used)
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
     typedef typename SC::V4 V4;
     constexpr int NP = SC::NP, NJ = 1;
     constexpr int NTHR = 512 / NJ, NST = 2048 / NTHR;   // threads; 16-byte staging chunks per thread
-    extern __shared__ __attribute__((aligned(16))) unsigned char Hp_raw[];   // [NP][16 clips][520]
+    extern __shared__ __attribute__((aligned(16))) unsigned char Hp_raw[];   // [NP][16 clips][528]
     PT* Hp = reinterpret_cast<PT*>(Hp_raw);
     __shared__ int abort_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

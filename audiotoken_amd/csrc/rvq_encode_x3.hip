@@ -14,7 +14,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 constexpr int QX_D = 128, QX_CODES = 1024, QX_CT = 64, QX_ROWS = 128;
-constexpr int QX_LD = QX_D + 8;                 // LDS row stride (bf16): 16 consecutive code rows hit 16 distinct bank groups
+constexpr int QX_LD = QX_D + 16;                // LDS row stride (bf16): + 32 B, conflict-free fragment reads under the real ds_read_b128 lane grouping (see seanet_res128x3.hip)
 constexpr int QX_PIECE = QX_CT * QX_LD;         // elements of one piece of a code tile
 constexpr int QX_TILE = 3 * QX_PIECE;
 
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 1) void rvq_encode_x3_kernel(const float* __re
                                                                 const float* __restrict__ codebooks, const __bf16* __restrict__ cb_s,
                                                                 long long cb_piece, const float* __restrict__ e2, int n_q,
                                                                 int16_t* __restrict__ codes) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 qx_lds[];   // [2 buffers][3 pieces][64 codes][136]
+    extern __shared__ __attribute__((aligned(16))) __bf16 qx_lds[];   // [2 buffers][3 pieces][64 codes][144]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const long long row_base = (long long)blockIdx.x * QX_ROWS + wave * 32;

@@ -21,7 +21,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int DX_TU = 32;                  // output rows per tile
 constexpr int DX_ROWS = 4 * DX_TU + 4;     // input rows per tile: row i <-> time 4*u0 - 4 + i
 constexpr int DX_CHUNKS = DX_ROWS * 16;    // float4 chunks of the input tile
-constexpr int DX_PL = 40, DX_LD = 72;      // input row i lives in plane i & 3 at index i >> 2 (40 per plane: 33 used + the tail of the last chunk), 64 + 8 channels per row
+constexpr int DX_PL = 40, DX_LD = 80;      // input row i lives in plane i & 3 at index i >> 2 (40 per plane: 33 used + the tail of the last chunk), 64 + 16 channels per row (+ 32 B: conflict-free fragment reads, see seanet_res128x3.hip)
 constexpr int DX_PIECE = 4 * DX_PL * DX_LD; // bf16 elements of one piece of the tile
 // physical LDS row: rows 32 apart (fragment lanes r16 and r16 + 8) swap odd/even so that they fall in different halves of the banks
 // scheduling pattern for one K step: after each of the 12 MFMAs up to 4 vector instructions of the side work (the rest follows)

@@ -20,7 +20,7 @@ constexpr int RY_TT = 64;                    // time rows per tile
 constexpr int RY_XROWS = 66;                 // row i <-> time t0 - 2 + i
 constexpr int RY_CHUNKS = RY_XROWS * 16;     // float4 chunks of the input tile
 constexpr int RY_PRE = (RY_CHUNKS + 255) / 256;
-constexpr int RY_LDX = 72, RY_LDH = 40;      // row strides (bf16)
+constexpr int RY_LDX = 80, RY_LDH = 40;      // row strides (bf16): x rows + 32 B (conflict-free fragment reads, see seanet_res128x3.hip); the h rows keep + 16 B (two workgroups per CU: 78.7 KB each)
 constexpr int RY_XP = RY_XROWS * RY_LDX;     // bf16 elements of one piece of an x tile
 constexpr int RY_HP = RY_TT * RY_LDH;
 

@@ -27,7 +27,7 @@ constexpr int SX_UO = 31;                  // outputs per tile
 constexpr int SX_XROWS = 80;               // x0 rows written (5 MFMA row tiles; 66 used)
 constexpr int SX_ROWS = 64;                // h / r rows
 constexpr int SX_RIDX = 34;                // r rows per parity plane (the masked 32nd output reads rows 62..65)
-constexpr int SX_LDX = 40, SX_LDH = 24, SX_LDR = 40;
+constexpr int SX_LDX = 48, SX_LDH = 24, SX_LDR = 48;   // x0 / r rows + 32 B (conflict-free fragment reads, see seanet_res128x3.hip); h rows keep + 16 B (two workgroups per CU)
 constexpr int SX_XP = SX_XROWS * SX_LDX, SX_HP = SX_ROWS * SX_LDH, SX_RP = 2 * SX_RIDX * SX_LDR;   // elements per piece
 constexpr int SX_WAV = 88;                 // waveform segment: Wv[s] = wav[|t0 - 10 + s|]
 constexpr int SX_LDS_BYTES = (6 * SX_XP + 3 * SX_HP + 3 * SX_RP) * 2 + (2 * SX_WAV + 32 + 112) * 4;
