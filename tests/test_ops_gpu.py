@@ -160,3 +160,33 @@ def test_split_gemm_vs_float64(cuda_device, M, N, K, kernel, scheme):
     print(f"split gemm M={M} N={N} K={K} scheme={scheme} kernel={kernel}: max err {err.max():.2e} (torch fp32 on CPU: {chain:.2e}), ref rms {np.sqrt((ref ** 2).mean()):.2f}")
     assert np.isfinite(got).all()
     assert err.max() <= 1.5e-5 * np.sqrt(K / 1024.0) * max(1.0, np.sqrt((ref ** 2).mean()))
+
+
+def test_split_gemm_xcd_order_and_soak(cuda_device):
+    """A launch large enough for the 256 x 256 shape WITH the XCD-aware tile order (>= 64 m-tiles), against float64 — every tile must be
+    produced exactly once — and 25 repeats that must be bit-identical: the two-group kernel's LDS-DMA ring is a hand-written
+    producer / consumer protocol, and a landing race shows up as run-to-run differences long before it shows up as a wrong token."""
+    lib = _cabi.load()
+    M, N, K = 20000, 1024, 1024
+    x = prng.irwin_hall("soak.x", (M, K), 1.0, 5)
+    w = prng.irwin_hall("soak.w", (N, K), 0.05, 5)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T
+    dev = cuda_device
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    nbytes = ((M + 255) // 256 * 256 + N) * K * 2 * 2
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    first = None
+    for it in range(25):
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+        _cabi.check(lib.at_op_gemm_split(xd.data_ptr(), wd.data_ptr(), 0, out.data_ptr(), M, N, K, 1, float(np.abs(w).max()), 0,
+                                         ws.data_ptr(), nbytes, status.data_ptr(), _cabi.current_stream_handle(dev)), "at_op_gemm_split")
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        if first is None:
+            first = out
+            err = np.abs(out.cpu().numpy().astype(np.float64) - ref).max()
+            print(f"split gemm (product dispatch) M={M} N={N} K={K}: max err vs float64 {err:.2e}")
+            assert err <= 1.5e-5 * max(1.0, np.sqrt((ref ** 2).mean()))
+        else:
+            assert torch.equal(out, first), f"run {it} differs from run 0"
