@@ -30,16 +30,21 @@ template <int NP> constexpr int ax_k_elems() { return NP * AX_KB * AX_KLD; }
 template <int NP> constexpr int ax_v_elems() { return NP * 64 * AX_VLD; }
 template <int NP> constexpr size_t ax_lds_bytes() { return (size_t)(ax_k_elems<NP>() + ax_v_elems<NP>()) * 2 + (size_t)(AX_QB * AX_QE_LD + AX_KB + 4) * 4; }
 
-template <class SC>
+// KVP (fp16 scheme only): k and v arrive ALREADY split — row-major fp16 pieces [which][piece][rows_pad][hid] written by the q / k / v
+// projection's epilogue (XB_EPI_QKV) — so a K / V tile is staged with four 16-byte loads and stores per thread and no vector arithmetic (the
+// splits were a third of this kernel's vector instructions, repeated by each of the 12 query-tile workgroups of a (clip, head)); V stays
+// row-major [key][64 d + 32 pad] in LDS and P.V takes its transposed fragments with ds_read_b64_tr_b16 (4 keys x 16 d per 16 lanes).
+template <class SC, bool KVP>
 __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ amask,
                                                                      const float* __restrict__ dist_emb, float* __restrict__ ctx, int T, int hid,
                                                                      int* __restrict__ status, typename SC::T* __restrict__ ctx_pieces, long long rows_pad,
-                                                                     int nheads, int nclips) {
+                                                                     int nheads, int nclips, const typename SC::T* __restrict__ kv_pieces) {
     typedef typename SC::T PT;
     typedef typename SC::V8 V8;
     typedef typename SC::V4 V4;
     constexpr int NP = SC::NP;
-    constexpr int AX_K_ELEMS = ax_k_elems<NP>(), AX_V_ELEMS = ax_v_elems<NP>();
+    constexpr int AX_VROW = 96;   // KVP: V rows [key][64 d + 32 pad] (192 B: the 4 rows of a transposing read fall on 4 disjoint bank quarters)
+    constexpr int AX_K_ELEMS = ax_k_elems<NP>(), AX_V_ELEMS = KVP ? NP * AX_KB * AX_VROW : ax_v_elems<NP>();
     // operand scales (1 for the bf16 scheme): q, k, v * XS; p * PS. S = acc / XS^2, O = acc / (PS XS)
     constexpr float XS = SC::RANGE_CHECK ? XB_F16_ACT_SCALE : 1.0f, PS = SC::RANGE_CHECK ? AX_P_SCALE : 1.0f;
     constexpr float S_SCALE2 = AX_SCALE2 / (XS * XS);
@@ -138,13 +143,34 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
     u4 kreg[2];
     unsigned vreg[8];
     float am = 0.f;
-    auto prefetch = [&](int kt) {
-        const int toff = kt * AX_KB * row_bytes;
-        kreg[0] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_voff + toff, 0, 0);
-        kreg[1] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_voff + toff + 16, 0, 0);
-        int vo = v_voff + toff;
+    // KVP: per-clip buffer descriptors of the four piece planes (k hi, k lo, v hi, v lo), as for the fp32 rows: keys >= T read 0.
+    // thread -> (key tid >> 3, 8 consecutive d of this head)
+    __amdgpu_buffer_rsrc_t prs[4] = {krs, krs, krs, krs};
+    u4 pk[2], pv[2];
+    int p_voff = 0;
+    if constexpr (KVP) {
+        const long long ps = rows_pad * (long long)hid;                       // elements of one piece plane
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { vreg[e] = __builtin_amdgcn_raw_buffer_load_b32(vrs, vo, 0, 0); vo += row_bytes; }
+        for (int j = 0; j < 4; ++j)
+            prs[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(kv_pieces + j * ps + rowbase * hid + h * 64), 0, (T * hid - h * 64) * 2, 0x00020000);
+        p_voff = (sk_key * hid + sk_d) * 2;
+    }
+    auto prefetch = [&](int kt) {
+        if constexpr (KVP) {
+            const int o = p_voff + kt * AX_KB * hid * 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                pk[i] = __builtin_amdgcn_raw_buffer_load_b128(prs[i], o, 0, 0);
+                pv[i] = __builtin_amdgcn_raw_buffer_load_b128(prs[2 + i], o, 0, 0);
+            }
+        } else {
+            const int toff = kt * AX_KB * row_bytes;
+            kreg[0] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_voff + toff, 0, 0);
+            kreg[1] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_voff + toff + 16, 0, 0);
+            int vo = v_voff + toff;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { vreg[e] = __builtin_amdgcn_raw_buffer_load_b32(vrs, vo, 0, 0); vo += row_bytes; }
+        }
         const int rr = kt * AX_KB + (tid & 31);
         am = amask[rowbase + (rr < T ? rr : T - 1)];
     };
@@ -152,7 +178,15 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
     for (int kt = 0; kt < nkt; ++kt) {
         const int r0 = kt * AX_KB;
         __syncthreads();   // previous tile fully consumed (also orders the QE stores before first use)
-        {
+        if constexpr (KVP) {
+            PT* kd = Ks + sk_key * AX_KLD + sk_d;
+            PT* vd = Vt + sk_key * AX_VROW + sk_d;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<u4*>(kd + i * AX_KB * AX_KLD) = pk[i];
+                *reinterpret_cast<u4*>(vd + i * AX_KB * AX_VROW) = pv[i];
+            }
+        } else {
             V8 kpc[NP];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -177,6 +211,8 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
 #pragma unroll
                 for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(vd + 8 * u + i * 64 * AX_VLD) = p4[i];
             }
+        }
+        {
             if (tid < AX_KB) {
                 const int rr = r0 + tid;
                 const float kbv = rr < T ? (am != 0.f ? 0.f : FMIN) : -INFINITY;
@@ -269,8 +305,26 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 V8 vf[NP];
+                if constexpr (KVP) {
+                    // lane (row d = dt * 32 + l32, half hh) needs keys 16 ks + 4 hh + {0..3} and + 8: two transposing reads of a 4-key x 16-d
+                    // block each; within its 16-lane group lane 4 q + p supplies the address of key q, d columns 4 p .. 4 p + 3
+                    typedef short s4_ __attribute__((__vector_size__(4 * sizeof(short))));
+                    const int li = lane & 15, d0 = dt * 32 + (lane & 16);
+                    const PT* vb = Vt + (ks * 16 + 4 * hh + (li >> 2)) * AX_VROW + d0 + 4 * (li & 3);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const s4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_*)(vb + p * AX_KB * AX_VROW));
+                        const s4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_*)(vb + p * AX_KB * AX_VROW + 8 * AX_VROW));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            vf[p][k] = __builtin_bit_cast(PT, (short)lo[k]);
+                            vf[p][4 + k] = __builtin_bit_cast(PT, (short)hi[k]);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) vf[p] = *reinterpret_cast<const V8*>(Vt + p * 64 * AX_VLD + (dt * 32 + l32) * AX_VLD + ks * 16 + 8 * hh);
+                }
 #pragma unroll
                 for (int t = 0; t < SC::NPROD; ++t) oacc[dt] = SC::mfma(vf[SC::prod_a(t)], pp[SC::prod_w(t)][ks], oacc[dt]);
             }
@@ -293,26 +347,29 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
         if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
 }
 
-template <class SC>
+template <class SC, bool KVP>
 static int launch_ax(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads, int* status,
-                     __bf16* ctx_pieces, long long rows_pad) {
+                     __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces) {
     const long long nblk = (long long)((T + AX_QB - 1) / AX_QB) * heads * B;
     dim3 grid((unsigned)((nblk + 7) / 8 * 8));
-    constexpr size_t lds = ax_lds_bytes<SC::NP>();
-    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, relpos_attention_x3_kernel<SC>, lds)) return rc; }
-    hipLaunchKernelGGL(relpos_attention_x3_kernel<SC>, grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T, heads * 64, status,
-                       reinterpret_cast<typename SC::T*>(ctx_pieces), rows_pad, heads, B);
+    constexpr size_t lds = KVP ? (size_t)(ax_k_elems<SC::NP>() + SC::NP * AX_KB * 96) * 2 + (size_t)(AX_QB * AX_QE_LD + AX_KB + 4) * 4 : ax_lds_bytes<SC::NP>();
+    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, relpos_attention_x3_kernel<SC, KVP>, lds)) return rc; }
+    hipLaunchKernelGGL((relpos_attention_x3_kernel<SC, KVP>), grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T, heads * 64, status,
+                       reinterpret_cast<typename SC::T*>(ctx_pieces), rows_pad, heads, B, reinterpret_cast<const typename SC::T*>(kv_pieces));
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
-                               int scheme, int* status, __bf16* ctx_pieces, long long rows_pad) {
+                               int scheme, int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces) {
     AT_REQUIRE(B >= 1 && T >= 1 && heads >= 1 && heads <= 64, "relpos_attention_x3: bad shape");
     AT_REQUIRE((long long)T * 3 * heads * 64 * 4 < (1ll << 31), "relpos_attention_x3: one clip's qkv rows exceed the buffer-descriptor range");
     AT_REQUIRE(ctx_pieces == nullptr || rows_pad >= (long long)B * T, "relpos_attention_x3: rows_pad too small");
-    if (scheme == XB_SCHEME_F16X2) return launch_ax<SchemeF16x2>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad);
-    return launch_ax<SchemeBf16x3>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad);
+    AT_REQUIRE(kv_pieces == nullptr || (scheme == XB_SCHEME_F16X2 && rows_pad >= (long long)B * T && (long long)T * heads * 64 * 2 < (1ll << 31)),
+               "relpos_attention_x3: pre-split k / v need the fp16 scheme and rows_pad");
+    if (scheme == XB_SCHEME_F16X2 && kv_pieces) return launch_ax<SchemeF16x2, true>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, kv_pieces);
+    if (scheme == XB_SCHEME_F16X2) return launch_ax<SchemeF16x2, false>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, nullptr);
+    return launch_ax<SchemeBf16x3, false>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, nullptr);
 }
 
 }  // namespace at

@@ -22,7 +22,8 @@ inline int xb_pieces(int scheme) { return scheme == XB_SCHEME_F16X2 ? 2 : 3; }
 // power-of-two scale that puts max |w| into [2^14, 2^15) (1 for an all-zero tensor)
 float xb_weight_scale(float max_abs);
 
-enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2, XB_EPI_GELU_SPLIT = 3, XB_EPI_GELU = 4, XB_EPI_ELU_SPLIT = 5, XB_EPI_RAW_ELU_SPLIT2 = 6 };
+enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2, XB_EPI_GELU_SPLIT = 3, XB_EPI_GELU = 4, XB_EPI_ELU_SPLIT = 5, XB_EPI_RAW_ELU_SPLIT2 = 6,
+       XB_EPI_QKV = 7 };
 
 struct Bf16x3Args {
     const __bf16* A = nullptr;   // activations: 3 K-blocked pieces [3][K/16][Mpad][16]
@@ -59,6 +60,10 @@ struct Bf16x3Args {
     // each with its own phase / padding / block description (SEANet: the residual block's shortcut operand and its conv operand).
     __bf16* S2 = nullptr;
     int S2pad = 0, S2phases = 1, S2front = 0, S2blocks = 0, S2block0 = 0;
+    // XB_EPI_QKV (the fused q / k / v projection, N = 3 * qkv_hid, plain linear mode): columns [0, qkv_hid) = q go to C as fp32 (ldc), columns
+    // [qkv_hid, 3 qkv_hid) = k, v are written as ROW-MAJOR pieces S[which = 0 k / 1 v][piece][Spad rows][qkv_hid] times split_scale — the operand
+    // images the attention kernel stages without splitting (attention_bf16x3.hip, KVP)
+    int qkv_hid = 0;
 };
 // fills the causal reflect padding of windowed-mode pieces [3][B][blocks][phases][Lp][16]: padded rows i < pad (row i lives in plane
 // i % phases at index i / phases) become copies of padded row 2 * pad - i

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
             case XB_EPI_ELU_SPLIT: epilogue(std::integral_constant<int, XB_EPI_ELU_SPLIT>{}); break;
             case XB_EPI_GLU: epilogue(std::integral_constant<int, XB_EPI_GLU>{}); break;
             case XB_EPI_GELU: epilogue(std::integral_constant<int, XB_EPI_GELU>{}); break;
+            case XB_EPI_QKV: epilogue(std::integral_constant<int, XB_EPI_QKV>{}); break;
             default: epilogue(std::integral_constant<int, XB_EPI_LINEAR>{}); break;
         }
     }
@@ -308,6 +309,8 @@ int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
     AT_REQUIRE(a.A && a.W && a.M >= 1 && a.N % 128 == 0 && a.K % XB_K == 0 && a.Mpad % 256 == 0 && a.Mpad >= a.M,
                "gemm_bf16x3: N % 128, K % 16, Mpad % 256");
     const bool split_out = a.epi == XB_EPI_SWISH_SPLIT || a.epi == XB_EPI_GELU_SPLIT || a.epi == XB_EPI_ELU_SPLIT || a.epi == XB_EPI_RAW_ELU_SPLIT2;
+    AT_REQUIRE(a.epi != XB_EPI_QKV || (a.S != nullptr && a.C != nullptr && a.qkv_hid > 0 && a.N == 3 * a.qkv_hid && a.qkv_hid % 256 == 0 && a.Spad >= a.M && a.batch == 1),
+               "gemm_bf16x3: XB_EPI_QKV needs C, S, N = 3 * qkv_hid, qkv_hid % 256");
     AT_REQUIRE(split_out ? (a.S != nullptr && a.Sphases >= 1 && (long long)a.Spad * a.Sphases >= a.M + (long long)a.Sfront * a.Sphases) : (a.C != nullptr && a.ldc % 2 == 0), "gemm_bf16x3: bad output");
     AT_REQUIRE(a.epi != XB_EPI_RAW_ELU_SPLIT2 || (a.S2 != nullptr && a.S2phases >= 1 && (long long)a.S2pad * a.S2phases >= a.M + (long long)a.S2front * a.S2phases), "gemm_bf16x3: bad second output");
     AT_REQUIRE(a.batch >= 1 && a.stride >= 1 && (a.cblocks == 0 || (a.K / XB_K) % a.cblocks == 0), "gemm_bf16x3: bad window description");

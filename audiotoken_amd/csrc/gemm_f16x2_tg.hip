@@ -176,6 +176,7 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         case XB_EPI_ELU_SPLIT: epilogue(std::integral_constant<int, XB_EPI_ELU_SPLIT>{}); break;
         case XB_EPI_GLU: epilogue(std::integral_constant<int, XB_EPI_GLU>{}); break;
         case XB_EPI_GELU: epilogue(std::integral_constant<int, XB_EPI_GELU>{}); break;
+        case XB_EPI_QKV: epilogue(std::integral_constant<int, XB_EPI_QKV>{}); break;
         case XB_EPI_RAW_ELU_SPLIT2: epilogue(std::integral_constant<int, XB_EPI_RAW_ELU_SPLIT2>{}); break;
         default: epilogue(std::integral_constant<int, XB_EPI_LINEAR>{}); break;
     }

@@ -85,7 +85,7 @@ const float* take(at_hubert* h, const std::string& name, std::vector<int64_t> sh
 
 struct Plan {
     int L[8];   // L[0] = N, L[i+1] = frames after conv i
-    size_t off_a, off_b, off_part, off_ss, off_fmask, off_x, off_t1, off_big, off_pos, off_xs, off_bigs;
+    size_t off_a, off_b, off_part, off_ss, off_fmask, off_x, off_t1, off_big, off_pos, off_xs, off_bigs, off_kvs;
     size_t Mpad;
     int Lp[8];              // rows per phase plane of the split-bf16 input of conv i (i = 1..6)
     int Mp[8];              // padded output rows per clip of conv i
@@ -124,6 +124,7 @@ Plan make_plan(int B, int N) {
     }
     p.off_xs = takef(p.Mpad * kHid * 3 / 2);
     p.off_bigs = takef(p.Mpad * kFfn * 3 / 2);
+    p.off_kvs = takef(p.Mpad * kHid * 2);           // k and v as two fp16 pieces each (XB_EPI_QKV)
     p.total_floats = cur;
     return p;
 }
@@ -432,6 +433,9 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
     float* pos = ws + p.off_pos;
     piece_t* xs = reinterpret_cast<piece_t*>(ws + p.off_xs);
     piece_t* bigs = reinterpret_cast<piece_t*>(ws + p.off_bigs);
+    piece_t* kvs = reinterpret_cast<piece_t*>(ws + p.off_kvs);
+    static const bool attn_kvp = !(std::getenv("AUDIOTOKEN_ATTN_KVP") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_KVP")) == 0);
+    const int attn_arith = (std::getenv("AUDIOTOKEN_ATTN_X3") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_X3")) == 0) ? 0 : h->arith;
     const long long Mpad = (long long)p.Mpad;
     float* big = ws + p.off_big;
     prof.begin("projection_posconv", 20, stream);
@@ -454,18 +458,30 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
     for (int li = 0; li < n_layers; ++li) {
         const LayerW& L = h->layers[li];
         prof.begin("attn_proj", 3, stream);
-        if (split) {
+        // f16x2: the projection's epilogue writes k / v as fp16 pieces, the attention kernel stages them unsplit and writes its context as the
+        // output projection's operand pieces (as in w2vbert.hip)
+        const bool kvp = split && attn_arith == ARITH_F16X2 && sc.scheme == XB_SCHEME_F16X2 && attn_kvp;
+        if (kvp) {
+            if (int rc = launch_split_blocked(x, kHid, M, Mpad, kHid, xs, stream, sc.scheme, sc.act_scale(), sc.status)) return rc;
+            Bf16x3Args qa;
+            qa.A = xs; qa.W = L.ws[sc.scheme][HW_QKV]; qa.bias = L.bqkv; qa.M = (int)M; qa.N = 3 * kHid; qa.K = kHid; qa.Mpad = (int)Mpad;
+            qa.epi = XB_EPI_QKV; qa.C = big; qa.ldc = 3 * kHid; qa.S = kvs; qa.Spad = (int)Mpad; qa.qkv_hid = kHid;
+            qa.scheme = sc.scheme; qa.status = sc.status; qa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[HW_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
+            if (int rc = launch_gemm_bf16x3(qa, stream)) return rc;
+        } else if (split) {
             if (int rc = linear_split(sc, x, kHid, nullptr, xs, L, HW_QKV, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream)) return rc;
         } else if (int rc = linear(x, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, nullptr, nullptr, 3 * kHid, stream)) {
             return rc;
         }
         prof.end(stream);
         prof.begin("attention", 1, stream);
-        if (int rc = launch_relpos_attention(big, fmask, nullptr, t1, B, T, stream, kHeads, (std::getenv("AUDIOTOKEN_ATTN_X3") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_X3")) == 0) ? 0 : h->arith, sc.status)) return rc;
+        const bool ctx_as_pieces = split && attn_arith > 0;
+        if (int rc = launch_relpos_attention(big, fmask, nullptr, ctx_as_pieces ? nullptr : t1, B, T, stream, kHeads, attn_arith, sc.status,
+                                             ctx_as_pieces ? xs : nullptr, Mpad, kvp ? kvs : nullptr)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
         if (split) {
-            if (int rc = linear_split(sc, t1, kHid, nullptr, xs, L, HW_O, L.bo, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
+            if (int rc = linear_split(sc, ctx_as_pieces ? nullptr : t1, kHid, xs, xs, L, HW_O, L.bo, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
         } else if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) {
             return rc;
         }

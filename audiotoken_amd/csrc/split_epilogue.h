@@ -49,6 +49,17 @@ struct XbEpilogue {
                      : E == XB_EPI_ELU_SPLIT ? elu1(v[k])
                                              : v[k] * __frcp_rn(1.0f + __expf(-v[k]));   // as the fp32 GEMM's epilogues
             write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
+        } else if constexpr (E == XB_EPI_QKV) {
+            if (n < a.qkv_hid) {
+                *reinterpret_cast<f4*>(Cb + (long long)m * a.ldc + n) = v;
+            } else {
+                const int which = n >= 2 * a.qkv_hid ? 1 : 0;
+                typename SC::V4 p[SC::NP];
+                over |= split4<SC>(v, a.split_scale, p);
+                PT* d = reinterpret_cast<PT*>(a.S) + ((long long)which * SC::NP * a.Spad + m) * a.qkv_hid + (n - (1 + which) * a.qkv_hid);
+#pragma unroll
+                for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(d + (long long)i * a.Spad * a.qkv_hid) = p[i];
+            }
         } else if constexpr (E == XB_EPI_GLU) {
             float2 o;
             o.x = v.x * sigmoidf_(v.y);

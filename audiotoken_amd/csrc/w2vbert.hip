@@ -111,7 +111,7 @@ int tokens_of(int N, int mult) {
 
 struct Plan {
     int F, Tp;
-    size_t off_frames, off_fmask, off_spec, off_logmel, off_stats, off_feats, off_amask, off_x, off_t1, off_big, off_tok, off_t1s, off_bigs;
+    size_t off_frames, off_fmask, off_spec, off_logmel, off_stats, off_feats, off_amask, off_x, off_t1, off_big, off_tok, off_t1s, off_bigs, off_kvs;
     size_t Mpad;
     size_t total_floats;
 };
@@ -137,6 +137,7 @@ Plan make_plan(int B, int N, int mult) {
     p.Mpad = (M + 255) / 256 * 256;                       // split-bf16 operands: 3 pieces x 2 bytes = 1.5 floats per element
     p.off_t1s = takef(p.Mpad * kHid * 3 / 2);
     p.off_bigs = takef(p.Mpad * kFfn * 3 / 2);
+    p.off_kvs = takef(p.Mpad * kHid * 2 * 2 / 2);        // k and v as two fp16 pieces each (XB_EPI_QKV): 2 x 2 x 2 bytes per element
     p.total_floats = cur;
     return p;
 }
@@ -483,6 +484,8 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     float* big = ws + p.off_big;
     piece_t* t1s = reinterpret_cast<piece_t*>(ws + p.off_t1s);
     piece_t* bigs = reinterpret_cast<piece_t*>(ws + p.off_bigs);
+    piece_t* kvs = reinterpret_cast<piece_t*>(ws + p.off_kvs);
+    static const bool attn_kvp = !(std::getenv("AUDIOTOKEN_ATTN_KVP") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_KVP")) == 0);
     prof.begin("feature_projection", 2, stream);
     if (int rc = launch_layernorm(feats, h->fp_ln_g, h->fp_ln_b, nullptr, t1, M, kFeat, stream)) return rc;
     if (int rc = linear(t1, kFeat, h->fp_w, h->fp_b, x, kHid, M, EPI_NONE, 1.f, nullptr, amask, kHid, stream)) return rc;
@@ -508,11 +511,22 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             if (int rc = launch_layernorm_split(x, L.ln_att_g, L.ln_att_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
             prof.end(stream);
             prof.begin("attn_proj", 1, stream);
-            if (int rc = gemm_split(sc, t1s, L, W_QKV, L.bqkv, 3 * kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, big, nullptr, 3 * kHid, nullptr, stream)) return rc;
+            // f16x2: the projection's epilogue writes k and v directly as fp16 pieces (q stays fp32 for the rel-pos table); the attention kernel
+            // then stages K / V tiles without splitting them ($AUDIOTOKEN_ATTN_KVP=0: the kernel splits the fp32 rows itself)
+            const bool kvp = attn_arith == ARITH_F16X2 && sc.scheme == XB_SCHEME_F16X2 && attn_kvp;
+            if (kvp) {
+                Bf16x3Args qa;
+                qa.A = t1s; qa.W = L.ws[sc.scheme][W_QKV]; qa.bias = L.bqkv; qa.M = (int)M; qa.N = 3 * kHid; qa.K = kHid; qa.Mpad = (int)Mpad;
+                qa.epi = XB_EPI_QKV; qa.C = big; qa.ldc = 3 * kHid; qa.S = kvs; qa.Spad = (int)Mpad; qa.qkv_hid = kHid;
+                qa.scheme = sc.scheme; qa.status = sc.status; qa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[W_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
+                if (int rc = launch_gemm_bf16x3(qa, stream)) return rc;
+            } else if (int rc = gemm_split(sc, t1s, L, W_QKV, L.bqkv, 3 * kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, big, nullptr, 3 * kHid, nullptr, stream)) {
+                return rc;
+            }
             prof.end(stream);
             prof.begin("attention", 1, stream);
             if (attn_arith > 0) {
-                if (int rc = launch_relpos_attention(big, amask, L.dist, nullptr, B, T, stream, 16, attn_arith, sc.status, t1s, Mpad)) return rc;
+                if (int rc = launch_relpos_attention(big, amask, L.dist, nullptr, B, T, stream, 16, attn_arith, sc.status, t1s, Mpad, kvp ? kvs : nullptr)) return rc;
             } else {
                 if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, 0, nullptr)) return rc;
                 if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream, sc.scheme, as, sc.status)) return rc;

@@ -14,11 +14,14 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, cons
 // arith: 0 = fp32-MFMA kernel, 1 = bf16x3, 2 = f16x2 (attention_bf16x3.hip), -1 = the default ($AUDIOTOKEN_ATTN_X3=0 -> 0, else
 // $AUDIOTOKEN_SEMANTIC_ARITH, else f16x2); status: device word for the fp16 range check (nullable)
 // ctx_pieces != nullptr (split arithmetic only): the context is written as operand pieces [NP][hid/16][rows_pad][16] instead of fp32 ctx
+// kv_pieces != nullptr (f16x2 only): k and v are read as the row-major fp16 pieces [which][piece][rows_pad][hid] the q / k / v projection wrote
+// (XB_EPI_QKV) instead of being split from the fp32 qkv rows by every query-tile workgroup; qkv then only supplies q
 int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
-                            hipStream_t stream, int heads = 16, int arith = -1, int* status = nullptr, __bf16* ctx_pieces = nullptr, long long rows_pad = 0);
+                            hipStream_t stream, int heads = 16, int arith = -1, int* status = nullptr, __bf16* ctx_pieces = nullptr, long long rows_pad = 0,
+                            const __bf16* kv_pieces = nullptr);
 // the same attention with both products as operand splits on the 16-bit matrix cores (attention_bf16x3.hip); scheme = XB_SCHEME_*
 int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
-                               int scheme, int* status, __bf16* ctx_pieces = nullptr, long long rows_pad = 0);
+                               int scheme, int* status, __bf16* ctx_pieces = nullptr, long long rows_pad = 0, const __bf16* kv_pieces = nullptr);
 // pieces != nullptr: the output is written as the K-blocked operand pieces [NP][64][rows_pad][16] of `scheme` (times `scale`) instead of fp32
 int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,
                            hipStream_t stream, __bf16* pieces = nullptr, long long rows_pad = 0, int scheme = 0, float scale = 1.0f, int* status = nullptr);
