@@ -148,6 +148,9 @@ struct at_encodec {
     const piece_t* chain_f[4] = {nullptr, nullptr, nullptr, nullptr};
     float chain_fs[4] = {1.f, 1.f, 1.f, 1.f};
     bool chain_f16x2 = true;
+    // fused residual blocks on the fp16 scheme (option "res_f16x2"): power-of-two scales of [conv3, tail] per stage, encoder / decoder
+    float res_fs[4][2] = {}, dres_fs[4][2] = {};
+    bool res_f16x2 = true;
     float whh_fs[2] = {0.f, 0.f}, dwhh_fs[2] = {0.f, 0.f};   // W_hh scales of the fp16-scheme LSTM recurrence (option "lstm_f16x2")
     bool lstm_f16x2 = true;
     bool ih_f16x2 = true;   // option "ih_f16x2" / $AUDIOTOKEN_IH_F16X2: LSTM input projections on the fp16 scheme (three MFMA products instead of six)
@@ -685,6 +688,24 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             if (int rc = launch_split_blocked(h->res[3][1].w, 384, 256, 256, 384, d1, nullptr)) return rc;
             h->res3c_s = d0; h->res3t_s = d1;
         }
+        {   // power-of-two weight scales of the fused residual blocks' fp16 scheme (the kernels split their weights themselves, once per launch)
+            if (const char* e = std::getenv("AUDIOTOKEN_RES_F16X2")) h->res_f16x2 = std::atoi(e) != 0;
+            auto wmax = [&](size_t off, size_t n) { float mx = 0.f; for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(p.host[off + i])); return mx; };
+            int Cc = 32;
+            for (int s2 = 0; s2 < 4; ++s2) {
+                h->res_fs[s2][0] = xb_weight_scale(wmax(o_res[s2][0].w, (size_t)(Cc / 2) * 3 * Cc));
+                h->res_fs[s2][1] = xb_weight_scale(wmax(o_res[s2][1].w, (size_t)Cc * (Cc / 2 + Cc)));
+                Cc *= 2;
+            }
+            if (with_decoder) {
+                int Cd2 = kH / 2;
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    h->dres_fs[s2][0] = xb_weight_scale(wmax(d_res[s2][0].w, (size_t)(Cd2 / 2) * 3 * Cd2));
+                    h->dres_fs[s2][1] = xb_weight_scale(wmax(d_res[s2][1].w, (size_t)Cd2 * (Cd2 / 2 + Cd2)));
+                    Cd2 /= 2;
+                }
+            }
+        }
         {   // the same four weights as two fp16 pieces, each scaled by a power of two into [2^14, 2^15) (gemm_bf16x3.h, XB_SCHEME_F16X2)
             if (const char* e = std::getenv("AUDIOTOKEN_CHAIN_F16X2")) h->chain_f16x2 = std::atoi(e) != 0;
             const float* src[4] = {h->down[2].w, h->res[3][0].w, h->res[3][1].w, h->down[3].w};
@@ -786,6 +807,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 Res64Args ra;
                 ra.x = x; ra.out = r; ra.w3 = h->res[1][0].w; ra.b3 = h->res[1][0].b; ra.wt = h->res[1][1].w; ra.bt = h->res[1][1].b;
                 ra.B = g; ra.L = L;
+                if (h->res_f16x2) { ra.scheme = XB_SCHEME_F16X2; ra.act_scale = XB_F16_ACT_SCALE; ra.w3_scale = h->res_fs[1][0]; ra.wt_scale = h->res_fs[1][1]; ra.status = range_status; }
                 prof.begin("res1", 1, stream);
                 if (int rc = (h->res64_x3 && h->bf16x3) ? launch_seanet_res64x3(ra, stream) : launch_seanet_res64(ra, stream)) return rc;
                 prof.end(stream);
@@ -917,6 +939,7 @@ int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     if (std::string(name) == "res128_x3") { h->res128_x3 = value != 0; return 0; }
     if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }
     if (std::string(name) == "ih_f16x2") { h->ih_f16x2 = value != 0; return 0; }
+    if (std::string(name) == "res_f16x2") { h->res_f16x2 = value != 0; return 0; }
     if (std::string(name) == "lstm_f16x2") { h->lstm_f16x2 = value != 0; return 0; }
     if (std::string(name) == "chain_f16x2") { h->chain_f16x2 = value != 0; return 0; }
     if (std::string(name) == "lstm_spin_limit") { AT_REQUIRE(value >= 0, "lstm_spin_limit must be >= 0"); h->lstm_spin_limit = (unsigned)value; return 0; }

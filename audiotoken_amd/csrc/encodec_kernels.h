@@ -69,6 +69,10 @@ struct Res64Args {
     int S_scheme = 0;
     float S_scale = 1.0f;
     int* status = nullptr;
+    // operand scheme of the block's own contractions (seanet_res64x3 / seanet_res128x3): XB_SCHEME_BF16X3 (three bf16 pieces, six products)
+    // or XB_SCHEME_F16X2 (two fp16 pieces, three products) with the activation scale and the two weight matrices' power-of-two scales
+    int scheme = 0;
+    float act_scale = 1.0f, w3_scale = 1.0f, wt_scale = 1.0f;
 };
 // fills the causal reflect padding (5 front rows = index 0 of every plane) of those pieces
 int launch_reflect_front5(__bf16* S, int B, int cblocks, int Lp, hipStream_t stream, int npieces = 3);

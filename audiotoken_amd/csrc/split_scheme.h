@@ -21,6 +21,7 @@ struct SchemeBf16x3 {
     __device__ static constexpr int prod_a(int t) { constexpr int v[6] = {0, 2, 1, 0, 1, 0}; return v[t]; }
     __device__ static constexpr int prod_w(int t) { constexpr int v[6] = {2, 0, 1, 1, 0, 0}; return v[t]; }
     __device__ static __forceinline__ f16v mfma(V8 w, V8 a, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0); }
+    __device__ static __forceinline__ f4 mfma16(V8 w, V8 a, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0); }
 };
 struct SchemeF16x2 {
     typedef _Float16 T; typedef f16x8 V8; typedef f16x4 V4;
@@ -29,6 +30,7 @@ struct SchemeF16x2 {
     __device__ static constexpr int prod_a(int t) { constexpr int v[3] = {0, 1, 0}; return v[t]; }
     __device__ static constexpr int prod_w(int t) { constexpr int v[3] = {1, 0, 0}; return v[t]; }
     __device__ static __forceinline__ f16v mfma(V8 w, V8 a, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, c, 0, 0, 0); }
+    __device__ static __forceinline__ f4 mfma16(V8 w, V8 a, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, a, c, 0, 0, 0); }
 };
 
 // a scheme with its range check compiled out (operands known to fit: weights scaled on the host, LSTM states in (-1, 1))
