@@ -818,6 +818,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 ra.B = g; ra.L = L;
                 // with the strided conv as a split-bf16 GEMM the block writes that GEMM's operand pieces instead of fp32 rows
                 down2_gemm = h->down128_x3 && h->res128_x3 && h->bf16x3 && h->down2_s && L % 5 == 0 && L >= 10;
+                if (h->res_f16x2) { ra.scheme = XB_SCHEME_F16X2; ra.act_scale = XB_F16_ACT_SCALE; ra.w3_scale = h->res_fs[2][0]; ra.wt_scale = h->res_fs[2][1]; ra.status = range_status; }
                 if (down2_gemm) {
                     ra.S = reinterpret_cast<__bf16*>(r); ra.Lp = p.Lp2;
                     if (cf) { ra.S_scheme = XB_SCHEME_F16X2; ra.S_scale = XB_F16_ACT_SCALE; ra.status = range_status; }

@@ -35,11 +35,21 @@ __device__ __forceinline__ void rx_split(float v, __bf16& p1, __bf16& p2, __bf16
     p3 = (__bf16)(r1 - (float)p2);
 }
 
+// SC = operand scheme of the block's own contractions (see seanet_res64x3.hip): three bf16 pieces / six products, or (round 2, default) two
+// fp16 pieces / three products with power-of-two activation / weight scales and a range status bit.
+template <class SC>
 __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 rx_lds[];
-    __bf16* Xe = rx_lds;                 // split(ELU(x))
-    __bf16* Xr = Xe + 3 * RX_XP;         // split(x)
-    __bf16* Hs = Xr + 3 * RX_XP;         // split(ELU(conv3 + b3))
+    typedef typename SC::T PT;
+    typedef typename SC::V8 V8;
+    typedef typename SC::V4 V4;
+    constexpr int NP = SC::NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rx_lds_raw[];
+    PT* Xe = reinterpret_cast<PT*>(rx_lds_raw);   // split(ELU(x))
+    PT* Xr = Xe + NP * RX_XP;            // split(x)
+    PT* Hs = Xr + NP * RX_XP;            // split(ELU(conv3 + b3))
+    const float sa = SC::RANGE_CHECK ? a.act_scale : 1.0f;
+    const float sw3 = SC::RANGE_CHECK ? a.w3_scale : 1.0f, swt = SC::RANGE_CHECK ? a.wt_scale : 1.0f;
+    const float rs3 = SC::RANGE_CHECK ? 1.0f / (a.act_scale * a.w3_scale) : 1.0f, rst = SC::RANGE_CHECK ? 1.0f / (a.act_scale * a.wt_scale) : 1.0f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int L = a.L;
@@ -48,22 +58,33 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
     bool over = false;                               // fp16 range check of the f16x2 piece output
 
     // ---- weights -> 3 bf16 pieces in registers, once per workgroup (MFMA A operand: row r16, k = 32 ks + 8 q .. + 7) -------------
-    bf16x8 w3p[3][12], wtp[3][2][6];
-    auto wsplit = [&](const float* src, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+    V8 w3p[NP][12], wtp[NP][2][6];
+    auto wsplit = [&](const float* src, float scale, V8 (&dst)[NP]) {
         const f4 lo = *reinterpret_cast<const f4*>(src), hi = *reinterpret_cast<const f4*>(src + 4);
+        V4 plo[NP], phi[NP];
+        split4<SchemeNoCheck<SC>>(lo, scale, plo);
+        split4<SchemeNoCheck<SC>>(hi, scale, phi);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            __bf16 x1, x2, x3;
-            rx_split(k < 4 ? lo[k] : hi[k - 4], x1, x2, x3);
-            p1[k] = x1; p2[k] = x2; p3[k] = x3;
-        }
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dst[i][k] = plo[i][k]; dst[i][4 + k] = phi[i][k]; }
     };
 #pragma unroll
-    for (int ks = 0; ks < 12; ++ks) wsplit(a.w3 + (wave * 16 + r16) * 384 + ks * 32 + q * 8, w3p[0][ks], w3p[1][ks], w3p[2][ks]);
+    for (int ks = 0; ks < 12; ++ks) {
+        V8 t[NP];
+        wsplit(a.w3 + (wave * 16 + r16) * 384 + ks * 32 + q * 8, sw3, t);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) w3p[i][ks] = t[i];
+    }
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) wsplit(a.wt + (wave * 32 + n * 16 + r16) * 192 + ks * 32 + q * 8, wtp[0][n][ks], wtp[1][n][ks], wtp[2][n][ks]);
+        for (int ks = 0; ks < 6; ++ks) {
+            V8 t[NP];
+            wsplit(a.wt + (wave * 32 + n * 16 + r16) * 192 + ks * 32 + q * 8, swt, t);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) wtp[i][n][ks] = t[i];
+        }
     const f4 b3 = *reinterpret_cast<const f4*>(a.b3 + wave * 16 + q * 4);
 
     // input staging: chunk c = tid + 256 j -> (row = c / 32, float4 = c % 32)
@@ -82,8 +103,6 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
         }
     };
     if ((int)blockIdx.x < total_tiles) prefetch(blockIdx.x);
-    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
-
     // Which tile row a fragment column of the TAIL stands for. The 1x1 tail may take its rows in any order; with the split output the
     // 64 rows are sorted by (row % 5, row / 5): the 16 lanes of a row tile then hold consecutive indices of (mostly) one phase plane
     // and their 32-byte piece stores join into runs of up to 416 bytes instead of 96.
@@ -102,68 +121,57 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
             const int c = tid + 256 * j;
             const int row = c >> 5, c4 = c & 31;          // float4 c4 = half (c4 & 1) of the 8-channel chunk c4 >> 1
             const f4 v = pre[j];
-            bf16x4 r1, r2, r3, e1, e2, e3;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                __bf16 x1, x2, x3;
-                rx_split(v[k], x1, x2, x3);
-                r1[k] = x1; r2[k] = x2; r3[k] = x3;
-                rx_split(elu1(v[k]), x1, x2, x3);
-                e1[k] = x1; e2[k] = x2; e3[k] = x3;
-            }
+            const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
+            V4 rp[NP], ep[NP];
+            over |= split4<SC>(v, sa, rp);
+            split4<SchemeNoCheck<SC>>(e, sa, ep);      // |ELU(x)| <= max(|x|, 1): covered by the check of x
             const int off = rx_xoff(row, c4 >> 1) + ((c4 & 1) << 2);
-            *reinterpret_cast<bf16x4*>(Xr + off) = r1;
-            *reinterpret_cast<bf16x4*>(Xr + RX_XP + off) = r2;
-            *reinterpret_cast<bf16x4*>(Xr + 2 * RX_XP + off) = r3;
-            *reinterpret_cast<bf16x4*>(Xe + off) = e1;
-            *reinterpret_cast<bf16x4*>(Xe + RX_XP + off) = e2;
-            *reinterpret_cast<bf16x4*>(Xe + 2 * RX_XP + off) = e3;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                *reinterpret_cast<V4*>(Xr + i * RX_XP + off) = rp[i];
+                *reinterpret_cast<V4*>(Xe + i * RX_XP + off) = ep[i];
+            }
         }
         __syncthreads();
         // ---- h[:, 16w..16w+15] = ELU(conv3(ELU(x)) + b3): output row j uses x rows j, j+1, j+2; K step ks = (tap, 32 channels) --------
 #pragma unroll 1   // (unrolled, the compiler's schedule needs > 512 registers and spills weights)
         for (int mp = 0; mp < 4; mp += 2) {   // two 16-row tiles at a time: 24 fragment registers per buffer
             f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-            auto xread = [&](int ks, bf16x8 (&xf)[3][2]) {
+            auto xread = [&](int ks, V8 (&xf)[NP][2]) {
                 const int tap = ks >> 2, chunk = (ks & 3) * 4 + q;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const __bf16* src = Xe + rx_xoff(16 * (mp + m) + r16 + tap, chunk);
+                    const PT* src = Xe + rx_xoff(16 * (mp + m) + r16 + tap, chunk);
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) xf[p][m] = *reinterpret_cast<const bf16x8*>(src + p * RX_XP);
+                    for (int p = 0; p < NP; ++p) xf[p][m] = *reinterpret_cast<const V8*>(src + p * RX_XP);
                 }
             };
-            bf16x8 xa[3][2], xb[3][2];
+            V8 xa[NP][2], xb[NP][2];
             xread(0, xa);
 #pragma unroll
             for (int ks = 0; ks < 12; ks += 2) {
                 xread(ks + 1, xb);
                 __builtin_amdgcn_sched_barrier(0);   // keep the reads one step ahead of their MFMAs (one wave per SIMD)
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3p[PW[t]][ks], xa[PX[t]][m], acc[m], 0, 0, 0);
+                    for (int m = 0; m < 2; ++m) acc[m] = SC::mfma16(w3p[SC::prod_w(t)][ks], xa[SC::prod_a(t)][m], acc[m]);
                 if (ks + 2 < 12) xread(ks + 2, xa);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3p[PW[t]][ks + 1], xb[PX[t]][m], acc[m], 0, 0, 0);
+                    for (int m = 0; m < 2; ++m) acc[m] = SC::mfma16(w3p[SC::prod_w(t)][ks + 1], xb[SC::prod_a(t)][m], acc[m]);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const f4 v = acc[m] + b3;
-                bf16x4 h1, h2, h3;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    __bf16 x1, x2, x3;
-                    rx_split(elu1(v[k]), x1, x2, x3);
-                    h1[k] = x1; h2[k] = x2; h3[k] = x3;
-                }
+                const f4 v = acc[m] * rs3 + b3;
+                const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
+                V4 hp[NP];
+                over |= split4<SC>(e, sa, hp);
                 const int off = rx_hoff(16 * (mp + m) + r16, 2 * wave + (q >> 1)) + ((q & 1) << 2);   // channels 16 w + 4 q .. + 3
-                *reinterpret_cast<bf16x4*>(Hs + off) = h1;
-                *reinterpret_cast<bf16x4*>(Hs + RX_HP + off) = h2;
-                *reinterpret_cast<bf16x4*>(Hs + 2 * RX_HP + off) = h3;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(Hs + i * RX_HP + off) = hp[i];
             }
         }
         __syncthreads();
@@ -177,38 +185,38 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = f4{0.f, 0.f, 0.f, 0.f};
-            auto tread = [&](int ks, bf16x8 (&xf)[3][2]) {
+            auto tread = [&](int ks, V8 (&xf)[NP][2]) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int row = tail_row(16 * (mp + m) + r16);
-                    const __bf16* src = ks < 2 ? Hs + rx_hoff(row, ks * 4 + q) : Xr + rx_xoff(row + 2, (ks - 2) * 4 + q);
+                    const PT* src = ks < 2 ? Hs + rx_hoff(row, ks * 4 + q) : Xr + rx_xoff(row + 2, (ks - 2) * 4 + q);
                     const int ps = ks < 2 ? RX_HP : RX_XP;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) xf[p][m] = *reinterpret_cast<const bf16x8*>(src + p * ps);
+                    for (int p = 0; p < NP; ++p) xf[p][m] = *reinterpret_cast<const V8*>(src + p * ps);
                 }
             };
-            bf16x8 xa[3][2], xb[3][2];
+            V8 xa[NP][2], xb[NP][2];
             tread(0, xa);
 #pragma unroll
             for (int ks = 0; ks < 6; ks += 2) {
                 tread(ks + 1, xb);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
                         for (int n = 0; n < 2; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wtp[PW[t]][n][ks], xa[PX[t]][m], acc[m][n], 0, 0, 0);
+                            acc[m][n] = SC::mfma16(wtp[SC::prod_w(t)][n][ks], xa[SC::prod_a(t)][m], acc[m][n]);
                 if (ks + 2 < 6) tread(ks + 2, xa);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
                         for (int n = 0; n < 2; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wtp[PW[t]][n][ks + 1], xb[PX[t]][m], acc[m][n], 0, 0, 0);
+                            acc[m][n] = SC::mfma16(wtp[SC::prod_w(t)][n][ks + 1], xb[SC::prod_a(t)][m], acc[m][n]);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
                     const int plane = t % 5, idx = t / 5 + 1;
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        const f4 v = acc[m][n] + *reinterpret_cast<const f4*>(a.bt + wave * 32 + n * 16 + q * 4);
+                        const f4 v = acc[m][n] * rst + *reinterpret_cast<const f4*>(a.bt + wave * 32 + n * 16 + q * 4);
                         f4 o;
                         o.x = elu1(v.x); o.y = elu1(v.y); o.z = elu1(v.z); o.w = elu1(v.w);
                         if (a.S) {   // the consumer is the stride-5 split GEMM: K-blocked, phase-major pieces (bf16x3 or f16x2: a.S_scheme)
@@ -277,10 +285,17 @@ int launch_seanet_res128x3(const Res64Args& a, hipStream_t stream) {
     AT_REQUIRE(a.L >= 4 && a.B >= 1, "fused resblock needs at least 4 rows");
     const long long tiles = (long long)a.B * ((a.L + RX_TT - 1) / RX_TT);
     AT_REQUIRE(tiles < (1LL << 30) && (long long)a.L * 128 < (1LL << 30), "tile / offset arithmetic is 32-bit");
-    const size_t lds = (size_t)(6 * RX_XP + 3 * RX_HP) * sizeof(__bf16);
-    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_res128x3_kernel, lds)) return rc; }
     const int grid = (int)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(seanet_res128x3_kernel, dim3(grid), dim3(256), lds, stream, a);
+    if (a.scheme == XB_SCHEME_F16X2) {
+        AT_REQUIRE(a.act_scale > 0.f && a.w3_scale > 0.f && a.wt_scale > 0.f, "res128x3: the fp16 scheme needs its scales");
+        const size_t lds = (size_t)(4 * RX_XP + 2 * RX_HP) * 2;
+        { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_res128x3_kernel<SchemeF16x2>, lds)) return rc; }
+        hipLaunchKernelGGL(seanet_res128x3_kernel<SchemeF16x2>, dim3(grid), dim3(256), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)(6 * RX_XP + 3 * RX_HP) * 2;
+        { static LdsAttrFlags lds_attr_1; if (int rc = set_max_dynamic_lds(lds_attr_1, seanet_res128x3_kernel<SchemeBf16x3>, lds)) return rc; }
+        hipLaunchKernelGGL(seanet_res128x3_kernel<SchemeBf16x3>, dim3(grid), dim3(256), lds, stream, a);
+    }
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
