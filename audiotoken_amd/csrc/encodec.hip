@@ -150,6 +150,7 @@ struct at_encodec {
     bool chain_f16x2 = true;
     // fused residual blocks on the fp16 scheme (option "res_f16x2"): power-of-two scales of [conv3, tail] per stage, encoder / decoder
     float res_fs[4][2] = {}, dres_fs[4][2] = {};
+    float down_fs[4] = {};    // strided convs (stage-1 fused kernel on the fp16 scheme)
     bool res_f16x2 = true;
     float whh_fs[2] = {0.f, 0.f}, dwhh_fs[2] = {0.f, 0.f};   // W_hh scales of the fp16-scheme LSTM recurrence (option "lstm_f16x2")
     bool lstm_f16x2 = true;
@@ -697,6 +698,8 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
                 h->res_fs[s2][1] = xb_weight_scale(wmax(o_res[s2][1].w, (size_t)Cc * (Cc / 2 + Cc)));
                 Cc *= 2;
             }
+            Cc = 32;
+            for (int s2 = 0; s2 < 4; ++s2) { h->down_fs[s2] = xb_weight_scale(wmax(o_down[s2].w, (size_t)2 * Cc * 2 * kRatiosEnc[s2] * Cc)); Cc *= 2; }
             if (with_decoder) {
                 int Cd2 = kH / 2;
                 for (int s2 = 0; s2 < 4; ++s2) {
@@ -858,6 +861,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             if (s == 1 && h->fused_down64 && L % 4 == 0) {
                 Down64Args da;
                 da.x = r; da.out = out; da.w = h->down[1].w; da.b = h->down[1].b; da.B = g; da.L = L;
+                if (h->res_f16x2) { da.scheme = XB_SCHEME_F16X2; da.act_scale = XB_F16_ACT_SCALE; da.w_scale = h->down_fs[1]; da.status = range_status; }
                 if (int rc = (h->down64_x3 && h->bf16x3) ? launch_seanet_down64x3(da, stream) : launch_seanet_down64(da, stream)) return rc;
             } else if (s == 2 && down2_gemm) {
                 Bf16x3Args ga;

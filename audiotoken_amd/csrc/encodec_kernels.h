@@ -86,6 +86,10 @@ struct Down64Args {
     float* out;         // [B][L/4][128]
     const float *w, *b; // packed [128][8*64], [128]
     int B, L;
+    // seanet_down64x3: operand scheme (XB_SCHEME_BF16X3 / XB_SCHEME_F16X2 with its power-of-two scales) and the fp16 range status word
+    int scheme = 0;
+    float act_scale = 1.0f, w_scale = 1.0f;
+    int* status = nullptr;
 };
 int launch_seanet_down64(const Down64Args& a, hipStream_t stream);
 // the same conv on the bf16 matrix cores with exact 3-way bf16 splits of both operands (seanet_down64x3.hip)

@@ -11,6 +11,7 @@
 // kernel is compared with the unfused path by tolerance, not bit-identity (tests/test_acoustic_gpu.py).
 #include "gemm_core.h"
 #include "encodec_kernels.h"
+#include "split_scheme.h"
 #include <cstdlib>
 
 namespace at {
@@ -37,40 +38,47 @@ __device__ __forceinline__ void dx_interleave() {
 // fragment address is a per-lane base plus a compile-time offset (the XOR swizzle this replaces cost ~40 address registers)
 __device__ __forceinline__ int dx_off(int row) { return ((row & 3) * DX_PL + (row >> 2)) * DX_LD; }
 
-// NN = channel tiles per wave: 2 -> 4 waves x 384 weight registers (one wave per SIMD; the compiler parks weights in AGPRs and copies them
-// back: ~22 cycles per MFMA), 1 -> 8 waves x 192 registers (two waves per SIMD, no AGPR copies; default)
-template <int NN>
-__global__ __launch_bounds__(512 / NN, 1) void seanet_down64x3_kernel(Down64Args a) {
-    constexpr int NTHR = 512 / NN;
-    constexpr int DX_PRE = (DX_CHUNKS + NTHR - 1) / NTHR;   // 16-byte chunks of the input tile per thread: 9 or 5
-    constexpr int SJ = NN == 2 ? 3 : 6;                     // K steps between two chunks of side work
-    constexpr int DX_AHEAD = NN == 2 ? 18 : 12;             // K steps between a chunk's global load and its split into LDS (chunks in flight: 5 / 2)
-    extern __shared__ __attribute__((aligned(16))) __bf16 Xp[];   // [2 buffers][3 pieces][4 planes][40][72]
+// 8 waves, one 16-channel tile each: 16 K steps x NP weight fragments per lane (192 registers with three bf16 pieces, 128 with two fp16
+// pieces), two waves per SIMD. SC = operand scheme (split_scheme.h): three bf16 pieces / six products, or (round 2, default) two fp16 pieces /
+// three products with power-of-two activation / weight scales (a.act_scale, a.w_scale) and a range status bit. (The 4-wave x 384-register
+// shape of round 1 lost its A/B — the compiler parked weights in AGPRs, ~22 cycles per MFMA — and is gone.)
+template <class SC>
+__global__ __launch_bounds__(512, 1) void seanet_down64x3_kernel(Down64Args a) {
+    typedef typename SC::T PT;
+    typedef typename SC::V8 V8;
+    typedef typename SC::V4 V4;
+    constexpr int NP = SC::NP;
+    constexpr int NTHR = 512;
+    constexpr int DX_PRE = (DX_CHUNKS + NTHR - 1) / NTHR;   // 16-byte chunks of the input tile per thread: 5
+    constexpr int SJ = 6;                                   // K steps between two chunks of side work
+    constexpr int DX_AHEAD = 12;                            // K steps between a chunk's global load and its split into LDS (chunks in flight: 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char Xp_raw[];   // [2 buffers][NP pieces][4 planes][40][80]
+    PT* Xp = reinterpret_cast<PT*>(Xp_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int L = a.L, Lo = L / 4;
     const int tiles_per_clip = (Lo + DX_TU - 1) / DX_TU;
     const int total_tiles = a.B * tiles_per_clip;   // < 2^31: checked by the launcher
+    const float sa = SC::RANGE_CHECK ? a.act_scale : 1.0f, sw = SC::RANGE_CHECK ? a.w_scale : 1.0f;
+    const float rs = SC::RANGE_CHECK ? 1.0f / (a.act_scale * a.w_scale) : 1.0f;
+    bool over = false;
 
-    // ---- weights -> 3 bf16 pieces in registers, once: wr[p][n][ks] = split(W[32w + 16n + r16][32 ks + 8 q .. +7]) ------------------
-    bf16x8 wr[3][NN][16];
+    // ---- weights -> pieces in registers, once: wr[p][ks] = split(W[16w + r16][32 ks + 8 q .. +7] * sw) ------------------------------
+    V8 wr[NP][16];
 #pragma unroll
-    for (int n = 0; n < NN; ++n)
+    for (int ks = 0; ks < 16; ++ks) {
+        const float* src = a.w + (wave * 16 + r16) * 512 + ks * 32 + q * 8;
+        const f4 lo = *reinterpret_cast<const f4*>(src), hi = *reinterpret_cast<const f4*>(src + 4);
+        V4 plo[NP], phi[NP];
+        split4<SchemeNoCheck<SC>>(lo, sw, plo);
+        split4<SchemeNoCheck<SC>>(hi, sw, phi);
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const float* src = a.w + (wave * 16 * NN + n * 16 + r16) * 512 + ks * 32 + q * 8;
-            const f4 lo = *reinterpret_cast<const f4*>(src), hi = *reinterpret_cast<const f4*>(src + 4);
+        for (int i = 0; i < NP; ++i)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = k < 4 ? lo[k] : hi[k - 4];
-                const __bf16 p1 = (__bf16)v;
-                const float r1 = v - (float)p1;
-                const __bf16 p2 = (__bf16)r1;
-                wr[0][n][ks][k] = p1; wr[1][n][ks][k] = p2; wr[2][n][ks][k] = (__bf16)(r1 - (float)p2);
-            }
-        }
+            for (int k = 0; k < 4; ++k) { wr[i][ks][k] = plo[i][k]; wr[i][ks][4 + k] = phi[i][k]; }
+    }
     f4 pre[DX_PRE];
-    // chunk j of a tile: 16-byte piece c = tid + 256 j of its 132 x 64 input rows
+    // chunk j of a tile: 16-byte piece c = tid + 512 j of its 132 x 64 input rows
     auto load_chunk = [&](int j, const float* xb, int u0) {
         int c = tid + NTHR * j;
         c = c < DX_CHUNKS ? c : DX_CHUNKS - 1;
@@ -79,24 +87,16 @@ __global__ __launch_bounds__(512 / NN, 1) void seanet_down64x3_kernel(Down64Args
         tau = tau > L - 1 ? L - 1 : tau;       // rows past the end only feed outputs that are never stored
         pre[j] = *reinterpret_cast<const f4*>(xb + (unsigned)(tau * 64 + (c & 15) * 4));
     };
-    // split chunk j into the three bf16 pieces of LDS buffer X
-    auto stage_chunk = [&](int j, __bf16* X) {
+    // split chunk j into the pieces of LDS buffer X
+    auto stage_chunk = [&](int j, PT* X) {
         const int c = tid + NTHR * j;
-        {   // chunks past the tile (tid >= 64 of the last j) land in the pad rows: no branch, so the work can sit between MFMAs
+        {   // chunks past the tile (the tail of the last j) land in the pad rows: no branch, so the work can sit between MFMAs
             const int row = c >> 4, c4 = c & 15;          // 4 channels 4 c4 .. 4 c4 + 3 = half of the 8-channel chunk c4 >> 1
-            bf16x4 p1, p2, p3;
+            V4 pp[NP];
+            over |= split4<SC>(pre[j], sa, pp);
+            PT* d = X + dx_off(row) + c4 * 4;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v = pre[j][k];
-                const __bf16 x1 = (__bf16)v;
-                const float r1 = v - (float)x1;
-                const __bf16 x2 = (__bf16)r1;
-                p1[k] = x1; p2[k] = x2; p3[k] = (__bf16)(r1 - (float)x2);
-            }
-            __bf16* d = X + dx_off(row) + c4 * 4;
-            *reinterpret_cast<bf16x4*>(d) = p1;
-            *reinterpret_cast<bf16x4*>(d + DX_PIECE) = p2;
-            *reinterpret_cast<bf16x4*>(d + 2 * DX_PIECE) = p3;
+            for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(d + i * DX_PIECE) = pp[i];
         }
     };
     auto clip_base = [&](int tile, int& u0) {
@@ -124,105 +124,73 @@ __global__ __launch_bounds__(512 / NN, 1) void seanet_down64x3_kernel(Down64Args
     for (int tile = blockIdx.x; tile < total_tiles; tile += stride, buf ^= 1) {
         const int b = tile / tiles_per_clip;
         const int u0 = (tile - b * tiles_per_clip) * DX_TU;
-        const __bf16* X = Xp + buf * (3 * DX_PIECE);
-        __bf16* Xn = Xp + (buf ^ 1) * (3 * DX_PIECE);
+        const PT* X = Xp + buf * (NP * DX_PIECE);
+        PT* Xn = Xp + (buf ^ 1) * (NP * DX_PIECE);
         // branch-free side work: past the end the last tile is loaded / staged again into buffers nobody reads
         int u1, u2;
         const int t1 = tile + stride, t2 = tile + 2 * stride;
         const float* xb1 = clip_base(t1 < total_tiles ? t1 : total_tiles - 1, u1);
         const float* xb2 = clip_base(t2 < total_tiles ? t2 : total_tiles - 1, u2);
-        constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
-        // One 16-row m-tile at a time (8 accumulator registers live), the K loop software-pipelined one step ahead on the LDS
-        // reads. Spread over the 32 K steps: chunk j of the NEXT tile (loaded during the previous iteration) is split into the other
-        // buffer and the same registers are refilled with chunk j of the tile after it — the vector work sits between the MFMAs
-        // (a 16x16x32 bf16 MFMA holds vector issue for 8 of its 16 cycles) instead of in a phase of its own.
+        // One 16-row m-tile at a time (4 accumulator registers live). Spread over the 32 K steps: chunk j of the NEXT tile (loaded during
+        // the previous iteration) is split into the other buffer and the same registers are refilled with chunk j of the tile after it —
+        // the vector work sits between the MFMAs (a 16x16x32 MFMA holds vector issue for 8 of its 16 cycles) instead of in a phase of its own.
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            f4 acc[NN];
-#pragma unroll
-            for (int n = 0; n < NN; ++n) acc[n] = f4{0.f, 0.f, 0.f, 0.f};
-            auto xread = [&](int ks, bf16x8 (&xf)[3]) {
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+            auto xread = [&](int ks, V8 (&xf)[NP]) {
                 const int tap = ks >> 1, ch = (ks & 1) * 4 + q;    // 8-channel chunk of this lane's K slice
                 const int row = 4 * (16 * m + r16) + tap;
-                const __bf16* src = X + dx_off(row) + ch * 8;
+                const PT* src = X + dx_off(row) + ch * 8;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(src + p * DX_PIECE);
+                for (int p = 0; p < NP; ++p) xf[p] = *reinterpret_cast<const V8*>(src + p * DX_PIECE);
             };
             auto side_work = [&](int step) {   // step = 16 m + ks
-#ifndef DX_PROBE_NO_STAGE
                 if (step % SJ == 2 && step / SJ < DX_PRE) stage_chunk(step / SJ, Xn);
-#endif
-#ifndef DX_PROBE_NO_PREFETCH
-                // chunk j is loaded DX_AHEAD = 18 steps before it is split (about 5 of the 9 chunks are in flight at a time: the
-                // whole tile in registers does not fit beside 384 weight registers): in this iteration for j >= 6, else in the previous
+                // chunk j is loaded DX_AHEAD steps before it is split: in this iteration for the later chunks, else in the previous one
 #pragma unroll
                 for (int j = 0; j < DX_PRE; ++j) {
                     if (SJ * j + 2 - DX_AHEAD >= 0 && step == SJ * j + 2 - DX_AHEAD) load_chunk(j, xb1, u1);
                     if (SJ * j + 2 - DX_AHEAD < 0 && step == SJ * j + 2 - DX_AHEAD + 32) load_chunk(j, xb2, u2);
                 }
-#endif
             };
-            bf16x8 xa[3], xb[3];
-            auto mfmas = [&](int ks, bf16x8 (&xf)[3]) {
+            V8 xa[NP];
+            // two waves per SIMD: the partner wave covers the LDS latency, one fragment set is enough
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+            for (int ks = 0; ks < 16; ++ks) {
+                xread(ks, xa);
 #pragma unroll
-                    for (int n = 0; n < NN; ++n)
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[PW[t]][n][ks], xf[PX[t]], acc[n], 0, 0, 0);
-            };
-            if constexpr (NN == 1) {
-                // two waves per SIMD: the partner wave covers the LDS latency, one fragment set (12 registers) is enough
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    xread(ks, xa);
-                    mfmas(ks, xa);
-                    side_work(16 * m + ks);
-                    dx_interleave<6>();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                xread(0, xa);
-#ifdef DX_PROBE_KS
-                for (int ks = 0; ks < DX_PROBE_KS; ks += 2) {
-#else
-#pragma unroll
-                for (int ks = 0; ks < 16; ks += 2) {
-#endif
-                    xread(ks + 1, xb);
-                    __builtin_amdgcn_sched_barrier(0);   // keep the reads one step ahead of their MFMAs
-                    mfmas(ks, xa);
-                    side_work(16 * m + ks);
-                    dx_interleave<12>();
-                    if (ks + 2 < 16) xread(ks + 2, xa);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfmas(ks + 1, xb);
-                    side_work(16 * m + ks + 1);
-                    dx_interleave<12>();
-                }
+                for (int t = 0; t < SC::NPROD; ++t) acc = SC::mfma16(wr[SC::prod_w(t)][ks], xa[SC::prod_a(t)], acc);
+                side_work(16 * m + ks);
+                dx_interleave<SC::NPROD>();
+                __builtin_amdgcn_sched_barrier(0);
             }
             const int u = u0 + m * 16 + r16;
-#ifdef DX_PROBE_NO_STORE
-            if (u < Lo && acc[0][0] == 123.456f) {
-#else
             if (u < Lo) {
-#endif
-                float* dst = a.out + ((long long)b * Lo + u) * 128 + wave * 16 * NN + q * 4;
-#pragma unroll
-                for (int n = 0; n < NN; ++n) *reinterpret_cast<f4*>(dst + n * 16) = acc[n] + *reinterpret_cast<const f4*>(a.b + wave * 16 * NN + n * 16 + q * 4);
+                float* dst = a.out + ((long long)b * Lo + u) * 128 + wave * 16 + q * 4;
+                *reinterpret_cast<f4*>(dst) = acc * rs + *reinterpret_cast<const f4*>(a.b + wave * 16 + q * 4);
             }
         }
         __syncthreads();   // buffer buf ^ 1 is complete, buffer buf is free
     }
+    if constexpr (SC::RANGE_CHECK)
+        if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
 }
 
 int launch_seanet_down64x3(const Down64Args& a, hipStream_t stream) {
-    AT_REQUIRE(a.L >= 8 && a.L % 4 == 0 && a.B >= 1, "register-stationary stride-4 conv needs L % 4 == 0");
-    const size_t lds = (size_t)2 * 3 * DX_PIECE * sizeof(__bf16);
-    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_down64x3_kernel<1>, lds)) return rc; }
+    AT_REQUIRE(a.L >= 8 && a.L % 4 == 0 && a.B >= 1, "down64x3: L % 4 == 0, L >= 8");
     const long long tiles = (long long)a.B * ((a.L / 4 + DX_TU - 1) / DX_TU);
     AT_REQUIRE(tiles < (1LL << 30) && (long long)a.L * 64 < (1LL << 30), "tile / offset arithmetic is 32-bit");
     const int grid = (int)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(seanet_down64x3_kernel<1>, dim3(grid), dim3(512), lds, stream, a);   // 8 waves x 192 weight registers (the 4-wave x 384 shape lost its A/B: 5.8 vs 5.4 ms)
+    if (a.scheme == XB_SCHEME_F16X2) {
+        AT_REQUIRE(a.act_scale > 0.f && a.w_scale > 0.f, "down64x3: the fp16 scheme needs its scales");
+        const size_t lds = (size_t)2 * 2 * DX_PIECE * 2;
+        { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_down64x3_kernel<SchemeF16x2>, lds)) return rc; }
+        hipLaunchKernelGGL(seanet_down64x3_kernel<SchemeF16x2>, dim3(grid), dim3(512), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)2 * 3 * DX_PIECE * 2;
+        { static LdsAttrFlags lds_attr_1; if (int rc = set_max_dynamic_lds(lds_attr_1, seanet_down64x3_kernel<SchemeBf16x3>, lds)) return rc; }
+        hipLaunchKernelGGL(seanet_down64x3_kernel<SchemeBf16x3>, dim3(grid), dim3(512), lds, stream, a);
+    }
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
