@@ -68,6 +68,7 @@ SIGNATURES = {
                                             C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "at_w2vbert_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "at_w2vbert_get_option": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "at_encodec_get_option": (C.c_int, [C.c_void_p, C.c_char_p]),
     "at_w2vbert_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "at_w2vbert_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "at_hubert_create": (C.c_void_p, [C.c_int]),

@@ -128,6 +128,9 @@ struct at_encodec {
     const __bf16* down2_s = nullptr;
     bool rvq_x3 = true;             // RVQ search with the dot products on the bf16 matrix cores (rvq_encode_x3.hip); follows bf16x3
     const __bf16* cb_s = nullptr;   // codebooks as 3 bf16 pieces [3][n_cb * 1024][128]
+    const __bf16* cb_f = nullptr;   // codebooks * cb_fs as 2 fp16 pieces [2][n_cb * 1024][128] (option "rvq_f16x2")
+    float cb_fs = 1.f;
+    bool rvq_f16x2 = true;
     bool lstm_x3 = true;            // persistent LSTM with the recurrent product on the bf16 matrix cores (lstm_seq_x3.hip); follows bf16x3
     bool res256_x3 = true;          // 256-channel block as two split-bf16 GEMMs chained between the stage-2 and stage-3 strided convs; follows bf16x3
     const __bf16 *res3c_s = nullptr, *res3t_s = nullptr;
@@ -665,6 +668,17 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             h->extra_allocs.push_back(d);
             if (int rc = launch_split_plain(h->codebooks, n, d, nullptr)) return rc;
             h->cb_s = d;
+            // and as two fp16 pieces of E * 2^k (one power of two for all codebooks: the order of the distances is untouched)
+            if (const char* e = std::getenv("AUDIOTOKEN_RVQ_F16X2")) h->rvq_f16x2 = std::atoi(e) != 0;
+            float mx = 0.f;
+            const size_t cb_off = o_cb;
+            for (long long i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(p.host[cb_off + i]));
+            h->cb_fs = xb_weight_scale(mx);
+            __bf16* f = nullptr;
+            AT_CHECK_HIP(hipMalloc((void**)&f, (size_t)2 * n * sizeof(__bf16)));
+            h->extra_allocs.push_back(f);
+            if (int rc = launch_split_plain(h->codebooks, n, f, nullptr, XB_SCHEME_F16X2, h->cb_fs)) return rc;
+            h->cb_f = f;
         }
         {   // stage-2 strided conv weights [256][10 * 128] as K-blocked bf16 pieces
             __bf16* d = nullptr;
@@ -772,6 +786,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
         static const char* kDown[4] = {"down0", "down1", "down2", "down3"};
         Profiler& prof = h->prof;
         const bool fused0 = h->fused_stage0 && (N % 2 == 0);
+        int* range_status = reinterpret_cast<int*>(reinterpret_cast<unsigned*>(ws + p.off_sync) + 62);
         if (fused0) {
             // conv0 + resblock(32) + ELU + strided conv in one kernel: 4 B in, 128 B out per sample (seanet_stage0.hip)
             Stage0Args sa;
@@ -779,6 +794,10 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             sa.w0 = h->conv0.w; sa.b0 = h->conv0.b; sa.w3 = h->res[0][0].w; sa.b3 = h->res[0][0].b;
             sa.wt = h->res[0][1].w; sa.bt = h->res[0][1].b; sa.wd = h->down[0].w; sa.bd = h->down[0].b;
             sa.B = g; sa.N = N;
+            if (h->res_f16x2) {
+                sa.scheme = XB_SCHEME_F16X2; sa.act_scale = XB_F16_ACT_SCALE; sa.status = range_status;
+                sa.w3_scale = h->res_fs[0][0]; sa.wt_scale = h->res_fs[0][1]; sa.wd_scale = h->down_fs[0];
+            }
             prof.begin("stage0_fused", 1, stream);
             if (int rc = (h->stage0_x3 && h->bf16x3) ? launch_seanet_stage0x3(sa, stream) : launch_seanet_stage0(sa, stream)) return rc;
             prof.end(stream);
@@ -791,7 +810,6 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
         // operand scheme of that chain: two fp16 pieces / three products (default) or three bf16 pieces / six products
         const bool cf = h->chain_f16x2 && h->chain_f[0] != nullptr;
         const int cnp = cf ? 2 : 3;
-        int* range_status = reinterpret_cast<int*>(reinterpret_cast<unsigned*>(ws + p.off_sync) + 62);
         auto chain_cfg = [&](Bf16x3Args& a, int j, const __bf16* w_bf16) {
             if (cf) {
                 a.W = h->chain_f[j]; a.scheme = XB_SCHEME_F16X2; a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->chain_fs[j]);
@@ -903,17 +921,20 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                            sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
                            (h->bf16x3 && h->ih_f16x2) ? h->wih_f : nullptr, h->wih_fs, reinterpret_cast<int*>(sync + 62), h->lstm_f16x2 ? h->whh_fs : nullptr))
         return rc;
-    if (status_out) if (int rc = launch_status_combine(sync, status_out, stream)) return rc;
     float* emb = emb_out ? emb_out : ws + p.off_emb;
     prof.begin("final_conv", 1, stream);
     if (int rc = conv_gemm(h->fin, y, (long long)T * kH, T, emb, (long long)T * kDim, T, B, PRO_NONE, nullptr, 0, stream)) return rc;  // y holds ELU(lstm + skip)
     prof.end(stream);
     prof.begin("rvq", 1, stream);
+    const bool rf = h->rvq_f16x2 && h->cb_f;
     int rc = (h->rvq_x3 && h->bf16x3 && h->cb_s)
-                 ? launch_rvq_encode_x3(emb, (long long)B * T, T, h->codebooks, h->cb_s, (long long)h->n_codebooks * kCodes * kDim, h->e2, n_q, codes, stream)
+                 ? launch_rvq_encode_x3(emb, (long long)B * T, T, h->codebooks, rf ? h->cb_f : h->cb_s, (long long)h->n_codebooks * kCodes * kDim, h->e2, n_q,
+                                        codes, stream, rf ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, XB_F16_ACT_SCALE, h->cb_fs, reinterpret_cast<int*>(sync + 62))
                  : launch_rvq_encode(emb, (long long)B * T, T, h->codebooks, h->e2, n_q, codes, stream);
     prof.end(stream);
-    return rc;
+    if (rc) return rc;
+    if (status_out) return launch_status_combine(sync, status_out, stream);   // LSTM hand-off + every range verdict of the call, RVQ included
+    return 0;
 }
 
 int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes, int* T_out,
@@ -926,30 +947,50 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
     return encodec_encode_impl(h, wav, mask, B, N, n_q, codes, T_out, emb_out, workspace, workspace_bytes, stream, status_dev);
 }
 
+namespace {
+struct BoolOption { const char* name; bool at_encodec::*member; };
+const BoolOption kBoolOptions[] = {
+    {"persistent_lstm", &at_encodec::persistent_lstm},
+    {"fused_stage0", &at_encodec::fused_stage0},
+    {"fused_res64", &at_encodec::fused_res64},
+    {"fused_res128", &at_encodec::fused_res128},
+    {"fused_down64", &at_encodec::fused_down64},
+    {"down64_x3", &at_encodec::down64_x3},
+    {"rvq_x3", &at_encodec::rvq_x3},
+    {"lstm_x3", &at_encodec::lstm_x3},
+    {"res256_x3", &at_encodec::res256_x3},
+    {"down256_x3", &at_encodec::down256_x3},
+    {"down128_x3", &at_encodec::down128_x3},
+    {"stage0_x3", &at_encodec::stage0_x3},
+    {"res64_x3", &at_encodec::res64_x3},
+    {"res128_x3", &at_encodec::res128_x3},
+    {"fused_dectail", &at_encodec::fused_dectail},
+    {"ih_f16x2", &at_encodec::ih_f16x2},
+    {"res_f16x2", &at_encodec::res_f16x2},
+    {"rvq_f16x2", &at_encodec::rvq_f16x2},
+    {"lstm_f16x2", &at_encodec::lstm_f16x2},
+    {"chain_f16x2", &at_encodec::chain_f16x2},
+};
+}  // namespace
+
 int at_encodec_set_option(at_encodec_t* h, const char* name, int value) {
     AT_REQUIRE(h && name, "null pointer");
-    if (std::string(name) == "persistent_lstm") { h->persistent_lstm = value != 0; return 0; }
-    if (std::string(name) == "fused_stage0") { h->fused_stage0 = value != 0; return 0; }
-    if (std::string(name) == "fused_res64") { h->fused_res64 = value != 0; return 0; }
-    if (std::string(name) == "fused_res128") { h->fused_res128 = value != 0; return 0; }
-    if (std::string(name) == "fused_down64") { h->fused_down64 = value != 0; return 0; }
-    if (std::string(name) == "down64_x3") { h->down64_x3 = value != 0; return 0; }
-    if (std::string(name) == "rvq_x3") { h->rvq_x3 = value != 0; return 0; }
-    if (std::string(name) == "lstm_x3") { h->lstm_x3 = value != 0; return 0; }
-    if (std::string(name) == "res256_x3") { h->res256_x3 = value != 0; return 0; }
-    if (std::string(name) == "down256_x3") { h->down256_x3 = value != 0; return 0; }
-    if (std::string(name) == "down128_x3") { h->down128_x3 = value != 0; return 0; }
-    if (std::string(name) == "stage0_x3") { h->stage0_x3 = value != 0; return 0; }
-    if (std::string(name) == "res64_x3") { h->res64_x3 = value != 0; return 0; }
-    if (std::string(name) == "res128_x3") { h->res128_x3 = value != 0; return 0; }
-    if (std::string(name) == "fused_dectail") { h->fused_dectail = value != 0; return 0; }
-    if (std::string(name) == "ih_f16x2") { h->ih_f16x2 = value != 0; return 0; }
-    if (std::string(name) == "res_f16x2") { h->res_f16x2 = value != 0; return 0; }
-    if (std::string(name) == "lstm_f16x2") { h->lstm_f16x2 = value != 0; return 0; }
-    if (std::string(name) == "chain_f16x2") { h->chain_f16x2 = value != 0; return 0; }
-    if (std::string(name) == "lstm_spin_limit") { AT_REQUIRE(value >= 0, "lstm_spin_limit must be >= 0"); h->lstm_spin_limit = (unsigned)value; return 0; }
-    if (std::string(name) == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
+    const std::string n(name);
+    for (const BoolOption& o : kBoolOptions)
+        if (n == o.name) { h->*(o.member) = value != 0; return 0; }
+    if (n == "lstm_spin_limit") { AT_REQUIRE(value >= 0, "lstm_spin_limit must be >= 0"); h->lstm_spin_limit = (unsigned)value; return 0; }
+    if (n == "subbatch") { AT_REQUIRE(value >= 1, "subbatch must be >= 1"); h->sub_batch = value; return 0; }
     set_error(std::string("unknown option ") + name);
+    return -1;
+}
+
+int at_encodec_get_option(const at_encodec_t* h, const char* name) {
+    if (!h || !name) return -1;
+    const std::string n(name);
+    for (const BoolOption& o : kBoolOptions)
+        if (n == o.name) return h->*(o.member) ? 1 : 0;
+    if (n == "lstm_spin_limit") return (int)h->lstm_spin_limit;
+    if (n == "subbatch") return h->sub_batch;
     return -1;
 }
 

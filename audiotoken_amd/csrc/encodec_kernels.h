@@ -36,10 +36,13 @@ int lstm_seq_max_clips();
 // the same layer with the recurrent product as split-bf16 MFMAs: 16 workgroups of 32 hidden units per 16-clip group (lstm_seq_x3.hip)
 int launch_lstm_seq_x3(const LstmSeqArgs& a, hipStream_t stream);
 int lstm_seq_x3_max_clips();
-// RVQ search with split-bf16 dot products (rvq_encode_x3.hip); cb_s = codebooks as [3][n_cb * 1024][128] bf16 pieces (launch_split_plain)
-int launch_split_plain(const float* x, long long n, __bf16* out, hipStream_t stream);
+// RVQ search with split dot products (rvq_encode_x3.hip); cb_s = codebooks as [3][n_cb * 1024][128] bf16 pieces, or with
+// scheme = XB_SCHEME_F16X2 as [2][n_cb * 1024][128] fp16 pieces of E * cb_scale (launch_split_plain with the same scheme / scale);
+// the fp16 scheme also needs the residual scale and the device status word that receives the range verdict
+int launch_split_plain(const float* x, long long n, __bf16* out, hipStream_t stream, int scheme = 0, float scale = 1.f);
 int launch_rvq_encode_x3(const float* x, long long rows, int T, const float* codebooks, const __bf16* cb_s, long long cb_piece,
-                         const float* e2, int n_q, int16_t* codes, hipStream_t stream);
+                         const float* e2, int n_q, int16_t* codes, hipStream_t stream, int scheme = 0, float act_scale = 1.f,
+                         float cb_scale = 1.f, int* status = nullptr);
 
 // Fused SEANet stage 0 (seanet_stage0.hip): wav -> conv0 -> resblock(32) -> ELU -> conv k4 s2 -> x1 [B][N/2][64]
 struct Stage0Args {
@@ -50,6 +53,11 @@ struct Stage0Args {
     const float *wt, *bt;   // resblock tail packed [32][16 + 32] = [W1 | Wsc], summed bias [32]
     const float *wd, *bd;   // strided conv packed [64][4*32], [64]
     int B, N;
+    // operand scheme of the three split contractions (gemm_bf16x3.h): XB_SCHEME_F16X2 needs the activation scale, the power-of-two
+    // scales of the three weight tensors and the device status word that receives the range verdict
+    int scheme = 0;
+    float act_scale = 1.f, w3_scale = 1.f, wt_scale = 1.f, wd_scale = 1.f;
+    int* status = nullptr;
 };
 int launch_seanet_stage0(const Stage0Args& a, hipStream_t stream);
 int launch_seanet_stage0x3(const Stage0Args& a, hipStream_t stream);   // the same stage with split-bf16 contractions (seanet_stage0x3.hip)

@@ -16,6 +16,8 @@
 // Causal reflect padding as in seanet_stage0.hip (conv0 evaluated at |t|, two mirrored rows of the block output); N % 2 == 0.
 #include "gemm_core.h"
 #include "encodec_kernels.h"
+#include "gemm_bf16x3.h"
+#include "split_scheme.h"
 
 namespace at {
 
@@ -30,36 +32,36 @@ constexpr int SX_RIDX = 34;                // r rows per parity plane (the maske
 constexpr int SX_LDX = 48, SX_LDH = 24, SX_LDR = 48;   // x0 / r rows + 32 B (conflict-free fragment reads, see seanet_res128x3.hip); h rows keep + 16 B (two workgroups per CU)
 constexpr int SX_XP = SX_XROWS * SX_LDX, SX_HP = SX_ROWS * SX_LDH, SX_RP = 2 * SX_RIDX * SX_LDR;   // elements per piece
 constexpr int SX_WAV = 88;                 // waveform segment: Wv[s] = wav[|t0 - 10 + s|]
-constexpr int SX_LDS_BYTES = (6 * SX_XP + 3 * SX_HP + 3 * SX_RP) * 2 + (2 * SX_WAV + 32 + 112) * 4;
 
-__device__ __forceinline__ void sx_split(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
-    p1 = (__bf16)v;
-    const float r1 = v - (float)p1;
-    p2 = (__bf16)r1;
-    p3 = (__bf16)(r1 - (float)p2);
-}
-// 4 consecutive channels -> the three pieces at element offset `off` (piece stride ps)
-__device__ __forceinline__ void sx_store4(__bf16* base, int off, int ps, const f4& v) {
-    bf16x4 a, b, c;
+// 4 consecutive channels * scale -> the NP pieces at element offset `off` (piece stride ps); returns the scheme's range verdict
+template <class SC>
+__device__ __forceinline__ bool sx_store4(typename SC::T* base, int off, int ps, const f4& v, float scale) {
+    typename SC::V4 p[SC::NP];
+    const bool over = split4<SC>(v, scale, p);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        __bf16 x1, x2, x3;
-        sx_split(v[k], x1, x2, x3);
-        a[k] = x1; b[k] = x2; c[k] = x3;
-    }
-    *reinterpret_cast<bf16x4*>(base + off) = a;
-    *reinterpret_cast<bf16x4*>(base + ps + off) = b;
-    *reinterpret_cast<bf16x4*>(base + 2 * ps + off) = c;
+    for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(base + i * ps + off) = p[i];
+    return over;
 }
 __device__ __forceinline__ f4 sx_elu4(const f4& v) { return f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)}; }
 
+// SC = operand scheme of the three split contractions (conv3, tail, strided conv; conv0 stays on the fp32 MFMA): three bf16 pieces / six products,
+// or (round 2, default) two fp16 pieces / three products with power-of-two activation / weight scales and a range status bit (seanet_res64x3.hip).
+template <class SC>
 __global__ __launch_bounds__(256, 2) void seanet_stage0x3_kernel(Stage0Args a) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 sx_lds[];
-    __bf16* X0e = sx_lds;
-    __bf16* X0r = X0e + 3 * SX_XP;
-    __bf16* Hs = X0r + 3 * SX_XP;
-    __bf16* Rs = Hs + 3 * SX_HP;
-    float* Wv = reinterpret_cast<float*>(Rs + 3 * SX_RP);
+    typedef typename SC::T PT;
+    typedef typename SC::V8 V8;
+    typedef typename SC::V4 V4;
+    constexpr int NP = SC::NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sx_lds_raw[];
+    PT* X0e = reinterpret_cast<PT*>(sx_lds_raw);
+    PT* X0r = X0e + NP * SX_XP;
+    PT* Hs = X0r + NP * SX_XP;
+    PT* Rs = Hs + NP * SX_HP;
+    float* Wv = reinterpret_cast<float*>(Rs + NP * SX_RP);
+    const float sa = SC::RANGE_CHECK ? a.act_scale : 1.0f;
+    const float sw3 = SC::RANGE_CHECK ? a.w3_scale : 1.0f, swt = SC::RANGE_CHECK ? a.wt_scale : 1.0f, swd = SC::RANGE_CHECK ? a.wd_scale : 1.0f;
+    const float rs3 = 1.0f / (sa * sw3), rst = 1.0f / (sa * swt), rsd = 1.0f / (sa * swd);
+    bool over = false;
     float* B0s = Wv + 2 * SX_WAV;                    // conv0 bias [32]  (Wv: two segments, alternating tiles)
     float* Bs = B0s + 32;                            // b3 [16] | bt [32] | bd [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,24 +81,45 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0x3_kernel(Stage0Args a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) w0f[nt][ks] = (4 * ks + q) < 7 ? a.w0[(nt * 16 + r16) * 7 + 4 * ks + q] : 0.f;
     // bf16 pieces of the A operands (row r16, k = 32 ks + 8 q .. + 7); `kmax` zero-fills the tail's K padding
-    auto wsplit = [&](const float* row, int k0, int kmax, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+    auto wsplit = [&](const float* row, int k0, int kmax, float scale, V8 (&dst)[NP]) {
+        f4 lo, hi;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float v = (k0 + k) < kmax ? row[k0 + k] : 0.f;
-            __bf16 x1, x2, x3;
-            sx_split(v, x1, x2, x3);
-            p1[k] = x1; p2[k] = x2; p3[k] = x3;
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = (k0 + k) < kmax ? row[k0 + k] : 0.f;
+            hi[k] = (k0 + 4 + k) < kmax ? row[k0 + 4 + k] : 0.f;
         }
-    };
-    bf16x8 w3p[3][3], wtp[3][2][2], wdp[3][4];
+        V4 plo[NP], phi[NP];
+        split4<SchemeNoCheck<SC>>(lo, scale, plo);
+        split4<SchemeNoCheck<SC>>(hi, scale, phi);
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) wsplit(a.w3 + r16 * 96, ks * 32 + q * 8, 96, w3p[0][ks], w3p[1][ks], w3p[2][ks]);
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dst[i][k] = plo[i][k]; dst[i][4 + k] = phi[i][k]; }
+    };
+    V8 w3p[NP][3], wtp[NP][2][2], wdp[NP][4];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        V8 t[NP];
+        wsplit(a.w3 + r16 * 96, ks * 32 + q * 8, 96, sw3, t);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) w3p[i][ks] = t[i];
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wsplit(a.wt + (nt * 16 + r16) * 48, ks * 32 + q * 8, 48, wtp[0][nt][ks], wtp[1][nt][ks], wtp[2][nt][ks]);
+        for (int ks = 0; ks < 2; ++ks) {
+            V8 t[NP];
+            wsplit(a.wt + (nt * 16 + r16) * 48, ks * 32 + q * 8, 48, swt, t);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) wsplit(a.wd + (wave * 16 + r16) * 128, ks * 32 + q * 8, 128, wdp[0][ks], wdp[1][ks], wdp[2][ks]);
+            for (int i = 0; i < NP; ++i) wtp[i][nt][ks] = t[i];
+        }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        V8 t[NP];
+        wsplit(a.wd + (wave * 16 + r16) * 128, ks * 32 + q * 8, 128, swd, t);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) wdp[i][ks] = t[i];
+    }
 
     auto fetch_wav = [&](int tile) -> float {
         if (tile >= total_tiles || tid >= SX_WAV) return 0.f;
@@ -134,11 +157,10 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0x3_kernel(Stage0Args a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nt ? w0f[1][1] : w0f[0][1], Wseg[a1], acc, 0, 0, 0);
             const f4 o = acc + *reinterpret_cast<const f4*>(B0s + nt * 16 + q * 4);
             const int off = i * SX_LDX + nt * 16 + q * 4;
-            sx_store4(X0r, off, SX_XP, o);
-            sx_store4(X0e, off, SX_XP, sx_elu4(o));
+            over |= sx_store4<SC>(X0r, off, SX_XP, o, sa);
+            sx_store4<SchemeNoCheck<SC>>(X0e, off, SX_XP, sx_elu4(o), sa);   // |ELU(x)| <= max(|x|, 1)
         }
     };
-    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
     // Software pipeline over the workgroup's tiles (two barriers per tile): while tile t is in its strided-conv phase the same
     // waves run conv0 of tile t+1 into the (by then free) x0 buffers and park the waveform segment of tile t+2 in the other Wv buffer.
     const int stride = gridDim.x;
@@ -161,73 +183,73 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0x3_kernel(Stage0Args a) {
         {
             const int row = wave * 16 + r16;
             f4 acc = {0.f, 0.f, 0.f, 0.f};
-            bf16x8 xf[3][3];
+            V8 xf[3][NP];
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) xf[ks][p] = *reinterpret_cast<const bf16x8*>(X0e + p * SX_XP + (row + ks) * SX_LDX + q * 8);
+                for (int p = 0; p < NP; ++p) xf[ks][p] = *reinterpret_cast<const V8*>(X0e + p * SX_XP + (row + ks) * SX_LDX + q * 8);
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-                for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3p[PW[t]][ks], xf[ks][PX[t]], acc, 0, 0, 0);
-            sx_store4(Hs, row * SX_LDH + q * 4, SX_HP, sx_elu4(acc + *reinterpret_cast<const f4*>(Bs + q * 4)));
+                for (int t = 0; t < SC::NPROD; ++t) acc = SC::mfma16(w3p[SC::prod_w(t)][ks], xf[ks][SC::prod_a(t)], acc);
+            over |= sx_store4<SC>(Hs, row * SX_LDH + q * 4, SX_HP, sx_elu4(acc * rs3 + *reinterpret_cast<const f4*>(Bs + q * 4)), sa);
             // K step 0: k 0..15 = h (lanes q < 2), k 16..31 = x0 channels 0..15; K step 1: k 32..47 = x0 channels 16..31 (q < 2),
             // k 48..63 zero weights (the lanes re-read finite x0 data)
-            const __bf16* s0 = q < 2 ? Hs + row * SX_LDH + q * 8 : X0r + (row + 2) * SX_LDX + (q - 2) * 8;
+            const PT* s0 = q < 2 ? Hs + row * SX_LDH + q * 8 : X0r + (row + 2) * SX_LDX + (q - 2) * 8;
             const int ps0 = q < 2 ? SX_HP : SX_XP;
-            const __bf16* s1 = X0r + (row + 2) * SX_LDX + (2 + (q & 1)) * 8;
-            bf16x8 tf[2][3];
+            const PT* s1 = X0r + (row + 2) * SX_LDX + (2 + (q & 1)) * 8;
+            V8 tf[2][NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                tf[0][p] = *reinterpret_cast<const bf16x8*>(s0 + p * ps0);
-                tf[1][p] = *reinterpret_cast<const bf16x8*>(s1 + p * SX_XP);
+            for (int p = 0; p < NP; ++p) {
+                tf[0][p] = *reinterpret_cast<const V8*>(s0 + p * ps0);
+                tf[1][p] = *reinterpret_cast<const V8*>(s1 + p * SX_XP);
             }
             f4 acc2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wtp[PW[t]][nt][ks], tf[ks][PX[t]], acc2[nt], 0, 0, 0);
+                        acc2[nt] = SC::mfma16(wtp[SC::prod_w(t)][nt][ks], tf[ks][SC::prod_a(t)], acc2[nt]);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-                sx_store4(Rs, ((row & 1) * SX_RIDX + (row >> 1)) * SX_LDR + nt * 16 + q * 4, SX_RP,
-                          sx_elu4(acc2[nt] + *reinterpret_cast<const f4*>(Bs + 16 + nt * 16 + q * 4)));
+                over |= sx_store4<SC>(Rs, ((row & 1) * SX_RIDX + (row >> 1)) * SX_LDR + nt * 16 + q * 4, SX_RP,
+                                      sx_elu4(acc2[nt] * rst + *reinterpret_cast<const f4*>(Bs + 16 + nt * 16 + q * 4)), sa);
         }
         __syncthreads();
         if (t0 == 0) {   // reflect padding of the strided conv's input at the clip start: r[-1] = r[1], r[-2] = r[2]
-            if (tid < 48) {
+            if (tid < 16 * NP) {
                 const int p = tid >> 4, j = (tid >> 3) & 1, c = (tid & 7) * 4;   // j = 0 <-> t = -2 (copy of row 4); j = 1 <-> t = -1 (row 3)
                 const int src = 4 - j;
-                *reinterpret_cast<bf16x4*>(Rs + p * SX_RP + ((j & 1) * SX_RIDX + (j >> 1)) * SX_LDR + c) =
-                    *reinterpret_cast<const bf16x4*>(Rs + p * SX_RP + ((src & 1) * SX_RIDX + (src >> 1)) * SX_LDR + c);
+                *reinterpret_cast<V4*>(Rs + p * SX_RP + ((j & 1) * SX_RIDX + (j >> 1)) * SX_LDR + c) =
+                    *reinterpret_cast<const V4*>(Rs + p * SX_RP + ((src & 1) * SX_RIDX + (src >> 1)) * SX_LDR + c);
             }
             __syncthreads();
         }
         // ---- E: x1[u][16 wave .. + 15] = down0(ELU(r)): output u uses r rows 2u .. 2u+3 (K step = tap) ---------------------------
         {
             f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-            bf16x8 rf[4][3][2];
+            V8 rf[4][NP][2];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int om = 0; om < 2; ++om)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        rf[ks][p][om] = *reinterpret_cast<const bf16x8*>(Rs + p * SX_RP + ((ks & 1) * SX_RIDX + om * 16 + r16 + (ks >> 1)) * SX_LDR + q * 8);
+                    for (int p = 0; p < NP; ++p)
+                        rf[ks][p][om] = *reinterpret_cast<const V8*>(Rs + p * SX_RP + ((ks & 1) * SX_RIDX + om * 16 + r16 + (ks >> 1)) * SX_LDR + q * 8);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
                     for (int om = 0; om < 2; ++om)
-                        acc[om] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdp[PW[t]][ks], rf[ks][PX[t]][om], acc[om], 0, 0, 0);
+                        acc[om] = SC::mfma16(wdp[SC::prod_w(t)][ks], rf[ks][SC::prod_a(t)][om], acc[om]);
             const f4 bd = *reinterpret_cast<const f4*>(Bs + 48 + wave * 16 + q * 4);
 #pragma unroll
             for (int om = 0; om < 2; ++om) {
                 const int u = om * 16 + r16, tout = t0 / 2 + u;
-                if (u < SX_UO && tout < L1) *reinterpret_cast<f4*>(a.x1 + ((long long)b * L1 + tout) * 64 + wave * 16 + q * 4) = acc[om] + bd;
+                if (u < SX_UO && tout < L1) *reinterpret_cast<f4*>(a.x1 + ((long long)b * L1 + tout) * 64 + wave * 16 + q * 4) = acc[om] * rsd + bd;
             }
         }
         // ---- B of the next tile, A of the one after it (the x0 buffers were last read before the barrier above; Wv[par] before the
@@ -237,17 +259,29 @@ __global__ __launch_bounds__(256, 2) void seanet_stage0x3_kernel(Stage0Args a) {
         wnext = fetch_wav(tile + 3 * stride);
         __syncthreads();   // x0 of the next tile complete; Rs and Hs free
     }
+    if constexpr (SC::RANGE_CHECK)
+        if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
+}
+
+template <class SC>
+static int launch_stage0_scheme(const Stage0Args& a, hipStream_t stream, int grid) {
+    constexpr int lds = (2 * SC::NP * SX_XP + SC::NP * SX_HP + SC::NP * SX_RP) * 2 + (2 * SX_WAV + 32 + 112) * 4;
+    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, seanet_stage0x3_kernel<SC>, lds)) return rc; }
+    hipLaunchKernelGGL(seanet_stage0x3_kernel<SC>, dim3(grid), dim3(256), lds, stream, a);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_seanet_stage0x3(const Stage0Args& a, hipStream_t stream) {
     AT_REQUIRE(a.N % 2 == 0 && a.N >= 16 && a.B >= 1, "fused stage 0 needs an even sample count");
     const long long tiles = (long long)a.B * ((a.N + SX_ADV - 1) / SX_ADV);
     AT_REQUIRE(tiles < (1LL << 30), "tile arithmetic is 32-bit");
-    { static LdsAttrFlags lds_attr_0; if (int rc = set_max_dynamic_lds(lds_attr_0, seanet_stage0x3_kernel, SX_LDS_BYTES)) return rc; }
     const int grid = (int)(tiles < 512 ? tiles : 512);   // two resident workgroups per CU
-    hipLaunchKernelGGL(seanet_stage0x3_kernel, dim3(grid), dim3(256), SX_LDS_BYTES, stream, a);
-    AT_CHECK_HIP(hipGetLastError());
-    return 0;
+    if (a.scheme == XB_SCHEME_F16X2) {
+        AT_REQUIRE(a.act_scale > 0.f && a.w3_scale > 0.f && a.wt_scale > 0.f && a.wd_scale > 0.f, "two-piece fp16 stage 0 needs its scales");
+        return launch_stage0_scheme<SchemeF16x2>(a, stream, grid);
+    }
+    return launch_stage0_scheme<SchemeBf16x3>(a, stream, grid);
 }
 
 }  // namespace at

@@ -115,6 +115,9 @@ class AcousticEncoder(torch.nn.Module):
     def set_option(self, name: str, value: int) -> None:
         _cabi.check(self._h.lib.at_encodec_set_option(self._h.handle, name.encode(), int(value)), f"at_encodec_set_option({name})")
 
+    def get_option(self, name: str) -> int:
+        return int(self._h.lib.at_encodec_get_option(self._h.handle, name.encode()))
+
     def _sized_workspace(self, B: int, N: int):
         """Workspace for a [B, N] encode. The conv stack runs in sub-batches of `subbatch` clips (default 256, which needs
         ~0.22 GB per clip-10-s); when the allocation does not fit, the sub-batch is halved (option "subbatch") and the
@@ -151,10 +154,11 @@ class AcousticEncoder(torch.nn.Module):
                          "re-encoding with per-step LSTM launches (option persistent_lstm=0) from now on")
             self.set_option("persistent_lstm", 0)
         if status & 2:
-            logger.error(f"an activation exceeded the fp16 range of the f16x2 kernels (stage 2-3 convs, LSTM input projection; status {status}): "
-                         "the tokens of this batch were discarded; re-encoding with the bf16x3 kernels (options chain_f16x2=0, ih_f16x2=0) from now on")
-            self.set_option("ih_f16x2", 0)
-            self.set_option("chain_f16x2", 0)
+            logger.error(f"an activation exceeded the fp16 range of the f16x2 kernels (SEANet convs, LSTM input projection, RVQ search; status {status}): "
+                         "the tokens of this batch were discarded; re-encoding with the bf16x3 kernels "
+                         "(options chain_f16x2=0, ih_f16x2=0, res_f16x2=0, rvq_f16x2=0) from now on")
+            for opt in ("ih_f16x2", "chain_f16x2", "res_f16x2", "rvq_f16x2"):
+                self.set_option(opt, 0)
         codes = self.forward(input_batch, attention_mask)
         if self.last_status() != 0:
             raise _cabi.HipLibraryError("acoustic encode failed twice (LSTM status non-zero with per-step launches)")

@@ -261,6 +261,7 @@ def test_fused_decoder_kernels_equal_unfused(enc_weights):
         dec.set_option("res64_x3", 1)
 
 
+F16X2_OPTIONS = ["chain_f16x2", "ih_f16x2", "res_f16x2", "rvq_f16x2", "lstm_f16x2"]
 X3_OPTIONS = ["down64_x3", "res128_x3", "res64_x3", "stage0_x3", "down128_x3", "down256_x3", "res256_x3", "lstm_x3", "rvq_x3"]
 
 
@@ -274,16 +275,37 @@ def test_all_fp32_and_all_x3_whole_path(encoders):
     ref, margins = R.acoustic_encode(w, wav, 8, return_margins=True)
     emb_ref = R.seanet_encode(w, wav).permute(0, 2, 1)
     try:
-        for value, name in ((0, "all fp32-MFMA kernels"), (1, "all split-bf16 kernels")):
+        for value, f16, name in ((0, 1, "all fp32-MFMA kernels"), (1, 1, "all split kernels, two fp16 pieces (default)"),
+                                 (1, 0, "all split kernels, three bf16 pieces (the range-overflow fallback)")):
             for opt in X3_OPTIONS:
                 enc.set_option(opt, value)
+            for opt in F16X2_OPTIONS:
+                enc.set_option(opt, f16)
             codes, emb = enc(wav.cuda(), None, return_embeddings=True)
             assert enc.last_status() == 0
             assert (emb.cpu() - emb_ref).abs().max().item() < 1e-3
             P.assert_rvq_equal_or_explained(codes, ref, margins, P.RVQ_TIE, name)
     finally:
-        for opt in X3_OPTIONS:
+        for opt in X3_OPTIONS + F16X2_OPTIONS:
             enc.set_option(opt, 1)
+
+
+def test_fp16_range_overflow_is_reported_and_recovered(enc_weights):
+    """A waveform far outside [-1, 1] (x 3e4) overflows the fp16 range of the two-piece kernels: the status word must say so (bit 1) and
+    AcousticEncoder.verified must hand back the tokens of the three-bf16-piece kernels (full fp32 exponent range), equal to the oracle's or explained."""
+    from audiotoken_amd.configs import AcousticEncoderConfig
+    from audiotoken_amd.encoder import AcousticEncoder
+    enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=enc_weights)
+    wav = torch.from_numpy(W.synth_waveform(3, 24000 + 320 * 3, 24000, seed=23)) * 3e4
+    w = W.synth_encodec_weights(seed=0)
+    ref, margins = R.acoustic_encode(w, wav, 8, return_margins=True)
+    x = wav.cuda()
+    codes = enc(x, None)
+    assert enc.last_status() & 2, "the range overflow was not reported"
+    codes = enc.verified(codes, x, None)
+    assert enc.last_status() == 0
+    assert all(enc.get_option(o) == 0 for o in F16X2_OPTIONS if o != "lstm_f16x2")
+    P.assert_rvq_equal_or_explained(codes, ref, margins, P.RVQ_TIE, "after the range-overflow fallback")
 
 
 def test_forced_lstm_timeout_is_reported_and_recovered(enc_weights):

@@ -59,6 +59,10 @@ print("ASAN_DRIVER_OK")
 
 @pytest.mark.skipif(not os.path.exists(ASAN_LIB), reason="sanitizer build not present (make -C audiotoken_amd/csrc asan)")
 def test_host_side_under_address_sanitizer():
+    import shutil
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):   # bring an existing sanitizer build up to date (incremental)
+        mk = subprocess.run(["make", "-j8", "-C", os.path.join(ROOT, "audiotoken_amd", "csrc"), "asan"], capture_output=True, text=True, timeout=1500)
+        assert mk.returncode == 0, mk.stderr[-3000:]
     rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
     assert rt, "ASan runtime of the ROCm clang not found"
     env = dict(os.environ, LD_PRELOAD=rt[-1], AUDIOTOKEN_HIP_LIB=ASAN_LIB, AUDIOTOKEN_HOST_ONLY_TEST="1",
