@@ -49,9 +49,14 @@ BF16X3_ACOUSTIC = os.environ.get("AUDIOTOKEN_BF16X3_ACOUSTIC", "1") != "0"
 _X3_MASK = int(os.environ.get("AUDIOTOKEN_X3_KERNELS", "511"))
 ACOUSTIC_X3_GROUPS = tuple(g for bit, g in enumerate(("down1", "res2", "res1", "stage0_fused", "down2", "down3", "res3", "lstm_rec", "rvq"))
                            if BF16X3_ACOUSTIC and (_X3_MASK >> bit) & 1) + (("lstm_ih",) if BF16X3_ACOUSTIC else ())
-# groups that run on the two-piece fp16 scheme (three MFMA products per multiply-add) instead of three bf16 pieces (six)
-ACOUSTIC_F16X2_GROUPS = ((("down2", "res3", "down3") if os.environ.get("AUDIOTOKEN_CHAIN_F16X2", "1") != "0" else ())
-                         + (("lstm_ih",) if os.environ.get("AUDIOTOKEN_IH_F16X2", "1") != "0" else ())) if BF16X3_ACOUSTIC else ()
+# kernel groups behind each option of the two-piece fp16 scheme (three MFMA products per multiply-add instead of six); the live
+# option values are read back from the handle (at_encodec_get_option)
+ACOUSTIC_F16X2_OPTIONS = {"chain_f16x2": ("down2", "res3", "down3"), "ih_f16x2": ("lstm_ih",), "lstm_f16x2": ("lstm_rec",),
+                          "res_f16x2": ("stage0_fused", "res1", "down1", "res2"), "rvq_f16x2": ("rvq",)}
+
+
+def acoustic_f16x2_groups(enc):
+    return tuple(g for opt, groups in ACOUSTIC_F16X2_OPTIONS.items() if enc.get_option(opt) == 1 for g in groups if g in ACOUSTIC_X3_GROUPS)
 
 
 def free_port() -> int:
@@ -487,6 +492,7 @@ def run_acoustic(args, rank, world, dev, dist):
         breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches,
                         "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None,
                         "gbs": round(nbytes[k] * B / (per * 1e-3) / 1e9, 1) if per > 0 else None}
+    f16_groups = acoustic_f16x2_groups(enc)
     res = {
         "value": round(world * B * args.seconds * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "median_ms_per_step": round(median(per_step), 3),
@@ -495,8 +501,8 @@ def run_acoustic(args, rank, world, dev, dist):
                    "clips_per_gpu": B, "samples_per_clip": N, "frames_per_clip": T, "weights": "synthetic seed 0",
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
         "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS, "acoustic",
-                                3 if max(breakdown, key=lambda k: breakdown[k]["ms_per_step"]) in ACOUSTIC_F16X2_GROUPS else 6), "breakdown": breakdown,
-        "mfma_products_per_mac": {g: (3 if g in ACOUSTIC_F16X2_GROUPS else 6) for g in ACOUSTIC_X3_GROUPS},
+                                3 if max(breakdown, key=lambda k: breakdown[k]["ms_per_step"]) in f16_groups else 6), "breakdown": breakdown,
+        "mfma_products_per_mac": {g: (3 if g in f16_groups else 6) for g in ACOUSTIC_X3_GROUPS},
         "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)", "token_checksum": checksum,
         "lstm_handoff_status": status,
     }
@@ -676,8 +682,8 @@ def main(argv=None):
             "metric": "audio-sec tokenized / wall-sec", "value": primary["value"], "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (every contraction as operand splits on the 16-bit matrix cores, fp32 accumulate: three bf16 pieces / six products in the fused "
-                      "conv kernels, LSTM recurrence and RVQ search; two fp16 pieces / three products in the stage 2-3 convs and LSTM input projections)")
+            "dtype": ("f32 (contractions as operand splits on the 16-bit matrix cores with fp32 accumulate; per kernel group two fp16 pieces / three "
+                      "products or three bf16 pieces / six products: see mfma_products_per_mac; final conv on the fp32 MFMA)")
                      if ACOUSTIC_X3_GROUPS else "f32", "data": "synthetic",
             "config": primary["config"], "roofline": primary["roofline"], "breakdown": primary["breakdown"],
             "token_checksum": primary["token_checksum"],
