@@ -128,6 +128,9 @@ struct at_encodec {
     const __bf16* down2_s = nullptr;
     bool rvq_x3 = true;             // RVQ search with the dot products on the bf16 matrix cores (rvq_encode_x3.hip); follows bf16x3
     const __bf16* cb_s = nullptr;   // codebooks as 3 bf16 pieces [3][n_cb * 1024][128]
+    const piece_t* fin_f = nullptr; // final conv weight [128][7 * 512] * fin_fs as two fp16 pieces, K-blocks in window order (option "fin_f16x2")
+    float fin_fs = 1.f;
+    bool fin_f16x2 = true;
     const __bf16* cb_f = nullptr;   // codebooks * cb_fs as 2 fp16 pieces [2][n_cb * 1024][128] (option "rvq_f16x2")
     float cb_fs = 1.f;
     bool rvq_f16x2 = true;
@@ -392,6 +395,7 @@ struct EncPlan {
     int G;           // sub-batch
     size_t off_x[4], off_h[4], off_r[4];  // per-stage sub-batch buffers (floats)
     size_t off_x4, off_xg, off_h0, off_h1, off_c, off_y, off_emb, off_sync, off_xs;
+    int Mpf = 0, Lpf = 0;   // final conv as a windowed GEMM: padded output rows / operand rows per clip
     int Mp3, Lp3; size_t off_s3;   // stage-3 strided conv the same way, its input split by a separate pass or by the block's tail GEMM
     int Mpc, Lpc; size_t off_ac3, off_at3;   // 256-channel block as two split-bf16 GEMMs: pieces of ELU(x) (2 front rows) and of [h | x]
     int Mp2, Lp2;    // stage-2 strided conv as a windowed split-bf16 GEMM: padded output rows, rows per phase plane of its input pieces
@@ -438,7 +442,12 @@ EncPlan make_plan(int B, int N, int sub) {
     p.off_y = take((size_t)B * T * kH);
     p.off_emb = take((size_t)B * T * kDim);
     p.off_sync = take(1024);
-    p.off_xs = take((((size_t)B * T + 255) / 256 * 256) * kH * 3 / 2);   // split-bf16 copy of an LSTM layer's input
+    // split copy of an LSTM layer's input (three bf16 pieces at most); the same region then holds the final conv's operand: the LSTM
+    // output as two fp16 pieces in windowed layout [2][B][32][Lpf][16] (6 reflected front rows, output rows padded to 256 per clip)
+    p.Mpf = ((int)T + 255) / 256 * 256;
+    p.Lpf = p.Mpf + 8;
+    const size_t xs_lstm = (((size_t)B * T + 255) / 256 * 256) * kH * 3 / 2, xs_fin = (size_t)B * p.Lpf * kH + 64;
+    p.off_xs = take(xs_lstm > xs_fin ? xs_lstm : xs_fin);
     p.total_floats = cur;
     return p;
 }
@@ -684,14 +693,14 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             __bf16* d = nullptr;
             AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * 256 * 1280 * sizeof(__bf16)));
             h->extra_allocs.push_back(d);
-            if (int rc = launch_split_blocked(h->down[2].w, 1280, 256, 256, 1280, d, nullptr)) return rc;
+            if (int rc = launch_split_blocked(h->down[2].w, 1280, 256, 256, 1280, d, nullptr, XB_SCHEME_BF16X3, 1.0f, nullptr, 8, 5)) return rc;
             h->down2_s = d;
         }
         {   // stage-3 strided conv weights [512][16 * 256]
             __bf16* d = nullptr;
             AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)3 * 512 * 4096 * sizeof(__bf16)));
             h->extra_allocs.push_back(d);
-            if (int rc = launch_split_blocked(h->down[3].w, 4096, 512, 512, 4096, d, nullptr)) return rc;
+            if (int rc = launch_split_blocked(h->down[3].w, 4096, 512, 512, 4096, d, nullptr, XB_SCHEME_BF16X3, 1.0f, nullptr, 16, 8)) return rc;
             h->down3_s = d;
         }
         {   // 256-channel block: conv3 [128][3 * 256] and tail [256][128 + 256]
@@ -699,7 +708,7 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             AT_CHECK_HIP(hipMalloc((void**)&d0, (size_t)3 * 128 * 768 * sizeof(__bf16)));
             AT_CHECK_HIP(hipMalloc((void**)&d1, (size_t)3 * 256 * 384 * sizeof(__bf16)));
             h->extra_allocs.push_back(d0); h->extra_allocs.push_back(d1);
-            if (int rc = launch_split_blocked(h->res[3][0].w, 768, 128, 128, 768, d0, nullptr)) return rc;
+            if (int rc = launch_split_blocked(h->res[3][0].w, 768, 128, 128, 768, d0, nullptr, XB_SCHEME_BF16X3, 1.0f, nullptr, 16, 1)) return rc;
             if (int rc = launch_split_blocked(h->res[3][1].w, 384, 256, 256, 384, d1, nullptr)) return rc;
             h->res3c_s = d0; h->res3t_s = d1;
         }
@@ -728,6 +737,7 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             const float* src[4] = {h->down[2].w, h->res[3][0].w, h->res[3][1].w, h->down[3].w};
             const size_t off[4] = {o_down[2].w, o_res[3][0].w, o_res[3][1].w, o_down[3].w};
             const int ns[4] = {256, 128, 256, 512}, ks[4] = {1280, 768, 384, 4096};
+            const int wcb[4] = {8, 16, 0, 16}, wst[4] = {5, 1, 1, 8};   // window description of the three convs (the tail is a plain linear layer)
             for (int j = 0; j < 4; ++j) {
                 float mx = 0.f;
                 for (size_t i = 0; i < (size_t)ns[j] * ks[j]; ++i) mx = std::fmax(mx, std::fabs(p.host[off[j] + i]));
@@ -735,9 +745,21 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
                 piece_t* f = nullptr;
                 AT_CHECK_HIP(hipMalloc((void**)&f, (size_t)2 * ns[j] * ks[j] * sizeof(piece_t)));
                 h->extra_allocs.push_back(f);
-                if (int rc = launch_split_blocked(src[j], ks[j], ns[j], ns[j], ks[j], f, nullptr, XB_SCHEME_F16X2, sc, nullptr)) return rc;
+                if (int rc = launch_split_blocked(src[j], ks[j], ns[j], ns[j], ks[j], f, nullptr, XB_SCHEME_F16X2, sc, nullptr, wcb[j], wst[j])) return rc;
                 h->chain_f[j] = f;
                 h->chain_fs[j] = sc;
+            }
+            {   // final conv [128][7 * 512]
+                if (const char* e = std::getenv("AUDIOTOKEN_FIN_F16X2")) h->fin_f16x2 = std::atoi(e) != 0;
+                const size_t n = (size_t)kDim * 7 * kH;
+                float mx = 0.f;
+                for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(p.host[o_fin.w + i]));
+                h->fin_fs = xb_weight_scale(mx);
+                piece_t* f = nullptr;
+                AT_CHECK_HIP(hipMalloc((void**)&f, 2 * n * sizeof(piece_t)));
+                h->extra_allocs.push_back(f);
+                if (int rc = launch_split_blocked(h->fin.w, 7 * kH, kDim, kDim, 7 * kH, f, nullptr, XB_SCHEME_F16X2, h->fin_fs, nullptr, kH / 16, 1)) return rc;
+                h->fin_f = f;
             }
         }
         AT_CHECK_HIP(hipDeviceSynchronize());
@@ -923,7 +945,21 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
         return rc;
     float* emb = emb_out ? emb_out : ws + p.off_emb;
     prof.begin("final_conv", 1, stream);
-    if (int rc = conv_gemm(h->fin, y, (long long)T * kH, T, emb, (long long)T * kDim, T, B, PRO_NONE, nullptr, 0, stream)) return rc;  // y holds ELU(lstm + skip)
+    if (h->bf16x3 && h->fin_f16x2 && h->fin_f && T > 6) {
+        // y = ELU(lstm + skip) -> two fp16 pieces in windowed layout (6 reflected front rows), then the k = 7 conv as a windowed split GEMM
+        __bf16* yp = reinterpret_cast<__bf16*>(ws + p.off_xs);
+        int* range_status = reinterpret_cast<int*>(sync + 62);
+        if (int rc = launch_split_windowed(y, B, T, kH, 1, 6, p.Lpf, yp, stream, XB_SCHEME_F16X2, XB_F16_ACT_SCALE, range_status)) return rc;
+        Bf16x3Args fa;
+        fa.A = yp; fa.W = h->fin_f; fa.bias = h->fin.b;
+        fa.M = T; fa.Mpad = p.Mpf; fa.N = kDim; fa.K = 7 * kH;
+        fa.batch = B; fa.stride = 1; fa.cblocks = kH / 16; fa.Lp = p.Lpf;
+        fa.scheme = XB_SCHEME_F16X2; fa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->fin_fs); fa.split_scale = XB_F16_ACT_SCALE; fa.status = range_status;
+        fa.epi = XB_EPI_LINEAR; fa.C = emb; fa.ldc = kDim;
+        if (int rc = launch_gemm_bf16x3(fa, stream)) return rc;
+    } else if (int rc = conv_gemm(h->fin, y, (long long)T * kH, T, emb, (long long)T * kDim, T, B, PRO_NONE, nullptr, 0, stream)) {  // y holds ELU(lstm + skip)
+        return rc;
+    }
     prof.end(stream);
     prof.begin("rvq", 1, stream);
     const bool rf = h->rvq_f16x2 && h->cb_f;
@@ -968,6 +1004,7 @@ const BoolOption kBoolOptions[] = {
     {"ih_f16x2", &at_encodec::ih_f16x2},
     {"res_f16x2", &at_encodec::res_f16x2},
     {"rvq_f16x2", &at_encodec::rvq_f16x2},
+    {"fin_f16x2", &at_encodec::fin_f16x2},
     {"lstm_f16x2", &at_encodec::lstm_f16x2},
     {"chain_f16x2", &at_encodec::chain_f16x2},
 };

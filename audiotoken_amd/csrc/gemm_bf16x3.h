@@ -46,7 +46,10 @@ struct Bf16x3Args {
     // Cin channels and PHASE-MAJOR in time: input row t lives in plane t % stride at index t / stride (+ any front padding the
     // producer added), so output row m of tap j reads plane j % stride, index m + j / stride: consecutive output rows are
     // consecutive 32-byte chunks for every tap (a row-major time axis gave stride-spaced chunks: 20-30 % slower).
-    // K index = tap*Cin + c (the packed conv weight order). M, Mpad, Spad are PER CLIP; C / R are [batch][M][ldc];
+    // The K-blocks of a windowed GEMM run in WINDOW ORDER (xb_window_block below): channel block slowest, then phase plane, then row
+    // offset, so consecutive K-blocks read the same plane of the same channel block one row apart — the re-read of a tap-major order
+    // (every input row once per tap sharing its plane, far apart in time) left L2 and cost k / stride x the activation bytes. The
+    // weights are split into the same order (launch_split_blocked with the window description). M, Mpad, Spad are PER CLIP; C / R are [batch][M][ldc];
     // S is [3][batch][N/16][Sphases][Spad][16] with output row m in plane m % Sphases at index m / Sphases + Sfront.
     // Defaults describe a plain linear layer.
     int batch = 1, stride = 1;
@@ -65,15 +68,40 @@ struct Bf16x3Args {
     // images the attention kernel stages without splitting (attention_bf16x3.hip, KVP)
     int qkv_hid = 0;
 };
+// Window order of the K-blocks of a conv with `ktaps` taps, `stride` and `cblocks` 16-channel blocks. Tap j lives in phase plane
+// j % stride at row offset j / stride; plane p holds n_p = ceil((ktaps - p) / stride) taps. K-block kt = cbk * ktaps + i, where i walks the
+// planes in order and the row offsets inside a plane. xb_window_block: kt -> (plane image t = cbk * stride + p, row offset);
+// xb_window_dst: tap-major source block (tap * cblocks + cbk) -> kt.
+__host__ __device__ inline void xb_window_block(int kt, int stride, int ktaps, int& t, int& off) {
+    const int cbk = kt / ktaps, i = kt - cbk * ktaps;
+    const int q = ktaps / stride, r = ktaps - q * stride;   // planes p < r hold q + 1 taps, the others q
+    int p;
+    if (i < r * (q + 1)) { p = i / (q + 1); off = i - p * (q + 1); }
+    else { const int i2 = i - r * (q + 1); p = r + i2 / q; off = i2 - (p - r) * q; }
+    t = cbk * stride + p;
+}
+__host__ __device__ inline int xb_window_dst(int src_block, int cblocks, int stride, int ktaps) {
+    const int tap = src_block / cblocks, cbk = src_block - tap * cblocks;
+    const int off = tap / stride, p = tap - off * stride;
+    const int q = ktaps / stride, r = ktaps - q * stride;
+    const int i = (p < r ? p * (q + 1) : r * (q + 1) + (p - r) * q) + off;
+    return cbk * ktaps + i;
+}
+
 // fills the causal reflect padding of windowed-mode pieces [3][B][blocks][phases][Lp][16]: padded rows i < pad (row i lives in plane
 // i % phases at index i / phases) become copies of padded row 2 * pad - i
 int launch_reflect_front(__bf16* S, int B, int blocks, int phases, int Lp, int pad, hipStream_t stream, int npieces = 3);
 
-// fp32 row-major [rows][ld] (first K columns) * scale -> K-blocked pieces [pieces][K/16][rows_pad][16]; rows >= `rows` are zero-filled
+// fp32 row-major [rows][ld] (first K columns) * scale -> K-blocked pieces [pieces][K/16][rows_pad][16]; rows >= `rows` are zero-filled.
+// win_cblocks > 0: x is a packed conv weight (K index = tap * Cin + c, Cin = 16 * win_cblocks) and its K-blocks are written in the
+// window order of a conv with that stride (xb_window_dst).
 int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream,
-                         int scheme = XB_SCHEME_BF16X3, float scale = 1.0f, int* status = nullptr);
+                         int scheme = XB_SCHEME_BF16X3, float scale = 1.0f, int* status = nullptr, int win_cblocks = 0, int win_stride = 1);
 // fp32 [B][L][C] -> the windowed-mode pieces of a causal strided conv with kernel = 2 * stride (reflect front padding included)
 int launch_split_phase_major(const float* x, int B, int L, int C, int stride, int Lp, __bf16* out, hipStream_t stream);
+// the same for any front padding (`pad` reflected rows) and either scheme: fp32 [B][L][C] * scale -> [pieces][B][C/16][stride][Lp][16]
+int launch_split_windowed(const float* x, int B, int L, int C, int stride, int pad, int Lp, __bf16* out, hipStream_t stream,
+                          int scheme = XB_SCHEME_BF16X3, float scale = 1.0f, int* status = nullptr);
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream);
 // the fp16 scheme's kernel for launches that fill the chip (gemm_f16x2_tg.hip); launch_gemm_bf16x3 dispatches to it
 // ($AUDIOTOKEN_F16X2_TG=0 keeps the register-staged kernel)

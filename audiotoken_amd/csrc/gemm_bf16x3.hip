@@ -59,7 +59,8 @@ __device__ __forceinline__ void split3(float a, __bf16& p1, __bf16& p2, __bf16& 
 // the reads (256 B per row) and the writes (64 rows x 32 B = 2 KB per k-block) are contiguous.
 template <class SC>
 __global__ __launch_bounds__(256) void split_blocked_kernel(const float* __restrict__ x, int ld, long long rows, long long rows_pad, int K,
-                                                            typename SC::T* __restrict__ out, float scale, int* __restrict__ status) {
+                                                            typename SC::T* __restrict__ out, float scale, int* __restrict__ status,
+                                                            int win_cblocks, int win_stride) {
     __shared__ float tile[64][65];
     const long long r0 = (long long)blockIdx.x * 64;
     const int k0 = blockIdx.y * 64;
@@ -78,7 +79,9 @@ __global__ __launch_bounds__(256) void split_blocked_kernel(const float* __restr
         typename SC::V4 p[SC::NP];
         const f4 v = {tile[r][kb * 16 + qd * 4], tile[r][kb * 16 + qd * 4 + 1], tile[r][kb * 16 + qd * 4 + 2], tile[r][kb * 16 + qd * 4 + 3]};
         over |= split4<SC>(v, scale, p);
-        const long long o = ((long long)(k0 / 16 + kb) * rows_pad + r0 + r) * 16 + qd * 4;
+        int kdst = k0 / 16 + kb;
+        if (win_cblocks > 0) kdst = xb_window_dst(kdst, win_cblocks, win_stride, (K / 16) / win_cblocks);
+        const long long o = ((long long)kdst * rows_pad + r0 + r) * 16 + qd * 4;
         if (r0 + r < rows_pad) {
 #pragma unroll
             for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(out + i * ps + o) = p[i];
@@ -88,39 +91,37 @@ __global__ __launch_bounds__(256) void split_blocked_kernel(const float* __restr
         if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
 }
 
-// fp32 [B][L][C] -> the pieces a causal strided conv (kernel = 2 x stride, left reflect padding of `stride` rows) reads as a windowed
-// GEMM: [3][B][C/16][stride planes][Lp][16], padded row i = t + stride in plane i % stride at index i / stride; rows i < stride
-// are the reflection x[stride - i]. A wave owns one 16-channel block of one (clip, plane): lanes = (4-channel group, 16 consecutive
+// fp32 [B][L][C] * scale -> the pieces a causal conv with `pad` reflected front rows reads as a windowed GEMM:
+// [NP][B][C/16][stride planes][Lp][16], padded row i = t + pad in plane i % stride at index i / stride; rows i < pad are the
+// reflection x[pad - i]. A wave owns one 16-channel block of one (clip, plane): lanes = (4-channel group, 16 consecutive
 // indices), so a wave-store covers 512 contiguous bytes per piece and the reads are 64-byte runs.
-__global__ __launch_bounds__(256) void split_phase_major_kernel(const float* __restrict__ x, int L, int C, int stride, int Lp, int nidx,
-                                                                long long piece_stride, __bf16* __restrict__ out) {
+template <class SC>
+__global__ __launch_bounds__(256) void split_phase_major_kernel(const float* __restrict__ x, int L, int C, int stride, int pad, int Lp, int nidx,
+                                                                long long piece_stride, typename SC::T* __restrict__ out, float scale, int* __restrict__ status) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = lane & 3, ii = lane >> 2;
     const int cb = blockIdx.y * 4 + wave, cblocks = C / 16;
     const int b = blockIdx.z / stride, plane = blockIdx.z - b * stride;
     if (cb >= cblocks) return;
     const float* xb = x + (long long)b * L * C + cb * 16 + k * 4;
-    __bf16* ob = out + (((long long)b * cblocks + cb) * stride + plane) * Lp * 16 + k * 4;
+    typename SC::T* ob = out + (((long long)b * cblocks + cb) * stride + plane) * Lp * 16 + k * 4;
+    bool over = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int idx = blockIdx.x * 64 + j * 16 + ii;
         if (idx >= nidx) continue;
-        int t = idx * stride + plane - stride;
+        int t = idx * stride + plane - pad;
         t = t < 0 ? -t : t;
         f4 v = {0.f, 0.f, 0.f, 0.f};
         if (t < L) v = *reinterpret_cast<const f4*>(xb + (long long)t * C);
-        bf16x4 p1, p2, p3;
+        typename SC::V4 pc[SC::NP];
+        over |= split4<SC>(v, scale, pc);
+        typename SC::T* d = ob + (long long)idx * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __bf16 a, bb, c;
-            split3(v[i], a, bb, c);
-            p1[i] = a; p2[i] = bb; p3[i] = c;
-        }
-        __bf16* d = ob + (long long)idx * 16;
-        *reinterpret_cast<bf16x4*>(d) = p1;
-        *reinterpret_cast<bf16x4*>(d + piece_stride) = p2;
-        *reinterpret_cast<bf16x4*>(d + 2 * piece_stride) = p3;
+        for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(d + i * piece_stride) = pc[i];
     }
+    if constexpr (SC::RANGE_CHECK)
+        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
 }
 
 __global__ void reflect_front_kernel(__bf16* S, int B, int blocks, int phases, int Lp, int pad, int npieces) {
@@ -142,24 +143,34 @@ int launch_reflect_front(__bf16* S, int B, int blocks, int phases, int Lp, int p
     return 0;
 }
 
-int launch_split_phase_major(const float* x, int B, int L, int C, int stride, int Lp, __bf16* out, hipStream_t stream) {
-    AT_REQUIRE(C % 16 == 0 && L > stride && stride >= 1, "split_phase_major: C % 16, L > stride");
-    const int nidx = (L + stride + stride - 1) / stride;
-    AT_REQUIRE(nidx <= Lp, "split_phase_major: Lp too small");
+int launch_split_windowed(const float* x, int B, int L, int C, int stride, int pad, int Lp, __bf16* out, hipStream_t stream, int scheme, float scale,
+                          int* status) {
+    AT_REQUIRE(C % 16 == 0 && L > pad && stride >= 1 && pad >= 0, "split_windowed: C % 16, L > pad");
+    const int nidx = (L + pad + stride - 1) / stride;
+    AT_REQUIRE(nidx <= Lp, "split_windowed: Lp too small");
     dim3 grid((nidx + 63) / 64, (C / 16 + 3) / 4, B * stride);
-    hipLaunchKernelGGL(split_phase_major_kernel, grid, dim3(256), 0, stream, x, L, C, stride, Lp, nidx, (long long)B * (C / 16) * stride * Lp * 16, out);
+    const long long ps = (long long)B * (C / 16) * stride * Lp * 16;
+    if (scheme == XB_SCHEME_F16X2)
+        hipLaunchKernelGGL(split_phase_major_kernel<SchemeF16x2>, grid, dim3(256), 0, stream, x, L, C, stride, pad, Lp, nidx, ps, reinterpret_cast<_Float16*>(out), scale, status);
+    else
+        hipLaunchKernelGGL(split_phase_major_kernel<SchemeBf16x3>, grid, dim3(256), 0, stream, x, L, C, stride, pad, Lp, nidx, ps, out, 1.0f, nullptr);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
+int launch_split_phase_major(const float* x, int B, int L, int C, int stride, int Lp, __bf16* out, hipStream_t stream) {
+    return launch_split_windowed(x, B, L, C, stride, stride, Lp, out, stream, XB_SCHEME_BF16X3, 1.0f, nullptr);
+}
+
 int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream, int scheme, float scale,
-                         int* status) {
+                         int* status, int win_cblocks, int win_stride) {
     AT_REQUIRE(K % 64 == 0 && ld % 4 == 0 && rows_pad >= rows && rows_pad % 64 == 0, "split_blocked: K % 64, ld % 4, rows_pad % 64");
+    AT_REQUIRE(win_cblocks == 0 || (win_stride >= 1 && (K / 16) % win_cblocks == 0), "split_blocked: bad window description");
     dim3 grid((unsigned)(rows_pad / 64), K / 64);
     if (scheme == XB_SCHEME_F16X2)
-        hipLaunchKernelGGL(split_blocked_kernel<SchemeF16x2>, grid, dim3(256), 0, stream, x, ld, rows, rows_pad, K, reinterpret_cast<_Float16*>(out), scale, status);
+        hipLaunchKernelGGL(split_blocked_kernel<SchemeF16x2>, grid, dim3(256), 0, stream, x, ld, rows, rows_pad, K, reinterpret_cast<_Float16*>(out), scale, status, win_cblocks, win_stride);
     else
-        hipLaunchKernelGGL(split_blocked_kernel<SchemeBf16x3>, grid, dim3(256), 0, stream, x, ld, rows, rows_pad, K, out, scale, status);
+        hipLaunchKernelGGL(split_blocked_kernel<SchemeBf16x3>, grid, dim3(256), 0, stream, x, ld, rows, rows_pad, K, out, scale, status, win_cblocks, win_stride);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -192,13 +203,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
     static_assert((2 * XB_M) % NT == 0 && (2 * XB_N) % NT == 0, "tile rows must be a multiple of half the thread count");
     u4 sa[NP][CA], sw[NP][CW];
     auto load = [&](int kt) {
-        const int tapk = kt / cblocks, cbk = kt - tapk * cblocks;   // K tile -> (tap, channel block) -> (phase plane, row offset)
-        const int offk = tapk / a.stride, planek = tapk - offk * a.stride;
+        int tk, offk;   // K tile -> (plane image of a channel block, row offset), window order
+        xb_window_block(kt, a.stride, nk / cblocks, tk, offk);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int c = 0; c < CA; ++c)
-                sa[p][c] = *reinterpret_cast<const u4*>(Ab + p * psA + (((long long)cbk * a.stride + planek) * Lp + offk) * 16 + (tid + c * NT) * 8);
+                sa[p][c] = *reinterpret_cast<const u4*>(Ab + p * psA + ((long long)tk * Lp + offk) * 16 + (tid + c * NT) * 8);
 #pragma unroll
             for (int c = 0; c < CW; ++c) sw[p][c] = *reinterpret_cast<const u4*>(Wb + p * psW + ((long long)kt * a.N + n0) * 16 + (tid + c * NT) * 8);
         }

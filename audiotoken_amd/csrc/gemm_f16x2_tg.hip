@@ -91,15 +91,21 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
     const int srow = (wave & 3) * (BM / 4) + (lane >> 1), shalf = lane & 1;
     const PT* gA = reinterpret_cast<const PT*>(a.A) + clip * a_clip + ((long long)m0 + srow) * 16 + shalf * 8;
     const PT* gW = reinterpret_cast<const PT*>(a.W) + ((long long)n0 + srow) * 16 + shalf * 8;
+    // window order of the k-blocks (gemm_bf16x3.h, xb_window_block), walked incrementally: issue() is called for kp = 0, 1, 2, ... in order, so
+    // the (plane image, row offset) pair of the next k-block is one compare-and-carry away — no integer division in the loop
+    const int w_taps = nk2 * 2 / cblocks, w_q = w_taps / a.stride, w_r = w_taps - w_q * a.stride;
+    int w_t = 0, w_off = 0, w_p = 0;                 // plane image cbk * stride + p, row offset, plane
     auto issue = [&](int kp, int pair) {             // K step kp = k-blocks 2 kp, 2 kp + 1 -> ring slots 2 pair, 2 pair + 1
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int kt = 2 * kp + h;
             long long ka;
             if constexpr (WINDOWED) {
-                const int tapk = kt / cblocks, cbk = kt - tapk * cblocks;   // k-block -> (tap, channel block) -> (phase plane, row offset)
-                const int offk = tapk / a.stride, planek = tapk - offk * a.stride;
-                ka = (((long long)cbk * a.stride + planek) * Lp + offk) * 16;
+                ka = ((long long)w_t * Lp + w_off) * 16;
+                if (++w_off == (w_p < w_r ? w_q + 1 : w_q)) {          // next plane; planes beyond the taps (ktaps < stride) hold none
+                    w_off = 0; ++w_t; ++w_p;
+                    if (w_p == a.stride || (w_q == 0 && w_p == w_r)) { w_t += a.stride - w_p; w_p = 0; }
+                }
             } else {
                 ka = (long long)kt * Lp * 16;
             }

@@ -138,7 +138,7 @@ struct SplitCtx {
 int split_weights(at_hubert* h, int scheme) {
     if (h->split_done[scheme]) return 0;
     const int np = xb_pieces(scheme);
-    auto one = [&](const float* src, int n, int k, const piece_t** dst, float* scale_out) -> int {
+    auto one = [&](const float* src, int n, int k, const piece_t** dst, float* scale_out, int win_cblocks = 0, int win_stride = 1) -> int {
         piece_t* d = nullptr;
         AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)np * n * k * sizeof(piece_t)));
         h->allocs.push_back(reinterpret_cast<float*>(d));
@@ -149,12 +149,12 @@ int split_weights(at_hubert* h, int scheme) {
             sc = xb_weight_scale(it->second);
             *scale_out = sc;
         }
-        if (int rc = launch_split_blocked(src, k, n, n, k, d, nullptr, scheme, sc, nullptr)) return rc;
+        if (int rc = launch_split_blocked(src, k, n, n, k, d, nullptr, scheme, sc, nullptr, win_cblocks, win_stride)) return rc;
         *dst = d;
         return 0;
     };
     for (int i = 1; i < 7; ++i)
-        if (int rc = one(h->conv_w[i], kCd, kKs[i] * kCd, &h->conv_ws[scheme][i], &h->conv_wscale[i])) return rc;
+        if (int rc = one(h->conv_w[i], kCd, kKs[i] * kCd, &h->conv_ws[scheme][i], &h->conv_wscale[i], kCd / 16, kSt[i])) return rc;   // window order
     for (LayerW& L : h->layers) {
         const float* src[4] = {L.wqkv, L.wo, L.w1, L.w2};
         const int ns[4] = {3 * kHid, kHid, kFfn, kHid}, ks[4] = {kHid, kHid, kHid, kFfn};

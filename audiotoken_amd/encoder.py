@@ -154,10 +154,10 @@ class AcousticEncoder(torch.nn.Module):
                          "re-encoding with per-step LSTM launches (option persistent_lstm=0) from now on")
             self.set_option("persistent_lstm", 0)
         if status & 2:
-            logger.error(f"an activation exceeded the fp16 range of the f16x2 kernels (SEANet convs, LSTM input projection, RVQ search; status {status}): "
+            logger.error(f"an activation exceeded the fp16 range of the f16x2 kernels (SEANet convs, LSTM input projection, final conv, RVQ search; status {status}): "
                          "the tokens of this batch were discarded; re-encoding with the bf16x3 kernels "
-                         "(options chain_f16x2=0, ih_f16x2=0, res_f16x2=0, rvq_f16x2=0) from now on")
-            for opt in ("ih_f16x2", "chain_f16x2", "res_f16x2", "rvq_f16x2"):
+                         "(options chain_f16x2=0, ih_f16x2=0, res_f16x2=0, rvq_f16x2=0, fin_f16x2=0) from now on")
+            for opt in ("ih_f16x2", "chain_f16x2", "res_f16x2", "rvq_f16x2", "fin_f16x2"):
                 self.set_option(opt, 0)
         codes = self.forward(input_batch, attention_mask)
         if self.last_status() != 0:

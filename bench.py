@@ -52,11 +52,11 @@ ACOUSTIC_X3_GROUPS = tuple(g for bit, g in enumerate(("down1", "res2", "res1", "
 # kernel groups behind each option of the two-piece fp16 scheme (three MFMA products per multiply-add instead of six); the live
 # option values are read back from the handle (at_encodec_get_option)
 ACOUSTIC_F16X2_OPTIONS = {"chain_f16x2": ("down2", "res3", "down3"), "ih_f16x2": ("lstm_ih",), "lstm_f16x2": ("lstm_rec",),
-                          "res_f16x2": ("stage0_fused", "res1", "down1", "res2"), "rvq_f16x2": ("rvq",)}
+                          "res_f16x2": ("stage0_fused", "res1", "down1", "res2"), "rvq_f16x2": ("rvq",), "fin_f16x2": ("final_conv",)}
 
 
 def acoustic_f16x2_groups(enc):
-    return tuple(g for opt, groups in ACOUSTIC_F16X2_OPTIONS.items() if enc.get_option(opt) == 1 for g in groups if g in ACOUSTIC_X3_GROUPS)
+    return tuple(g for opt, groups in ACOUSTIC_F16X2_OPTIONS.items() if enc.get_option(opt) == 1 for g in groups if g in ACOUSTIC_X3_GROUPS or g == "final_conv")
 
 
 def free_port() -> int:
@@ -502,7 +502,7 @@ def run_acoustic(args, rank, world, dev, dist):
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
         "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS, "acoustic",
                                 3 if max(breakdown, key=lambda k: breakdown[k]["ms_per_step"]) in f16_groups else 6), "breakdown": breakdown,
-        "mfma_products_per_mac": {g: (3 if g in f16_groups else 6) for g in ACOUSTIC_X3_GROUPS},
+        "mfma_products_per_mac": {**{g: (3 if g in f16_groups else 6) for g in ACOUSTIC_X3_GROUPS}, "final_conv": 3 if "final_conv" in f16_groups else 1},
         "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)", "token_checksum": checksum,
         "lstm_handoff_status": status,
     }

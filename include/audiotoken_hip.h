@@ -68,8 +68,8 @@ int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int 
 
 /* Same as at_encodec_encode, plus a device uint32 status word (stream-ordered): 0 on success; bit 0 (1) = a bounded wait inside the
  * persistent LSTM kernel gave up (the call still terminates); bit 1 (2) = an activation did not fit the fp16 range of an f16x2 kernel ("chain_f16x2",
- * "ih_f16x2", "res_f16x2", "rvq_f16x2"). In both cases the codes are invalid and the caller repeats the batch on the safe path (options
- * persistent_lstm = 0 / chain_f16x2 = ih_f16x2 = res_f16x2 = rvq_f16x2 = 0). */
+ * "ih_f16x2", "res_f16x2", "rvq_f16x2", "fin_f16x2"). In both cases the codes are invalid and the caller repeats the batch on the safe path (options
+ * persistent_lstm = 0 / chain_f16x2 = ih_f16x2 = res_f16x2 = rvq_f16x2 = fin_f16x2 = 0). */
 int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes,
                               int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream,
                               uint32_t* status_dev);
@@ -87,6 +87,8 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
  *   $AUDIOTOKEN_CHAIN_F16X2) or as the three-piece bf16 splits, six products; see csrc/gemm_bf16x3.h;
  *   "res_f16x2", "rvq_f16x2" 1/0 — the fused SEANet kernels of the encoder (stage 0, the 64- and 128-channel residual blocks, the stage-1 strided conv) /
  *   the RVQ search on the same two-piece fp16 scheme (default on, $AUDIOTOKEN_RES_F16X2 / $AUDIOTOKEN_RVQ_F16X2) or on three bf16 pieces;
+ *   "fin_f16x2" 1/0 — the encoder's final k = 7 conv as a windowed split GEMM on the two-piece fp16 scheme (default on, $AUDIOTOKEN_FIN_F16X2) or on
+ *   the fp32 MFMA;
  *   "lstm_f16x2" 1/0 — the persistent LSTM's recurrent product on the two-piece fp16 scheme (h in (-1, 1) always fits: no range check) or on
  *   three bf16 pieces (default on, $AUDIOTOKEN_LSTM_F16X2; needs "lstm_x3" = 1);
  *   "lstm_spin_limit" n >= 0 — polls of a hand-off flag before a workgroup of the persistent LSTM gives up and the status word of the

@@ -261,7 +261,7 @@ def test_fused_decoder_kernels_equal_unfused(enc_weights):
         dec.set_option("res64_x3", 1)
 
 
-F16X2_OPTIONS = ["chain_f16x2", "ih_f16x2", "res_f16x2", "rvq_f16x2", "lstm_f16x2"]
+F16X2_OPTIONS = ["chain_f16x2", "ih_f16x2", "res_f16x2", "rvq_f16x2", "fin_f16x2", "lstm_f16x2"]
 X3_OPTIONS = ["down64_x3", "res128_x3", "res64_x3", "stage0_x3", "down128_x3", "down256_x3", "res256_x3", "lstm_x3", "rvq_x3"]
 
 
