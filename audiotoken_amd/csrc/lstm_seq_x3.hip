@@ -17,9 +17,25 @@
 #include "encodec_kernels.h"
 #include "split_scheme.h"
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 #include <cmath>
 
 namespace at {
+
+// -DLX_DEBUG_STAMPS (tools/lstm_stamps.sh; never in the product build): workgroup 0 / thread 0 records the cycle counter at five points of every
+// step and the launcher prints the average phase lengths of the launch to stderr. Round-2 figures (256 clips, T = 750, layer 1, cycles at ~2.1 GHz):
+// wait for the 16 flags 2354 | h load + split + LDS + barrier 1565 | 48 MFMAs x 2 waves per SIMD 1736 | gates + store drain + barrier + flag
+// 1945 | tail 152 = 3.7 us per step; with the line-sized publish of h and y (FAST below) 2049 | 1584 | 1712 | 1643 | 220 (one box, same
+// session: 6.24 ms -> 5.06 ms for the two layers of 256 x 750 steps). A flag-less variant (producers publish packed piece pairs into a ring of sentinel-armed slots, consumers
+// poll the data) shortened the publish to 822 cycles but lengthened the wait to 4009-4673 (the last of 128 scattered 16-byte write-throughs
+// per workgroup lands later than one flag word behind a drain; polling the tile from every wave also slowed the stores): 8.1-11 ms vs 6.1 ms.
+#ifdef LX_DEBUG_STAMPS
+__device__ unsigned long long lx_stamps[8192 * 6];
+#define LX_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && t < 8192) lx_stamps[t * 6 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LX_STAMP(i) do {} while (0)
+#endif
 
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 constexpr float LX_H_SCALE = 16384.0f;   // fp16 scheme: h (|h| < 1) is split as h * 2^14
@@ -48,6 +64,8 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
     extern __shared__ __attribute__((aligned(16))) unsigned char Hp_raw[];   // [NP][16 clips][528]
     PT* Hp = reinterpret_cast<PT*>(Hp_raw);
     __shared__ int abort_s;
+    __shared__ __attribute__((aligned(16))) float Hx[LX_CLIPS][32];   // this workgroup's h_t slice, gathered for line-sized stores
+    __shared__ __attribute__((aligned(16))) float Hy[LX_CLIPS][32];   // and its y_t = act(h_t + skip) slice (layer 2)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int group = blockIdx.x % a.n_groups;
@@ -99,16 +117,24 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
     unsigned* flags = a.sync + LX_FLAGS + group * LX_FLAG_STRIDE;
     const PT* hb = Hp + r16 * LX_LDH + q * 8;                            // fragment base: + 32 ks elements, + piece
 
-    for (int t = 0; t < T; ++t) {
-        // input-side gates and the skip inputs of this step: independent of the recurrence, issued before the wait
-        f4 xg[NJ];
-        float skipv[NJ];
+    // input-side gates and the skip input of a step: independent of the recurrence
+    auto fetch = [&](int tt, f4 (&xg)[NJ], float (&sk)[NJ]) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            skipv[j] = 0.f;
-            xg[j] = *reinterpret_cast<const f4*>(a.xg + (own_row + t) * (4 * LX_H) + unit[j] * 4);
-            if (a.y_out) skipv[j] = a.skip[(own_row + t) * LX_H + unit[j]];
+            xg[j] = *reinterpret_cast<const f4*>(a.xg + (own_row + tt) * (4 * LX_H) + unit[j] * 4);
+            sk[j] = 0.f;
+            if (a.y_out) sk[j] = a.skip[(own_row + tt) * LX_H + unit[j]];
         }
+    };
+    // FAST (the fp16 scheme; the bf16 scheme has no registers to spare for it): the h_t slice is published by one wave as whole lines (below).
+    // Tried on top of it and measured slower (stamps, tools/lstm_stamps.sh): fetching xg / skip one step ahead (the HBM loads then delay the h tile
+    // loads they are issued behind: 5.6-6.4 ms) and polling the flags through the scalar memory path (5.6 ms).
+    constexpr bool FAST = SC::NP == 2, YG = FAST;
+    for (int t = 0; t < T; ++t) {
+        LX_STAMP(0);
+        f4 xg[NJ];
+        float skipv[NJ];
+        fetch(t, xg, skipv);   // issued before the wait
         __builtin_amdgcn_sched_barrier(0);
         f4 acc[NJ];
 #pragma unroll
@@ -134,6 +160,8 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
             }
             __syncthreads();       // also: every wave has finished reading the previous step's pieces
             if (abort_s) return;   // uniform: a member of the group is not making progress
+            LX_STAMP(1);
+            LX_STAMP(2);
             // ---- h_{t-1} [16][512] -> sc1 loads to registers -> split -> LDS pieces -----------------------------------------------
             u4 stage[NST];
             const int toff = (t - 1) * (LX_H * 4);
@@ -149,6 +177,7 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
                 for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(d + i * LX_HP) = pp[i];
             }
             __syncthreads();
+            LX_STAMP(3);
             // ---- gates += h_{t-1} . W_slice^T: 16 K steps x 6 products x 2 row tiles = 192 MFMAs per wave; fragments one K step ahead ----
             V8 xa[NP], xb[NP];
 #pragma unroll
@@ -175,6 +204,7 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[j] *= acc_scale;   // exact: a power of two (1 for the bf16 scheme)
         }
+        LX_STAMP(4);
         // ---- cell update (torch CPU LSTMCell order: gates = (hW + b_hh) + igates; c = f*c + i*g unfused) -----------------------------
         float hn[NJ];
 #pragma unroll
@@ -184,15 +214,44 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
             const float c_new = __fadd_rn(__fmul_rn(fg, cst[j]), __fmul_rn(ig, cg));
             hn[j] = og * lstm_tanh(c_new);
             cst[j] = c_new;
-            if (clip_ok)
+            if (FAST) {
+                Hx[r16][(NJ * wave + j) * 4 + q] = hn[j];
+                if (a.y_out && YG) {
+                    const float yv = hn[j] + skipv[j];
+                    Hy[r16][(NJ * wave + j) * 4 + q] = a.y_elu ? elu1(yv) : yv;
+                }
+            } else if (clip_ok)
                 __hip_atomic_store(reinterpret_cast<unsigned*>(a.h_out) + (own_row + t) * LX_H + unit[j], __float_as_uint(hn[j]),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1): no release fence needed
         }
-        // ---- publish: every storing wave drains, workgroup barrier, one lane signals ----------------------------------------------
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- publish: the slice [16 clips][32 units] is gathered in LDS and ONE wave stores it as whole 128-byte lines (two 16-byte
+        // write-through stores per lane instead of 8 waves x 16 partial lines), drains and signals: no second barrier ----------------------
+        if (!FAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(flags + slice, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.y_out && clip_ok) {
+        if (!FAST) {
+            if (tid == 0) __hip_atomic_store(flags + slice, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = lane + 64 * i, row = idx >> 3, c4 = idx & 7;
+                const u4 v = *reinterpret_cast<const u4*>(&Hx[row][c4 * 4]);
+                if (b0 + row < a.B)
+                    __builtin_amdgcn_raw_buffer_store_b128(v, hrsrc, (((b0 + row) * T + t) * LX_H + slice * 32 + c4 * 4) * 4, 0, 16);   // aux 16 = sc1: write-through; < 2^31: launcher
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(flags + slice, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        LX_STAMP(5);
+        if (YG) {
+            if (a.y_out && wave == 1) {   // the y slice as whole lines too, by a wave that is not the publisher (plain stores: later kernels read them)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = lane + 64 * i, row = idx >> 3, c4 = idx & 7;
+                    if (b0 + row < a.B)
+                        *reinterpret_cast<u4*>(a.y_out + ((long long)(b0 + row) * T + t) * LX_H + slice * 32 + c4 * 4) = *reinterpret_cast<const u4*>(&Hy[row][c4 * 4]);
+                }
+            }
+        } else if (a.y_out && clip_ok) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const float yv = hn[j] + skipv[j];
@@ -226,6 +285,23 @@ static int launch_lx(const LstmSeqArgs& a, float w_scale, float h_scale, hipStre
     return 0;
 }
 
+#ifdef LX_DEBUG_STAMPS
+static void lx_print_stamps(int T, hipStream_t stream) {
+    (void)hipStreamSynchronize(stream);
+    static std::vector<unsigned long long> hbuf(8192 * 6);
+    (void)hipMemcpyFromSymbol(hbuf.data(), HIP_SYMBOL(lx_stamps), hbuf.size() * 8);
+    double ph[6] = {0, 0, 0, 0, 0, 0};
+    const int n = (T < 8192 ? T : 8192) - 2;
+    for (int t = 1; t <= n; ++t) {
+        const unsigned long long* s0 = &hbuf[t * 6];
+        for (int i = 0; i < 5; ++i) ph[i] += (double)(s0[i + 1] >= s0[i] ? s0[i + 1] - s0[i] : 0);
+        ph[5] += (double)(hbuf[(t + 1) * 6] - s0[5]);
+    }
+    std::fprintf(stderr, "lstm stamps (cycles, avg over %d steps): wait %.0f  (unused) %.0f  load+split+lds %.0f  mfma %.0f  gates+publish %.0f  tail %.0f\n",
+                 n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n);
+}
+#endif
+
 int launch_lstm_seq_x3(const LstmSeqArgs& a_in, hipStream_t stream) {
     LstmSeqArgs a = a_in;
     AT_REQUIRE(a.B >= 1 && a.B <= lstm_seq_x3_max_clips() && a.T >= 1, "lstm_seq_x3: too many clips for one launch on this device");
@@ -233,8 +309,11 @@ int launch_lstm_seq_x3(const LstmSeqArgs& a_in, hipStream_t stream) {
     a.h_bytes = (long long)a.B * a.T * LX_H * 4;
     AT_REQUIRE(a.h_bytes < (1ll << 31), "lstm_seq_x3: h buffer exceeds the 2 GB buffer-descriptor range");
     AT_CHECK_HIP(hipMemsetAsync(a.sync + LX_FLAGS, 0, LX_MAX_GROUPS * LX_FLAG_STRIDE * sizeof(unsigned), stream));   // flags, every launch
-    if (a.w_scale_f16 > 0.f) return launch_lx<SchemeF16x2>(a, a.w_scale_f16, LX_H_SCALE, stream);
-    return launch_lx<SchemeBf16x3>(a, 1.0f, 1.0f, stream);
+    const int rc = a.w_scale_f16 > 0.f ? launch_lx<SchemeF16x2>(a, a.w_scale_f16, LX_H_SCALE, stream) : launch_lx<SchemeBf16x3>(a, 1.0f, 1.0f, stream);
+#ifdef LX_DEBUG_STAMPS
+    if (rc == 0) lx_print_stamps(a.T, stream);
+#endif
+    return rc;
 }
 
 }  // namespace at
