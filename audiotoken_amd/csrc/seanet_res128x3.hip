@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
     typedef typename SC::V8 V8;
     typedef typename SC::V4 V4;
     constexpr int NP = SC::NP;
+    constexpr int MT = NP == 2 ? 4 : 2;   // conv3 row tiles per pass: all four with two pieces (12 MFMAs = 192 cycles cover a fragment read; one wave per SIMD)
     extern __shared__ __attribute__((aligned(16))) unsigned char rx_lds_raw[];
     PT* Xe = reinterpret_cast<PT*>(rx_lds_raw);   // split(ELU(x))
     PT* Xr = Xe + NP * RX_XP;            // split(x)
@@ -135,18 +136,20 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
         __syncthreads();
         // ---- h[:, 16w..16w+15] = ELU(conv3(ELU(x)) + b3): output row j uses x rows j, j+1, j+2; K step ks = (tap, 32 channels) --------
 #pragma unroll 1   // (unrolled, the compiler's schedule needs > 512 registers and spills weights)
-        for (int mp = 0; mp < 4; mp += 2) {   // two 16-row tiles at a time: 24 fragment registers per buffer
-            f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-            auto xread = [&](int ks, V8 (&xf)[NP][2]) {
+        for (int mp = 0; mp < 4; mp += MT) {   // MT 16-row tiles at a time: 4 MT NP fragment registers per buffer
+            f4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = f4{0.f, 0.f, 0.f, 0.f};
+            auto xread = [&](int ks, V8 (&xf)[NP][MT]) {
                 const int tap = ks >> 2, chunk = (ks & 3) * 4 + q;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < MT; ++m) {
                     const PT* src = Xe + rx_xoff(16 * (mp + m) + r16 + tap, chunk);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) xf[p][m] = *reinterpret_cast<const V8*>(src + p * RX_XP);
                 }
             };
-            V8 xa[NP][2], xb[NP][2];
+            V8 xa[NP][MT], xb[NP][MT];
             xread(0, xa);
 #pragma unroll
             for (int ks = 0; ks < 12; ks += 2) {
@@ -155,16 +158,16 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
 #pragma unroll
                 for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m] = SC::mfma16(w3p[SC::prod_w(t)][ks], xa[SC::prod_a(t)][m], acc[m]);
+                    for (int m = 0; m < MT; ++m) acc[m] = SC::mfma16(w3p[SC::prod_w(t)][ks], xa[SC::prod_a(t)][m], acc[m]);
                 if (ks + 2 < 12) xread(ks + 2, xa);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m] = SC::mfma16(w3p[SC::prod_w(t)][ks + 1], xb[SC::prod_a(t)][m], acc[m]);
+                    for (int m = 0; m < MT; ++m) acc[m] = SC::mfma16(w3p[SC::prod_w(t)][ks + 1], xb[SC::prod_a(t)][m], acc[m]);
             }
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 const f4 v = acc[m] * rs3 + b3;
                 const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
                 V4 hp[NP];
