@@ -131,6 +131,7 @@ struct at_encodec {
     const piece_t* fin_f = nullptr; // final conv weight [128][7 * 512] * fin_fs as two fp16 pieces, K-blocks in window order (option "fin_f16x2")
     float fin_fs = 1.f;
     bool fin_f16x2 = true;
+    bool res128_rs = true;          // 128-channel block (fp16 scheme): the role-split kernel (seanet_res128rs.hip) instead of seanet_res128x3.hip; same bits
     const __bf16* cb_f = nullptr;   // codebooks * cb_fs as 2 fp16 pieces [2][n_cb * 1024][128] (option "rvq_f16x2")
     float cb_fs = 1.f;
     bool rvq_f16x2 = true;
@@ -867,7 +868,9 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                     if (cf) { ra.S_scheme = XB_SCHEME_F16X2; ra.S_scale = XB_F16_ACT_SCALE; ra.status = range_status; }
                 }
                 prof.begin("res2", down2_gemm ? 2 : 1, stream);
-                if (int rc = (h->res128_x3 && h->bf16x3) ? launch_seanet_res128x3(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
+                const bool x3 = h->res128_x3 && h->bf16x3;
+                if (int rc = (x3 && h->res128_rs && ra.scheme == XB_SCHEME_F16X2) ? launch_seanet_res128rs(ra, stream)
+                             : x3 ? launch_seanet_res128x3(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
                 if (down2_gemm)
                     if (int rc = launch_reflect_front5(ra.S, g, 8, p.Lp2, stream, cnp)) return rc;
                 prof.end(stream);
@@ -1005,6 +1008,7 @@ const BoolOption kBoolOptions[] = {
     {"res_f16x2", &at_encodec::res_f16x2},
     {"rvq_f16x2", &at_encodec::rvq_f16x2},
     {"fin_f16x2", &at_encodec::fin_f16x2},
+    {"res128_rs", &at_encodec::res128_rs},
     {"lstm_f16x2", &at_encodec::lstm_f16x2},
     {"chain_f16x2", &at_encodec::chain_f16x2},
 };

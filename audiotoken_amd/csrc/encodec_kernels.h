@@ -87,6 +87,9 @@ int launch_reflect_front5(__bf16* S, int B, int cblocks, int Lp, hipStream_t str
 int launch_seanet_res64(const Res64Args& a, hipStream_t stream);
 // the 128-channel block on the bf16 matrix cores with exact 3-way bf16 splits of all operands (seanet_res128x3.hip)
 int launch_seanet_res128x3(const Res64Args& a, hipStream_t stream);
+// the same block, fp16 scheme only, with role-split waves (conv3 waves / tail waves, one barrier per 32-row tile: seanet_res128rs.hip);
+// bit-identical to launch_seanet_res128x3 with scheme = XB_SCHEME_F16X2
+int launch_seanet_res128rs(const Res64Args& a, hipStream_t stream);
 int launch_seanet_res64x3(const Res64Args& a, hipStream_t stream);   // seanet_res64x3.hip
 // Encoder stage-1 strided conv (64 -> 128, k 8, stride 4) with register-stationary weights (seanet_down64.hip)
 struct Down64Args {

@@ -290,6 +290,26 @@ def test_all_fp32_and_all_x3_whole_path(encoders):
             enc.set_option(opt, 1)
 
 
+def test_role_split_res128_is_bit_identical(encoders):
+    """seanet_res128rs.hip (conv3 waves / tail waves, 32-row tiles, one barrier per tile) performs the products of
+    seanet_res128x3_kernel<SchemeF16x2> in the same order per output element: embeddings and codes must be IDENTICAL, at ragged lengths
+    (stage-2 lengths that are not multiples of 32, and of 5: the fp32-row output instead of the piece output) and batch sizes."""
+    enc = encoders[8]
+    try:
+        for B, N, seed in ((5, 24000 + 320 * 7, 1), (3, 24000 * 3 + 320 * 5 + 13, 2), (2, 320 * 9, 3), (17, 320 * 40, 4)):
+            wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=900 + seed)).cuda()
+            enc.set_option("res128_rs", 1)
+            c1, e1 = enc(wav, None, return_embeddings=True)
+            assert enc.last_status() == 0
+            enc.set_option("res128_rs", 0)
+            c0, e0 = enc(wav, None, return_embeddings=True)
+            assert enc.last_status() == 0
+            assert torch.equal(e1, e0), f"role-split block differs at B={B} N={N}: max {(e1 - e0).abs().max().item():.3e}"
+            assert torch.equal(c1, c0)
+    finally:
+        enc.set_option("res128_rs", 1)
+
+
 def test_fp16_range_overflow_is_reported_and_recovered(enc_weights):
     """A waveform far outside [-1, 1] (x 3e4) overflows the fp16 range of the two-piece kernels: the status word must say so (bit 1) and
     AcousticEncoder.verified must hand back the tokens of the three-bf16-piece kernels (full fp32 exponent range), equal to the oracle's or explained."""
