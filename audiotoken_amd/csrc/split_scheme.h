@@ -50,20 +50,37 @@ __device__ __forceinline__ void split_n(float a, typename SC::T (&p)[SC::NP]) {
 // call; an infinity fails it — a NaN can only descend from one, or from a NaN in the caller's input)
 template <class SC>
 __device__ __forceinline__ bool split4(const f4& v, float scale, typename SC::V4 (&p)[SC::NP]) {
-    bool over = false;
-    if constexpr (SC::RANGE_CHECK) {
-        const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * scale;
-        over = !(m <= 65504.0f);
-    }
+    if constexpr (SC::NP == 2) {
+        // the fp16 scheme written on value PAIRS so that it compiles to the packed forms (v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32: three
+        // instructions per value instead of five; the element-wise form below left half of the pairs to scalar code). Same arithmetic: the scale
+        // is a power of two (x * s exact), hi = rne(x s), x s - hi exact, lo = rne(x s - hi).
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const f2 a = f2{v[0], v[1]} * scale, b = f2{v[2], v[3]} * scale;
+        bool over = false;
+        if constexpr (SC::RANGE_CHECK) over = !(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(b[0]), fabsf(b[1]))) <= 65504.0f);
+        const h2 ah = __builtin_convertvector(a, h2), bh = __builtin_convertvector(b, h2);
+        const f2 ar = a - __builtin_convertvector(ah, f2), br = b - __builtin_convertvector(bh, f2);
+        const h2 al = __builtin_convertvector(ar, h2), bl = __builtin_convertvector(br, h2);
+        p[0] = typename SC::V4{ah[0], ah[1], bh[0], bh[1]};
+        p[1] = typename SC::V4{al[0], al[1], bl[0], bl[1]};
+        return over;
+    } else {
+        bool over = false;
+        if constexpr (SC::RANGE_CHECK) {
+            const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * scale;
+            over = !(m <= 65504.0f);
+        }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float x = v[k] * scale;
-        typename SC::T q[SC::NP];
-        split_n<SC>(x, q);
+        for (int k = 0; k < 4; ++k) {
+            const float x = v[k] * scale;
+            typename SC::T q[SC::NP];
+            split_n<SC>(x, q);
 #pragma unroll
-        for (int i = 0; i < SC::NP; ++i) p[i][k] = q[i];
+            for (int i = 0; i < SC::NP; ++i) p[i][k] = q[i];
+        }
+        return over;
     }
-    return over;
 }
 
 // pieces of the 4 consecutive columns col .. col + 3 (col % 4 == 0) of row `row`, into K-blocked pieces [NP][K/16][rows_pad][16]
