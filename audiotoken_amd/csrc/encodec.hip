@@ -131,6 +131,7 @@ struct at_encodec {
     const piece_t* fin_f = nullptr; // final conv weight [128][7 * 512] * fin_fs as two fp16 pieces, K-blocks in window order (option "fin_f16x2")
     float fin_fs = 1.f;
     bool fin_f16x2 = true;
+    const float* sc0_w = nullptr;   // stage 0: shortcut folded into conv0, [32][7] weights then [32] bias (Stage0Args::wsc0 / bsc0)
     bool res128_rs = true;          // 128-channel block (fp16 scheme): the role-split kernel (seanet_res128rs.hip) instead of seanet_res128x3.hip; same bits
     const __bf16* cb_f = nullptr;   // codebooks * cb_fs as 2 fp16 pieces [2][n_cb * 1024][128] (option "rvq_f16x2")
     float cb_fs = 1.f;
@@ -713,6 +714,28 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             if (int rc = launch_split_blocked(h->res[3][1].w, 384, 256, 256, 384, d1, nullptr)) return rc;
             h->res3c_s = d0; h->res3t_s = d1;
         }
+        {   // stage 0: Wsc . conv0 as one 7-tap conv of the waveform (float64 products, rounded once) for seanet_stage0x3.hip
+            std::vector<float> f(32 * 7 + 32);
+            const float* wt = p.host.data() + o_res[0][1].w;   // [32][16 + 32] = [W1 | Wsc]
+            const float* bt = p.host.data() + o_res[0][1].b;   // b1 + bsc
+            const float* w0 = p.host.data() + o_conv0.w;       // [32][7]
+            const float* b0 = p.host.data() + o_conv0.b;
+            for (int c = 0; c < 32; ++c) {
+                for (int j = 0; j < 7; ++j) {
+                    double acc = 0.0;
+                    for (int k = 0; k < 32; ++k) acc += (double)wt[c * 48 + 16 + k] * (double)w0[k * 7 + j];
+                    f[c * 7 + j] = (float)acc;
+                }
+                double accb = (double)bt[c];
+                for (int k = 0; k < 32; ++k) accb += (double)wt[c * 48 + 16 + k] * (double)b0[k];
+                f[32 * 7 + c] = (float)accb;
+            }
+            float* d = nullptr;
+            AT_CHECK_HIP(hipMalloc((void**)&d, f.size() * sizeof(float)));
+            h->extra_allocs.push_back(d);
+            AT_CHECK_HIP(hipMemcpy(d, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+            h->sc0_w = d;
+        }
         {   // power-of-two weight scales of the fused residual blocks' fp16 scheme (the kernels split their weights themselves, once per launch)
             if (const char* e = std::getenv("AUDIOTOKEN_RES_F16X2")) h->res_f16x2 = std::atoi(e) != 0;
             auto wmax = [&](size_t off, size_t n) { float mx = 0.f; for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(p.host[off + i])); return mx; };
@@ -817,6 +840,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             sa.w0 = h->conv0.w; sa.b0 = h->conv0.b; sa.w3 = h->res[0][0].w; sa.b3 = h->res[0][0].b;
             sa.wt = h->res[0][1].w; sa.bt = h->res[0][1].b; sa.wd = h->down[0].w; sa.bd = h->down[0].b;
             sa.B = g; sa.N = N;
+            sa.wsc0 = h->sc0_w; sa.bsc0 = h->sc0_w ? h->sc0_w + 32 * 7 : nullptr;
             if (h->res_f16x2) {
                 sa.scheme = XB_SCHEME_F16X2; sa.act_scale = XB_F16_ACT_SCALE; sa.status = range_status;
                 sa.w3_scale = h->res_fs[0][0]; sa.wt_scale = h->res_fs[0][1]; sa.wd_scale = h->down_fs[0];

@@ -58,6 +58,10 @@ struct Stage0Args {
     int scheme = 0;
     float act_scale = 1.f, w3_scale = 1.f, wt_scale = 1.f, wd_scale = 1.f;
     int* status = nullptr;
+    // seanet_stage0x3 only: the block's 1x1 shortcut folded into conv0 — Wsc . conv0 is itself a 7-tap conv of the waveform with weights
+    // wsc0 = Wsc . W0 [32][7]; bsc0 = Wsc . b0 + (b1 + bsc) [32] (computed in float64 at finalize). The kernel then never splits or stores the
+    // raw conv0 output: the tail's split contraction is K = 16 (h only) and the shortcut is two fp32 MFMAs on the waveform segment.
+    const float *wsc0 = nullptr, *bsc0 = nullptr;
 };
 int launch_seanet_stage0(const Stage0Args& a, hipStream_t stream);
 int launch_seanet_stage0x3(const Stage0Args& a, hipStream_t stream);   // the same stage with split-bf16 contractions (seanet_stage0x3.hip)

@@ -54,9 +54,8 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
     typedef typename SC::V4 V4;
     constexpr int NP = SC::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char sx_lds_raw[];
-    PT* X0e = reinterpret_cast<PT*>(sx_lds_raw);
-    PT* X0r = X0e + NP * SX_XP;
-    PT* Hs = X0r + NP * SX_XP;
+    PT* X0e = reinterpret_cast<PT*>(sx_lds_raw);   // split(ELU(x0)); the raw x0 is never stored (the shortcut is folded into conv0: Stage0Args::wsc0)
+    PT* Hs = X0e + NP * SX_XP;
     PT* Rs = Hs + NP * SX_HP;
     float* Wv = reinterpret_cast<float*>(Rs + NP * SX_RP);
     const float sa = SC::RANGE_CHECK ? a.act_scale : 1.0f;
@@ -74,13 +73,18 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
     // ---- weights -> registers, once per workgroup ------------------------------------------------------------------
     if (tid < 32) B0s[tid] = a.b0[tid];
     if (tid < 16) Bs[tid] = a.b3[tid];
-    if (tid < 32) Bs[16 + tid] = a.bt[tid];
+    if (tid < 32) Bs[16 + tid] = a.bsc0[tid];   // Wsc . b0 + (b1 + bsc)
     if (tid < 64) Bs[48 + tid] = a.bd[tid];
     float w0f[2][2];   // conv0 as a K = 8 fp32 MFMA (7 taps + a zero column): A fragment w0f[nt][s] = W0[nt*16 + r16][4s + q]
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) w0f[nt][ks] = (4 * ks + q) < 7 ? a.w0[(nt * 16 + r16) * 7 + 4 * ks + q] : 0.f;
+    float wscf[2][2];  // the shortcut of the block as the 7-tap conv Wsc . W0 of the waveform, same fragment form
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wscf[nt][ks] = (4 * ks + q) < 7 ? a.wsc0[(nt * 16 + r16) * 7 + 4 * ks + q] : 0.f;
     // bf16 pieces of the A operands (row r16, k = 32 ks + 8 q .. + 7); `kmax` zero-fills the tail's K padding
     auto wsplit = [&](const float* row, int k0, int kmax, float scale, V8 (&dst)[NP]) {
         f4 lo, hi;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
 #pragma unroll
             for (int k = 0; k < 4; ++k) { dst[i][k] = plo[i][k]; dst[i][4 + k] = phi[i][k]; }
     };
-    V8 w3p[NP][3], wtp[NP][2][2], wdp[NP][4];
+    V8 w3p[NP][3], wtp[NP][2], wdp[NP][4];   // wtp: W1 only (K = 16, zero-padded to one K step of 32)
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
         V8 t[NP];
@@ -106,14 +110,12 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
         for (int i = 0; i < NP; ++i) w3p[i][ks] = t[i];
     }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt) {
+        V8 t[NP];
+        wsplit(a.wt + (nt * 16 + r16) * 48, q * 8, 16, swt, t);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            V8 t[NP];
-            wsplit(a.wt + (nt * 16 + r16) * 48, ks * 32 + q * 8, 48, swt, t);
-#pragma unroll
-            for (int i = 0; i < NP; ++i) wtp[i][nt][ks] = t[i];
-        }
+        for (int i = 0; i < NP; ++i) wtp[i][nt] = t[i];
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         V8 t[NP];
@@ -133,6 +135,22 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
     };
     // ---- B: conv0 of a tile at time |t0 - 4 + i| on the fp32 MFMA (as seanet_stage0.hip) -> split raw and ELU copies. 10 units of
     //      (row tile, channel tile) over the 4 waves. Only the first tile of a clip needs the reflect index map ------------------------
+    // waveform-segment indices of the two K = 4 tap groups of x0 row i (time t0 - 4 + i): only the first tile of a clip needs the reflect maps
+    auto tap_index = [&](int t0, int i, int& a0, int& a1) {
+        if (t0 == 0) {
+            int tau = i - 4;
+            tau = tau < 0 ? -tau : tau;
+            a0 = tau + q - 6;
+            a0 = (a0 < 0 ? -a0 : a0) + 10;
+            a1 = tau + q - 2;
+            a1 = (a1 < 0 ? -a1 : a1) + 10;
+        } else {
+            a0 = i + q;
+            a1 = i + 4 + q;
+        }
+        a0 = a0 < SX_WAV - 1 ? a0 : SX_WAV - 1;   // rows >= 66 and the zero tap stay inside the (finite) segment
+        a1 = a1 < SX_WAV - 1 ? a1 : SX_WAV - 1;
+    };
     auto conv0_tile = [&](int tile, const float* Wseg) {
         if (tile >= total_tiles) return;
         const int t0 = (tile % tiles_per_clip) * SX_ADV;
@@ -140,26 +158,13 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
             const int mt = unit >> 1, nt = unit & 1;
             const int i = mt * 16 + r16;
             int a0, a1;
-            if (t0 == 0) {
-                int tau = i - 4;
-                tau = tau < 0 ? -tau : tau;
-                a0 = tau + q - 6;
-                a0 = (a0 < 0 ? -a0 : a0) + 10;
-                a1 = tau + q - 2;
-                a1 = (a1 < 0 ? -a1 : a1) + 10;
-            } else {
-                a0 = i + q;
-                a1 = i + 4 + q;
-            }
-            a0 = a0 < SX_WAV - 1 ? a0 : SX_WAV - 1;   // rows >= 66 and the zero tap stay inside the (finite) segment
-            a1 = a1 < SX_WAV - 1 ? a1 : SX_WAV - 1;
+            tap_index(t0, i, a0, a1);
             f4 acc = {0.f, 0.f, 0.f, 0.f};
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nt ? w0f[1][0] : w0f[0][0], Wseg[a0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nt ? w0f[1][1] : w0f[0][1], Wseg[a1], acc, 0, 0, 0);
             const f4 o = acc + *reinterpret_cast<const f4*>(B0s + nt * 16 + q * 4);
             const int off = i * SX_LDX + nt * 16 + q * 4;
-            over |= sx_store4<SC>(X0r, off, SX_XP, o, sa);
-            sx_store4<SchemeNoCheck<SC>>(X0e, off, SX_XP, sx_elu4(o), sa);   // |ELU(x)| <= max(|x|, 1)
+            over |= sx_store4<SC>(X0e, off, SX_XP, sx_elu4(o), sa);
         }
     };
     // Software pipeline over the workgroup's tiles (two barriers per tile): while tile t is in its strided-conv phase the same
@@ -194,29 +199,29 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
 #pragma unroll
                 for (int t = 0; t < SC::NPROD; ++t) acc = SC::mfma16(w3p[SC::prod_w(t)][ks], xf[ks][SC::prod_a(t)], acc);
             over |= sx_store4<SC>(Hs, row * SX_LDH + q * 4, SX_HP, sx_elu4(acc * rs3 + *reinterpret_cast<const f4*>(Bs + q * 4)), sa);
-            // K step 0: k 0..15 = h (lanes q < 2), k 16..31 = x0 channels 0..15; K step 1: k 32..47 = x0 channels 16..31 (q < 2),
-            // k 48..63 zero weights (the lanes re-read finite x0 data)
-            const PT* s0 = q < 2 ? Hs + row * SX_LDH + q * 8 : X0r + (row + 2) * SX_LDX + (q - 2) * 8;
-            const int ps0 = q < 2 ? SX_HP : SX_XP;
-            const PT* s1 = X0r + (row + 2) * SX_LDX + (2 + (q & 1)) * 8;
-            V8 tf[2][NP];
+            // tail: W1 . h as ONE split K step (k 0..15 = h: lanes q < 2; k 16..31 zero weights, those lanes re-read finite h data) plus the
+            // shortcut Wsc . x0[row + 2] as the folded 7-tap conv of the waveform on the fp32 MFMA (x0 row i <-> time t0 - 4 + i)
+            const PT* s0 = Hs + row * SX_LDH + (q & 1) * 8;
+            V8 tf[NP];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                tf[0][p] = *reinterpret_cast<const V8*>(s0 + p * ps0);
-                tf[1][p] = *reinterpret_cast<const V8*>(s1 + p * SX_XP);
+            for (int p = 0; p < NP; ++p) tf[p] = *reinterpret_cast<const V8*>(s0 + p * SX_HP);
+            int a0, a1;
+            tap_index(t0, row + 2, a0, a1);
+            const float* Wseg = Wv + par * SX_WAV;
+            f4 acc2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, sc[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                sc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wscf[nt][0], Wseg[a0], f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                sc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wscf[nt][1], Wseg[a1], sc[nt], 0, 0, 0);
             }
-            f4 acc2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
-                for (int t = 0; t < SC::NPROD; ++t)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc2[nt] = SC::mfma16(wtp[SC::prod_w(t)][nt][ks], tf[ks][SC::prod_a(t)], acc2[nt]);
+                for (int nt = 0; nt < 2; ++nt) acc2[nt] = SC::mfma16(wtp[SC::prod_w(t)][nt], tf[SC::prod_a(t)], acc2[nt]);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 over |= sx_store4<SC>(Rs, ((row & 1) * SX_RIDX + (row >> 1)) * SX_LDR + nt * 16 + q * 4, SX_RP,
-                                      sx_elu4(acc2[nt] * rst + *reinterpret_cast<const f4*>(Bs + 16 + nt * 16 + q * 4)), sa);
+                                      sx_elu4((acc2[nt] * rst + sc[nt]) + *reinterpret_cast<const f4*>(Bs + 16 + nt * 16 + q * 4)), sa);
         }
         __syncthreads();
         if (t0 == 0) {   // reflect padding of the strided conv's input at the clip start: r[-1] = r[1], r[-2] = r[2]
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
 
 template <class SC>
 static int launch_stage0_scheme(const Stage0Args& a, hipStream_t stream, int grid) {
-    constexpr int lds = (2 * SC::NP * SX_XP + SC::NP * SX_HP + SC::NP * SX_RP) * 2 + (2 * SX_WAV + 32 + 112) * 4;
+    constexpr int lds = (SC::NP * SX_XP + SC::NP * SX_HP + SC::NP * SX_RP) * 2 + (2 * SX_WAV + 32 + 112) * 4;
     { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, seanet_stage0x3_kernel<SC>, lds)) return rc; }
     hipLaunchKernelGGL(seanet_stage0x3_kernel<SC>, dim3(grid), dim3(256), lds, stream, a);
     AT_CHECK_HIP(hipGetLastError());
@@ -275,6 +280,7 @@ static int launch_stage0_scheme(const Stage0Args& a, hipStream_t stream, int gri
 
 int launch_seanet_stage0x3(const Stage0Args& a, hipStream_t stream) {
     AT_REQUIRE(a.N % 2 == 0 && a.N >= 16 && a.B >= 1, "fused stage 0 needs an even sample count");
+    AT_REQUIRE(a.wsc0 != nullptr && a.bsc0 != nullptr, "stage 0 needs the folded shortcut weights (Stage0Args::wsc0)");
     const long long tiles = (long long)a.B * ((a.N + SX_ADV - 1) / SX_ADV);
     AT_REQUIRE(tiles < (1LL << 30), "tile arithmetic is 32-bit");
     const int per_cu = a.scheme == XB_SCHEME_F16X2 ? 3 : 2;   // resident workgroups per CU (fp16 scheme: 51 KB LDS, 160 registers; measured 6.5 -> 6.0 ms vs two)

@@ -21,6 +21,13 @@ int main(int argc, char** argv) {
     at::Stage0Args a;
     a.wav = up(hw); a.w0 = up(w0); a.b0 = up(b0); a.w3 = up(w3); a.b3 = up(b3); a.wt = up(wt); a.bt = up(bt); a.wd = up(wd); a.bd = up(bd);
     a.B = B; a.N = N;
+    // the shortcut folded into conv0 (what encodec.hip's finalize computes): wsc0 = Wsc . W0, bsc0 = Wsc . b0 + bt
+    std::vector<float> wsc0(32 * 7), bsc0(32);
+    for (int c = 0; c < 32; ++c) {
+        for (int j = 0; j < 7; ++j) { double acc = 0; for (int k = 0; k < 32; ++k) acc += (double)wt[c * 48 + 16 + k] * w0[k * 7 + j]; wsc0[c * 7 + j] = (float)acc; }
+        double accb = bt[c]; for (int k = 0; k < 32; ++k) accb += (double)wt[c * 48 + 16 + k] * b0[k]; bsc0[c] = (float)accb;
+    }
+    a.wsc0 = up(wsc0); a.bsc0 = up(bsc0);
     const size_t no = (size_t)B * (N / 2) * 64;
     float *o0, *o1; hipMalloc(&o0, no * 4); hipMalloc(&o1, no * 4);
     hipMemset(o0, 0xff, no * 4); hipMemset(o1, 0xff, no * 4);
