@@ -323,19 +323,28 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long r0 = (long long)blockIdx.x * LNS_ROWS;
     bool over = false;
-#pragma unroll 1
+    // all four rows of the wave are loaded before the first is reduced: one row at a time left 4 KB per wave in flight (3.5 TB/s, 70 % of the
+    // wave cycles waiting)
+    f4 vall[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const long long row = r0 + wave * 4 + rr;
+        if (row < rows) {
+            const f4* xr = reinterpret_cast<const f4*>(x + row * LNS_D);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vall[rr][j] = xr[lane + 64 * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vall[rr][j] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int lr = wave * 4 + rr;
         const long long row = r0 + lr;
         f4 v[4];
-        if (row < rows) {
-            const f4* xr = reinterpret_cast<const f4*>(x + row * LNS_D);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = xr[lane + 64 * j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = f4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int j = 0; j < 4; ++j) v[j] = vall[rr][j];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
