@@ -127,7 +127,9 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
         }
     };
     // FAST (the fp16 scheme; the bf16 scheme has no registers to spare for it): the h_t slice is published by one wave as whole lines (below).
-    // Tried on top of it and measured slower (stamps, tools/lstm_stamps.sh): fetching xg / skip one step ahead (the HBM loads then delay the h tile
+    // Tried on top of it and measured slower (stamps, tools/lstm_stamps.sh): every wave polling only the two producers whose slices it stages and
+    // loading them without the workgroup barrier (staging 1580 -> 1030 cycles but the wait 2050 -> 3020: eight polling waves per workgroup slow
+    // the flag's way to the pollers, as in the flag-less variant; 5.45 ms); fetching xg / skip one step ahead (the HBM loads then delay the h tile
     // loads they are issued behind: 5.6-6.4 ms) and polling the flags through the scalar memory path (5.6 ms).
     constexpr bool FAST = SC::NP == 2, YG = FAST;
     for (int t = 0; t < T; ++t) {
