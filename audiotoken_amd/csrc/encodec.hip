@@ -1119,7 +1119,6 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
                            sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
                            (h->bf16x3 && h->ih_f16x2) ? h->dwih_f : nullptr, h->dwih_fs, reinterpret_cast<int*>(sync + 62), h->lstm_f16x2 ? h->dwhh_fs : nullptr))
         return rc;
-    if (status_dev) if (int rc = launch_status_combine(sync, status_dev, stream)) return rc;
     const int Lout = p.L[4];
     for (int b0 = 0; b0 < B; b0 += p.G) {
         const int g = (B - b0) < p.G ? (B - b0) : p.G;
@@ -1148,8 +1147,14 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
                 Res64Args ra;
                 ra.x = u; ra.out = r; ra.w3 = h->dres[s][0].w; ra.b3 = h->dres[s][0].b; ra.wt = h->dres[s][1].w; ra.bt = h->dres[s][1].b;
                 ra.B = g; ra.L = Lo;
+                if (h->res_f16x2 && h->dres_fs[s][0] > 0.f) {   // the blocks' own contractions on the two-piece fp16 scheme, as in the encoder
+                    ra.scheme = XB_SCHEME_F16X2; ra.act_scale = XB_F16_ACT_SCALE; ra.w3_scale = h->dres_fs[s][0]; ra.wt_scale = h->dres_fs[s][1];
+                    ra.status = reinterpret_cast<int*>(sync + 62);
+                }
+                const bool x3_128 = h->res128_x3 && h->bf16x3;
                 if (int rc = Co == 64 ? ((h->res64_x3 && h->bf16x3) ? launch_seanet_res64x3(ra, stream) : launch_seanet_res64(ra, stream))
-                                      : (h->res128_x3 && h->bf16x3) ? launch_seanet_res128x3(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
+                                      : (x3_128 && h->res128_rs && ra.scheme == XB_SCHEME_F16X2) ? launch_seanet_res128rs(ra, stream)
+                                      : x3_128 ? launch_seanet_res128x3(ra, stream) : launch_seanet_res128(ra, stream)) return rc;
             } else {
                 // the last block's output goes to conv_last, which applies the ELU itself
                 if (int rc = resblock(h->dres[s], u, ws + p.off_h[s], r, Lo, g, stream, s < 3 ? EPI_ELU : EPI_NONE)) return rc;
@@ -1160,6 +1165,7 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
         if (!tail_done)
             if (int rc = launch_conv_last(in, h->dlast.w, h->dlast.b, wav + (long long)b0 * Lout, g, Lout, stream)) return rc;
     }
+    if (status_dev) return launch_status_combine(sync, status_dev, stream);   // LSTM hand-off + every range verdict of the call
     return 0;
 }
 
