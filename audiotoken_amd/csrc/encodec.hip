@@ -132,6 +132,9 @@ struct at_encodec {
     float fin_fs = 1.f;
     bool fin_f16x2 = true;
     const float* sc0_w = nullptr;   // stage 0: shortcut folded into conv0, [32][7] weights then [32] bias (Stage0Args::wsc0 / bsc0)
+    const piece_t* dup_f[3] = {nullptr, nullptr, nullptr};   // decoder transposed convs [r * Cout][2 * Cin] * dup_fs as two fp16 pieces, window order (option "up_f16x2")
+    float dup_fs[3] = {};
+    bool up_f16x2 = true;
     bool res128_rs = true;          // 128-channel block (fp16 scheme): the role-split kernel (seanet_res128rs.hip) instead of seanet_res128x3.hip; same bits
     const __bf16* cb_f = nullptr;   // codebooks * cb_fs as 2 fp16 pieces [2][n_cb * 1024][128] (option "rvq_f16x2")
     float cb_fs = 1.f;
@@ -459,6 +462,8 @@ struct DecPlan {
     int G;
     size_t off_z, off_x0, off_xg, off_h0, off_h1, off_c, off_y, off_sync, off_xs;
     size_t off_u[4], off_h[4], off_r[4];
+    size_t off_ap;     // operand pieces of a transposed conv run as a windowed split GEMM: [2][G][Cin/16][Lpu][16] fp16 (one float per element)
+    int Mpu[3], Lpu[3];   // per stage: padded output rows / operand rows per clip
     size_t total_floats;
 };
 
@@ -484,6 +489,18 @@ DecPlan make_dec_plan(int B, int T, int sub) {
         p.off_u[s] = take((size_t)p.G * p.L[s + 1] * C);
         p.off_h[s] = take((size_t)p.G * p.L[s + 1] * (C / 2));
         p.off_r[s] = take((size_t)p.G * p.L[s + 1] * C);
+    }
+    {
+        size_t ap = 0;
+        int Cin = kH;
+        for (int s = 0; s < 3; ++s) {
+            p.Mpu[s] = (p.L[s] + 255) / 256 * 256;
+            p.Lpu[s] = p.Mpu[s] + 8;
+            const size_t n = (size_t)p.G * Cin * p.Lpu[s];
+            ap = n > ap ? n : ap;
+            Cin /= 2;
+        }
+        p.off_ap = take(ap + 64);
     }
     p.total_floats = cur;
     return p;
@@ -752,6 +769,17 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
                 for (int s2 = 0; s2 < 4; ++s2) {
                     h->dres_fs[s2][0] = xb_weight_scale(wmax(d_res[s2][0].w, (size_t)(Cd2 / 2) * 3 * Cd2));
                     h->dres_fs[s2][1] = xb_weight_scale(wmax(d_res[s2][1].w, (size_t)Cd2 * (Cd2 / 2 + Cd2)));
+                    if (s2 < 3) {   // transposed conv of this stage as a two-tap windowed split GEMM: [r * Cout][2 * Cin], Cin = 2 * Cd2
+                        const int Cin_u = 2 * Cd2, Nu = kRatiosDec[s2] * Cd2, Ku = 2 * Cin_u;
+                        if (Nu % 64 == 0 && Ku % 64 == 0) {
+                            h->dup_fs[s2] = xb_weight_scale(wmax(d_up[s2].w, (size_t)Nu * Ku));
+                            piece_t* f = nullptr;
+                            AT_CHECK_HIP(hipMalloc((void**)&f, (size_t)2 * Nu * Ku * sizeof(piece_t)));
+                            h->extra_allocs.push_back(f);
+                            if (int rc = launch_split_blocked(h->dup[s2].w, Ku, Nu, Nu, Ku, f, nullptr, XB_SCHEME_F16X2, h->dup_fs[s2], nullptr, Cin_u / 16, 1)) return rc;
+                            h->dup_f[s2] = f;
+                        }
+                    }
                     Cd2 /= 2;
                 }
             }
@@ -1033,6 +1061,7 @@ const BoolOption kBoolOptions[] = {
     {"rvq_f16x2", &at_encodec::rvq_f16x2},
     {"fin_f16x2", &at_encodec::fin_f16x2},
     {"res128_rs", &at_encodec::res128_rs},
+    {"up_f16x2", &at_encodec::up_f16x2},
     {"lstm_f16x2", &at_encodec::lstm_f16x2},
     {"chain_f16x2", &at_encodec::chain_f16x2},
 };
@@ -1140,8 +1169,21 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
             float* u = ws + p.off_u[s];
             // ConvTranspose1d(k = 2r, stride r) of the (already ELU'd) input, trimmed right by r, as one GEMM with N = r*Cout:
             // out[t][p*Cout + co] = x[t-1].W[:, co, p+r] + x[t].W[:, co, p]; [Li][r*Cout] is [Lo][Cout] in memory.
-            if (int rc = conv_gemm(h->dup[s], in, (long long)Li * Cin, Li, u, (long long)Lo * Co, Li, g, PRO_NONE, nullptr, 0, stream, 0))
+            if (s < 3 && h->bf16x3 && h->up_f16x2 && h->dup_f[s] && Li > 1) {
+                // as a two-tap windowed split GEMM on the fp16 scheme: the (already ELU'd) input -> pieces with ONE ZERO front row (x[-1] = 0)
+                __bf16* ap = reinterpret_cast<__bf16*>(ws + p.off_ap);
+                int* range_status = reinterpret_cast<int*>(sync + 62);
+                if (int rc = launch_split_windowed(in, g, Li, Cin, 1, 1, p.Lpu[s], ap, stream, XB_SCHEME_F16X2, XB_F16_ACT_SCALE, range_status, 0)) return rc;
+                Bf16x3Args ua;
+                ua.A = ap; ua.W = h->dup_f[s]; ua.bias = h->dup[s].b;
+                ua.M = Li; ua.Mpad = p.Mpu[s]; ua.N = kRatiosDec[s] * Co; ua.K = 2 * Cin;
+                ua.batch = g; ua.stride = 1; ua.cblocks = Cin / 16; ua.Lp = p.Lpu[s];
+                ua.scheme = XB_SCHEME_F16X2; ua.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->dup_fs[s]); ua.split_scale = XB_F16_ACT_SCALE; ua.status = range_status;
+                ua.epi = XB_EPI_LINEAR; ua.C = u; ua.ldc = ua.N;
+                if (int rc = launch_gemm_bf16x3(ua, stream)) return rc;
+            } else if (int rc = conv_gemm(h->dup[s], in, (long long)Li * Cin, Li, u, (long long)Lo * Co, Li, g, PRO_NONE, nullptr, 0, stream, 0)) {
                 return rc;
+            }
             float* r = ws + p.off_r[s];
             if ((Co == 64 && h->fused_res64) || (Co == 128 && h->fused_res128)) {
                 Res64Args ra;

@@ -99,9 +99,10 @@ int launch_split_blocked(const float* x, int ld, long long rows, long long rows_
                          int scheme = XB_SCHEME_BF16X3, float scale = 1.0f, int* status = nullptr, int win_cblocks = 0, int win_stride = 1);
 // fp32 [B][L][C] -> the windowed-mode pieces of a causal strided conv with kernel = 2 * stride (reflect front padding included)
 int launch_split_phase_major(const float* x, int B, int L, int C, int stride, int Lp, __bf16* out, hipStream_t stream);
-// the same for any front padding (`pad` reflected rows) and either scheme: fp32 [B][L][C] * scale -> [pieces][B][C/16][stride][Lp][16]
+// the same for any front padding (`pad` rows: reflected, or zeros with reflect = 0) and either scheme: fp32 [B][L][C] * scale ->
+// [pieces][B][C/16][stride][Lp][16]
 int launch_split_windowed(const float* x, int B, int L, int C, int stride, int pad, int Lp, __bf16* out, hipStream_t stream,
-                          int scheme = XB_SCHEME_BF16X3, float scale = 1.0f, int* status = nullptr);
+                          int scheme = XB_SCHEME_BF16X3, float scale = 1.0f, int* status = nullptr, int reflect = 1);
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream);
 // the fp16 scheme's kernel for launches that fill the chip (gemm_f16x2_tg.hip); launch_gemm_bf16x3 dispatches to it
 // ($AUDIOTOKEN_F16X2_TG=0 keeps the register-staged kernel)

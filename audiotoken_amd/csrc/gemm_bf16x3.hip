@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void split_blocked_kernel(const float* __restr
 // indices), so a wave-store covers 512 contiguous bytes per piece and the reads are 64-byte runs.
 template <class SC>
 __global__ __launch_bounds__(256) void split_phase_major_kernel(const float* __restrict__ x, int L, int C, int stride, int pad, int Lp, int nidx,
-                                                                long long piece_stride, typename SC::T* __restrict__ out, float scale, int* __restrict__ status) {
+                                                                long long piece_stride, typename SC::T* __restrict__ out, float scale, int* __restrict__ status,
+                                                                int reflect) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = lane & 3, ii = lane >> 2;
     const int cb = blockIdx.y * 4 + wave, cblocks = C / 16;
@@ -111,9 +112,10 @@ __global__ __launch_bounds__(256) void split_phase_major_kernel(const float* __r
         const int idx = blockIdx.x * 64 + j * 16 + ii;
         if (idx >= nidx) continue;
         int t = idx * stride + plane - pad;
+        const bool front_zero = t < 0 && !reflect;   // zero front padding (the transposed convs' x[-1]) instead of the reflection
         t = t < 0 ? -t : t;
         f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t < L) v = *reinterpret_cast<const f4*>(xb + (long long)t * C);
+        if (t < L && !front_zero) v = *reinterpret_cast<const f4*>(xb + (long long)t * C);
         typename SC::V4 pc[SC::NP];
         over |= split4<SC>(v, scale, pc);
         typename SC::T* d = ob + (long long)idx * 16;
@@ -144,22 +146,22 @@ int launch_reflect_front(__bf16* S, int B, int blocks, int phases, int Lp, int p
 }
 
 int launch_split_windowed(const float* x, int B, int L, int C, int stride, int pad, int Lp, __bf16* out, hipStream_t stream, int scheme, float scale,
-                          int* status) {
+                          int* status, int reflect) {
     AT_REQUIRE(C % 16 == 0 && L > pad && stride >= 1 && pad >= 0, "split_windowed: C % 16, L > pad");
     const int nidx = (L + pad + stride - 1) / stride;
     AT_REQUIRE(nidx <= Lp, "split_windowed: Lp too small");
     dim3 grid((nidx + 63) / 64, (C / 16 + 3) / 4, B * stride);
     const long long ps = (long long)B * (C / 16) * stride * Lp * 16;
     if (scheme == XB_SCHEME_F16X2)
-        hipLaunchKernelGGL(split_phase_major_kernel<SchemeF16x2>, grid, dim3(256), 0, stream, x, L, C, stride, pad, Lp, nidx, ps, reinterpret_cast<_Float16*>(out), scale, status);
+        hipLaunchKernelGGL(split_phase_major_kernel<SchemeF16x2>, grid, dim3(256), 0, stream, x, L, C, stride, pad, Lp, nidx, ps, reinterpret_cast<_Float16*>(out), scale, status, reflect);
     else
-        hipLaunchKernelGGL(split_phase_major_kernel<SchemeBf16x3>, grid, dim3(256), 0, stream, x, L, C, stride, pad, Lp, nidx, ps, out, 1.0f, nullptr);
+        hipLaunchKernelGGL(split_phase_major_kernel<SchemeBf16x3>, grid, dim3(256), 0, stream, x, L, C, stride, pad, Lp, nidx, ps, out, 1.0f, nullptr, reflect);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_split_phase_major(const float* x, int B, int L, int C, int stride, int Lp, __bf16* out, hipStream_t stream) {
-    return launch_split_windowed(x, B, L, C, stride, stride, Lp, out, stream, XB_SCHEME_BF16X3, 1.0f, nullptr);
+    return launch_split_windowed(x, B, L, C, stride, stride, Lp, out, stream, XB_SCHEME_BF16X3, 1.0f, nullptr, 1);
 }
 
 int launch_split_blocked(const float* x, int ld, long long rows, long long rows_pad, int K, __bf16* out, hipStream_t stream, int scheme, float scale,

@@ -44,10 +44,11 @@ class AcousticDecoder(torch.nn.Module):
                          "decoding again with per-step LSTM launches (option persistent_lstm=0) from now on")
             self.set_option("persistent_lstm", 0)
         if status & 2:
-            logger.error(f"fp16 range overflow in the decoder's f16x2 kernels (LSTM input projection, residual blocks; status {status}): waveform "
-                         "discarded; decoding again with the bf16x3 kernels (options ih_f16x2=0, res_f16x2=0) from now on")
+            logger.error(f"fp16 range overflow in the decoder's f16x2 kernels (LSTM input projection, residual blocks, transposed convs; status {status}): "
+                         "waveform discarded; decoding again without them (options ih_f16x2=0, res_f16x2=0, up_f16x2=0) from now on")
             self.set_option("ih_f16x2", 0)
             self.set_option("res_f16x2", 0)
+            self.set_option("up_f16x2", 0)
         wav = self.forward(tokens)
         if self.last_status() != 0:
             raise _cabi.HipLibraryError("acoustic decode failed twice (LSTM status non-zero with per-step launches)")

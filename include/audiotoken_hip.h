@@ -89,6 +89,7 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
  *   the RVQ search on the same two-piece fp16 scheme (default on, $AUDIOTOKEN_RES_F16X2 / $AUDIOTOKEN_RVQ_F16X2) or on three bf16 pieces;
  *   "res128_rs" 1/0 — the 128-channel block on the fp16 scheme as the role-split kernel (csrc/seanet_res128rs.hip, default) or as
  *   csrc/seanet_res128x3.hip; bit-identical results;
+ *   "up_f16x2" 1/0 — the decoder's first three transposed convs as two-tap windowed split GEMMs on the fp16 scheme (default on) or as fp32-MFMA GEMMs;
  *   "fin_f16x2" 1/0 — the encoder's final k = 7 conv as a windowed split GEMM on the two-piece fp16 scheme (default on, $AUDIOTOKEN_FIN_F16X2) or on
  *   the fp32 MFMA;
  *   "lstm_f16x2" 1/0 — the persistent LSTM's recurrent product on the two-piece fp16 scheme (h in (-1, 1) always fits: no range check) or on
