@@ -50,7 +50,7 @@ struct TgCfg {
 // contiguous range of m-tiles and walks it in groups of `ga` m-tiles x all n-tiles, m fastest — the ~32 tiles an XCD runs at a time then
 // share `ga` activation tiles and 32 / ga weight tiles in ITS L2, and an activation tile is fetched into one L2 instead of all eight
 // (n-fastest order: 8 x the activation bytes leave the Infinity Cache; the K = 4096 GEMM moved 12.6 GB per launch that way).
-template <bool WINDOWED, int TI, int TJ>
+template <bool WINDOWED, int TI, int TJ, bool SPLITDMA>
 __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_kernel(Bf16x3Args a, int ga) {
     using Cfg = TgCfg<TI, TJ>;
     constexpr int BM = Cfg::BM, TG_PIECE = Cfg::PIECE, TG_SLOT = Cfg::SLOT;
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
     // the (plane image, row offset) pair of the next k-block is one compare-and-carry away — no integer division in the loop
     const int w_taps = nk2 * 2 / cblocks, w_q = w_taps / a.stride, w_r = w_taps - w_q * a.stride;
     int w_t = 0, w_off = 0, w_p = 0;                 // plane image cbk * stride + p, row offset, plane
-    auto issue = [&](int kp, int pair) {             // K step kp = k-blocks 2 kp, 2 kp + 1 -> ring slots 2 pair, 2 pair + 1
+    // issue_A / issue_W: the activation / weight chunks of K step kp (k-blocks 2 kp, 2 kp + 1) -> ring slots 2 pair, 2 pair + 1
+    auto issue_A = [&](int kp, int pair) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int kt = 2 * kp + h;
@@ -109,15 +110,24 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
             } else {
                 ka = (long long)kt * Lp * 16;
             }
-            const long long kw = (long long)kt * a.N * 16;
             PT* s = lds + (2 * pair + h) * TG_SLOT + (wave & 3) * (BM / 4) * 16;  // wave-uniform; the hardware adds lane * 16 B
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < Cfg::DMA_PER_CHUNK; ++j) {            // rows + 32 j: 512 elements further in both images
+                for (int j = 0; j < Cfg::DMA_PER_CHUNK; ++j)              // rows + 32 j: 512 elements further in both images
                     __builtin_amdgcn_global_load_lds((glb_void*)(gA + p * psA + ka + j * 512), (lds_void*)(s + p * TG_PIECE + j * 512), 16, 0, 0);
+        }
+    };
+    auto issue_W = [&](int kp, int pair) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long kw = (long long)(2 * kp + h) * a.N * 16;
+            PT* s = lds + (2 * pair + h) * TG_SLOT + (wave & 3) * (BM / 4) * 16;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < Cfg::DMA_PER_CHUNK; ++j)
                     __builtin_amdgcn_global_load_lds((glb_void*)(gW + p * psW + kw + j * 512), (lds_void*)(s + (2 + p) * TG_PIECE + j * 512), 16, 0, 0);
-                }
         }
     };
     const int fr = lane & 15, fq = lane >> 4;
@@ -127,7 +137,13 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    if (grp == 0) issue(0, 0);
+    // SPLITDMA: the DMA issue is shared — the leaders move the activation chunks ONE step ahead (issued in their segment L, awaited after
+    // their C), the trailers the weight chunks TWO steps ahead (issued at the END of their segment L, when every read of that slot pair has
+    // returned — the leaders' at barrier A, their own by lgkmcnt(0) — and awaited one period later at the same place, i.e. before the barrier
+    // that opens the leaders' segment L of that step). The leaders' L then carries 8 DMA instructions instead of 16 (it was the longest
+    // segment: ~2400 cycles against 1536 of MFMAs), the trailers' L, which had ~1000 cycles of slack, the other 8.
+    if (grp == 0) { issue_A(0, 0); issue_W(0, 0); }
+    if (SPLITDMA && grp == 1 && nk2 > 1) issue_W(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();      // the trailing group starts one barrier late
@@ -145,8 +161,12 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         // DMA of the NEXT step: its slot pair is free once the barrier that closed the trailing group's segment L of step kp - 1 has
         // passed (= the barrier in front of this segment, for the leaders), and it must have landed before the barrier that opens the
         // leading group's segment L of step kp + 1 (= the one that closes their C(kp): they wait there).
-        if (grp == 0 && kp + 1 < nk2) issue(kp + 1, (kp + 1) & 1);
+        if (grp == 0 && kp + 1 < nk2) { issue_A(kp + 1, (kp + 1) & 1); if (!SPLITDMA) issue_W(kp + 1, (kp + 1) & 1); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (SPLITDMA && grp == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // W(kp + 1), issued one period ago, has landed: the leaders read it after the next barrier
+            if (kp + 2 < nk2) issue_W(kp + 2, kp & 1);                  // into the pair whose reads have just completed
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- C: hi.lo, lo.hi, hi.hi (smallest first) -------------------------------------------------------------------------
@@ -195,13 +215,18 @@ bool gemm_f16x2_tg_eligible(const Bf16x3Args& a) {
     return a.N % 128 == 0 && a.K % 32 == 0 && a.Mpad % 256 == 0;
 }
 
-template <bool WINDOWED, int TI, int TJ>
-static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream) {
+template <bool WINDOWED, int TI, int TJ, bool SPLITDMA>
+static int launch_tg2(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream) {
     using Cfg = TgCfg<TI, TJ>;
-    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<WINDOWED, TI, TJ>, Cfg::LDS_BYTES)) return rc; }
-    hipLaunchKernelGGL((gemm_f16x2_tg_kernel<WINDOWED, TI, TJ>), grid, dim3(512), Cfg::LDS_BYTES, stream, a, ga);
+    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<WINDOWED, TI, TJ, SPLITDMA>, Cfg::LDS_BYTES)) return rc; }
+    hipLaunchKernelGGL((gemm_f16x2_tg_kernel<WINDOWED, TI, TJ, SPLITDMA>), grid, dim3(512), Cfg::LDS_BYTES, stream, a, ga);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
+}
+template <bool WINDOWED, int TI, int TJ>
+static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream) {
+    static const bool split = !(std::getenv("AUDIOTOKEN_TG_SPLITDMA") && std::atoi(std::getenv("AUDIOTOKEN_TG_SPLITDMA")) == 0);
+    return split ? launch_tg2<WINDOWED, TI, TJ, true>(a, ga, grid, stream) : launch_tg2<WINDOWED, TI, TJ, false>(a, ga, grid, stream);
 }
 
 int launch_gemm_f16x2_tg(const Bf16x3Args& a, hipStream_t stream) {
