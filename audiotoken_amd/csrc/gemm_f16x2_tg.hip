@@ -25,6 +25,7 @@
 #include "split_epilogue.h"
 #include <type_traits>
 #include <cstdlib>
+#include <cstdio>
 
 namespace at {
 
@@ -44,6 +45,17 @@ struct TgCfg {
     static constexpr int DMA_PER_CHUNK = BM / 128;     // 1-KB pieces (32 rows) of a chunk per leading wave
 };
 
+// -DTG_DEBUG_STAMPS (tools/tg_stamps.sh; never in the product build): wave 0 (leading group) and wave 4 (trailing group) of workgroup 0 sum the
+// cycle counter over the segments of their K steps; the launcher prints the averages per K step for the first launches of each shape
+#ifdef TG_DEBUG_STAMPS
+__device__ unsigned long long tg_stamps[2][8];
+#define TG_T(i) const unsigned long long tg_t##i = __builtin_readcyclecounter()
+#define TG_ACC(k, a_, b_) tg_d[k] += tg_t##b_ - tg_t##a_
+#else
+#define TG_T(i) do {} while (0)
+#define TG_ACC(k, a_, b_) do {} while (0)
+#endif
+
 // WINDOWED = false: a plain linear layer (one tap, stride 1): the k-block -> row offset map is a multiplication; true: conv1d windows
 // (per k-block two integer divisions on the scalar unit — kept off the linear layers' instruction stream)
 // ga > 0: XCD-aware tile order. Workgroups b and b + 8 share an XCD (round-robin dispatch: speed only, never correctness): XCD x gets a
@@ -54,6 +66,9 @@ template <bool WINDOWED, int TI, int TJ, bool SPLITDMA>
 __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_kernel(Bf16x3Args a, int ga) {
     using Cfg = TgCfg<TI, TJ>;
     constexpr int BM = Cfg::BM, TG_PIECE = Cfg::PIECE, TG_SLOT = Cfg::SLOT;
+#ifdef TG_DEBUG_STAMPS
+    const unsigned long long tg_entry = __builtin_readcyclecounter();
+#endif
     typedef SchemeF16x2 SC;
     typedef _Float16 PT;
     typedef f16x8 V8;
@@ -147,7 +162,11 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();      // the trailing group starts one barrier late
+#ifdef TG_DEBUG_STAMPS
+    unsigned long long tg_d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int kp = 0; kp < nk2; ++kp) {
+        TG_T(0);
         // ---- L -------------------------------------------------------------------------------------------------------------
         const PT* s = lds + (kp & 1) * 2 * TG_SLOT + foff;
         V8 xa[2][TI], wb[2][TJ];
@@ -162,13 +181,18 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         // passed (= the barrier in front of this segment, for the leaders), and it must have landed before the barrier that opens the
         // leading group's segment L of step kp + 1 (= the one that closes their C(kp): they wait there).
         if (grp == 0 && kp + 1 < nk2) { issue_A(kp + 1, (kp + 1) & 1); if (!SPLITDMA) issue_W(kp + 1, (kp + 1) & 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        TG_T(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TG_T(2);
         if (SPLITDMA && grp == 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // W(kp + 1), issued one period ago, has landed: the leaders read it after the next barrier
             if (kp + 2 < nk2) issue_W(kp + 2, kp & 1);                  // into the pair whose reads have just completed
         }
         __builtin_amdgcn_sched_barrier(0);
+        TG_T(3);
         __builtin_amdgcn_s_barrier();
+        TG_T(4);
         // ---- C: hi.lo, lo.hi, hi.hi (smallest first) -------------------------------------------------------------------------
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -179,21 +203,52 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[SC::prod_w(t)][j], xa[SC::prod_a(t)][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        TG_T(5);
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the leaders' share of step kp + 1 has landed
         __builtin_amdgcn_sched_barrier(0);
+        TG_T(6);
         __builtin_amdgcn_s_barrier();
+        TG_T(7);
+        TG_ACC(0, 0, 1); TG_ACC(1, 1, 2); TG_ACC(2, 2, 3); TG_ACC(3, 3, 4); TG_ACC(4, 4, 5); TG_ACC(5, 5, 6); TG_ACC(6, 6, 7);
     }
+#ifdef TG_DEBUG_STAMPS
+    const unsigned long long tg_loop_end = __builtin_readcyclecounter();
+#endif
     if (grp == 0) __builtin_amdgcn_s_barrier();      // pairs the trailing group's last barrier
     // lane holds, per 16 x 16 tile (i, j): output row m = .. + lane & 15 and the 4 consecutive columns n = .. + 4 (lane >> 4) ..
     XbEpilogue<SC> ep(a, clip);
+    // bias quads once per column tile, residual quads one row tile ahead of the stores (split_epilogue.h: inside apply() they would each
+    // wait for the previous store)
     auto epilogue = [&](auto mode) {
         constexpr int E = decltype(mode)::value;
+        constexpr bool PLAIN = E == XB_EPI_LINEAR || E == XB_EPI_GELU;
+        f4 bj[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bj[j] = ep.load_bias(n0 + wn * TJ * 16 + j * 16 + 4 * fq);
+        const int mbase = m0 + wm * TI * 16 + fr;
+        f4 rcur[TJ], rnext[TJ];
+        auto load_row = [&](int i, f4 (&r)[TJ]) {
+            const int m = mbase + i * 16;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                r[j] = (PLAIN && m < a.M) ? ep.load_residual(m, n0 + wn * TJ * 16 + j * 16 + 4 * fq) : f4{0.f, 0.f, 0.f, 0.f};
+        };
+        if constexpr (PLAIN) load_row(0, rcur);
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            const int m = m0 + wm * TI * 16 + i * 16 + fr;
-            if (m >= a.M) continue;
+            const int m = mbase + i * 16;
+            if constexpr (PLAIN) {
+                if (i + 1 < TI) load_row(i + 1, rnext);
+            }
+            if (m < a.M) {
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) ep.template apply<E>(m, n0 + wn * TJ * 16 + j * 16 + 4 * fq, acc[i][j]);
+                for (int j = 0; j < TJ; ++j) ep.template apply_with<E>(m, n0 + wn * TJ * 16 + j * 16 + 4 * fq, acc[i][j], bj[j], rcur[j]);
+            }
+            if constexpr (PLAIN) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) rcur[j] = rnext[j];
+            }
         }
     };
     switch (a.epi) {
@@ -207,6 +262,12 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         default: epilogue(std::integral_constant<int, XB_EPI_LINEAR>{}); break;
     }
     ep.finish();
+#ifdef TG_DEBUG_STAMPS
+    if (blockIdx.x == (gridDim.x * 3) / 4 && (tid == 0 || tid == 256)) {
+        for (int i = 0; i < 7; ++i) tg_stamps[grp][i] = tg_d[i];
+        tg_stamps[grp][7] = ((__builtin_readcyclecounter() - tg_loop_end) << 32) | ((tg_loop_end - tg_entry) & 0xffffffffull);   // epilogue | entry..loop end
+    }
+#endif
 }
 
 // eligibility: the fp16 scheme, whole 128-column tiles, K steps of 32, row padding of 256
@@ -221,6 +282,23 @@ static int launch_tg2(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream
     { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<WINDOWED, TI, TJ, SPLITDMA>, Cfg::LDS_BYTES)) return rc; }
     hipLaunchKernelGGL((gemm_f16x2_tg_kernel<WINDOWED, TI, TJ, SPLITDMA>), grid, dim3(512), Cfg::LDS_BYTES, stream, a, ga);
     AT_CHECK_HIP(hipGetLastError());
+#ifdef TG_DEBUG_STAMPS
+    {
+        static int printed = 0;
+        if (printed < 12) {
+            ++printed;
+            (void)hipStreamSynchronize(stream);
+            unsigned long long hbuf[2][8];
+            (void)hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(tg_stamps), sizeof(hbuf));
+            const double nk = a.K / 32;
+            for (int g = 0; g < 2; ++g)
+                std::fprintf(stderr, "tg stamps M %d N %d K %d tile %d split %d %s: issue %.0f  lds-wait %.0f  dma-wait+issue %.0f  barrierA %.0f  mfma %.0f  dma-wait %.0f  barrierB %.0f (cycles per K step)\n",
+                             a.M, a.N, a.K, TI * 64, (int)SPLITDMA, g ? "trailers" : "leaders ", hbuf[g][0] / nk, hbuf[g][1] / nk, hbuf[g][2] / nk, hbuf[g][3] / nk,
+                             hbuf[g][4] / nk, hbuf[g][5] / nk, hbuf[g][6] / nk),
+                std::fprintf(stderr, "    whole tile: entry -> end of K loop %llu cycles (%d K steps), epilogue %llu\n", hbuf[g][7] & 0xffffffffull, (int)nk, hbuf[g][7] >> 32);
+        }
+    }
+#endif
     return 0;
 }
 template <bool WINDOWED, int TI, int TJ>
