@@ -303,7 +303,7 @@ static int launch_tg2(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream
 }
 template <bool WINDOWED, int TI, int TJ>
 static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream) {
-    static const bool split = !(std::getenv("AUDIOTOKEN_TG_SPLITDMA") && std::atoi(std::getenv("AUDIOTOKEN_TG_SPLITDMA")) == 0);
+    static const bool split = std::getenv("AUDIOTOKEN_TG_SPLITDMA") && std::atoi(std::getenv("AUDIOTOKEN_TG_SPLITDMA")) != 0;
     return split ? launch_tg2<WINDOWED, TI, TJ, true>(a, ga, grid, stream) : launch_tg2<WINDOWED, TI, TJ, false>(a, ga, grid, stream);
 }
 
