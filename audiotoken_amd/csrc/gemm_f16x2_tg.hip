@@ -62,7 +62,7 @@ __device__ unsigned long long tg_stamps[2][8];
 // contiguous range of m-tiles and walks it in groups of `ga` m-tiles x all n-tiles, m fastest — the ~32 tiles an XCD runs at a time then
 // share `ga` activation tiles and 32 / ga weight tiles in ITS L2, and an activation tile is fetched into one L2 instead of all eight
 // (n-fastest order: 8 x the activation bytes leave the Infinity Cache; the K = 4096 GEMM moved 12.6 GB per launch that way).
-template <bool WINDOWED, int TI, int TJ, bool SPLITDMA>
+template <bool WINDOWED, int TI, int TJ>
 __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_kernel(Bf16x3Args a, int ga) {
     using Cfg = TgCfg<TI, TJ>;
     constexpr int BM = Cfg::BM, TG_PIECE = Cfg::PIECE, TG_SLOT = Cfg::SLOT;
@@ -152,13 +152,12 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    // SPLITDMA: the DMA issue is shared — the leaders move the activation chunks ONE step ahead (issued in their segment L, awaited after
-    // their C), the trailers the weight chunks TWO steps ahead (issued at the END of their segment L, when every read of that slot pair has
-    // returned — the leaders' at barrier A, their own by lgkmcnt(0) — and awaited one period later at the same place, i.e. before the barrier
-    // that opens the leaders' segment L of that step). The leaders' L then carries 8 DMA instructions instead of 16 (it was the longest
-    // segment: ~2400 cycles against 1536 of MFMAs), the trailers' L, which had ~1000 cycles of slack, the other 8.
+    // (Round 2 tried sharing the DMA issue between the groups — leaders: activation chunks one step ahead; trailers: weight chunks two steps ahead,
+    // issued at the end of their read segment — which shortens the leaders' longest segment (in-kernel stamps: 1 800 -> 900 cycles, FFN GEMMs
+    // +2.3 %), and a persistent-tile form on top of it (+1 %). With ONE workgroup per CU every test passed; with two co-resident workgroups (the
+    // 128 x 128 shape) tiles of the chained acoustic GEMMs came out wrong sporadically — only when the trailing waves issue LDS-DMA, never with the
+    // leaders issuing the same chunks. Not understood, so not shipped: tests/test_acoustic_gpu.py::test_repeated_encodes_are_identical caught it.)
     if (grp == 0) { issue_A(0, 0); issue_W(0, 0); }
-    if (SPLITDMA && grp == 1 && nk2 > 1) issue_W(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();      // the trailing group starts one barrier late
@@ -180,15 +179,11 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         // DMA of the NEXT step: its slot pair is free once the barrier that closed the trailing group's segment L of step kp - 1 has
         // passed (= the barrier in front of this segment, for the leaders), and it must have landed before the barrier that opens the
         // leading group's segment L of step kp + 1 (= the one that closes their C(kp): they wait there).
-        if (grp == 0 && kp + 1 < nk2) { issue_A(kp + 1, (kp + 1) & 1); if (!SPLITDMA) issue_W(kp + 1, (kp + 1) & 1); }
+        if (grp == 0 && kp + 1 < nk2) { issue_A(kp + 1, (kp + 1) & 1); issue_W(kp + 1, (kp + 1) & 1); }
         __builtin_amdgcn_sched_barrier(0);
         TG_T(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TG_T(2);
-        if (SPLITDMA && grp == 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // W(kp + 1), issued one period ago, has landed: the leaders read it after the next barrier
-            if (kp + 2 < nk2) issue_W(kp + 2, kp & 1);                  // into the pair whose reads have just completed
-        }
         __builtin_amdgcn_sched_barrier(0);
         TG_T(3);
         __builtin_amdgcn_s_barrier();
@@ -276,11 +271,11 @@ bool gemm_f16x2_tg_eligible(const Bf16x3Args& a) {
     return a.N % 128 == 0 && a.K % 32 == 0 && a.Mpad % 256 == 0;
 }
 
-template <bool WINDOWED, int TI, int TJ, bool SPLITDMA>
-static int launch_tg2(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream) {
+template <bool WINDOWED, int TI, int TJ>
+static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream) {
     using Cfg = TgCfg<TI, TJ>;
-    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<WINDOWED, TI, TJ, SPLITDMA>, Cfg::LDS_BYTES)) return rc; }
-    hipLaunchKernelGGL((gemm_f16x2_tg_kernel<WINDOWED, TI, TJ, SPLITDMA>), grid, dim3(512), Cfg::LDS_BYTES, stream, a, ga);
+    { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<WINDOWED, TI, TJ>, Cfg::LDS_BYTES)) return rc; }
+    hipLaunchKernelGGL((gemm_f16x2_tg_kernel<WINDOWED, TI, TJ>), grid, dim3(512), Cfg::LDS_BYTES, stream, a, ga);
     AT_CHECK_HIP(hipGetLastError());
 #ifdef TG_DEBUG_STAMPS
     {
@@ -291,20 +286,16 @@ static int launch_tg2(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream
             unsigned long long hbuf[2][8];
             (void)hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(tg_stamps), sizeof(hbuf));
             const double nk = a.K / 32;
-            for (int g = 0; g < 2; ++g)
-                std::fprintf(stderr, "tg stamps M %d N %d K %d tile %d split %d %s: issue %.0f  lds-wait %.0f  dma-wait+issue %.0f  barrierA %.0f  mfma %.0f  dma-wait %.0f  barrierB %.0f (cycles per K step)\n",
-                             a.M, a.N, a.K, TI * 64, (int)SPLITDMA, g ? "trailers" : "leaders ", hbuf[g][0] / nk, hbuf[g][1] / nk, hbuf[g][2] / nk, hbuf[g][3] / nk,
-                             hbuf[g][4] / nk, hbuf[g][5] / nk, hbuf[g][6] / nk),
+            for (int g = 0; g < 2; ++g) {
+                std::fprintf(stderr, "tg stamps M %d N %d K %d tile %d %s: issue %.0f  lds-wait %.0f  (unused) %.0f  barrierA %.0f  mfma %.0f  dma-wait %.0f  barrierB %.0f (cycles per K step)\n",
+                             a.M, a.N, a.K, TI * 64, g ? "trailers" : "leaders ", hbuf[g][0] / nk, hbuf[g][1] / nk, hbuf[g][2] / nk, hbuf[g][3] / nk,
+                             hbuf[g][4] / nk, hbuf[g][5] / nk, hbuf[g][6] / nk);
                 std::fprintf(stderr, "    whole tile: entry -> end of K loop %llu cycles (%d K steps), epilogue %llu\n", hbuf[g][7] & 0xffffffffull, (int)nk, hbuf[g][7] >> 32);
+            }
         }
     }
 #endif
     return 0;
-}
-template <bool WINDOWED, int TI, int TJ>
-static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream) {
-    static const bool split = std::getenv("AUDIOTOKEN_TG_SPLITDMA") && std::atoi(std::getenv("AUDIOTOKEN_TG_SPLITDMA")) != 0;
-    return split ? launch_tg2<WINDOWED, TI, TJ, true>(a, ga, grid, stream) : launch_tg2<WINDOWED, TI, TJ, false>(a, ga, grid, stream);
 }
 
 int launch_gemm_f16x2_tg(const Bf16x3Args& a, hipStream_t stream) {
