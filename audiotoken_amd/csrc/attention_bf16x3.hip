@@ -293,11 +293,14 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                PT q[NP];
-                split_n<SC>(s[8 * ks + j] * PS, q);   // p <= 1: p * 2^10 always fits
+            for (int jq = 0; jq < 2; ++jq) {   // quads, so that the fp16 scheme's split compiles to the packed forms (split_scheme.h)
+                const f4 pv = {s[8 * ks + 4 * jq], s[8 * ks + 4 * jq + 1], s[8 * ks + 4 * jq + 2], s[8 * ks + 4 * jq + 3]};
+                typename SC::V4 q4[NP];
+                split4<SchemeNoCheck<SC>>(pv, PS, q4);   // p <= 1: p * 2^10 always fits
 #pragma unroll
-                for (int i = 0; i < NP; ++i) pp[i][ks][j] = q[i];
+                for (int i = 0; i < NP; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pp[i][ks][4 * jq + j] = q4[i][j];
             }
         // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------------------------
 #pragma unroll
