@@ -310,7 +310,8 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, cons
 // Workgroup = 16 consecutive rows (4 waves x 4 rows); the pieces go through LDS so that every (piece, k-block) is written as one
 // contiguous 512-byte run (16 rows x 32 B) — a wave writing its own row directly scatters 32-byte segments (measured slower in round 1).
 // ------------------------------------------------------------------------------------------------------
-constexpr int LNS_ROWS = 16, LNS_D = 1024;
+constexpr int LNS_ROWS = 8, LNS_D = 1024;    // rows per workgroup: 2 per wave (32 KB of LDS with two pieces: four workgroups per CU)
+constexpr int LNS_RW = LNS_ROWS / 4;          // rows per wave
 
 template <class SC, bool WRITE_Y>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -323,12 +324,12 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long r0 = (long long)blockIdx.x * LNS_ROWS;
     bool over = false;
-    // all four rows of the wave are loaded before the first is reduced: one row at a time left 4 KB per wave in flight (3.5 TB/s, 70 % of the
-    // wave cycles waiting)
-    f4 vall[4][4];
+    // all rows of the wave are loaded before the first is reduced (one row at a time left 4 KB per wave in flight: 3.5 TB/s, 70 % of the wave
+    // cycles waiting); 8 rows per workgroup instead of 16 puts four workgroups on a CU: 16.0 -> 13.7 ms per semantic_m step (4 rows: no further gain)
+    f4 vall[LNS_RW][4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const long long row = r0 + wave * 4 + rr;
+    for (int rr = 0; rr < LNS_RW; ++rr) {
+        const long long row = r0 + wave * LNS_RW + rr;
         if (row < rows) {
             const f4* xr = reinterpret_cast<const f4*>(x + row * LNS_D);
 #pragma unroll
@@ -339,8 +340,8 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
         }
     }
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int lr = wave * 4 + rr;
+    for (int rr = 0; rr < LNS_RW; ++rr) {
+        const int lr = wave * LNS_RW + rr;
         const long long row = r0 + lr;
         f4 v[4];
 #pragma unroll
@@ -384,11 +385,12 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
         }
     }
     __syncthreads();
-    // (piece, k-block) = 16 rows x 32 B = 512 contiguous bytes = 32 chunks of 16 B: thread -> chunk
+    // (piece, k-block) = LNS_ROWS rows x 32 B contiguous = 2 LNS_ROWS chunks of 16 B: thread -> chunk
     typedef unsigned int u4_ __attribute__((ext_vector_type(4)));
     const long long ps = rows_pad * (long long)LNS_D;
-    for (int e = threadIdx.x; e < NP * (LNS_D / 16) * 32; e += 256) {
-        const int ch = e & 31, kb = (e >> 5) & 63, pi = e >> 11;
+    constexpr int CH = 2 * LNS_ROWS;
+    for (int e = threadIdx.x; e < NP * (LNS_D / 16) * CH; e += 256) {
+        const int ch = e % CH, kb = (e / CH) & 63, pi = e / (CH * 64);
         const int lr = ch >> 1;
         if (r0 + lr < rows_pad)
             *reinterpret_cast<u4_*>(out + pi * ps + ((long long)kb * rows_pad + r0 + lr) * 16 + (ch & 1) * 8) =
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
 
 int launch_layernorm_split(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, __bf16* out, long long rows, long long rows_pad,
                            int D, int scheme, float scale, int* status, hipStream_t stream) {
-    AT_REQUIRE(D == LNS_D && rows_pad >= rows && rows_pad % LNS_ROWS == 0 && out, "layernorm_split: D must be 1024, rows_pad a multiple of 16");
+    AT_REQUIRE(D == LNS_D && rows_pad >= rows && rows_pad % LNS_ROWS == 0 && out, "layernorm_split: D must be 1024, rows_pad a multiple of 8");
     const unsigned blocks = (unsigned)(rows_pad / LNS_ROWS);
     if (scheme == XB_SCHEME_F16X2) {
         _Float16* o = reinterpret_cast<_Float16*>(out);
