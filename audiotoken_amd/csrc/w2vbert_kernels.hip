@@ -688,11 +688,11 @@ int launch_relpos_attention(const float* qkv, const float* amask, const float* d
 // Workgroup = 8 consecutive time steps of one clip x all 1024 channels; thread = 4 channels. Each input row is
 // read once per workgroup (38 rows for 8 outputs) instead of 31 times; tap weights [31][1024] stay in registers.
 // ------------------------------------------------------------------------------------------------------
-constexpr int DW_TT = 8, DW_K = 31;
+constexpr int DW_K = 31;
 
 // SC = void: fp32 output [B*T][1024]; SC = an operand scheme: the output goes straight to the pointwise-conv-2 GEMM as K-blocked pieces
 // [NP][64][rows_pad][16] (thread = 4 channels = one quarter of a k-block row: an 8-byte store per piece)
-template <class SC>
+template <class SC, int DW_TT>
 __global__ __launch_bounds__(256) void dwconv_ln_swish_kernel(const float* __restrict__ g, const float* __restrict__ w /*[31][1024]*/,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ out, int T, void* __restrict__ pieces, long long rows_pad, float scale,
@@ -771,13 +771,14 @@ __global__ __launch_bounds__(256) void dwconv_ln_swish_kernel(const float* __res
 
 int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,
                            hipStream_t stream, __bf16* pieces, long long rows_pad, int scheme, float scale, int* status) {
-    dim3 grid((T + DW_TT - 1) / DW_TT, B);
+    constexpr int TT = 16;   // output rows per workgroup: 46 input rows per 16 outputs (8 rows: 38 per 8 — 1.4 ms more per semantic_m step, same box)
+    dim3 grid((T + TT - 1) / TT, B);
     if (pieces && scheme == XB_SCHEME_F16X2)
-        hipLaunchKernelGGL(dwconv_ln_swish_kernel<SchemeF16x2>, grid, dim3(256), 0, stream, g, w, gamma, beta, out, T, (void*)pieces, rows_pad, scale, status);
+        hipLaunchKernelGGL((dwconv_ln_swish_kernel<SchemeF16x2, TT>), grid, dim3(256), 0, stream, g, w, gamma, beta, out, T, (void*)pieces, rows_pad, scale, status);
     else if (pieces)
-        hipLaunchKernelGGL(dwconv_ln_swish_kernel<SchemeBf16x3>, grid, dim3(256), 0, stream, g, w, gamma, beta, out, T, (void*)pieces, rows_pad, scale, status);
+        hipLaunchKernelGGL((dwconv_ln_swish_kernel<SchemeBf16x3, TT>), grid, dim3(256), 0, stream, g, w, gamma, beta, out, T, (void*)pieces, rows_pad, scale, status);
     else
-        hipLaunchKernelGGL(dwconv_ln_swish_kernel<void>, grid, dim3(256), 0, stream, g, w, gamma, beta, out, T, nullptr, 0, 1.0f, nullptr);
+        hipLaunchKernelGGL((dwconv_ln_swish_kernel<void, TT>), grid, dim3(256), 0, stream, g, w, gamma, beta, out, T, nullptr, 0, 1.0f, nullptr);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
