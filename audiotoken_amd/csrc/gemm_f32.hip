@@ -24,7 +24,7 @@ __device__ __forceinline__ f4 apply_act4(f4 v, int epi) {
     if (epi == EPI_SWISH) {
         // x * sigmoid(x) with v_exp_f32 / v_rcp_f32 (each ~1 ulp): the FFN epilogue evaluates 64 of these per lane per tile
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = v[k] * __frcp_rn(1.0f + __expf(-v[k]));
+        for (int k = 0; k < 4; ++k) v[k] = v[k] * sigmoidf_(v[k]);
     } else if (epi == EPI_ELU) {
         v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
     } else if (epi == EPI_GELU) {
