@@ -157,10 +157,22 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
     // +2.3 %), and a persistent-tile form on top of it (+1 %). With ONE workgroup per CU every test passed; with two co-resident workgroups (the
     // 128 x 128 shape) tiles of the chained acoustic GEMMs came out wrong sporadically — only when the trailing waves issue LDS-DMA, never with the
     // leaders issuing the same chunks. Not understood, so not shipped: tests/test_acoustic_gpu.py::test_repeated_encodes_are_identical caught it.)
+#ifdef TG_DEBUG_STAMPS
+    const unsigned long long tg_p0 = __builtin_readcyclecounter();
+#endif
     if (grp == 0) { issue_A(0, 0); issue_W(0, 0); }
+#ifdef TG_DEBUG_STAMPS
+    const unsigned long long tg_p1 = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TG_DEBUG_STAMPS
+    const unsigned long long tg_p2 = __builtin_readcyclecounter();
+#endif
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();      // the trailing group starts one barrier late
+#ifdef TG_DEBUG_STAMPS
+    const unsigned long long tg_p3 = __builtin_readcyclecounter();
+#endif
 #ifdef TG_DEBUG_STAMPS
     unsigned long long tg_d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -261,6 +273,7 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
     if (blockIdx.x == (gridDim.x * 3) / 4 && (tid == 0 || tid == 256)) {
         for (int i = 0; i < 7; ++i) tg_stamps[grp][i] = tg_d[i];
         tg_stamps[grp][7] = ((__builtin_readcyclecounter() - tg_loop_end) << 32) | ((tg_loop_end - tg_entry) & 0xffffffffull);   // epilogue | entry..loop end
+        tg_stamps[grp][2] = ((tg_p0 - tg_entry) << 48) | ((tg_p1 - tg_p0) << 32) | ((tg_p2 - tg_p1) << 16) | ((tg_p3 - tg_p2) & 0xffff);   // prologue: setup | issue | DMA wait | barriers
     }
 #endif
 }
@@ -290,7 +303,8 @@ static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream)
                 std::fprintf(stderr, "tg stamps M %d N %d K %d tile %d %s: issue %.0f  lds-wait %.0f  (unused) %.0f  barrierA %.0f  mfma %.0f  dma-wait %.0f  barrierB %.0f (cycles per K step)\n",
                              a.M, a.N, a.K, TI * 64, g ? "trailers" : "leaders ", hbuf[g][0] / nk, hbuf[g][1] / nk, hbuf[g][2] / nk, hbuf[g][3] / nk,
                              hbuf[g][4] / nk, hbuf[g][5] / nk, hbuf[g][6] / nk);
-                std::fprintf(stderr, "    whole tile: entry -> end of K loop %llu cycles (%d K steps), epilogue %llu\n", hbuf[g][7] & 0xffffffffull, (int)nk, hbuf[g][7] >> 32);
+                std::fprintf(stderr, "    whole tile: entry -> end of K loop %llu cycles (%d K steps), epilogue %llu; prologue: set-up %llu  issue %llu  DMA wait %llu  barriers %llu\n",
+                             hbuf[g][7] & 0xffffffffull, (int)nk, hbuf[g][7] >> 32, hbuf[g][2] >> 48, (hbuf[g][2] >> 32) & 0xffff, (hbuf[g][2] >> 16) & 0xffff, hbuf[g][2] & 0xffff);
             }
         }
     }
