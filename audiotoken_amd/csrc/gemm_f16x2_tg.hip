@@ -156,7 +156,9 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
     // issued at the end of their read segment — which shortens the leaders' longest segment (in-kernel stamps: 1 800 -> 900 cycles, FFN GEMMs
     // +2.3 %), and a persistent-tile form on top of it (+1 %). With ONE workgroup per CU every test passed; with two co-resident workgroups (the
     // 128 x 128 shape) tiles of the chained acoustic GEMMs came out wrong sporadically — only when the trailing waves issue LDS-DMA, never with the
-    // leaders issuing the same chunks. Not understood, so not shipped: tests/test_acoustic_gpu.py::test_repeated_encodes_are_identical caught it.)
+    // leaders issuing the same chunks. Not understood, so not shipped: tests/test_acoustic_gpu.py::test_repeated_encodes_are_identical caught it.
+    // Also measured, same box A/B on semantic_m: issuing the DMA before the fragment reads of the segment (+-0), 2-4 of the weight instructions
+    // between the first MFMAs of C instead of in L (-0.2 ... -0.7 %), staggering the CUs' tile phases by up to 15 us (+-0).)
 #ifdef TG_DEBUG_STAMPS
     const unsigned long long tg_p0 = __builtin_readcyclecounter();
 #endif
