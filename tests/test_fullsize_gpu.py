@@ -1,5 +1,7 @@
 """GPU: BASELINE.json-size runs checked through size-independent properties (batch independence, causality /
-prefix invariance, determinism) plus one full-depth oracle comparison per tokenizer."""
+prefix invariance, determinism), full-depth oracle comparisons, and — `test_bench_batch_*` — the benchmark's OWN batches
+(audiotoken_amd/synthetic.py, the generator bench.py times) with a pinned token checksum and >= 32 / 5 / 4 clips oracle-checked on the
+"equal, or explained" bar of tests/parity.py, the differing-id counts printed."""
 import numpy as np
 import pytest
 import torch
@@ -8,6 +10,11 @@ from audiotoken_amd import weights as W
 from tests import parity as P
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def w2vbert_19():
+    return W.synth_w2vbert_weights(n_layers=19, seed=0, with_vq=True)
 
 
 def test_acoustic_full_batch_properties(cuda_device):
@@ -38,12 +45,12 @@ def test_acoustic_full_batch_properties(cuda_device):
         P.assert_rvq_equal_or_explained(codes[i:i + 1], ref, margins, P.RVQ_TIE, f"acoustic 10 s clip {i}")
 
 
-def test_semantic_m_full_depth_properties(cuda_device):
+def test_semantic_m_full_depth_properties(cuda_device, w2vbert_19):
     """configs[3] per-GPU share: 64 clips x 30 s, 19 conformer layers."""
     from audiotoken_amd.configs import Wav2VecBertConfig
     from audiotoken_amd.encoder import Wav2VecBertEncoder
     from oracle import w2vbert_ref as R
-    w = W.synth_w2vbert_weights(n_layers=19, seed=0, with_vq=True)
+    w = w2vbert_19
     enc = Wav2VecBertEncoder(Wav2VecBertConfig(), device="cuda:0", quantize=True, weights=w)
     B, N = 64, 480000
     base = torch.from_numpy(W.synth_waveform(4, N, 16000, seed=1234)).cuda()
@@ -134,3 +141,112 @@ def test_audiotoken_encode_full_clip(cuda_device):
     ref, margins = R.acoustic_encode(w, torch.from_numpy(wav), 8, return_margins=True)
     P.assert_rvq_equal_or_explained(got, ref, margins, P.RVQ_TIE, "AudioToken.encode, one 10 s clip")
     assert torch.equal(got, tok.encode(torch.from_numpy(wav)))
+
+
+# ---- the benchmark's own batches --------------------------------------------------------------------------------------------------
+# Which clips go to the oracle: 37 is odd, so j -> 37 j mod 256 visits distinct clips and all 16 base waveforms of the repeated batch
+ACOUSTIC_ORACLE_CLIPS = sorted((37 * j) % 256 for j in range(32))
+
+
+def _report(what, n_ids, n_differ, n_unexplained):
+    print(f"[parity-at-size] {what}: {n_differ} of {n_ids} ids differ from the oracle, {n_unexplained} unexplained")
+
+
+def test_bench_batch_acoustic_vs_oracle(cuda_device):
+    """bench.py's acoustic batch (configs[1], 256 x 10 s, rank 0): the token checksum equals the committed constant — a change of the
+    default arithmetic cannot move ids unnoticed — and 32 of the 256 clips (all 16 base waveforms, scales 0.5 .. 1.0) equal the CPU
+    oracle's ids or are explained by an oracle near-tie (reference audiotoken/encoder.py:44-57)."""
+    from audiotoken_amd import synthetic as S
+    from audiotoken_amd.configs import AcousticEncoderConfig
+    from audiotoken_amd.encoder import AcousticEncoder
+    from oracle import encodec_ref as R
+    w = W.synth_encodec_weights(seed=0, with_decoder=False)
+    enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=w)
+    wav = S.acoustic_batch(256, 240000, cuda_device)
+    codes = enc(wav, None)
+    assert enc.last_status() == 0
+    checksum = S.token_checksum(codes)
+    print(f"[parity-at-size] acoustic bench batch token_checksum {checksum} (pinned {S.PINNED_CHECKSUMS['acoustic']})")
+    wt = {k: torch.from_numpy(v) for k, v in w.items()}
+    n_differ = n_bad = 0
+    for c0 in range(0, len(ACOUSTIC_ORACLE_CLIPS), 8):
+        idx = ACOUSTIC_ORACLE_CLIPS[c0:c0 + 8]
+        ref, margins = R.acoustic_encode(wt, wav[idx].cpu(), 8, return_margins=True)
+        n_ids, n_frames, bad = P.explain_rvq_mismatches(codes[idx], ref, margins, P.RVQ_TIE)
+        n_differ += n_ids
+        n_bad += bad
+    _report(f"acoustic bench batch, {len(ACOUSTIC_ORACLE_CLIPS)} of 256 clips", len(ACOUSTIC_ORACLE_CLIPS) * 8 * 750, n_differ, n_bad)
+    assert n_bad == 0, f"{n_bad} frames differ from the oracle without a near-tie"
+    assert checksum == S.PINNED_CHECKSUMS["acoustic"], \
+        f"acoustic token_checksum moved: {checksum} != pinned {S.PINNED_CHECKSUMS['acoustic']} — ids at size changed with the arithmetic"
+
+
+def test_bench_batch_semantic_m_vs_oracle(cuda_device, w2vbert_19):
+    """bench.py's semantic_m batch (configs[3] per-GPU share, 64 x 30 s, 19 layers): pinned checksum; 4 clips against the oracle at full
+    depth; then the same batch with two ragged clips (masks cut at 300 000 / 123 456 samples), both against the oracle at their valid positions
+    (reference audiotoken/encoder.py:163-186)."""
+    from audiotoken_amd import synthetic as S
+    from audiotoken_amd.configs import Wav2VecBertConfig
+    from audiotoken_amd.encoder import Wav2VecBertEncoder
+    from oracle import w2vbert_ref as R
+    w = w2vbert_19
+    enc = Wav2VecBertEncoder(Wav2VecBertConfig(), device="cuda:0", quantize=True, weights=w)
+    wav = S.semantic_m_batch(64, 480000, cuda_device)
+    mask = torch.ones_like(wav)
+    toks = enc(wav, mask)
+    assert enc.last_status() == 0
+    checksum = S.token_checksum(toks)
+    print(f"[parity-at-size] semantic_m bench batch token_checksum {checksum} (pinned {S.PINNED_CHECKSUMS['semantic_m']})")
+    wt = {k: torch.from_numpy(v) for k, v in w.items()}
+    n_differ = n_bad = n_ids = 0
+    for i in (1, 22, 43, 63):
+        ref, margins = R.semantic_m_encode(wt, wav[i:i + 1].cpu(), mask[i:i + 1].cpu(), 2, 19, return_margins=True)
+        _, am = R.processor(wav[i:i + 1].cpu(), mask[i:i + 1].cpu(), 2)
+        valid = am.bool().unsqueeze(1)
+        n, bad, _ = P.explain_token_mismatches(toks[i:i + 1], ref, margins, P.VQ_TIE, valid)
+        n_differ += n; n_bad += bad; n_ids += int(valid.sum())
+    # ragged rows: the reference zeroes nothing itself — the harness right-pads with zeros and mask 0 (datasets.py:98-103)
+    wav2, mask2 = wav.clone(), mask.clone()
+    for i, cut in ((3, 300000), (40, 123456)):
+        mask2[i, cut:] = 0
+        wav2[i, cut:] = 0
+    toks2 = enc(wav2, mask2)
+    assert enc.last_status() == 0
+    for i in (3, 40):
+        ref, margins = R.semantic_m_encode(wt, wav2[i:i + 1].cpu(), mask2[i:i + 1].cpu(), 2, 19, return_margins=True)
+        _, am = R.processor(wav2[i:i + 1].cpu(), mask2[i:i + 1].cpu(), 2)
+        valid = am.bool().unsqueeze(1)
+        n, bad, _ = P.explain_token_mismatches(toks2[i:i + 1], ref, margins, P.VQ_TIE, valid)
+        n_differ += n; n_bad += bad; n_ids += int(valid.sum())
+    # rows the ragged edit did not touch are unchanged (batch independence at size)
+    keep = [i for i in range(64) if i not in (3, 40)]
+    assert torch.equal(toks2[keep], toks[keep])
+    _report("semantic_m bench batch, 4 full + 2 ragged of 64 clips, 19 layers", n_ids, n_differ, n_bad)
+    assert n_bad == 0
+    assert checksum == S.PINNED_CHECKSUMS["semantic_m"], f"semantic_m token_checksum moved: {checksum} != pinned {S.PINNED_CHECKSUMS['semantic_m']}"
+
+
+def test_bench_batch_semantic_s_vs_oracle(cuda_device):
+    """bench.py's semantic_s batch (configs[2], 128 x 30 s, HuBERT 11 layers + k-means): pinned checksum, 4 clips against the oracle
+    (reference audiotoken/encoder.py:87-108)."""
+    from audiotoken_amd import synthetic as S
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder
+    from oracle import hubert_ref as R
+    w = W.synth_hubert_weights(11, 0, True)
+    enc = HubertEncoder(HubertEncoderConfig(), device="cuda:0", quantize=True, weights=w)
+    wav = S.semantic_s_batch(128, 480000, cuda_device)
+    mask = torch.ones_like(wav)
+    toks = enc(wav, mask)
+    assert enc.last_status() == 0
+    checksum = S.token_checksum(toks)
+    print(f"[parity-at-size] semantic_s bench batch token_checksum {checksum} (pinned {S.PINNED_CHECKSUMS['semantic_s']})")
+    n_differ = n_bad = 0
+    clips = (0, 3, 5, 6)
+    for i in clips:
+        ref, margins = R.semantic_s_encode(w, wav[i:i + 1].cpu(), mask[i:i + 1].cpu(), 11, return_margins=True)
+        n, bad, _ = P.explain_token_mismatches(toks[i:i + 1], ref, margins, P.VQ_TIE)
+        n_differ += n; n_bad += bad
+    _report(f"semantic_s bench batch, {len(clips)} of 128 clips (8 distinct), 11 layers", len(clips) * 1499, n_differ, n_bad)
+    assert n_bad == 0
+    assert checksum == S.PINNED_CHECKSUMS["semantic_s"], f"semantic_s token_checksum moved: {checksum} != pinned {S.PINNED_CHECKSUMS['semantic_s']}"

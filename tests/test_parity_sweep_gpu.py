@@ -1,0 +1,82 @@
+"""GPU: randomised parity sweep over WEIGHT seeds x waveform seeds (the driver-run successor of tests/sweeps/parity_sweep.py): the HIP path
+in its default arithmetic against the CPU oracle for every tokenizer and the decoder, on the "equal, or explained" bar of tests/parity.py —
+no percentage thresholds. Each case prints its differing-id count; DESIGN.md §5 quotes them."""
+import pytest
+import torch
+
+from audiotoken_amd import weights as W
+from tests import parity as P
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = (0, 1, 2, 3, 4, 5)
+
+
+@pytest.mark.parametrize("s", SEEDS)
+def test_sweep_acoustic(cuda_device, s):
+    """3 clips of 3 s + 320 s samples, 8 codebooks, weight seed 100 + s (reference audiotoken/encoder.py:44-57)."""
+    from audiotoken_amd.configs import AcousticEncoderConfig
+    from audiotoken_amd.encoder import AcousticEncoder
+    from oracle import encodec_ref as R
+    w = W.synth_encodec_weights(seed=100 + s, with_decoder=False)
+    enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=w)
+    wav = torch.from_numpy(W.synth_waveform(3, 72000 + 320 * s, 24000, seed=500 + s))
+    got = enc(wav.cuda(), None)
+    assert enc.last_status() == 0
+    ref, margins = R.acoustic_encode(w, wav, 8, return_margins=True)
+    P.assert_rvq_equal_or_explained(got, ref, margins, P.RVQ_TIE, f"[sweep] acoustic, weight seed {100 + s}")
+
+
+@pytest.mark.parametrize("s", SEEDS[:4])
+def test_sweep_decoder(cuda_device, s):
+    """Random codes -> waveform, weight seed 100 + s (reference audiotoken/decoder.py:66-76): max abs error < 1e-3 (measured ~2e-5)."""
+    from audiotoken_amd.configs import AcousticDecoderConfig
+    from audiotoken_amd.decoder import AcousticDecoder
+    from oracle import encodec_ref as R
+    w = W.synth_encodec_weights(seed=100 + s)
+    dec = AcousticDecoder(config=AcousticDecoderConfig(bandwidth=6), device="cuda:0", weights=w)
+    g = torch.Generator().manual_seed(900 + s)
+    codes = torch.randint(0, 1024, (2, 8, 40 + s), dtype=torch.long, generator=g)
+    got = dec(codes.cuda()).cpu().reshape(-1)
+    assert dec.last_status() == 0
+    ref = R.acoustic_decode(w, codes).reshape(-1)
+    err = float((got - ref).abs().max())
+    print(f"[sweep] decoder, weight seed {100 + s}: max abs err {err:.2e} at waveform scale {float(ref.abs().max()):.2f}")
+    assert err < 1e-3
+
+
+@pytest.mark.parametrize("s", SEEDS)
+def test_sweep_semantic_m(cuda_device, s):
+    """4 conformer layers, 2 clips of 4 s, one ragged; weight seed 200 + s (reference audiotoken/encoder.py:163-186)."""
+    from audiotoken_amd.configs import Wav2VecBertConfig
+    from audiotoken_amd.encoder import Wav2VecBertEncoder
+    from oracle import w2vbert_ref as R
+    w = W.synth_w2vbert_weights(n_layers=4, seed=200 + s, with_vq=True)
+    enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=4), device="cuda:0", quantize=True, weights=w)
+    wav = torch.from_numpy(W.synth_waveform(2, 64000, 16000, seed=600 + s))
+    mask = torch.ones_like(wav)
+    mask[1, 40000 + 1000 * s:] = 0
+    wav = wav * mask
+    got = enc(wav.cuda(), mask.cuda())
+    assert enc.last_status() == 0
+    wt = {k: torch.from_numpy(v) for k, v in w.items()}
+    ref, margins = R.semantic_m_encode(wt, wav, mask, 2, 4, return_margins=True)
+    _, am = R.processor(wav, mask, 2)
+    P.assert_tokens_equal_or_explained(got, ref, margins, P.VQ_TIE, f"[sweep] semantic_m, weight seed {200 + s}, valid positions", am.bool().unsqueeze(1))
+
+
+@pytest.mark.parametrize("s", SEEDS)
+def test_sweep_semantic_s(cuda_device, s):
+    """3 transformer layers, 2 clips of 3 s; weight seed 300 + s (reference audiotoken/encoder.py:87-108)."""
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    from oracle import hubert_ref as R
+    w = W.synth_hubert_weights(3, 300 + s, True)
+    enc = HubertEncoder(HubertEncoderConfig(output_layer=3), device="cuda:0", quantize=True, weights=w)
+    wav = torch.from_numpy(W.synth_waveform(2, 48000, 16000, seed=700 + s))
+    norm = torch.stack([hubert_processor(wav[i:i + 1])[0] for i in range(2)])
+    mask = torch.ones_like(norm)
+    got = enc(norm.cuda(), mask.cuda())
+    assert enc.last_status() == 0
+    ref, margins = R.semantic_s_encode(w, norm, mask, 3, return_margins=True)
+    P.assert_tokens_equal_or_explained(got, ref, margins, P.VQ_TIE, f"[sweep] semantic_s, weight seed {300 + s}")
