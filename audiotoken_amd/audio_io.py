@@ -9,12 +9,19 @@ from __future__ import annotations
 
 import math
 import os
+import struct
 from typing import Iterator, Tuple
 
 import numpy as np
 import torch
 
 from .configs import AUDIO_EXTS
+
+
+class AudioDecodeError(Exception):
+    """A file this build cannot turn into a mono waveform: a codec it does not ship (flac / mp3 / ogg need ffmpeg), a damaged or truncated
+    header, more than one channel. ``encode_batch_files`` skips such a file, records it in ``AudioToken.skipped_files`` and reports it at
+    the end of the run; anything else (a bug in resampling or chunking) propagates like in the reference (audiotoken/datasets.py __iter__)."""
 
 
 def _load_wav(path_or_file) -> Tuple[torch.Tensor, int]:
@@ -90,9 +97,12 @@ def read_audio(x, model_sample_rate: int) -> torch.Tensor:
 def process_audio_chunks(file_name, target_sample_rate: int, chunk_size: int, file_stream=None) -> Iterator[Tuple[torch.Tensor, str]]:
     """Reference ``process_audio_chunks`` (audiotoken/utils.py:71-101): ``chunk_size``-second chunks at the SOURCE
     rate, each resampled on its own (so chunk seams follow the reference), yielded as ``([1, n], file_name)``."""
-    audio, sr = load(file_name, file_stream)
+    try:
+        audio, sr = load(file_name, file_stream)
+    except (NotImplementedError, ValueError, EOFError, OSError, struct.error) as e:   # codec not shipped / unsupported extension / damaged or truncated header / unreadable
+        raise AudioDecodeError(f"{file_name}: {type(e).__name__}: {e}") from e
     if audio.shape[0] != 1:
-        raise AssertionError(f"Audio needs to be mono, provided {audio.shape[0]} channels for {file_name}")
+        raise AudioDecodeError(f"Audio needs to be mono, provided {audio.shape[0]} channels for {file_name}")
     step = int(chunk_size * sr)
     for i in range(0, audio.shape[-1], step):
         chunk = audio[:, i:i + step]

@@ -41,6 +41,7 @@ class AudioToken:
         self.compile = compile
         self.kwargs = kwargs
         self.device = device
+        self.skipped_files: List[tuple] = []   # (path, reason) of the inputs the last encode_batch_files could not decode
         self.num_codebooks = kwargs.get("num_codebooks", 16)
         assert self.num_codebooks in [2, 4, 8, 16], "num_codebooks must be one of [2, 4, 8, 16]"
         self.load_config()
@@ -125,32 +126,40 @@ class AudioToken:
     def _chunk_stream(self, files, chunk_size: int, num_workers: int = 0):
         """File -> streamed ``chunk_size``-second chunks -> segments (reference datasets.py:107-139). Decoding and resampling
         run ``num_workers`` files ahead on a thread pool (prefetch.py); the segment order equals the sequential one."""
-        from .audio_io import iterate_tar, iterate_zip, process_audio_chunks
+        from .audio_io import AudioDecodeError, iterate_tar, iterate_zip, process_audio_chunks
         from .prefetch import background, ordered_map
         sr = self.model_config.model_sample_rate
 
         def load(file_path: str):
             """One unit of host work: plain audio files are decoded completely; archives return a streaming source. A file that
-            cannot be decoded (a codec this build does not ship, stereo, a truncated header) is logged and skipped, like the
-            unsupported extensions below — it must not abort a run whose earlier files have already been appended to."""
+            cannot be decoded (AudioDecodeError: a codec this build does not ship, more than one channel, a damaged header) is skipped, recorded
+            in ``self.skipped_files`` and reported at the end of the run — it must not abort a run whose earlier files have already been
+            appended to. Any other exception propagates, as in the reference (datasets.py __iter__)."""
             if file_path.endswith(AUDIO_EXTS):
                 try:
                     return list(process_audio_chunks(file_path, sr, chunk_size))
-                except Exception as e:
-                    logger.error(f"Skipping {file_path}: {type(e).__name__}: {e}")
+                except AudioDecodeError as e:
+                    logger.error(f"Skipping {file_path}: {e}")
+                    self.skipped_files.append((file_path, str(e)))
                     return []
             if file_path.endswith(TAR_EXTS):
                 return background(lambda: iterate_tar(file_path, sr, chunk_size)) if num_workers > 0 else iterate_tar(file_path, sr, chunk_size)
             if file_path.endswith(ZIP_EXTS):
                 return background(lambda: iterate_zip(file_path, sr, chunk_size)) if num_workers > 0 else iterate_zip(file_path, sr, chunk_size)
             logger.error(f"File {file_path} not supported for processing. Only {AUDIO_EXTS + TAR_EXTS + ZIP_EXTS} supported")
+            self.skipped_files.append((file_path, "unsupported extension"))
             return []
 
         for source in ordered_map(load, [str(f) for f in files], num_workers):
-            for waveform, file_name in source:
-                yield from iter_chunk(waveform, file_name, sample_rate=self.model_config.model_sample_rate, chunk_size=chunk_size,
-                                      model_token_rate=self.model_config.model_token_rate, pad_token=self.model_config.pad_token,
-                                      transform=self.transform_func)
+            try:
+                for waveform, file_name in source:
+                    yield from iter_chunk(waveform, file_name, sample_rate=self.model_config.model_sample_rate, chunk_size=chunk_size,
+                                          model_token_rate=self.model_config.model_token_rate, pad_token=self.model_config.pad_token,
+                                          transform=self.transform_func)
+            finally:   # an exception in the consumer (or an abandoned run) must not leave an archive's producer thread and its handle behind
+                close = getattr(source, "close", None)
+                if close is not None:
+                    close()
 
     def encode_batch_files(self, batch_size: int, outdir: os.PathLike, chunk_size: int = 30, num_workers: int = 12,
                            audio_files: Optional[List[os.PathLike]] = None, audio_dir: Optional[Union[os.PathLike, Path]] = None,
@@ -161,6 +170,7 @@ class AudioToken:
         every rank takes a contiguous block of files (all chunks of a file stay on one rank, preserving the append
         order)."""
         self.load_encoder()
+        self.skipped_files = []
         assert audio_files or audio_dir, "Either audio_files or audio_dir must be provided"
         assert not (audio_files and audio_dir), "Provide either audio_files or audio_dir, not both"
         outdir = sanitize_path(outdir)
@@ -209,6 +219,9 @@ class AudioToken:
                 else:
                     save_rel_audio_tokens(tokens_batch, file_pointer, str(outdir), str(audio_dir))
         logger.debug(f"Encoding batch files took: {time.time() - start_time:.2f}s")
+        if self.skipped_files:
+            logger.error(f"encode_batch_files: {len(self.skipped_files)} input(s) were skipped and have NO token file (AudioToken.skipped_files): "
+                         + "; ".join(f"{p} ({why})" for p, why in self.skipped_files[:8]) + (" ..." if len(self.skipped_files) > 8 else ""))
 
     def load_decoder(self, **kwargs):
         """core.py:291-315 — only the acoustic decoder exists here (the semantic decoders are out of scope)."""

@@ -31,9 +31,13 @@
 namespace at {
 
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+// Clamped to [2^-60, 2^60]: a tensor whose max |w| is tiny or denormal would otherwise get a scale near (or at) infinity — w s = inf / NaN and
+// acc_scale = 1 / (16 s) = 0, i.e. silent NaN or zero outputs (the weight splits run without a status word). Below ~1e-30 the tensor is
+// treated as all-zero (scale 1): its pieces underflow to zero exactly as its fp32 products would against normalised activations.
 float xb_weight_scale(float max_abs) {
-    if (!(max_abs > 0.f) || !std::isfinite(max_abs)) return 1.0f;
-    return std::exp2(std::floor(std::log2(32767.0f / max_abs)));
+    if (!(max_abs > 1e-30f) || !std::isfinite(max_abs)) return 1.0f;
+    const float e = std::floor(std::log2(32767.0f / max_abs));
+    return std::exp2(std::fmin(std::fmax(e, -60.0f), 60.0f));
 }
 
 constexpr int XB_K = 16;
@@ -365,4 +369,33 @@ extern "C" int at_op_gemm_split(const float* X, const float* W, const float* bia
         return a.scheme == XB_SCHEME_F16X2 ? launch_scheme<SchemeF16x2>(a, stream) : launch_scheme<SchemeBf16x3>(a, stream);
     }
     return launch_gemm_bf16x3(a, stream);
+}
+
+// A causal conv1d (reflect front padding k - stride, as the SEANet convs) on the WINDOWED two-piece fp16 split GEMM, for the parity / soak tests
+// of the two-group kernel's windowed instantiations: X [B][L][Cin] fp32 channels-last, W [Cout][k * Cin] (tap-major), C [B][L / stride][Cout].
+extern "C" int at_op_conv_split(const float* X, const float* W, const float* bias, float* C, int B, int L, int Cin, int Cout, int ktaps, int stride,
+                                float w_max_abs, void* workspace, size_t workspace_bytes, int32_t* status_dev, at_stream_t stream_) {
+    using namespace at;
+    AT_REQUIRE(X && W && C && workspace && B >= 1 && Cin % 16 == 0 && Cout % 128 == 0 && ktaps >= stride && stride >= 1 && L % stride == 0 && (ktaps * Cin) % 64 == 0,
+               "at_op_conv_split: Cin % 16, Cout % 128, k >= stride, L % stride, (k Cin) % 64");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int M = L / stride, Mpad = (M + 255) / 256 * 256, pad = ktaps - stride, K = ktaps * Cin;
+    const int Lp = Mpad + (ktaps - 1) / stride + 1;
+    AT_REQUIRE(L > pad, "at_op_conv_split: L > k - stride");
+    const size_t a_el = (size_t)2 * B * (Cin / 16) * stride * Lp * 16, w_el = (size_t)2 * Cout * K;
+    AT_REQUIRE(workspace_bytes >= (a_el + w_el) * sizeof(piece_t), "at_op_conv_split: workspace too small");
+    piece_t* xs = reinterpret_cast<piece_t*>(workspace);
+    piece_t* wsp = xs + a_el;
+    const float sw = xb_weight_scale(w_max_abs);
+    if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
+    AT_CHECK_HIP(hipMemsetAsync(xs, 0, a_el * sizeof(piece_t), stream));   // rows past the data (read by the padded output rows only) stay finite
+    if (int rc = launch_split_windowed(X, B, L, Cin, stride, pad, Lp, xs, stream, XB_SCHEME_F16X2, XB_F16_ACT_SCALE, reinterpret_cast<int*>(status_dev), 1)) return rc;
+    if (int rc = launch_split_blocked(W, K, Cout, Cout, K, wsp, stream, XB_SCHEME_F16X2, sw, nullptr, Cin / 16, stride)) return rc;
+    Bf16x3Args a;
+    a.A = xs; a.W = wsp; a.bias = bias; a.M = M; a.Mpad = Mpad; a.N = Cout; a.K = K;
+    a.batch = B; a.stride = stride; a.cblocks = Cin / 16; a.Lp = Lp;
+    a.scheme = XB_SCHEME_F16X2; a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * sw); a.split_scale = XB_F16_ACT_SCALE; a.status = reinterpret_cast<int*>(status_dev);
+    a.epi = XB_EPI_LINEAR; a.C = C; a.ldc = Cout;
+    AT_REQUIRE(gemm_f16x2_tg_eligible(a), "at_op_conv_split: shape not eligible for the two-group kernel");
+    return launch_gemm_f16x2_tg(a, stream);
 }

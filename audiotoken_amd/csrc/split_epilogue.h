@@ -40,12 +40,27 @@ struct XbEpilogue {
     __device__ __forceinline__ f4 load_residual(int m, int n) const {
         return Rb ? *reinterpret_cast<const f4*>(Rb + (long long)m * a.ldr + n) : f4{0.f, 0.f, 0.f, 0.f};
     }
-    // apply() with the bias quad (and, for the two plain modes, the residual quad) supplied by the caller
-    template <int E>
+    // apply() with the bias quad (and, for the two plain modes, the residual quad) supplied by the caller. PH1: the caller has checked
+    // a.Sphases == 1 (the piece output of a plain linear layer): the generic plane / index split of write_split is an integer division per
+    // quad by a run-time value — the fast path's address is base + block * pad + row (in the swish epilogue of a 256 x 256 tile the
+    // division sequences and 64-bit multiplies were ~500 of 2 000 instructions per lane, a third of its vector-unit time).
+    template <int E, bool PH1 = false>
     __device__ __forceinline__ void apply_with(int m, int n, f4 v, const f4& bias4, const f4& res4) {
         if constexpr (SC::RANGE_CHECK) v *= a.acc_scale;
         v += bias4;
-        finish_quad<E, true>(m, n, v, res4);
+        finish_quad<E, true, PH1>(m, n, v, res4);
+    }
+    // phases == 1: [pieces][batch][blocks][pad][16]
+    __device__ __forceinline__ void write_split_ph1(__bf16* S_, int pad, int front, int blocks, int block0, int m, int n, const f4& v) {
+        PT* S = reinterpret_cast<PT*>(S_);
+        const int nb = blocks > 0 ? blocks : a.N / 16;
+        const long long s_clip = (long long)pad * nb * 16;
+        const long long psS = s_clip * a.batch;
+        typename SC::V4 p[SC::NP];
+        over |= split4<SC>(v, a.split_scale, p);
+        PT* d = S + clip * s_clip + (long long)(block0 + (n >> 4)) * pad * 16 + (m + front) * 16 + (n & 15);
+#pragma unroll
+        for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(d + i * psS) = p[i];
     }
 
     template <int E>
@@ -55,7 +70,7 @@ struct XbEpilogue {
         finish_quad<E, false>(m, n, v, f4{0.f, 0.f, 0.f, 0.f});
     }
 
-    template <int E, bool HAVE_RES>
+    template <int E, bool HAVE_RES, bool PH1 = false>
     __device__ __forceinline__ void finish_quad(int m, int n, f4 v, const f4& res4) {
         if constexpr (E == XB_EPI_RAW_ELU_SPLIT2) {
             write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, v);
@@ -68,7 +83,8 @@ struct XbEpilogue {
                 w[k] = E == XB_EPI_GELU_SPLIT ? gelu_erf(v[k])
                      : E == XB_EPI_ELU_SPLIT ? elu1(v[k])
                                              : v[k] * sigmoidf_(v[k]);   // v_exp_f32 + v_rcp_f32 (~1 ulp each), as the fp32 GEMM's epilogue (the correctly rounded reciprocal cost 5 more instructions per value)
-            write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
+            if constexpr (PH1) write_split_ph1(a.S, a.Spad, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
+            else write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
         } else if constexpr (E == XB_EPI_QKV) {
             if (n < a.qkv_hid) {
                 *reinterpret_cast<f4*>(Cb + (long long)m * a.ldc + n) = v;

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import queue
 import threading
+import weakref
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Iterable, Iterator, List, TypeVar
@@ -41,38 +42,53 @@ def ordered_map(fn: Callable[[T], R], items: Iterable[T], num_workers: int) -> I
                 f.cancel()
 
 
+def _put(q: "queue.Queue", stop: threading.Event, x) -> bool:
+    while not stop.is_set():
+        try:
+            q.put(x, timeout=0.1)
+            return True
+        except queue.Full:
+            continue
+    return False
+
+
+def _produce(q: "queue.Queue", stop: threading.Event, gen_fn) -> None:
+    """Thread body of `background`. It holds the queue, the stop event and the generator factory — NOT the iterator object: a thread
+    target bound to the object would keep it alive, so its __del__ could never run while the producer is blocked in put()."""
+    gen = None
+    try:
+        gen = iter(gen_fn())
+        for x in gen:
+            if not _put(q, stop, x):
+                return
+        _put(q, stop, _END)
+    except BaseException as e:  # delivered to the consumer
+        _put(q, stop, e)
+    finally:
+        close = getattr(gen, "close", None)   # run the generator's finally blocks (tar / zip handles) in this thread
+        if close is not None:
+            try:
+                close()
+            except Exception:
+                pass
+
+
 class background(Iterator[T]):
     """Run a generator in one background thread, handing its items over through a bounded queue (order preserved).
 
     An iterator OBJECT, not a generator function: the thread starts when the object is made (so an archive streams ahead while
     earlier files are still being consumed), and ``close()`` / garbage collection / an exception in the consumer stops the producer —
     every ``put`` of the producer, including the final sentinel and a forwarded exception, gives up once ``stop`` is set, so the thread
-    (and the tar / zip handle it holds) never outlives an abandoned consumer."""
+    (and the tar / zip handle it holds) never outlives an abandoned consumer. The thread references only the queue, the event and the
+    generator factory; ``weakref.finalize`` sets the event when the object is collected without ``close()``."""
 
     def __init__(self, gen_fn: Callable[[], Iterable[T]], depth: int = 8):
         self._q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
         self._stop = threading.Event()
         self._done = False
-        self._thread = threading.Thread(target=self._run, args=(gen_fn,), name="audiotoken-io-stream", daemon=True)
+        self._thread = threading.Thread(target=_produce, args=(self._q, self._stop, gen_fn), name="audiotoken-io-stream", daemon=True)
+        self._finalizer = weakref.finalize(self, self._stop.set)
         self._thread.start()
-
-    def _put(self, x) -> bool:
-        while not self._stop.is_set():
-            try:
-                self._q.put(x, timeout=0.1)
-                return True
-            except queue.Full:
-                continue
-        return False
-
-    def _run(self, gen_fn):
-        try:
-            for x in gen_fn():
-                if not self._put(x):
-                    return
-            self._put(_END)
-        except BaseException as e:  # delivered to the consumer
-            self._put(e)
 
     def __iter__(self):
         return self
@@ -93,8 +109,10 @@ class background(Iterator[T]):
         self._done = True
         self._stop.set()
 
-    def __del__(self):
-        self._stop.set()
+    def join(self, timeout: float = None) -> bool:
+        """Wait for the producer thread to end (tests); True when it has."""
+        self._thread.join(timeout)
+        return not self._thread.is_alive()
 
 
 def chunks_of_files(files: List[str], load_chunks: Callable[[str], list], num_workers: int) -> Iterator:

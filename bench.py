@@ -1,27 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: audio-seconds tokenized per wall-second on MI355X (BASELINE.json metric).
+"""Headline benchmark: audio-seconds tokenized per wall-second (acoustic + semantic_m) on MI355X — BASELINE.json's metric.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload both|acoustic|semantic_m] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload both|all|acoustic|semantic_m|semantic_s] [--no-cpu-baseline] [--no-verify]
 
-One "step" = one pass of the hot path (the reference's ``self.encoder(input_batch, attention_mask)`` call,
-audiotoken/core.py:276) over one synthetic batch that is already resident in HBM. At N=1 the workload is
-BASELINE.json configs[1]: Tokenizers.acoustic, 256 clips x 10 s @ 24 kHz, 8 codebooks. With N>1 (launched by
-torch.distributed.run, one rank per GPU) every rank encodes its own 256-clip shard — clips are independent, so
-there is no data-path collective ("weak" scaling); RCCL is used only for the start barrier, the weight
-broadcast check and the max-over-ranks time.
-
-The metric names two tokenizers ("acoustic + semantic_m"). The top-level fields of the JSON line are the acoustic
-workload (configs[1]); with --workload both (default) the same line carries a "semantic_m" object (BASELINE configs[3]
-per-GPU share: 64 clips x 30 s @16 kHz, 19 conformer layers, VQ 2048) with its own value / roofline / cpu_baseline and
-a "combined" figure = audio-seconds of both / (t_acoustic + t_semantic_m).
+One "step" = one pass of the hot path (the reference's ``self.encoder(input_batch, attention_mask)`` call, audiotoken/core.py:276) over
+one synthetic batch of EACH tokenizer the metric names, already resident in HBM: BASELINE configs[1] — Tokenizers.acoustic, 256 clips x 10 s
+@24 kHz, 8 codebooks — followed by BASELINE configs[3]'s per-GPU share — Tokenizers.semantic_m, 64 clips x 30 s @16 kHz, 19 conformer layers,
+VQ 2048. Both encodes sit inside ONE timed region (W warm-up steps, then exactly K steps between barrier + synchronize); top-level
+``value`` = audio-seconds of both / that time = the combined figure, ``ms_per_step`` = the whole step. Per-tokenizer rates, rooflines and CPU
+baselines are the named sub-objects ``acoustic`` and ``semantic_m`` (their times come from HIP events around each encode inside the same
+region). With --workload acoustic / semantic_m the step holds that tokenizer only. With N>1 (one rank per GPU) every rank encodes its own
+shard — clips are independent, so there is no data-path collective ("weak" scaling); RCCL is used only for the start barrier, the weight
+broadcast and the max-over-ranks time.
 
 Multi-GPU: `python bench.py --gpus N` with no WORLD_SIZE in the environment starts N FRESH child ranks itself
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py ...`, before this process has touched the GPU) and relays rank 0's
 JSON line; under an external `torch.distributed.run` (WORLD_SIZE set) it is simply one of the ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  "roofline":     dominant kernel group's achieved rate vs the gfx950 peak, timed with HIP events on the launch stream
-  "cpu_baseline": the CPU oracle (a port of the reference's CPU path) timed on this host on a bounded sample.
+  "roofline":       the dominant kernel group of the whole step: achieved rate vs the gfx950 peak, timed with HIP events on the launch stream
+  "cpu_baseline":   the CPU oracle (a port of the reference's CPU path) timed on this host on a bounded sample, per tokenizer
+  "verify":         a short post-timing oracle check of the timed batches' tokens (clips checked, ids differing, unexplained)
+  "argmin_kernels": the RVQ / VQ / k-means searches against BOTH roofs (bytes/s / 8 TB/s and FLOP/s / peak), the binding one labelled.
 """
 from __future__ import annotations
 
@@ -281,7 +281,7 @@ def hubert_flops_per_clip(N: int, n_layers: int):
 def run_hubert(args, rank, world, dev, dist):
     from audiotoken_amd import weights as W
     from audiotoken_amd.configs import HubertEncoderConfig
-    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    from audiotoken_amd.hubert import HubertEncoder
     from audiotoken_amd.distributed import broadcast_weights
 
     nl, B, secs = 11, args.hub_batch, args.sem_seconds
@@ -290,24 +290,24 @@ def run_hubert(args, rank, world, dev, dist):
     weights = broadcast_weights(weights, dev, dist)
     enc = HubertEncoder(HubertEncoderConfig(output_layer=nl), device=str(dev), quantize=True, weights=weights)
     del weights
-    gen_B = min(B, 8)
-    host = W.synth_waveform(gen_B, N, 16000, seed=1234, first_clip=rank * B)
-    host = np.stack([hubert_processor(torch.from_numpy(host[i:i + 1]))[0].numpy() for i in range(gen_B)])
-    wav = torch.from_numpy(host).to(dev).repeat((B + gen_B - 1) // gen_B, 1)[:B].contiguous()
+    from audiotoken_amd import synthetic as S
+    wav = S.semantic_s_batch(B, N, dev, rank)
     mask = torch.ones_like(wav)
+    enc._bench_inputs = (wav, mask)
     enc(wav, mask)
     enc.enable_profile(False)
-    elapsed, toks, per_step = timed_steps(lambda: enc(wav, mask), args.steps, max(0, args.warmup - 1), dist)
+    fallback, fb_status = settle_status(enc, lambda: enc(wav, mask), "semantic_s")
+    elapsed, toks, per_step = timed_steps(lambda: enc(wav, mask), args.steps, args.warmup, dist)
     elapsed = max_over_ranks(elapsed, dev, dist)
     prof = tapped_breakdown(enc, lambda: enc(wav, mask), min(args.steps, 2))
     flops, T = hubert_flops_per_clip(N, nl)
     arith = enc.get_option("arith")
     products = {0: 1, 1: 6, 2: 3}[arith]
-    assert enc.last_status() == 0, "semantic_s status word non-zero (fp16 range overflow): the timed run is invalid"
+    assert enc.last_status() == 0, "semantic_s status word non-zero after the timed region: the timed run is invalid"
     breakdown = {}
     for k, (per, launches) in prof.items():
         breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches,
-                        "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None, "gbs": None}
+                        "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 and k in flops else None, "gbs": None}
     res = {
         "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "dtype": {0: "f32", 1: "f32 (linear layers and convs: three bf16 pieces per operand, six MFMA products, fp32 accumulate)",
@@ -315,9 +315,13 @@ def run_hubert(args, rank, world, dev, dist):
         "config": {"workload": f"Tokenizers.semantic_s encode, {B} clips x {secs:g} s @16 kHz per GPU, mHuBERT-base 11 layers, k-means 1000",
                    "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0"},
         "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if arith else (), "semantic_s", products), "breakdown": breakdown,
-        "token_checksum": int(toks.to(torch.int64).sum().item()),
+        "token_checksum": S.token_checksum(toks),
+        "checksum_pinned": (S.token_checksum(toks) == S.PINNED_CHECKSUMS["semantic_s"]) if (rank == 0 and B == 128 and N == 480000) else None,
         "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
+        "fallback_batches": fallback * args.steps, "fallback_status": fb_status,
     }
+    if "kmeans" in breakdown and breakdown["kmeans"]["ms_per_step"] > 0:
+        res["argmin"] = argmin_entry("kmeans", breakdown["kmeans"]["ms_per_step"], flops["kmeans"] * B, (4.0 * T * 768 + 2.0 * T) * B, 1)
     del enc
     torch.cuda.empty_cache()
     return res
@@ -455,7 +459,48 @@ def median(xs):
     return xs[len(xs) // 2]
 
 
-def run_acoustic(args, rank, world, dev, dist):
+def timed_region(workloads, steps, warmup, dist):
+    """The contract's timed region over a step made of one encode per workload: W untimed warm-up steps, then EXACTLY `steps` steps bracketed by
+    barrier + synchronize on both sides. HIP events on the launch stream around every encode give each workload's share of the step."""
+    for _ in range(warmup):
+        for w in workloads:
+            w["out"] = w["call"]()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(workloads) + 1)] for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        evs[i][0].record()
+        for j, w in enumerate(workloads):
+            w["out"] = w["call"]()
+            evs[i][j + 1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    for j, w in enumerate(workloads):
+        w["per_step_ms"] = [evs[i][j].elapsed_time(evs[i][j + 1]) for i in range(steps)]
+    return elapsed
+
+
+def settle_status(enc, call, name):
+    """What the product path does at its synchronisation point (AcousticEncoder.verified / Wav2VecBertEncoder.verified): a non-zero device status
+    word after the untimed first call means this batch does not fit the fast kernels (fp16 range of the f16x2 arithmetic, LSTM hand-off) — the
+    handle falls back and the batch is repeated. The benchmark then times the fallback (what this input costs in production) and says so
+    instead of aborting: returns the number of batches per step that took the fallback (0 or 1)."""
+    status = enc.last_status()
+    if status == 0:
+        return 0, 0
+    out = call()
+    enc.verified(out, *enc._bench_inputs)
+    assert enc.last_status() == 0, f"{name}: status word non-zero on the fallback path too"
+    return 1, status
+
+
+def setup_acoustic(args, rank, world, dev, dist):
+    from audiotoken_amd import synthetic as S
     from audiotoken_amd import weights as W
     from audiotoken_amd.configs import AcousticEncoderConfig, num_codebooks_to_bandwidth
     from audiotoken_amd.encoder import AcousticEncoder
@@ -468,23 +513,30 @@ def run_acoustic(args, rank, world, dev, dist):
     t0 = time.perf_counter()
     weights = broadcast_weights(weights, dev, dist)
     bcast_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
     enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=num_codebooks_to_bandwidth(n_q)), device=str(dev), weights=weights)
-    # synthetic clips: rank r owns clips [r*B, (r+1)*B) of the global batch
-    gen_B = min(B, 16)
-    base = torch.from_numpy(W.synth_waveform(gen_B, N, 24000, seed=1234, first_clip=rank * B)).to(dev)
-    wav = base.repeat((B + gen_B - 1) // gen_B, 1)[:B].contiguous()
-    if B > gen_B:  # make repeated clips distinct without regenerating on the host
-        wav = (wav * torch.linspace(0.5, 1.0, B, device=dev).unsqueeze(1)).contiguous()
+    torch.cuda.synchronize()
+    finalize_ms = (time.perf_counter() - t0) * 1e3
+    wav = S.acoustic_batch(B, N, dev, rank)        # rank r owns clips [r B, (r + 1) B) of the global batch
     mask = torch.ones_like(wav)
-    enc(wav, mask)  # allocate workspace outside the timed region
-    enc.enable_profile(False)   # no event taps inside the timed region
-    elapsed, codes, per_step = timed_steps(lambda: enc(wav, mask), args.steps, args.warmup, dist)
+    enc._bench_inputs = (wav, mask)
+    call = lambda: enc(wav, mask)
+    call()                                          # allocate the workspace outside the timed region
+    enc.enable_profile(False)                       # no event taps inside the timed region
+    fallback, status = settle_status(enc, call, "acoustic")
+    return {"name": "acoustic", "enc": enc, "call": call, "wav": wav, "mask": mask, "weights": weights, "audio_s": B * args.seconds, "B": B, "N": N, "n_q": n_q,
+            "broadcast_ms": bcast_ms, "finalize_ms": finalize_ms, "fallback_batches_per_step": fallback, "fallback_status": status}
+
+
+def report_acoustic(wl, args, rank, world, dev, dist):
+    from audiotoken_amd import synthetic as S
+    enc, wav, mask, B, N, n_q = wl["enc"], wl["wav"], wl["mask"], wl["B"], wl["N"], wl["n_q"]
     status = enc.last_status()
-    assert status == 0, f"persistent LSTM hand-off status {status}: the timed run is invalid"
-    rank_ms = elapsed / args.steps * 1e3
-    elapsed = max_over_ranks(elapsed, dev, dist)
-    checksum = int(codes.to(torch.int64).sum().item())
-    prof = tapped_breakdown(enc, lambda: enc(wav, mask), min(args.steps, 3))
+    assert status == 0, f"acoustic status word {status} after the timed region: the timed run is invalid"
+    rank_ms = sum(wl["per_step_ms"]) / len(wl["per_step_ms"])
+    ms = max_over_ranks(rank_ms, dev, dist)
+    checksum = S.token_checksum(wl["out"])
+    prof = tapped_breakdown(enc, wl["call"], min(args.steps, 3))
     flops, T = acoustic_flops_per_clip(N, n_q)
     nbytes = acoustic_bytes_per_clip(N, n_q)
     breakdown = {}
@@ -493,33 +545,89 @@ def run_acoustic(args, rank, world, dev, dist):
                         "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None,
                         "gbs": round(nbytes[k] * B / (per * 1e-3) / 1e9, 1) if per > 0 else None}
     f16_groups = acoustic_f16x2_groups(enc)
+    dom = max(breakdown, key=lambda k: breakdown[k]["ms_per_step"])
     res = {
-        "value": round(world * B * args.seconds * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "median_ms_per_step": round(median(per_step), 3),
-        "elapsed": elapsed, "audio_s_per_step": world * B * args.seconds, "rank_ms": rank_ms, "broadcast_ms": round(bcast_ms, 1),
-        "config": {"workload": f"Tokenizers.acoustic encode, {B} clips x {args.seconds:g} s @24 kHz per GPU, num_codebooks={n_q}",
+        "value": round(world * B * args.seconds / (ms * 1e-3), 2), "unit": "audio-s/s", "ms_per_step": round(ms, 3), "median_ms_per_step": round(median(wl["per_step_ms"]), 3),
+        "rank_ms": rank_ms, "broadcast_ms": round(wl["broadcast_ms"], 1), "finalize_ms": round(wl["finalize_ms"], 1),
+        "dtype": ("f32 (contractions as operand splits on the 16-bit matrix cores with fp32 accumulate; per kernel group two fp16 pieces / three "
+                  "products or three bf16 pieces / six products: see mfma_products_per_mac; conv0 on the fp32 MFMA)") if ACOUSTIC_X3_GROUPS else "f32",
+        "config": {"workload": f"Tokenizers.acoustic encode, {B} clips x {args.seconds:g} s @24 kHz per GPU, num_codebooks={n_q} (BASELINE configs[1])",
                    "clips_per_gpu": B, "samples_per_clip": N, "frames_per_clip": T, "weights": "synthetic seed 0",
                    "parallelism": f"clip-sharded x{world}, no data-path collective"},
-        "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS, "acoustic",
-                                3 if max(breakdown, key=lambda k: breakdown[k]["ms_per_step"]) in f16_groups else 6), "breakdown": breakdown,
+        "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS, "acoustic", 3 if dom in f16_groups else 6), "breakdown": breakdown,
         "mfma_products_per_mac": {**{g: (3 if g in f16_groups else 6) for g in ACOUSTIC_X3_GROUPS}, "final_conv": 3 if "final_conv" in f16_groups else 1},
         "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)", "token_checksum": checksum,
-        "lstm_handoff_status": status,
+        "checksum_pinned": (checksum == S.PINNED_CHECKSUMS["acoustic"]) if (rank == 0 and B == 256 and N == 240000 and n_q == 8) else None,
+        "lstm_handoff_status": status, "fallback_batches": wl["fallback_batches_per_step"] * args.steps, "fallback_status": wl["fallback_status"],
     }
-    # SURVEY.md §8(d) wall (first H2D enqueue -> last token D2H), pipelined as encode_batch_files runs it. Reported beside `value`
-    # (which, by the bench contract, is the rate with inputs resident in HBM), never as it.
+    if "rvq" in breakdown and breakdown["rvq"]["ms_per_step"] > 0:
+        res["argmin"] = argmin_entry("rvq", breakdown["rvq"]["ms_per_step"], flops["rvq"] * B, (4.0 * T * 128 + 2.0 * T * n_q) * B,
+                                     3 if "rvq" in f16_groups else (6 if "rvq" in ACOUSTIC_X3_GROUPS else 1))
+    # SURVEY.md §8(d) wall (first H2D enqueue -> last token D2H), pipelined as encode_batch_files runs it, on ALL ranks at once behind a barrier
+    # (the host-side contention of N feeding processes is the only thing that can bend the weak-scaling curve); max over ranks. Reported
+    # beside `value` (which, by the bench contract, is the rate with inputs resident in HBM), never as it.
     try:
         host = wav.cpu().pin_memory()
+        if dist is not None:
+            dist.barrier()
         pp = pipelined_pcie(lambda d: enc(d, None), host, dev, max(10, args.steps))
-        res["pcie_inclusive"] = {"value": round(world * B * args.seconds / (pp["median_ms"] * 1e-3), 2), "unit": "audio-s/s",
-                                 "median_ms_per_step": round(pp["median_ms"], 3), "mean_ms_per_step": round(pp["mean_ms"], 3), "iters": pp["iters"],
-                                 "note": "pinned host waveforms -> H2D on a copy stream during the previous encode -> encode -> D2H tokens; median over batches"}
+        med = max_over_ranks(pp["median_ms"], dev, dist)
+        res["pcie_inclusive"] = {"value": round(world * B * args.seconds / (med * 1e-3), 2), "unit": "audio-s/s",
+                                 "median_ms_per_step": round(med, 3), "mean_ms_per_step": round(max_over_ranks(pp["mean_ms"], dev, dist), 3), "iters": pp["iters"],
+                                 "note": "pinned host waveforms -> H2D on a copy stream during the previous encode -> encode -> D2H tokens; median over batches; "
+                                         "all ranks run it concurrently, max over ranks"}
         del host
     except Exception as e:  # pragma: no cover - informational only
         res["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
-    del enc
-    torch.cuda.empty_cache()
+        if dist is not None:
+            raise
     return res
+
+
+def argmin_entry(kernel, ms, flops, nbytes, products):
+    """north_star asks for the argmin (codebook search) kernels against the MEMORY roofline; SURVEY.md §8(d) shows they sit right of the ridge
+    (500-4 000 FLOP/B), so both roofs are reported and the binding one labelled."""
+    peak = BF16_MFMA_PEAK_TFLOPS if products > 1 else F32_MFMA_PEAK_TFLOPS
+    tf = flops / (ms * 1e-3) / 1e12
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    t_c, t_m = flops * products / (peak * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+    return {"kernel": kernel, "ms_per_step": round(ms, 3), "algorithmic_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5),
+            "algorithmic_tflops": round(tf, 2), "executed_tflops": round(tf * products, 2), "products_per_mac": products,
+            "mfma_peak_tflops": peak, "frac_of_mfma_peak_executed": round(tf * products / peak, 4),
+            "flop_per_byte": round(flops / nbytes, 1), "binding": "compute (mfma)" if t_c >= t_m else "hbm"}
+
+
+def verify_acoustic(wl, n_clips=4):
+    """Post-timing oracle check on rank 0: `n_clips` clips of the timed batch against the CPU oracle, on the tests' bar (tests/parity.py):
+    a frame may differ only where the oracle's own top-2 margin at the first differing stage is < 1e-3."""
+    from oracle import encodec_ref as R
+    B = wl["B"]
+    idx = sorted({(i * (B - 1)) // max(1, n_clips - 1) for i in range(n_clips)}) if B > 1 else [0]
+    wt = {k: torch.from_numpy(v) for k, v in wl["weights"].items()}
+    with torch.no_grad():
+        ref, margins = R.acoustic_encode(wt, wl["wav"][idx].cpu(), wl["n_q"], return_margins=True)
+    got = wl["out"][idx].cpu().long()
+    mism = got != ref.long()
+    frames = mism.any(dim=1)
+    first = mism.float().argmax(dim=1)
+    m0 = margins.gather(1, first.unsqueeze(1)).squeeze(1)
+    return {"clips_checked": len(idx), "clips": idx, "ids_checked": int(got.numel()), "ids_differ": int(mism.sum()), "frames_differ": int(frames.sum()),
+            "frames_unexplained": int((frames & (m0 >= 1e-3)).sum()), "max_margin_among_differing": float(m0[frames].max()) if bool(frames.any()) else 0.0}
+
+
+def verify_semantic(wl, n_clips=1):
+    from oracle import w2vbert_ref as R
+    idx = [wl["B"] // 3][:n_clips]
+    wt = {k: torch.from_numpy(v) for k, v in wl["weights"].items()}
+    wav = wl["wav"][idx].cpu()
+    with torch.no_grad():
+        ref, margins = R.semantic_m_encode(wt, wav, torch.ones_like(wav), 2, wl["nl"], return_margins=True)
+        _, am = R.processor(wav, torch.ones_like(wav), 2)
+    valid = am.bool().unsqueeze(1)
+    mism = (wl["out"][idx].cpu().long() != ref.long()) & valid
+    m = margins[mism]
+    return {"clips_checked": len(idx), "clips": idx, "ids_checked": int(valid.sum()), "ids_differ": int(mism.sum()),
+            "ids_unexplained": int((m >= 1e-3).sum()), "max_margin_among_differing": float(m.max()) if m.numel() else 0.0}
 
 
 def run_decode(args, rank, world, dev, dist):
@@ -548,7 +656,8 @@ def run_decode(args, rank, world, dev, dist):
     return res
 
 
-def run_semantic(args, rank, world, dev, dist):
+def setup_semantic(args, rank, world, dev, dist):
+    from audiotoken_amd import synthetic as S
     from audiotoken_amd import weights as W
     from audiotoken_amd.configs import Wav2VecBertConfig
     from audiotoken_amd.encoder import Wav2VecBertEncoder
@@ -558,50 +667,64 @@ def run_semantic(args, rank, world, dev, dist):
     B, secs = args.sem_batch, args.sem_seconds
     N = int(round(secs * 16000))
     weights = W.synth_w2vbert_weights(n_layers=nl, seed=0, with_vq=True) if rank == 0 else None
+    t0 = time.perf_counter()
     weights = broadcast_weights(weights, dev, dist)
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
     enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=nl), device=str(dev), quantize=True, weights=weights)
-    del weights
-    gen_B = min(B, 8)
-    base = torch.from_numpy(W.synth_waveform(gen_B, N, 16000, seed=1234, first_clip=rank * B)).to(dev)
-    wav = base.repeat((B + gen_B - 1) // gen_B, 1)[:B].contiguous()
-    if B > gen_B:
-        wav = (wav * torch.linspace(0.5, 1.0, B, device=dev).unsqueeze(1)).contiguous()
+    torch.cuda.synchronize()
+    finalize_ms = (time.perf_counter() - t0) * 1e3
+    wav = S.semantic_m_batch(B, N, dev, rank)
     mask = torch.ones_like(wav)
-    enc(wav, mask)
+    enc._bench_inputs = (wav, mask)
+    call = lambda: enc(wav, mask)
+    call()
     enc.enable_profile(False)
-    elapsed, toks, per_step = timed_steps(lambda: enc(wav, mask), args.steps, max(0, args.warmup - 1), dist)
-    rank_ms = elapsed / args.steps * 1e3
-    elapsed = max_over_ranks(elapsed, dev, dist)
-    prof = tapped_breakdown(enc, lambda: enc(wav, mask), min(args.steps, 2))
+    fallback, status = settle_status(enc, call, "semantic_m")
+    return {"name": "semantic_m", "enc": enc, "call": call, "wav": wav, "mask": mask, "weights": weights if rank == 0 else None, "audio_s": B * secs, "B": B, "N": N, "nl": nl,
+            "secs": secs, "broadcast_ms": bcast_ms, "finalize_ms": finalize_ms, "fallback_batches_per_step": fallback, "fallback_status": status}
+
+
+def report_semantic(wl, args, rank, world, dev, dist):
+    from audiotoken_amd import synthetic as S
+    enc, B, N, nl, secs = wl["enc"], wl["B"], wl["N"], wl["nl"], wl["secs"]
+    assert enc.last_status() == 0, "semantic_m status word non-zero after the timed region: the timed run is invalid"
+    rank_ms = sum(wl["per_step_ms"]) / len(wl["per_step_ms"])
+    ms = max_over_ranks(rank_ms, dev, dist)
+    toks = wl["out"]
+    prof = tapped_breakdown(enc, wl["call"], min(args.steps, 2))
     T = toks.shape[-1]
     F = 1 + (N - 400) // 160
     flops = semantic_flops_per_clip(T, nl, F)
     arith = enc.get_option("arith")                    # 0 f32 MFMA, 1 bf16x3 (six products), 2 f16x2 (three products)
     products = {0: 1, 1: 6, 2: 3}[arith]
-    assert enc.last_status() == 0, "semantic_m status word non-zero (fp16 range overflow): the timed run is invalid"
     breakdown = {}
     ln_bytes = {"layernorm": 8.0 * T * 1024 * (4 * nl) + 8.0 * T * 1024 * nl}   # LayerNorm -> pieces: 4 B in + 4 B out per element; final LN 4 + 4
     for k, (per, launches) in prof.items():
         breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches,
                         "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 and k in flops else None,
                         "gbs": round(ln_bytes[k] * B / (per * 1e-3) / 1e9, 1) if per > 0 and k in ln_bytes else None}
-    flops = dict(flops, layernorm=0.0)
+    flops_all = dict(flops, layernorm=0.0)
+    checksum = S.token_checksum(toks)
     res = {
-        "value": round(world * B * secs * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "median_ms_per_step": round(median(per_step), 3), "elapsed": elapsed, "audio_s_per_step": world * B * secs, "rank_ms": rank_ms,
+        "value": round(world * B * secs / (ms * 1e-3), 2), "unit": "audio-s/s", "ms_per_step": round(ms, 3),
+        "median_ms_per_step": round(median(wl["per_step_ms"]), 3), "rank_ms": rank_ms,
+        "broadcast_ms": round(wl["broadcast_ms"], 1), "finalize_ms": round(wl["finalize_ms"], 1),
         "dtype": {0: "f32", 1: "f32 (linear layers: three bf16 pieces per operand, six MFMA products, fp32 accumulate)",
                   2: "f32 (linear layers: two fp16 pieces per operand, three MFMA products, fp32 accumulate)"}[arith],
-        "config": {"workload": f"Tokenizers.semantic_m encode, {B} clips x {secs:g} s @16 kHz per GPU, {nl} conformer layers, VQ 2048x1024",
+        "config": {"workload": f"Tokenizers.semantic_m encode, {B} clips x {secs:g} s @16 kHz per GPU, {nl} conformer layers, VQ 2048x1024 (BASELINE configs[3] per-GPU share)",
                    "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0",
                    "parallelism": f"clip-sharded x{world}, no data-path collective",
                    "note": "BASELINE configs[3] is 512 clips over 8 GPUs = 64 per GPU; at N=1 one step is one such 64-clip micro-batch"},
-        "roofline": roofline_of(breakdown, flops, None, B, ("ffn", "attn_proj", "conv_module") if arith else (), "semantic_m", products), "breakdown": breakdown,
+        "roofline": roofline_of(breakdown, flops_all, None, B, ("ffn", "attn_proj", "conv_module") if arith else (), "semantic_m", products), "breakdown": breakdown,
         "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)",
-        "token_checksum": int(toks.to(torch.int64).sum().item()),
-        "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
+        "token_checksum": checksum,
+        "checksum_pinned": (checksum == S.PINNED_CHECKSUMS["semantic_m"]) if (rank == 0 and B == 64 and N == 480000 and nl == 19) else None,
+        "total_tflops": round(sum(flops.values()) * B / (ms * 1e-3) / 1e12, 2),
+        "fallback_batches": wl["fallback_batches_per_step"] * args.steps, "fallback_status": wl["fallback_status"],
     }
-    del enc
-    torch.cuda.empty_cache()
+    if "vq" in breakdown and breakdown["vq"]["ms_per_step"] > 0:
+        res["argmin"] = argmin_entry("vq", breakdown["vq"]["ms_per_step"], flops["vq"] * B, (4.0 * T * 1024 + 2.0 * T) * B, 1)
     return res
 
 
@@ -619,6 +742,7 @@ def parse_args(argv=None):
     ap.add_argument("--sem-seconds", type=float, default=30.0)
     ap.add_argument("--sem-layers", type=int, default=19)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle check of the timed batches (rank 0, N = 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --workload selftest run on CPU (tests)")
     return ap.parse_args(argv)
 
@@ -647,78 +771,132 @@ def main(argv=None):
     rank, world, dist = init_ranks(args.backend, dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    ac = sem = None
-    sem_err = None
-    hub = hub_err = None
     if args.workload == "selftest":
         ac = run_selftest(args, rank, world, dev, dist)
+        ranks = rank_report(rank, ac.get("rank_ms", ac["ms_per_step"]), dev, dist)
+        if rank == 0:
+            out = {"metric": "audio-sec tokenized / wall-sec", "value": ac["value"], "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": ac["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none (selftest)", "data": "synthetic",
+                   "config": ac["config"], "roofline": None, "breakdown": {}, "token_checksum": ac["token_checksum"], "broadcast_ms": ac["broadcast_ms"],
+                   "rccl_ranks": ranks["rccl_ranks"], "per_rank_ms": ranks["per_rank_ms"], "backend": args.backend if world > 1 else None, "cpu_baseline": None,
+                   "cpu_baseline_note": "skipped at N>1: the CPU oracle is timed on rank 0 at N=1 only" if world > 1 else "skipped: selftest"}
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
+
+    # ---- the metric's step: one acoustic batch + one semantic_m batch in ONE timed region ------------------------------------------------
+    workloads = []
     if args.workload in ("all", "both", "acoustic"):
-        ac = run_acoustic(args, rank, world, dev, dist)
+        workloads.append(setup_acoustic(args, rank, world, dev, dist))
+    sem_err = None
+    if args.workload in ("all", "both", "semantic_m"):
+        try:
+            workloads.append(setup_semantic(args, rank, world, dev, dist))
+        except Exception as e:  # keep the acoustic line even if the second workload cannot be set up on this box
+            if args.workload == "semantic_m" or dist is not None:
+                raise
+            sem_err = f"{type(e).__name__}: {e}"
+    res = {}
+    if workloads:
+        elapsed = timed_region(workloads, args.steps, args.warmup, dist)
+        rank_ms = elapsed / args.steps * 1e3
+        elapsed = max_over_ranks(elapsed, dev, dist)
+        for wl in workloads:
+            res[wl["name"]] = (report_acoustic if wl["name"] == "acoustic" else report_semantic)(wl, args, rank, world, dev, dist)
+        audio_s = sum(wl["audio_s"] for wl in workloads)
+        value = world * audio_s * args.steps / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+    verify = None
+    if rank == 0 and world == 1 and not args.no_verify and workloads:
+        verify = {}
+        for wl in workloads:
+            try:
+                verify[wl["name"]] = verify_acoustic(wl) if wl["name"] == "acoustic" else verify_semantic(wl)
+            except Exception as e:  # pragma: no cover - informational
+                verify[wl["name"]] = {"error": f"{type(e).__name__}: {e}"}
+    for wl in workloads:   # release the encoders before the extra workloads
+        wl.pop("enc", None); wl.pop("call", None); wl.pop("wav", None); wl.pop("mask", None); wl.pop("out", None); wl.pop("weights", None)
+    torch.cuda.empty_cache()
+
     dec = None
     if args.workload == "all":
         try:
             dec = run_decode(args, rank, world, dev, dist)
         except Exception as e:
+            if dist is not None:
+                raise
             dec = {"error": f"{type(e).__name__}: {e}"}
+    hub = hub_err = None
     if args.workload in ("all", "semantic_s"):
         try:
             hub = run_hubert(args, rank, world, dev, dist)
         except Exception as e:
-            if args.workload == "semantic_s":
+            if args.workload == "semantic_s" or dist is not None:
                 raise
             hub_err = f"{type(e).__name__}: {e}"
-    if args.workload in ("all", "both", "semantic_m"):
-        try:
-            sem = run_semantic(args, rank, world, dev, dist)
-        except Exception as e:  # keep the acoustic line even if the second workload cannot run on this box
-            if args.workload == "semantic_m":
-                raise
-            sem_err = f"{type(e).__name__}: {e}"
+    if not workloads:   # --workload semantic_s alone
+        value, ms_per_step, rank_ms = hub["value"], hub["ms_per_step"], hub["ms_per_step"]
 
-    primary = ac if ac is not None else (sem if sem is not None else hub)
-    ranks = rank_report(rank, primary.get("rank_ms", primary["ms_per_step"]), dev, dist)   # collective: every rank calls it
+    ranks = rank_report(rank, rank_ms, dev, dist)   # collective: every rank calls it
     if rank == 0:
+        ac, sem = res.get("acoustic"), res.get("semantic_m")
+        parts = [r for r in (ac, sem) if r is not None] or [hub]
+        dominant = max(parts, key=lambda r: r["roofline"]["avg_launch_ms"] * r["roofline"]["launches_per_step"])
+        names = [n for n, r in (("acoustic", ac), ("semantic_m", sem)) if r is not None] or ["semantic_s"]
         out = {
-            "metric": "audio-sec tokenized / wall-sec", "value": primary["value"], "unit": "audio-s/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
+            "metric": "audio-sec tokenized / wall-sec (" + " + ".join(names) + ")", "value": round(value, 2), "unit": "audio-s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (contractions as operand splits on the 16-bit matrix cores with fp32 accumulate; per kernel group two fp16 pieces / three "
-                      "products or three bf16 pieces / six products: see mfma_products_per_mac; final conv on the fp32 MFMA)")
-                     if ACOUSTIC_X3_GROUPS else "f32", "data": "synthetic",
-            "config": primary["config"], "roofline": primary["roofline"], "breakdown": primary["breakdown"],
-            "token_checksum": primary["token_checksum"],
+            "dtype": dominant["dtype"], "data": "synthetic",
+            "config": {"workload": " + ".join(r["config"]["workload"] for r in parts),
+                       "step": "one pass of the hot path over one batch of each tokenizer named in `metric`, both inside one timed region; value = audio-seconds of "
+                               "all of them / that time (BASELINE.json's combined metric); per-tokenizer rates in the named sub-objects",
+                       "audio_s_per_step_per_gpu": sum(r["config"]["clips_per_gpu"] * r["config"]["samples_per_clip"] / (24000 if "frames_per_clip" in r["config"] else 16000) for r in parts),
+                       "weights": "synthetic seed 0", "parallelism": f"clip-sharded x{world}, no data-path collective"},
+            "roofline": dict(dominant["roofline"], workload=names[parts.index(dominant)] if dominant in parts else "semantic_s"),
             "rccl_ranks": ranks["rccl_ranks"], "per_rank_ms": ranks["per_rank_ms"],
             "backend": args.backend if world > 1 else None,
         }
-        for k in ("median_ms_per_step", "pcie_inclusive", "broadcast_ms", "breakdown_note", "lstm_handoff_status", "mfma_products_per_mac"):
-            if k in primary:
-                out[k] = primary[k]
-        want_cpu = not args.no_cpu_baseline and world == 1 and args.workload != "selftest"
+        if ac is not None and sem is not None:
+            out["combined"] = {"value": out["value"], "unit": "audio-s/s", "definition": "audio-seconds of both workloads / time of the steps that hold both (= the top-level value)",
+                               "same_clips_rate": round(1.0 / (1.0 / ac["value"] + 1.0 / sem["value"]), 2),
+                               "same_clips_definition": "audio-seconds / wall-second when every clip goes through BOTH tokenizers: 1 / (1 / acoustic + 1 / semantic_m)"}
+        want_cpu = not args.no_cpu_baseline and world == 1
         if not want_cpu:
             out["cpu_baseline"] = None
             out["cpu_baseline_note"] = ("skipped: --no-cpu-baseline" if args.no_cpu_baseline else
                                         "skipped at N>1: the CPU oracle is timed on rank 0 at N=1 only")
         else:
             if ac is not None:
-                out["cpu_baseline"] = cpu_baseline_acoustic(args.num_codebooks)
-            elif sem is not None:
-                out["cpu_baseline"] = cpu_baseline_semantic(args.sem_layers)
-        if ac is not None and sem is not None:
-            s = {k: v for k, v in sem.items() if k not in ("elapsed", "audio_s_per_step", "rank_ms")}
-            if want_cpu:
-                s["cpu_baseline"] = cpu_baseline_semantic(args.sem_layers)
-            out["semantic_m"] = s
-            tot_audio = (ac["audio_s_per_step"] + sem["audio_s_per_step"]) * args.steps
-            out["combined"] = {"value": round(tot_audio / (ac["elapsed"] + sem["elapsed"]), 2), "unit": "audio-s/s",
-                               "definition": "audio-seconds of both workloads / (t_acoustic + t_semantic_m)"}
-        elif sem_err:
-            out["semantic_m"] = {"error": sem_err}
+                ac["cpu_baseline"] = cpu_baseline_acoustic(args.num_codebooks)
+            if sem is not None:
+                sem["cpu_baseline"] = cpu_baseline_semantic(args.sem_layers)
+            cb = [r["cpu_baseline"] for r in (ac, sem) if r is not None]
+            if len(cb) == 2:   # the same combined definition on the host: audio-seconds of one step of each / the CPU time they would take
+                a_s, s_s = ac["config"]["clips_per_gpu"] * args.seconds, sem["config"]["clips_per_gpu"] * args.sem_seconds
+                out["cpu_baseline"] = {"value": round((a_s + s_s) / (a_s / cb[0]["value"] + s_s / cb[1]["value"]), 3), "unit": "audio-s/s", "cores": cb[0]["cores"], "kind": "port",
+                                       "sample": "combined like `value` from the two per-tokenizer samples: " + cb[0]["sample"] + " | " + cb[1]["sample"]}
+            elif cb:
+                out["cpu_baseline"] = cb[0]
+        if verify is not None:
+            out["verify"] = verify
+        argmin = {r["argmin"]["kernel"]: r["argmin"] for r in (ac, sem, hub) if r is not None and "argmin" in r}
+        if argmin:
+            out["argmin_kernels"] = dict(argmin, note="north_star's 'memory-bound roofline on the argmin kernel' cannot bind at these shapes (SURVEY.md §8(d): 500-4 000 FLOP/B, "
+                                                      "right of the ridge): both roofs are given, `binding` names the one that limits the kernel")
+        for name, r in (("acoustic", ac), ("semantic_m", sem)):
+            if r is not None:
+                out[name] = {k: v for k, v in r.items() if k not in ("rank_ms",)}
+            elif name == "semantic_m" and sem_err:
+                out[name] = {"error": sem_err}
         if dec is not None:
             out["acoustic_decode"] = dec
-        if hub is not None and primary is not hub:
+        if hub is not None:
             out["semantic_s"] = hub
         elif hub_err:
             out["semantic_s"] = {"error": hub_err}
+        out["fallback_batches"] = sum(r.get("fallback_batches", 0) for r in (ac, sem, hub) if r is not None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -230,6 +230,11 @@ int at_required_tensors(const char* model, int n, int with_extras, char* buf, si
  * workspace >= (round_up(M, 256) + N) * K * pieces * 2 bytes. status_dev: nullable device word (bit 1 = fp16 range overflow). */
 int at_op_gemm_split(const float* X, const float* W, const float* bias, float* C, int M, int N, int K, int scheme, float w_max_abs,
                      int kernel, void* workspace, size_t workspace_bytes, int32_t* status_dev, at_stream_t stream);
+/* A causal conv1d (reflect front padding k - stride; ref: encodec SConv1d) on the WINDOWED two-piece fp16 split GEMM
+ * (csrc/gemm_f16x2_tg.hip), for the parity / soak tests: X [B][L][Cin] float32 channels-last, W [Cout][k * Cin] (tap-major), C [B][L / stride][Cout].
+ * Cin % 16, Cout % 128, L % stride == 0. workspace >= 2 * (B * Cin * stride * (round_up(L / stride, 256) + (k - 1) / stride + 1) + Cout * k * Cin) * 2 bytes. */
+int at_op_conv_split(const float* X, const float* W, const float* bias, float* C, int B, int L, int Cin, int Cout, int ktaps, int stride,
+                     float w_max_abs, void* workspace, size_t workspace_bytes, int32_t* status_dev, at_stream_t stream);
 int at_op_rvq_encode(const float* x, int64_t rows, int T, const float* codebooks, const float* e2, int n_q,
                      int16_t* codes, at_stream_t stream);
 

@@ -86,12 +86,14 @@ def log_mel(wave: torch.Tensor) -> torch.Tensor:
     prev = frames[..., :-1].clone()
     frames[..., 1:] = frames[..., 1:] - 0.97 * prev             # :171-172 (pre-update neighbours)
     frames[..., 0] = frames[..., 0] * (1 - 0.97)                # :173
-    frames = frames * povey_window()                            # :175
+    # (.to(dtype) is the identity for the reference's float32; a float64 `wave` evaluates the same formulas with an exact front-end — used by
+    # tests/test_edge_inputs_gpu.py to measure how much of the reference's output on an ill-conditioned input is its own rounding noise)
+    frames = frames * povey_window().to(frames.dtype)           # :175
     buf = F.pad(frames, (0, NFFT - FRAME))
     spec = torch.fft.rfft(buf)                                  # :177
     power = spec.abs().pow(2.0)                                 # :181
-    mel = torch.matmul(power, mel_filter_bank())                # :184
-    mel = torch.maximum(mel, torch.tensor(MEL_FLOOR, dtype=torch.float32))
+    mel = torch.matmul(power, mel_filter_bank().to(power.dtype))  # :184
+    mel = torch.maximum(mel, torch.tensor(MEL_FLOOR, dtype=mel.dtype))
     return torch.log(mel)
 
 

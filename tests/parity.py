@@ -54,27 +54,41 @@ def assert_rvq_equal_or_explained(got, ref, margins, tie, what):
 # A second, measured explanation for inputs that amplify rounding noise (an impulse: LayerNorm of an almost constant vector): Euclidean
 # distance is 1-Lipschitz in the quantised vector, so two implementations whose vectors differ by delta = ||x_got - x_ref||_2 at a position can
 # only pick different codes there when the oracle's top-2 margin is <= 2 delta. The contract allows float intermediates to differ by 1e-3 per
-# element; the bar uses the MEASURED delta of that position (normally ~1e-4), and separately asserts the per-element difference <= FLOAT_TOL.
+# element; the bar uses the MEASURED delta of that position (normally ~1e-4), and separately bounds the per-element difference: <= FLOAT_TOL, or —
+# where the reference's own output is ill-conditioned — <= NOISE_FACTOR x the amount by which the ORACLE differs from ITSELF when its front-end
+# (framing, DFT, log-mel, per-bin normalisation) is evaluated in float64 instead of float32 (`x_ref_exact`): the reference's own rounding noise at
+# that position, which no second implementation (another BLAS build of the reference included) reproduces.
 FLOAT_TOL = 1e-3
+NOISE_FACTOR = 4.0
 
 
-def assert_tokens_equal_or_explained_by_delta(got, ref, margins, x_got, x_ref, tie, what, valid=None):
-    """got / ref / margins [B, 1, T]; x_got / x_ref [B, T, D] = the vectors that were quantised (HIP path / oracle). A differing id must have an
-    oracle margin < tie, or <= 2 ||x_got - x_ref||_2 at its position with max |x_got - x_ref| <= FLOAT_TOL there. Prints the three counts."""
+def assert_tokens_equal_or_explained_by_delta(got, ref, margins, x_got, x_ref, tie, what, valid=None, x_ref_exact=None):
+    """got / ref / margins [B, 1, T]; x_got / x_ref [B, T, D] = the vectors that were quantised (HIP path / oracle); x_ref_exact = the oracle's
+    vectors with a float64 front-end (optional). A differing id must have an oracle margin < tie, or <= 2 ||x_got - x_ref||_2 at its position with
+    max |x_got - x_ref| <= max(FLOAT_TOL, NOISE_FACTOR max |x_ref - x_ref_exact|) there. Prints the counts."""
     got, ref = got.cpu().long(), ref.cpu().long()
     mism = (got != ref)[:, 0]                                   # [B, T]
     if valid is not None:
         mism = mism & valid.cpu().bool().reshape(mism.shape)
     d = (x_got.cpu().float() - x_ref.cpu().float())
     delta, dmax = d.norm(dim=-1), d.abs().amax(dim=-1)          # [B, T]
+    cap = torch.full_like(dmax, FLOAT_TOL)
+    noise = torch.zeros_like(dmax)
+    if x_ref_exact is not None:
+        noise = (x_ref.cpu().float() - x_ref_exact.cpu().float()).abs().amax(dim=-1)
+        cap = torch.maximum(cap, NOISE_FACTOR * noise)
     m = margins.cpu()[:, 0]
     by_tie = mism & (m < tie)
-    by_delta = mism & ~by_tie & (m <= 2.0 * delta) & (dmax <= FLOAT_TOL)
+    by_delta = mism & ~by_tie & (m <= 2.0 * delta) & (dmax <= cap)
     bad = mism & ~by_tie & ~by_delta
     total = int(valid.sum()) if valid is not None else mism.numel()
     scope = valid.cpu().bool().reshape(mism.shape) if valid is not None else torch.ones_like(mism)
     print(f"{what}: {int(mism.sum())} of {total} ids differ from the oracle: {int(by_tie.sum())} at an oracle top-2 margin < {tie:g}, {int(by_delta.sum())} at a margin <= "
           f"2 x the measured vector difference (largest such margin {float(m[by_delta].max()) if bool(by_delta.any()) else 0.0:.2e}), {int(bad.sum())} unexplained; "
-          f"max |x_got - x_ref| over the compared positions {float(dmax[scope].max()):.2e}")
+          f"max |x_got - x_ref| over the compared positions {float(dmax[scope].max()):.2e}, the oracle's own float32-vs-float64-front-end difference there "
+          f"{float(noise[scope].max()):.2e}")
     assert int(bad.sum()) == 0, f"{what}: {int(bad.sum())} token ids differ from the oracle without an explanation"
+    # away from the ill-conditioned positions the float contract holds as stated
+    over = scope & (dmax > cap)
+    assert not bool(over.any()), f"{what}: quantised vectors differ by {float(dmax[over].max()):.2e} > the tolerance at {int(over.sum())} positions"
     return int(mism.sum())

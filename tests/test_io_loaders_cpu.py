@@ -129,3 +129,39 @@ def test_batch_files_sharding_logic(tmp_path, monkeypatch):
     assert segs == [sr, sr, sr, sr, sr, sr]            # f1's 500-sample and f2's 1000-sample tails are < 3200: skipped
     out = {n: np.load(tmp_path / "o" / n) for n in sorted(os.listdir(tmp_path / "o"))}
     assert {k: v.shape for k, v in out.items()} == {"f0.npy": (2, 75), "f1.npy": (2, 150), "f2.npy": (2, 225)}
+
+
+def test_undecodable_files_are_skipped_visibly_and_bugs_propagate(tmp_path, monkeypatch):
+    """A file this build cannot decode (flac: no ffmpeg here; a stereo WAV; a damaged header) is skipped, but the caller can see it:
+    ``AudioToken.skipped_files`` lists it and the run logs a summary. Any other exception (a bug in resampling / chunking) propagates, like
+    the reference's dataset iterator (audiotoken/datasets.py __iter__) lets it."""
+    from audiotoken_amd import AudioToken, Tokenizers
+    from audiotoken_amd import audio_io as A
+    sr = 24000
+    _write_wav(tmp_path / "good.wav", W.synth_waveform(1, sr, sr, seed=1)[0], sr)
+    (tmp_path / "music.flac").write_bytes(b"fLaC\x00\x00\x00\x22")
+    (tmp_path / "broken.wav").write_bytes(b"RIFF\x00\x00")
+    from scipy.io import wavfile
+    wavfile.write(str(tmp_path / "stereo.wav"), sr, np.zeros((sr, 2), np.float32))
+    tok = AudioToken(Tokenizers.acoustic, device="cpu", num_codebooks=2)
+
+    class Fake(torch.nn.Module):
+        def forward(self, x, m):
+            return torch.zeros((x.shape[0], 2, 75), dtype=torch.int16)
+
+    tok.encoder = Fake()
+    monkeypatch.setattr(tok, "load_encoder", lambda: None)
+    files = [tmp_path / n for n in ("music.flac", "good.wav", "broken.wav", "stereo.wav", "notes.txt")]
+    tok.encode_batch_files(batch_size=2, outdir=tmp_path / "o", chunk_size=1, audio_files=files, num_workers=2)
+    assert sorted(os.listdir(tmp_path / "o")) == ["good.npy"]
+    skipped = {os.path.basename(p): why for p, why in tok.skipped_files}
+    assert set(skipped) == {"music.flac", "broken.wav", "stereo.wav", "notes.txt"}
+    assert "NotImplementedError" in skipped["music.flac"] and "mono" in skipped["stereo.wav"] and skipped["notes.txt"] == "unsupported extension"
+    # a second run starts from an empty list
+    tok.encode_batch_files(batch_size=2, outdir=tmp_path / "o2", chunk_size=1, audio_files=[tmp_path / "good.wav"], num_workers=0)
+    assert tok.skipped_files == []
+    # a bug is not a decode error: it must surface
+    _write_wav(tmp_path / "sr16.wav", W.synth_waveform(1, 16000, 16000, seed=2)[0], 16000)
+    monkeypatch.setattr(A, "resample", lambda *a, **k: (_ for _ in ()).throw(ZeroDivisionError("bug in resample")))
+    with pytest.raises(ZeroDivisionError):
+        tok.encode_batch_files(batch_size=2, outdir=tmp_path / "o3", chunk_size=1, audio_files=[tmp_path / "sr16.wav"], num_workers=0)

@@ -190,3 +190,81 @@ def test_split_gemm_xcd_order_and_soak(cuda_device):
             assert err <= 1.5e-5 * max(1.0, np.sqrt((ref ** 2).mean()))
         else:
             assert torch.equal(out, first), f"run {it} differs from run 0"
+
+
+def _conv_split(dev, x, wp, b, k, s, reps=1):
+    """x [B, L, Cin] channels-last, wp [Cout, k * Cin] tap-major -> list of `reps` outputs [B, L / s, Cout] of at_op_conv_split."""
+    lib = _cabi.load()
+    B, L, Cin = x.shape
+    Cout = wp.shape[0]
+    M = L // s
+    Lp = (M + 255) // 256 * 256 + (k - 1) // s + 1
+    nbytes = 2 * (B * Cin * s * Lp + Cout * k * Cin) * 2
+    xd, wd, bd = x.to(dev).contiguous(), wp.to(dev).contiguous(), b.to(dev).contiguous()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    outs = []
+    for _ in range(reps):
+        out = torch.full((B, M, Cout), float("nan"), dtype=torch.float32, device=dev)
+        _cabi.check(lib.at_op_conv_split(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, L, Cin, Cout, k, s, float(wp.abs().max()),
+                                         ws.data_ptr(), nbytes, status.data_ptr(), _cabi.current_stream_handle(dev)), "at_op_conv_split")
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        outs.append(out)
+    return outs
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,k,s,tile", [
+    (3, 1000, 128, 256, 10, 5, 128), (2, 2048, 256, 512, 16, 8, 128), (2, 777, 512, 128, 7, 1, 128), (5, 640, 256, 128, 3, 1, 128),
+    (40, 6000, 128, 256, 10, 5, 128), (64, 12000, 128, 256, 10, 5, 256),
+])
+def test_conv_split_windowed_vs_oracle_and_soak(cuda_device, B, L, Cin, Cout, k, s, tile):
+    """The WINDOWED instantiations of the two-group GEMM (gemm_f16x2_tg_kernel<true, 2, 4> at two workgroups per CU, <true, 4, 8> with the XCD-aware
+    persistent tile walk) as a causal conv1d against the CPU oracle's conv (encodec SConv1d), then 25 bit-identical repeats: a landing or refill
+    race of the LDS-DMA ring (gemm_f16x2_tg.hip, RAW / WAR) shows up as run-to-run differences long before it shows up as a wrong token."""
+    x = torch.from_numpy(prng.uniform(f"cs.x{B}.{L}", (B, L, Cin), -2.0, 2.0, seed=11))
+    w = torch.from_numpy(prng.uniform(f"cs.w{Cout}.{k}", (Cout, Cin, k), -0.2, 0.2, seed=11))
+    b = torch.from_numpy(prng.uniform("cs.b", (Cout,), -1.0, 1.0, seed=11))
+    wp = w.permute(0, 2, 1).reshape(Cout, k * Cin).contiguous()
+    reps = 25 if B >= 5 else 3
+    outs = _conv_split(cuda_device, x, wp, b, k, s, reps)
+    nchk = min(B, 3)
+    ref = R.conv1d_causal(x[:nchk].permute(0, 2, 1).double(), w.double(), b.double(), s).permute(0, 2, 1).float()
+    got = outs[0][:nchk].cpu()
+    assert ref.shape == got.shape
+    err = (got - ref).abs().max().item()
+    print(f"conv split B={B} L={L} {Cin}->{Cout} k={k} s={s} ({tile}-row tiles): max err {err:.2e} at scale {ref.abs().max().item():.1f}; {reps} repeats")
+    assert not torch.isnan(outs[0]).any(), "NaN in the output (unwritten tiles?)"
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item())
+    for i, o in enumerate(outs[1:], 1):
+        assert torch.equal(o, outs[0]), f"run {i} differs from run 0"
+
+
+def test_split_gemm_small_tile_soak(cuda_device):
+    """gemm_f16x2_tg_kernel<false, 2, 4>: the 128 x 128 shape with TWO workgroups per CU (628 tiles on 512 persistent workgroups), the configuration
+    in which round 2's shared-DMA variant produced sporadically wrong tiles (root cause and reproducer: tools/lds_dma_war.hip). Against float64, then
+    25 bit-identical repeats."""
+    lib = _cabi.load()
+    M, N, K = 20000, 512, 1024
+    x = prng.irwin_hall("soak2.x", (M, K), 1.0, 5)
+    w = prng.irwin_hall("soak2.w", (N, K), 0.05, 5)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T
+    dev = cuda_device
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    nbytes = ((M + 255) // 256 * 256 + N) * K * 2 * 2
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    first = None
+    for it in range(25):
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+        _cabi.check(lib.at_op_gemm_split(xd.data_ptr(), wd.data_ptr(), 0, out.data_ptr(), M, N, K, 1, float(np.abs(w).max()), 1,
+                                         ws.data_ptr(), nbytes, status.data_ptr(), _cabi.current_stream_handle(dev)), "at_op_gemm_split")
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        if first is None:
+            first = out
+            err = np.abs(out.cpu().numpy().astype(np.float64) - ref).max()
+            print(f"split gemm (two-group kernel, 128-row tiles) M={M} N={N} K={K}: max err vs float64 {err:.2e}")
+            assert err <= 1.5e-5 * max(1.0, np.sqrt((ref ** 2).mean()))
+        else:
+            assert torch.equal(out, first), f"run {it} differs from run 0"

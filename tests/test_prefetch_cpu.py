@@ -126,3 +126,40 @@ def test_background_forwards_exceptions_and_end():
     with pytest.raises(RuntimeError, match="boom"):
         next(it)
     assert list(background(lambda: iter([1, 2, 3]))) == [1, 2, 3]
+
+
+def test_background_stops_when_garbage_collected_or_consumer_fails():
+    """The producer thread must not keep the iterator alive (it references the queue, the event and the generator factory only): dropping the
+    object without close() — what an exception in the consumer does — ends the thread and runs the generator's finally block (the tar / zip handle)."""
+    import gc
+    import threading
+    import time
+    from audiotoken_amd.prefetch import background
+    closed = threading.Event()
+
+    def endless():
+        try:
+            i = 0
+            while True:
+                yield i
+                i += 1
+        finally:
+            closed.set()
+
+    b = background(endless, depth=2)
+    assert next(b) == 0
+    th = b._thread
+    del b
+    gc.collect()
+    th.join(3.0)
+    assert not th.is_alive(), "the producer thread outlived its abandoned iterator"
+    assert closed.wait(1.0), "the generator's finally block did not run"
+
+    # explicit close(), and join()
+    closed.clear()
+    b = background(endless, depth=1)
+    assert [next(b), next(b)] == [0, 1]
+    b.close()
+    assert b.join(3.0) and closed.wait(1.0)
+    with pytest.raises(StopIteration):
+        next(b)
