@@ -86,6 +86,12 @@ SIGNATURES = {
     "at_hubert_get_option": (C.c_int, [C.c_void_p, C.c_char_p]),
     "at_hubert_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "at_hubert_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
+    "at_encodec_range_sites": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "at_encodec_range_report": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "at_w2vbert_range_sites": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "at_w2vbert_range_report": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "at_hubert_range_sites": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "at_hubert_range_report": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "at_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "at_op_relpos_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "at_op_dwconv_ln_swish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -170,3 +176,16 @@ def set_tensor(lib, fn, handle, name: str, arr: np.ndarray):
     arr = np.ascontiguousarray(arr, dtype=np.float32)
     shape = (C.c_int64 * arr.ndim)(*arr.shape)
     check(fn(handle, name.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim), f"set_tensor({name})")
+
+
+def range_report(lib, model: str, handle) -> dict:
+    """{site: largest |x * scale| the site's split writers saw in the handle's last call} (include/audiotoken_hip.h, at_*_range_report); the
+    fp16 scheme overflows at 65504. Synchronises the device."""
+    names = C.create_string_buffer(2048)
+    n = getattr(lib, f"at_{model}_range_sites")(names, 2048)
+    if n < 0:
+        raise HipLibraryError(f"at_{model}_range_sites failed")
+    vals = (C.c_float * 64)()
+    check(getattr(lib, f"at_{model}_range_report")(handle, vals, 64) - n, f"at_{model}_range_report")
+    keys = names.value.decode().split("\n")[:n]
+    return {k: float(vals[i]) for i, k in enumerate(keys)}

@@ -58,6 +58,30 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Unsigned division by a run-time constant without the hardware's reciprocal sequence (Granlund-Montgomery): the host prepares (magic, sh1, sh2)
+// from the divisor, the device computes n / d = (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, magic), exact for every 32-bit n. Uniform operands
+// stay on the scalar unit (s_mul_hi_u32); the compiler's own expansion of `/` goes through v_rcp_iflag_f32 on the VECTOR unit even for uniform values
+// and hoists the reciprocal out of loops — two registers held across the whole two-group GEMM kernel, which has none to spare.
+struct FastDivU {
+    unsigned magic = 1, sh1 = 0, sh2 = 0, d = 1;
+    FastDivU() = default;
+    explicit FastDivU(unsigned div) : d(div ? div : 1) {
+        unsigned l = 0;
+        while ((1ull << l) < d) ++l;
+        magic = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+        sh1 = l < 1 ? l : 1;
+        sh2 = l > 1 ? l - 1 : 0;
+    }
+    __host__ __device__ __forceinline__ unsigned div(unsigned n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned t = __umulhi(n, magic);
+#else
+        const unsigned t = (unsigned)(((unsigned long long)n * magic) >> 32);
+#endif
+        return (t + ((n - t) >> sh1)) >> sh2;
+    }
+};
+
 // ---- the one dense contraction every layer maps onto ----------------------------------------
 // out[b][m][n] = epi( alpha * ( sum_kk A(b,m,kk) * W[n][kk] + bias[n] ) ) (+ R[b][m][n])
 // where A(b,m,kk) = pro( X[b][ row(m, kk / Cin) ][ kk % Cin ] ),  row(m,tap) = m*stride + tap - pad_left,

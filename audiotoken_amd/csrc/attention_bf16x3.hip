@@ -16,9 +16,21 @@
 #include "w2vbert_kernels.h"
 #include "split_scheme.h"
 
+#include <cstdio>
+
 namespace at {
 
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+// -DAX_DEBUG_STAMPS (tools/ax_stamps.sh; never in the product build): wave 0 of one workgroup sums the cycle counter over the phases of its key tiles
+#ifdef AX_DEBUG_STAMPS
+__device__ unsigned long long ax_stamps[12];
+#define AX_T(i) const unsigned long long ax_t##i = __builtin_readcyclecounter()
+#define AX_ACC(k, a_, b_) ax_d[k] += ax_t##b_ - ax_t##a_
+#else
+#define AX_T(i) do {} while (0)
+#define AX_ACC(k, a_, b_) do {} while (0)
+#endif
 
 constexpr int AX_QB = 128, AX_KB = 32;
 constexpr int AX_KLD = 72;    // bf16 per K row (64 d + 8 pad: 144-byte stride, conflict-free 16-byte fragment reads)
@@ -48,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
     // operand scales (1 for the bf16 scheme): q, k, v * XS; p * PS. S = acc / XS^2, O = acc / (PS XS)
     constexpr float XS = SC::RANGE_CHECK ? XB_F16_ACT_SCALE : 1.0f, PS = SC::RANGE_CHECK ? AX_P_SCALE : 1.0f;
     constexpr float S_SCALE2 = AX_SCALE2 / (XS * XS);
-    bool over = false;
+    RangeMax over;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     PT* Ks = reinterpret_cast<PT*>(smem_raw);                    // [NP][32 keys][72]
     PT* Vt = Ks + AX_K_ELEMS;                                    // [NP][64 d][40], keys permuted inside each 16-group
@@ -175,9 +187,15 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
         am = amask[rowbase + (rr < T ? rr : T - 1)];
     };
     prefetch(0);
+#ifdef AX_DEBUG_STAMPS
+    unsigned long long ax_d[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long ax_begin = __builtin_readcyclecounter();
+#endif
     for (int kt = 0; kt < nkt; ++kt) {
         const int r0 = kt * AX_KB;
+        AX_T(0);
         __syncthreads();   // previous tile fully consumed (also orders the QE stores before first use)
+        AX_T(1);
         if constexpr (KVP) {
             PT* kd = Ks + sk_key * AX_KLD + sk_d;
             PT* vd = Vt + sk_key * AX_VROW + sk_d;
@@ -221,8 +239,11 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
                 if (tid == 0) kb_any[0] = anyb != 0ull ? 1 : 0;
             }
         }
+        AX_T(2);
         __syncthreads();
+        AX_T(3);
         if (kt + 1 < nkt) prefetch(kt + 1);
+        AX_T(4);
         // ---- S^T = K . Q^T: lane holds s[r] = q_lq . k_(r0 + 8*(r/4) + 4*hh + r%4) ------------------------------------------------
         f16v s;
 #pragma unroll
@@ -235,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
 #pragma unroll
             for (int t = 0; t < SC::NPROD; ++t) s = SC::mfma(kf[SC::prod_a(t)], qpc[SC::prod_w(t)][ds], s);
         }
+        AX_T(5);
         // ---- bias + mask, online softmax in the exp2 domain ------------------------------------------------------------------------
         const bool far_left = (r0 + AX_KB - 1) - wl_min <= -64;
         const bool far_right = r0 - wl_max >= 8;
@@ -288,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
         } else {
             lrun += rs;
         }
+        AX_T(6);
         // ---- P pieces (B operand of P.V: k-step ks uses registers 8ks .. 8ks+7 = keys 16ks + {0..3, 8..11} + 4hh) -----------------
         V8 pp[NP][2];
 #pragma unroll
@@ -302,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
 #pragma unroll
                     for (int j = 0; j < 4; ++j) pp[i][ks][4 * jq + j] = q4[i][j];
             }
+        AX_T(7);
         // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------------------------
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -331,7 +355,16 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
 #pragma unroll
                 for (int t = 0; t < SC::NPROD; ++t) oacc[dt] = SC::mfma(vf[SC::prod_a(t)], pp[SC::prod_w(t)][ks], oacc[dt]);
             }
+        AX_T(8);
+        AX_ACC(0, 0, 1); AX_ACC(1, 1, 2); AX_ACC(2, 2, 3); AX_ACC(3, 3, 4); AX_ACC(4, 4, 5); AX_ACC(5, 5, 6); AX_ACC(6, 6, 7); AX_ACC(7, 7, 8);
     }
+#ifdef AX_DEBUG_STAMPS
+    if (blockIdx.x == (gridDim.x / 2) && threadIdx.x == 0) {
+        for (int i = 0; i < 8; ++i) ax_stamps[i] = ax_d[i];
+        ax_stamps[8] = __builtin_readcyclecounter() - ax_begin;
+        ax_stamps[9] = (unsigned long long)nkt;
+    }
+#endif
     // lane holds O[lq][dv = 32 dt + 8*(r/4) + 4 hh + r%4]
     if (lq < T) {
         const float inv = (1.0f / lrun) * (1.0f / (PS * XS));
@@ -347,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
             }
     }
     if constexpr (SC::RANGE_CHECK)
-        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
+        range_publish(status, status ? status + 1 : nullptr, over);
 }
 
 template <class SC, bool KVP>
@@ -360,6 +393,20 @@ static int launch_ax(const float* qkv, const float* amask, const float* dist_emb
     hipLaunchKernelGGL((relpos_attention_x3_kernel<SC, KVP>), grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T, heads * 64, status,
                        reinterpret_cast<typename SC::T*>(ctx_pieces), rows_pad, heads, B, reinterpret_cast<const typename SC::T*>(kv_pieces));
     AT_CHECK_HIP(hipGetLastError());
+#ifdef AX_DEBUG_STAMPS
+    {
+        static int printed = 0;
+        if (printed < 4) {
+            ++printed;
+            (void)hipStreamSynchronize(stream);
+            unsigned long long hb[12];
+            (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(ax_stamps), sizeof(hb));
+            const double n = (double)(hb[9] ? hb[9] : 1);
+            std::fprintf(stderr, "ax stamps B %d T %d heads %d kvp %d (cycles per 32-key tile, wave 0 of one workgroup): barrier1 %.0f  stage->LDS %.0f  barrier2 %.0f  prefetch issue %.0f  K reads + S mfma %.0f  softmax %.0f  P split %.0f  V reads + PV mfma %.0f | loop total %.0f per tile, %llu tiles\n",
+                         B, T, heads, (int)KVP, hb[0] / n, hb[1] / n, hb[2] / n, hb[3] / n, hb[4] / n, hb[5] / n, hb[6] / n, hb[7] / n, hb[8] / n, hb[9]);
+        }
+    }
+#endif
     return 0;
 }
 

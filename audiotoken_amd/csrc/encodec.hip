@@ -165,8 +165,9 @@ struct at_encodec {
     bool res_f16x2 = true;
     float whh_fs[2] = {0.f, 0.f}, dwhh_fs[2] = {0.f, 0.f};   // W_hh scales of the fp16-scheme LSTM recurrence (option "lstm_f16x2")
     bool lstm_f16x2 = true;
-    bool ih_f16x2 = true;   // option "ih_f16x2" / $AUDIOTOKEN_IH_F16X2: LSTM input projections on the fp16 scheme (three MFMA products instead of six)
+    bool ih_f16x2 = true;   // option "ih_f16x2": LSTM input projections on the fp16 scheme (three MFMA products instead of six)
     std::vector<void*> extra_allocs;
+    int* range_tab = nullptr;   // device, {flag, census} per AcSite, zeroed at the start of every encode / decode (at_encodec_range_report reads it)
     int sub_batch = at::sub_batch();   // clips per pass through the conv stack: bounds the workspace (option "subbatch")
     bool persistent_lstm = false;   // whole-sequence persistent LSTM (needs one resident workgroup per CU for 256 CUs)
     unsigned lstm_spin_limit = 1u << 18;   // option "lstm_spin_limit": flag polls before a persistent-LSTM workgroup gives up
@@ -323,10 +324,21 @@ int resblock(const ConvW (&r)[3], const float* x, float* hbuf, float* out, int L
 }
 
 // 2-layer LSTM + skip over [B][T][512]; xg/c/h0 are scratch. y = lstm(x) + x.
-// status word of the *_checked entry points: bit 0 = an LSTM hand-off wait gave up (sync[63]), bit 1 = fp16 range overflow (sync[62])
-__global__ void status_combine_kernel(const unsigned* sync, unsigned* out) { out[0] = (sync[63] ? 1u : 0u) | (sync[62] & 2u); }
-int launch_status_combine(const unsigned* sync, unsigned* out, hipStream_t stream) {
-    hipLaunchKernelGGL(status_combine_kernel, dim3(1), dim3(1), 0, stream, sync, out);
+// Range table of a handle (device, zeroed per call): one {flag word, census word} pair per SITE = per place where activations are split into
+// fp16 pieces. A split writer ORs XB_STATUS_F16_OVERFLOW into its site's flag word and raises the census word to the largest |x * scale| it saw
+// (split_scheme.h, range_publish); at_encodec_range_report() returns the census, i.e. the measured headroom to 65504 per site.
+enum AcSite { AS_STAGE0 = 0, AS_RES1, AS_DOWN1, AS_RES2, AS_DOWN2, AS_RES3_CONV, AS_RES3_TAIL, AS_LSTM_IH, AS_FINAL, AS_RVQ,
+              AS_DEC_LSTM_IH, AS_DEC_UP, AS_DEC_RES, AC_NSITES };
+static const char* const kAcSiteNames[AC_NSITES] = {"stage0", "res1", "down1", "res2", "down2", "res3_conv", "res3_tail", "lstm_ih", "final_conv_in", "rvq",
+                                                   "dec_lstm_ih", "dec_up", "dec_res"};
+// status word of the *_checked entry points: bit 0 = an LSTM hand-off wait gave up (sync[63]), bit 1 = fp16 range overflow at any site
+__global__ void status_combine_kernel(const unsigned* sync, const int* range_tab, int nsites, unsigned* out) {
+    unsigned v = sync[63] ? 1u : 0u;
+    for (int k = 0; k < nsites; ++k) v |= (unsigned)range_tab[2 * k] & (unsigned)XB_STATUS_F16_OVERFLOW;
+    out[0] = v;
+}
+int launch_status_combine(const unsigned* sync, const int* range_tab, unsigned* out, hipStream_t stream) {
+    hipLaunchKernelGGL(status_combine_kernel, dim3(1), dim3(1), 0, stream, sync, range_tab, (int)AC_NSITES, out);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -663,8 +675,6 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
         h->rvq_x3 = (mask & 256) != 0;
     }
     if (h->bf16x3) {
-        if (const char* e = std::getenv("AUDIOTOKEN_IH_F16X2")) h->ih_f16x2 = std::atoi(e) != 0;
-        if (const char* e = std::getenv("AUDIOTOKEN_LSTM_F16X2")) h->lstm_f16x2 = std::atoi(e) != 0;
         for (int dec = 0; dec < (with_decoder ? 2 : 1); ++dec)
             for (int l = 0; l < 2; ++l) {
                 __bf16* d = nullptr;
@@ -697,7 +707,6 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             if (int rc = launch_split_plain(h->codebooks, n, d, nullptr)) return rc;
             h->cb_s = d;
             // and as two fp16 pieces of E * 2^k (one power of two for all codebooks: the order of the distances is untouched)
-            if (const char* e = std::getenv("AUDIOTOKEN_RVQ_F16X2")) h->rvq_f16x2 = std::atoi(e) != 0;
             float mx = 0.f;
             const size_t cb_off = o_cb;
             for (long long i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(p.host[cb_off + i]));
@@ -754,7 +763,6 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             h->sc0_w = d;
         }
         {   // power-of-two weight scales of the fused residual blocks' fp16 scheme (the kernels split their weights themselves, once per launch)
-            if (const char* e = std::getenv("AUDIOTOKEN_RES_F16X2")) h->res_f16x2 = std::atoi(e) != 0;
             auto wmax = [&](size_t off, size_t n) { float mx = 0.f; for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(p.host[off + i])); return mx; };
             int Cc = 32;
             for (int s2 = 0; s2 < 4; ++s2) {
@@ -785,7 +793,6 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             }
         }
         {   // the same four weights as two fp16 pieces, each scaled by a power of two into [2^14, 2^15) (gemm_bf16x3.h, XB_SCHEME_F16X2)
-            if (const char* e = std::getenv("AUDIOTOKEN_CHAIN_F16X2")) h->chain_f16x2 = std::atoi(e) != 0;
             const float* src[4] = {h->down[2].w, h->res[3][0].w, h->res[3][1].w, h->down[3].w};
             const size_t off[4] = {o_down[2].w, o_res[3][0].w, o_res[3][1].w, o_down[3].w};
             const int ns[4] = {256, 128, 256, 512}, ks[4] = {1280, 768, 384, 4096};
@@ -802,7 +809,6 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
                 h->chain_fs[j] = sc;
             }
             {   // final conv [128][7 * 512]
-                if (const char* e = std::getenv("AUDIOTOKEN_FIN_F16X2")) h->fin_f16x2 = std::atoi(e) != 0;
                 const size_t n = (size_t)kDim * 7 * kH;
                 float mx = 0.f;
                 for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(p.host[o_fin.w + i]));
@@ -815,6 +821,11 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
             }
         }
         AT_CHECK_HIP(hipDeviceSynchronize());
+    }
+    if (!host_only_test()) {
+        AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, 64 * sizeof(int)));
+        h->extra_allocs.push_back(h->range_tab);
+        AT_CHECK_HIP(hipMemset(h->range_tab, 0, 64 * sizeof(int)));
     }
     h->finalized = true;
     return 0;
@@ -853,14 +864,15 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     if (T_out) *T_out = T;
 
     float* x4 = ws + p.off_x4;
-    AT_CHECK_HIP(hipMemsetAsync(ws + p.off_sync, 0, 1024 * sizeof(unsigned), stream));   // LSTM flags + the two status words
+    AT_CHECK_HIP(hipMemsetAsync(ws + p.off_sync, 0, 1024 * sizeof(unsigned), stream));   // LSTM flags + the LSTM status word
+    AT_CHECK_HIP(hipMemsetAsync(h->range_tab, 0, 64 * sizeof(int), stream));
     for (int b0 = 0; b0 < B; b0 += p.G) {
         const int g = (B - b0) < p.G ? (B - b0) : p.G;
         static const char* kRes[4] = {"res0", "res1", "res2", "res3"};
         static const char* kDown[4] = {"down0", "down1", "down2", "down3"};
         Profiler& prof = h->prof;
         const bool fused0 = h->fused_stage0 && (N % 2 == 0);
-        int* range_status = reinterpret_cast<int*>(reinterpret_cast<unsigned*>(ws + p.off_sync) + 62);
+        auto rs = [&](int site) { return h->range_tab + 2 * site; };
         if (fused0) {
             // conv0 + resblock(32) + ELU + strided conv in one kernel: 4 B in, 128 B out per sample (seanet_stage0.hip)
             Stage0Args sa;
@@ -870,7 +882,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             sa.B = g; sa.N = N;
             sa.wsc0 = h->sc0_w; sa.bsc0 = h->sc0_w ? h->sc0_w + 32 * 7 : nullptr;
             if (h->res_f16x2) {
-                sa.scheme = XB_SCHEME_F16X2; sa.act_scale = XB_F16_ACT_SCALE; sa.status = range_status;
+                sa.scheme = XB_SCHEME_F16X2; sa.act_scale = XB_F16_ACT_SCALE; sa.status = rs(AS_STAGE0);
                 sa.w3_scale = h->res_fs[0][0]; sa.wt_scale = h->res_fs[0][1]; sa.wd_scale = h->down_fs[0];
             }
             prof.begin("stage0_fused", 1, stream);
@@ -885,10 +897,10 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
         // operand scheme of that chain: two fp16 pieces / three products (default) or three bf16 pieces / six products
         const bool cf = h->chain_f16x2 && h->chain_f[0] != nullptr;
         const int cnp = cf ? 2 : 3;
-        auto chain_cfg = [&](Bf16x3Args& a, int j, const __bf16* w_bf16) {
+        auto chain_cfg = [&](Bf16x3Args& a, int j, const __bf16* w_bf16) {   // j: 0 = stage-2 strided conv, 1 = conv3 of the block, 2 = its tail, 3 = stage-3 conv
             if (cf) {
                 a.W = h->chain_f[j]; a.scheme = XB_SCHEME_F16X2; a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->chain_fs[j]);
-                a.split_scale = XB_F16_ACT_SCALE; a.status = range_status;
+                a.split_scale = XB_F16_ACT_SCALE; a.status = rs(j == 0 ? AS_DOWN2 : j == 1 ? AS_RES3_CONV : AS_RES3_TAIL);
             } else {
                 a.W = w_bf16;
             }
@@ -903,7 +915,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 Res64Args ra;
                 ra.x = x; ra.out = r; ra.w3 = h->res[1][0].w; ra.b3 = h->res[1][0].b; ra.wt = h->res[1][1].w; ra.bt = h->res[1][1].b;
                 ra.B = g; ra.L = L;
-                if (h->res_f16x2) { ra.scheme = XB_SCHEME_F16X2; ra.act_scale = XB_F16_ACT_SCALE; ra.w3_scale = h->res_fs[1][0]; ra.wt_scale = h->res_fs[1][1]; ra.status = range_status; }
+                if (h->res_f16x2) { ra.scheme = XB_SCHEME_F16X2; ra.act_scale = XB_F16_ACT_SCALE; ra.w3_scale = h->res_fs[1][0]; ra.wt_scale = h->res_fs[1][1]; ra.status = rs(AS_RES1); }
                 prof.begin("res1", 1, stream);
                 if (int rc = (h->res64_x3 && h->bf16x3) ? launch_seanet_res64x3(ra, stream) : launch_seanet_res64(ra, stream)) return rc;
                 prof.end(stream);
@@ -914,10 +926,10 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 ra.B = g; ra.L = L;
                 // with the strided conv as a split-bf16 GEMM the block writes that GEMM's operand pieces instead of fp32 rows
                 down2_gemm = h->down128_x3 && h->res128_x3 && h->bf16x3 && h->down2_s && L % 5 == 0 && L >= 10;
-                if (h->res_f16x2) { ra.scheme = XB_SCHEME_F16X2; ra.act_scale = XB_F16_ACT_SCALE; ra.w3_scale = h->res_fs[2][0]; ra.wt_scale = h->res_fs[2][1]; ra.status = range_status; }
+                if (h->res_f16x2) { ra.scheme = XB_SCHEME_F16X2; ra.act_scale = XB_F16_ACT_SCALE; ra.w3_scale = h->res_fs[2][0]; ra.wt_scale = h->res_fs[2][1]; ra.status = rs(AS_RES2); }
                 if (down2_gemm) {
                     ra.S = reinterpret_cast<__bf16*>(r); ra.Lp = p.Lp2;
-                    if (cf) { ra.S_scheme = XB_SCHEME_F16X2; ra.S_scale = XB_F16_ACT_SCALE; ra.status = range_status; }
+                    if (cf) { ra.S_scheme = XB_SCHEME_F16X2; ra.S_scale = XB_F16_ACT_SCALE; ra.status = rs(AS_RES2); }
                 }
                 prof.begin("res2", down2_gemm ? 2 : 1, stream);
                 const bool x3 = h->res128_x3 && h->bf16x3;
@@ -956,7 +968,7 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             if (s == 1 && h->fused_down64 && L % 4 == 0) {
                 Down64Args da;
                 da.x = r; da.out = out; da.w = h->down[1].w; da.b = h->down[1].b; da.B = g; da.L = L;
-                if (h->res_f16x2) { da.scheme = XB_SCHEME_F16X2; da.act_scale = XB_F16_ACT_SCALE; da.w_scale = h->down_fs[1]; da.status = range_status; }
+                if (h->res_f16x2) { da.scheme = XB_SCHEME_F16X2; da.act_scale = XB_F16_ACT_SCALE; da.w_scale = h->down_fs[1]; da.status = rs(AS_DOWN1); }
                 if (int rc = (h->down64_x3 && h->bf16x3) ? launch_seanet_down64x3(da, stream) : launch_seanet_down64(da, stream)) return rc;
             } else if (s == 2 && down2_gemm) {
                 Bf16x3Args ga;
@@ -996,14 +1008,14 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);   // zeroed at the start of the call (the conv stack's range status lives in it)
     if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
                            sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
-                           (h->bf16x3 && h->ih_f16x2) ? h->wih_f : nullptr, h->wih_fs, reinterpret_cast<int*>(sync + 62), h->lstm_f16x2 ? h->whh_fs : nullptr))
+                           (h->bf16x3 && h->ih_f16x2) ? h->wih_f : nullptr, h->wih_fs, h->range_tab + 2 * AS_LSTM_IH, h->lstm_f16x2 ? h->whh_fs : nullptr))
         return rc;
     float* emb = emb_out ? emb_out : ws + p.off_emb;
     prof.begin("final_conv", 1, stream);
     if (h->bf16x3 && h->fin_f16x2 && h->fin_f && T > 6) {
         // y = ELU(lstm + skip) -> two fp16 pieces in windowed layout (6 reflected front rows), then the k = 7 conv as a windowed split GEMM
         __bf16* yp = reinterpret_cast<__bf16*>(ws + p.off_xs);
-        int* range_status = reinterpret_cast<int*>(sync + 62);
+        int* range_status = h->range_tab + 2 * AS_FINAL;
         if (int rc = launch_split_windowed(y, B, T, kH, 1, 6, p.Lpf, yp, stream, XB_SCHEME_F16X2, XB_F16_ACT_SCALE, range_status)) return rc;
         Bf16x3Args fa;
         fa.A = yp; fa.W = h->fin_f; fa.bias = h->fin.b;
@@ -1020,11 +1032,11 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     const bool rf = h->rvq_f16x2 && h->cb_f;
     int rc = (h->rvq_x3 && h->bf16x3 && h->cb_s)
                  ? launch_rvq_encode_x3(emb, (long long)B * T, T, h->codebooks, rf ? h->cb_f : h->cb_s, (long long)h->n_codebooks * kCodes * kDim, h->e2, n_q,
-                                        codes, stream, rf ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, XB_F16_ACT_SCALE, h->cb_fs, reinterpret_cast<int*>(sync + 62))
+                                        codes, stream, rf ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, XB_F16_ACT_SCALE, h->cb_fs, h->range_tab + 2 * AS_RVQ)
                  : launch_rvq_encode(emb, (long long)B * T, T, h->codebooks, h->e2, n_q, codes, stream);
     prof.end(stream);
     if (rc) return rc;
-    if (status_out) return launch_status_combine(sync, status_out, stream);   // LSTM hand-off + every range verdict of the call, RVQ included
+    if (status_out) return launch_status_combine(sync, h->range_tab, status_out, stream);   // LSTM hand-off + every range verdict of the call, RVQ included
     return 0;
 }
 
@@ -1088,6 +1100,26 @@ int at_encodec_get_option(const at_encodec_t* h, const char* name) {
     return -1;
 }
 
+// The measured fp16 headroom of the LAST encode / decode call of this handle: for every site (at_encodec_range_sites) the largest |x * scale| a
+// split writer saw, 0 for sites that did not run on the fp16 scheme; the scheme overflows at 65504. Synchronises the device.
+int at_encodec_range_report(at_encodec_t* h, float* max_scaled, int cap) {
+    AT_REQUIRE(h && h->finalized && h->range_tab && max_scaled && cap >= (int)AC_NSITES, "at_encodec_range_report: bad arguments");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    int host[2 * AC_NSITES];
+    AT_CHECK_HIP(hipDeviceSynchronize());
+    AT_CHECK_HIP(hipMemcpy(host, h->range_tab, sizeof(host), hipMemcpyDeviceToHost));
+    for (int k = 0; k < (int)AC_NSITES; ++k) { float f; std::memcpy(&f, &host[2 * k + 1], sizeof(f)); max_scaled[k] = f; }
+    return (int)AC_NSITES;
+}
+int at_encodec_range_sites(char* names, size_t cap) {
+    std::string s;
+    for (int k = 0; k < (int)AC_NSITES; ++k) { s += kAcSiteNames[k]; s += "\n"; }
+    if (!names || cap < s.size() + 1) return -(int)(s.size() + 1);
+    std::memcpy(names, s.c_str(), s.size() + 1);
+    return (int)AC_NSITES;
+}
+
 int at_encodec_profile(at_encodec_t* h, int enable) {
     AT_REQUIRE(h != nullptr, "null handle");
     h->prof.reset();
@@ -1142,11 +1174,12 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
     Profiler noprof;
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
     AT_CHECK_HIP(hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), stream));
+    AT_CHECK_HIP(hipMemsetAsync(h->range_tab, 0, 64 * sizeof(int), stream));
     // every activation that is only consumed through ELU is stored already ELU'd (once per element, in the producer's
     // epilogue) so the transposed convs run the plain-linear GEMM path: y (LSTM + skip) and the block outputs of stages 0-2
     if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,
                            sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
-                           (h->bf16x3 && h->ih_f16x2) ? h->dwih_f : nullptr, h->dwih_fs, reinterpret_cast<int*>(sync + 62), h->lstm_f16x2 ? h->dwhh_fs : nullptr))
+                           (h->bf16x3 && h->ih_f16x2) ? h->dwih_f : nullptr, h->dwih_fs, h->range_tab + 2 * AS_DEC_LSTM_IH, h->lstm_f16x2 ? h->dwhh_fs : nullptr))
         return rc;
     const int Lout = p.L[4];
     for (int b0 = 0; b0 < B; b0 += p.G) {
@@ -1172,7 +1205,7 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
             if (s < 3 && h->bf16x3 && h->up_f16x2 && h->dup_f[s] && Li > 1) {
                 // as a two-tap windowed split GEMM on the fp16 scheme: the (already ELU'd) input -> pieces with ONE ZERO front row (x[-1] = 0)
                 __bf16* ap = reinterpret_cast<__bf16*>(ws + p.off_ap);
-                int* range_status = reinterpret_cast<int*>(sync + 62);
+                int* range_status = h->range_tab + 2 * AS_DEC_UP;
                 if (int rc = launch_split_windowed(in, g, Li, Cin, 1, 1, p.Lpu[s], ap, stream, XB_SCHEME_F16X2, XB_F16_ACT_SCALE, range_status, 0)) return rc;
                 Bf16x3Args ua;
                 ua.A = ap; ua.W = h->dup_f[s]; ua.bias = h->dup[s].b;
@@ -1191,7 +1224,7 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
                 ra.B = g; ra.L = Lo;
                 if (h->res_f16x2 && h->dres_fs[s][0] > 0.f) {   // the blocks' own contractions on the two-piece fp16 scheme, as in the encoder
                     ra.scheme = XB_SCHEME_F16X2; ra.act_scale = XB_F16_ACT_SCALE; ra.w3_scale = h->dres_fs[s][0]; ra.wt_scale = h->dres_fs[s][1];
-                    ra.status = reinterpret_cast<int*>(sync + 62);
+                    ra.status = h->range_tab + 2 * AS_DEC_RES;
                 }
                 const bool x3_128 = h->res128_x3 && h->bf16x3;
                 if (int rc = Co == 64 ? ((h->res64_x3 && h->bf16x3) ? launch_seanet_res64x3(ra, stream) : launch_seanet_res64(ra, stream))
@@ -1207,7 +1240,7 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
         if (!tail_done)
             if (int rc = launch_conv_last(in, h->dlast.w, h->dlast.b, wav + (long long)b0 * Lout, g, Lout, stream)) return rc;
     }
-    if (status_dev) return launch_status_combine(sync, status_dev, stream);   // LSTM hand-off + every range verdict of the call
+    if (status_dev) return launch_status_combine(sync, h->range_tab, status_dev, stream);   // LSTM hand-off + every range verdict of the call
     return 0;
 }
 

@@ -67,6 +67,9 @@ struct Bf16x3Args {
     // [qkv_hid, 3 qkv_hid) = k, v are written as ROW-MAJOR pieces S[which = 0 k / 1 v][piece][Spad rows][qkv_hid] times split_scale — the operand
     // images the attention kernel stages without splitting (attention_bf16x3.hip, KVP)
     int qkv_hid = 0;
+    // filled by launch_gemm_f16x2_tg from Sphases / S2phases (at_common.h, FastDivU): the epilogue's row -> (plane, index) split without the
+    // compiler's reciprocal sequence
+    FastDivU fdS, fdS2;
 };
 // Window order of the K-blocks of a conv with `ktaps` taps, `stride` and `cblocks` 16-channel blocks. Tap j lives in phase plane
 // j % stride at row offset j / stride; plane p holds n_p = ceil((ktaps - p) / stride) taps. K-block kt = cbk * ktaps + i, where i walks the
@@ -104,8 +107,10 @@ int launch_split_phase_major(const float* x, int B, int L, int C, int stride, in
 int launch_split_windowed(const float* x, int B, int L, int C, int stride, int pad, int Lp, __bf16* out, hipStream_t stream,
                           int scheme = XB_SCHEME_BF16X3, float scale = 1.0f, int* status = nullptr, int reflect = 1);
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream);
+// Range tables (split_scheme.h, RangeMax / range_publish): every `status` pointer handed to a split writer addresses a {flag word, census word}
+// PAIR of its site in a table the model handle owns; this ORs the sites' flag words into the caller's single status word at the end of a call
+int launch_range_combine(const int* range_tab, int nsites, int* status_out, hipStream_t stream);
 // the fp16 scheme's kernel for launches that fill the chip (gemm_f16x2_tg.hip); launch_gemm_bf16x3 dispatches to it
-// ($AUDIOTOKEN_F16X2_TG=0 keeps the register-staged kernel)
 bool gemm_f16x2_tg_eligible(const Bf16x3Args& a);
 int launch_gemm_f16x2_tg(const Bf16x3Args& a, hipStream_t stream);
 

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void split_blocked_kernel(const float* __restr
     }
     __syncthreads();
     const long long ps = rows_pad * (long long)K;
-    bool over = false;
+    RangeMax over;
     // thread -> (k-block kb of 4, row r, quarter qd of the 16 k): 4 values = 8 bytes per piece
     for (int e = threadIdx.x; e < 4 * 64 * 4; e += 256) {
         const int qd = e & 3, r = (e >> 2) & 63, kb = e >> 8;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void split_blocked_kernel(const float* __restr
         }
     }
     if constexpr (SC::RANGE_CHECK)
-        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
+        range_publish(status, status ? status + 1 : nullptr, over);
 }
 
 // fp32 [B][L][C] * scale -> the pieces a causal conv with `pad` reflected front rows reads as a windowed GEMM:
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void split_phase_major_kernel(const float* __r
     if (cb >= cblocks) return;
     const float* xb = x + (long long)b * L * C + cb * 16 + k * 4;
     typename SC::T* ob = out + (((long long)b * cblocks + cb) * stride + plane) * Lp * 16 + k * 4;
-    bool over = false;
+    RangeMax over;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int idx = blockIdx.x * 64 + j * 16 + ii;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void split_phase_major_kernel(const float* __r
         for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(d + i * piece_stride) = pc[i];
     }
     if constexpr (SC::RANGE_CHECK)
-        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
+        range_publish(status, status ? status + 1 : nullptr, over);
 }
 
 __global__ void reflect_front_kernel(__bf16* S, int B, int blocks, int phases, int Lp, int pad, int npieces) {
@@ -316,10 +316,28 @@ static int launch_scheme(const Bf16x3Args& a, hipStream_t stream) {
     if (a.epi == XB_EPI_RAW_ELU_SPLIT2) return launch_xb<SC, 4, 1, 2, 4, true>(a, stream);
     if (tiles256 < 256 || a.N % 256 != 0) return launch_xb<SC, 2, 2, 2, 2>(a, stream);   // 4x as many 128 x 128 tiles: same arithmetic, fills the chip
     // large launches: 256 x 128 tiles, 4 waves, TWO workgroups per CU (one loads while the other multiplies) measured 1-2 % ahead of
-    // 256 x 256 with 8 waves and one workgroup per CU (less operand traffic, no overlap); $AUDIOTOKEN_XB_TILE=0 selects the latter.
-    static const int big = std::getenv("AUDIOTOKEN_XB_TILE") ? std::atoi(std::getenv("AUDIOTOKEN_XB_TILE")) : 1;
-    if (big == 1) return launch_xb<SC, 4, 1, 2, 4>(a, stream);
-    return launch_xb<SC, 4, 2, 2, 4>(a, stream);
+    // 256 x 256 with 8 waves and one workgroup per CU (less operand traffic, no overlap).
+    return launch_xb<SC, 4, 1, 2, 4>(a, stream);
+}
+
+__global__ void range_combine_kernel(const int* tab, int nsites, int* out) {
+    int v = 0;
+    for (int k = 0; k < nsites; ++k) v |= tab[2 * k] & XB_STATUS_F16_OVERFLOW;
+    if (v) atomicOr(out, v);
+}
+int launch_range_combine(const int* range_tab, int nsites, int* status_out, hipStream_t stream) {
+    if (!range_tab || !status_out) return 0;
+    hipLaunchKernelGGL(range_combine_kernel, dim3(1), dim3(1), 0, stream, range_tab, nsites, status_out);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// the operator-level test entry points have no handle: one {flag, census} pair per device, allocated on first use and kept
+static int* op_range_pair() {
+    static int* pairs[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    if (!pairs[dev] && hipMalloc((void**)&pairs[dev], 2 * sizeof(int)) != hipSuccess) pairs[dev] = nullptr;
+    return pairs[dev];
 }
 
 int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
@@ -333,8 +351,7 @@ int launch_gemm_bf16x3(const Bf16x3Args& a, hipStream_t stream) {
     AT_REQUIRE(a.batch >= 1 && a.stride >= 1 && (a.cblocks == 0 || (a.K / XB_K) % a.cblocks == 0), "gemm_bf16x3: bad window description");
     AT_REQUIRE((a.Lp > 0 ? a.Lp : a.Mpad) >= a.Mpad + ((a.cblocks > 0 ? (a.K / XB_K) / a.cblocks : 1) - 1) / a.stride, "gemm_bf16x3: Lp too small for the last tile");
     AT_REQUIRE(a.scheme == XB_SCHEME_BF16X3 || a.scheme == XB_SCHEME_F16X2, "gemm_bf16x3: unknown scheme");
-    static const bool tg = std::getenv("AUDIOTOKEN_F16X2_TG") ? std::atoi(std::getenv("AUDIOTOKEN_F16X2_TG")) != 0 : true;
-    if (tg && gemm_f16x2_tg_eligible(a)) return launch_gemm_f16x2_tg(a, stream);
+    if (gemm_f16x2_tg_eligible(a)) return launch_gemm_f16x2_tg(a, stream);   // the register-staged kernel below serves the other shapes (and at_op_gemm_split kernel = 2)
     if (a.scheme == XB_SCHEME_F16X2) return launch_scheme<SchemeF16x2>(a, stream);
     return launch_scheme<SchemeBf16x3>(a, stream);
 }
@@ -355,20 +372,28 @@ extern "C" int at_op_gemm_split(const float* X, const float* W, const float* bia
     piece_t* xs = reinterpret_cast<piece_t*>(workspace);
     piece_t* wsp = xs + (size_t)Mpad * K * np;
     const float sa = scheme == XB_SCHEME_F16X2 ? XB_F16_ACT_SCALE : 1.0f, sw = scheme == XB_SCHEME_F16X2 ? xb_weight_scale(w_max_abs) : 1.0f;
-    if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
-    if (int rc = launch_split_blocked(X, K, M, Mpad, K, xs, stream, scheme, sa, reinterpret_cast<int*>(status_dev))) return rc;
-    if (int rc = launch_split_blocked(W, K, N, N, K, wsp, stream, scheme, sw, reinterpret_cast<int*>(status_dev))) return rc;
+    int* pair = status_dev ? op_range_pair() : nullptr;
+    if (status_dev) {
+        AT_REQUIRE(pair != nullptr, "at_op_gemm_split: cannot allocate the range pair");
+        AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
+        AT_CHECK_HIP(hipMemsetAsync(pair, 0, 2 * sizeof(int), stream));
+    }
+    if (int rc = launch_split_blocked(X, K, M, Mpad, K, xs, stream, scheme, sa, pair)) return rc;
+    if (int rc = launch_split_blocked(W, K, N, N, K, wsp, stream, scheme, sw, pair)) return rc;
     Bf16x3Args a;
     a.A = xs; a.W = wsp; a.bias = bias; a.M = M; a.N = N; a.K = K; a.Mpad = (int)Mpad; a.epi = XB_EPI_LINEAR; a.C = C; a.ldc = N;
-    a.scheme = scheme; a.acc_scale = 1.0f / (sa * sw); a.split_scale = sa; a.status = reinterpret_cast<int*>(status_dev);
+    a.scheme = scheme; a.acc_scale = 1.0f / (sa * sw); a.split_scale = sa; a.status = pair;
+    int rc;
     if (kernel == 1) {   // force the two-group kernel (gemm_f16x2_tg.hip) whatever the launch size
         AT_REQUIRE(gemm_f16x2_tg_eligible(a), "at_op_gemm_split: the two-group kernel needs f16x2, N % 128, K % 32");
-        return launch_gemm_f16x2_tg(a, stream);
+        rc = launch_gemm_f16x2_tg(a, stream);
+    } else if (kernel == 2) {   // force the register-staged kernel
+        rc = a.scheme == XB_SCHEME_F16X2 ? launch_scheme<SchemeF16x2>(a, stream) : launch_scheme<SchemeBf16x3>(a, stream);
+    } else {
+        rc = launch_gemm_bf16x3(a, stream);
     }
-    if (kernel == 2) {   // force the register-staged kernel
-        return a.scheme == XB_SCHEME_F16X2 ? launch_scheme<SchemeF16x2>(a, stream) : launch_scheme<SchemeBf16x3>(a, stream);
-    }
-    return launch_gemm_bf16x3(a, stream);
+    if (rc) return rc;
+    return launch_range_combine(pair, 1, reinterpret_cast<int*>(status_dev), stream);
 }
 
 // A causal conv1d (reflect front padding k - stride, as the SEANet convs) on the WINDOWED two-piece fp16 split GEMM, for the parity / soak tests
@@ -387,15 +412,21 @@ extern "C" int at_op_conv_split(const float* X, const float* W, const float* bia
     piece_t* xs = reinterpret_cast<piece_t*>(workspace);
     piece_t* wsp = xs + a_el;
     const float sw = xb_weight_scale(w_max_abs);
-    if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
+    int* pair = status_dev ? op_range_pair() : nullptr;
+    if (status_dev) {
+        AT_REQUIRE(pair != nullptr, "at_op_conv_split: cannot allocate the range pair");
+        AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
+        AT_CHECK_HIP(hipMemsetAsync(pair, 0, 2 * sizeof(int), stream));
+    }
     AT_CHECK_HIP(hipMemsetAsync(xs, 0, a_el * sizeof(piece_t), stream));   // rows past the data (read by the padded output rows only) stay finite
-    if (int rc = launch_split_windowed(X, B, L, Cin, stride, pad, Lp, xs, stream, XB_SCHEME_F16X2, XB_F16_ACT_SCALE, reinterpret_cast<int*>(status_dev), 1)) return rc;
+    if (int rc = launch_split_windowed(X, B, L, Cin, stride, pad, Lp, xs, stream, XB_SCHEME_F16X2, XB_F16_ACT_SCALE, pair, 1)) return rc;
     if (int rc = launch_split_blocked(W, K, Cout, Cout, K, wsp, stream, XB_SCHEME_F16X2, sw, nullptr, Cin / 16, stride)) return rc;
     Bf16x3Args a;
     a.A = xs; a.W = wsp; a.bias = bias; a.M = M; a.Mpad = Mpad; a.N = Cout; a.K = K;
     a.batch = B; a.stride = stride; a.cblocks = Cin / 16; a.Lp = Lp;
-    a.scheme = XB_SCHEME_F16X2; a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * sw); a.split_scale = XB_F16_ACT_SCALE; a.status = reinterpret_cast<int*>(status_dev);
+    a.scheme = XB_SCHEME_F16X2; a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * sw); a.split_scale = XB_F16_ACT_SCALE; a.status = pair;
     a.epi = XB_EPI_LINEAR; a.C = C; a.ldc = Cout;
     AT_REQUIRE(gemm_f16x2_tg_eligible(a), "at_op_conv_split: shape not eligible for the two-group kernel");
-    return launch_gemm_f16x2_tg(a, stream);
+    if (int rc = launch_gemm_f16x2_tg(a, stream)) return rc;
+    return launch_range_combine(pair, 1, reinterpret_cast<int*>(status_dev), stream);
 }

@@ -65,7 +65,7 @@ struct TgCfg {
 // -DTG_DEBUG_STAMPS (tools/tg_stamps.sh; never in the product build): wave 0 (leading group) and wave 4 (trailing group) of one workgroup sum the
 // cycle counter over the segments of the K steps of their FIRST tile; the launcher prints the averages per K step for the first launches of each shape
 #ifdef TG_DEBUG_STAMPS
-__device__ unsigned long long tg_stamps[2][10];
+__device__ unsigned long long tg_stamps[2][16];
 #define TG_T(i) const unsigned long long tg_t##i = __builtin_readcyclecounter()
 #define TG_ACC(k, a_, b_) tg_d[k] += tg_t##b_ - tg_t##a_
 #else
@@ -79,8 +79,11 @@ __device__ unsigned long long tg_stamps[2][10];
 // share `ga` activation tiles and 32 / ga weight tiles in ITS L2, and an activation tile is fetched into one L2 instead of all eight
 // (n-fastest order: 8 x the activation bytes leave the Infinity Cache; the K = 4096 GEMM moved 12.6 GB per launch that way). Workgroup b
 // takes the entries b >> 3, (b >> 3) + gridDim.x / 8, ... of its XCD's list. ga == 0: tiles blockIdx.x, + gridDim.x, ... n fastest.
+// the divisors of the tile walk as FastDivU (at_common.h): ga * ntn, ntn, ntm, ga
+struct TgSched { FastDivU gantn, ntn, ntm, ga; };
+
 template <bool WINDOWED, int TI, int TJ>
-__global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_kernel(Bf16x3Args a, int ga) {
+__global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_kernel(Bf16x3Args a, int ga, TgSched sd) {
     using Cfg = TgCfg<TI, TJ>;
     constexpr int BM = Cfg::BM, TG_PIECE = Cfg::PIECE, TG_KB = Cfg::KB, TG_PAIR = Cfg::PAIR;
 #ifdef TG_DEBUG_STAMPS
@@ -106,14 +109,15 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         if (ga > 0) {
             const int q = (int)(blockIdx.x >> 3) + it * (int)(gridDim.x >> 3);
             if (q >= (x_hi - x_lo) * ntn) return false;
-            const int g = q / (ga * ntn), r = q - g * ga * ntn, base = x_lo + g * ga;
+            const int g = (int)sd.gantn.div((unsigned)q), r = q - g * ga * ntn, base = x_lo + g * ga;
             const int gn = min(ga, x_hi - base);
-            nt = r / gn; mt = base + (r - nt * gn);
+            nt = gn == ga ? (int)sd.ga.div((unsigned)r) : r / gn;   // (the generic division only in an XCD's last, partial group)
+            mt = base + (r - nt * gn);
         } else {
             const int t = (int)blockIdx.x + it * (int)gridDim.x;
             if (t >= mtn * ntn) return false;
-            nt = t % ntn;   // n fastest: the activation tile is fetched once per row of blocks
-            mt = t / ntn;
+            mt = (int)sd.ntn.div((unsigned)t);   // n fastest: the activation tile is fetched once per row of blocks
+            nt = t - mt * ntn;
         }
         return true;
     };
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
     const int w_taps = nk2 * 2 / cblocks, w_q = w_taps / a.stride, w_r = w_taps - w_q * a.stride;
     int w_t = 0, w_off = 0, w_p = 0;                 // plane image cbk * stride + p, row offset, plane
     auto begin_stream = [&](int mt, int nt) {
-        const int clip = mt / ntm, m0 = (mt - clip * ntm) * BM;
+        const int clip = (int)sd.ntm.div((unsigned)mt), m0 = (mt - clip * ntm) * BM;
         uA = reinterpret_cast<const PT*>(a.A) + clip * a_clip + ((long long)m0 + (wave & 3) * (BM / 4)) * 16;
         uW = reinterpret_cast<const PT*>(a.W) + ((long long)nt * BM + (wave & 3) * (BM / 4)) * 16;
         w_t = 0; w_off = 0; w_p = 0;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         if (grp == 0) { issue_A(0, 0); issue_W(0, 0); }
         else if (nk2 > 1) issue_W(1, 1);
     };
-    bool over = false;
+    RangeMax over;
     int mt, nt;
     if (!tile_at(0, mt, nt)) return;
     begin_stream(mt, nt);
@@ -188,10 +192,11 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
     const unsigned long long tg_p0 = __builtin_readcyclecounter();
     unsigned long long tg_d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tg_loop_begin = 0, tg_loop_end = 0, tg_epi_end = 0, tg_next_begin = 0;
+    unsigned long long tg_all_loop = 0, tg_all_epi = 0, tg_all_gap = 0, tg_tiles = 0, tg_mark = tg_p0;   // sums over ALL tiles of this workgroup
 #endif
     issue_first();
     for (int it = 0;; ++it) {
-        const int e_clip = mt / ntm, e_m0 = (mt - e_clip * ntm) * BM, e_n0 = nt * BM;
+        const int e_clip = (int)sd.ntm.div((unsigned)mt), e_m0 = (mt - e_clip * ntm) * BM, e_n0 = nt * BM;
         f4 acc[TI][TJ];
 #pragma unroll
         for (int i = 0; i < TI; ++i)
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
 #ifdef TG_DEBUG_STAMPS
         if (it == 0) tg_loop_begin = __builtin_readcyclecounter();
         if (it == 1) tg_next_begin = __builtin_readcyclecounter();
+        { const unsigned long long t = __builtin_readcyclecounter(); tg_all_gap += t - tg_mark; tg_mark = t; }
 #endif
         int wpair = 0;                                     // weight ring pair of step kp = kp % 3
         for (int kp = 0; kp < nk2; ++kp) {
@@ -264,43 +270,112 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         if (grp == 0) __builtin_amdgcn_s_barrier();      // pairs the trailing group's last barrier: every read of the rings has retired
 #ifdef TG_DEBUG_STAMPS
         if (it == 0) tg_loop_end = __builtin_readcyclecounter();
+        { const unsigned long long t = __builtin_readcyclecounter(); tg_all_loop += t - tg_mark; tg_mark = t; }
 #endif
         // the next tile's first chunks fly during this tile's epilogue
         int mt2 = 0, nt2 = 0;
         const bool more = tile_at(it + 1, mt2, nt2);
         if (more) { begin_stream(mt2, nt2); issue_first(); }
         // lane holds, per 16 x 16 tile (i, j): output row m = .. + lane & 15 and the 4 consecutive columns n = .. + 4 (lane >> 4) ..
-        XbEpilogue<SC> ep(a, e_clip);
+        XbEpilogue<SC, true> ep(a, e_clip);
         const int el = lane_id(), fr = el & 15, fq = el >> 4;
-        // bias quads once per column tile; residual quads HALF a row tile (TJ / 2 quads) ahead of the stores (split_epilogue.h: inside apply()
-        // each load would sit behind the previous quad's store; a whole row tile ahead cost 32 more registers than the persistent loop leaves)
+        // bias quads once per column tile; residual quads one row tile ahead of the stores (split_epilogue.h: inside apply() each load would sit
+        // behind the previous quad's store)
         auto epilogue = [&](auto mode, auto ph1) {
             constexpr int E = decltype(mode)::value;
             constexpr bool PH1 = decltype(ph1)::value;
             constexpr bool PLAIN = E == XB_EPI_LINEAR || E == XB_EPI_GELU;
-            constexpr int H = TJ / 2;
+            // ROW LAYOUT (256 x 256 tiles; the modes whose outputs are row-major: fp32 C, the q rows and k / v row-major pieces of the fused
+            // projection, GLU): in the MFMA layout a lane owns 4 consecutive columns of ONE row per 16 x 16 tile, so a wave-instruction touches 16
+            // rows x 64 B (32 B for the 8-byte forms) — half cache lines, 16 DRAM pages per instruction. In-kernel stamps (tools/tg_stamps.sh, all
+            // tiles of a workgroup) gave 43-50 k cycles for the residual epilogue of a tile against 14-23 k for the modes that write contiguous
+            // K-blocked pieces. Each wave therefore transposes one 16-row tile at a time through its own 8 KB of LDS (the activation pair 1 and weight
+            // pair 2 are free while the next tile's first chunks land in pairs 0 / 0, 1): 8 ds_write_b128 in the MFMA layout, 8 ds_read_b128 with
+            // lane l -> row 2 r + (l >> 5), columns 4 (l & 31) .. + 3, i.e. two rows x 512 contiguous bytes per instruction for the residual load and
+            // the store. 16-byte chunks are XOR-swizzled with row & 7: conflict-free for both forms (writes: 8 contiguous lanes = 8 rows of one chunk;
+            // reads: the lane groups of MI355X_MICROARCH.md stay distinct mod 16 under an XOR < 8). Wave-local: LDS operations of one wave execute
+            // in order, no barrier. The arithmetic per element is unchanged (same operands, same order): bit-identical to the MFMA-layout path.
+            constexpr bool ROWLAYOUT = TI * TJ > 8 && (PLAIN || E == XB_EPI_QKV || E == XB_EPI_GLU);
+            if constexpr (ROWLAYOUT) {
+                static_assert(TJ == 8, "row layout: 128-column wave tiles");
+                float* wl = reinterpret_cast<float*>((wave < 4 ? ldsA + TG_PAIR : ldsW + 2 * TG_PAIR) + (wave & 3) * 4096);   // 8 KB per wave
+                const int rrow = el >> 5, rc = el & 31;                                   // row-layout coordinates of this lane
+                const int ncol = e_n0 + wn * TJ * 16 + rc * 4;
+                const f4 bias4 = ep.load_bias(ncol);
+                const int mrow0 = e_m0 + wm * TI * 16 + rrow;                              // + i * 16 + 2 r
+                // Residual quads. The memory counter retires loads AND stores in issue order (MI355X_MICROARCH.md: "a load's data waits for every
+                // older one of them"), so a residual load issued behind a row tile's stores is only usable once those stores have been acknowledged:
+                // with the loads one (half) row tile ahead every row tile paid a store round trip + a load round trip (stamps: 39-50 k cycles per tile).
+                // Here row tile 0 is requested first and row tile i + 1 right after the accumulators of row tile i have gone to LDS — whose 32
+                // registers it takes over — BEFORE that row tile's stores: no load ever waits behind the stores of the row tile in front of it.
+                if constexpr (PLAIN) {
+                    // C / R addressed as (tile origin: scalar registers) + (32-bit lane offset inside the tile, < 256 rows x ldc): no 64-bit vector
+                    // address arithmetic, one address register per access
+                    const char* rb = ep.Rb ? reinterpret_cast<const char*>(ep.Rb + (long long)e_m0 * a.ldr + e_n0) : nullptr;
+                    char* cb = reinterpret_cast<char*>(ep.Cb + (long long)e_m0 * a.ldc + e_n0);
+                    const unsigned rowl = (unsigned)(wm * TI * 16 + rrow), coll = (unsigned)(wn * TJ * 16 + rc * 4);
+                    const unsigned offC = (rowl * (unsigned)a.ldc + coll) * 4u, offR = (rowl * (unsigned)a.ldr + coll) * 4u;
+                    const unsigned stepC = (unsigned)a.ldc * 8u, stepR = (unsigned)a.ldr * 8u;      // two rows further
+                    f4 res[TI][8];
+                    auto load_res = [&](int i) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            res[i][k] = (rb && mrow0 + i * 16 + 2 * k < a.M) ? *reinterpret_cast<const f4*>(rb + (offR + (unsigned)(i * 8 + k) * stepR)) : f4{0.f, 0.f, 0.f, 0.f};
+                    };
+                    load_res(0);
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j)
+                            *reinterpret_cast<f4*>(wl + fr * 128 + (((j * 4 + fq) ^ (fr & 7)) << 2)) = acc[i][j];
+                        if (i + 1 < TI) load_res(i + 1);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int row = 2 * k + rrow;
+                            const f4 q = *reinterpret_cast<const f4*>(wl + row * 128 + ((rc ^ (row & 7)) << 2));
+                            if (mrow0 + i * 16 + 2 * k < a.M)
+                                *reinterpret_cast<f4*>(cb + (offC + (unsigned)(i * 8 + k) * stepC)) = ep.template plain_value<E>(q, bias4, res[i][k]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j)
+                            *reinterpret_cast<f4*>(wl + fr * 128 + (((j * 4 + fq) ^ (fr & 7)) << 2)) = acc[i][j];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int row = 2 * k + rrow, m = mrow0 + i * 16 + 2 * k;
+                            const f4 q = *reinterpret_cast<const f4*>(wl + row * 128 + ((rc ^ (row & 7)) << 2));
+                            if (m < a.M) ep.template apply_with<E, false>(m, ncol, q, bias4, f4{0.f, 0.f, 0.f, 0.f});
+                        }
+                    }
+                }
+                return;
+            }
+            constexpr int NCH = 1, H = TJ / NCH;   // residual chunks per row tile (register path: the 128 x 128 shape and the K-blocked piece outputs)
             f4 bj[TJ];
 #pragma unroll
             for (int j = 0; j < TJ; ++j) bj[j] = ep.load_bias(e_n0 + wn * TJ * 16 + j * 16 + 4 * fq);
             const int mbase = e_m0 + wm * TI * 16 + fr;
             f4 rcur[H], rnext[H];
             auto load_half = [&](int idx, f4 (&r)[H]) {
-                const int m = mbase + (idx >> 1) * 16, j0 = (idx & 1) * H;
+                const int m = mbase + (idx / NCH) * 16, j0 = (idx % NCH) * H;
 #pragma unroll
                 for (int j = 0; j < H; ++j)
                     r[j] = (PLAIN && m < a.M) ? ep.load_residual(m, e_n0 + wn * TJ * 16 + (j0 + j) * 16 + 4 * fq) : f4{0.f, 0.f, 0.f, 0.f};
             };
             if constexpr (PLAIN) load_half(0, rcur);
 #pragma unroll
-            for (int idx = 0; idx < 2 * TI; ++idx) {
-                const int m = mbase + (idx >> 1) * 16, j0 = (idx & 1) * H;
+            for (int idx = 0; idx < NCH * TI; ++idx) {
+                const int m = mbase + (idx / NCH) * 16, j0 = (idx % NCH) * H;
                 if constexpr (PLAIN) {
-                    if (idx + 1 < 2 * TI) load_half(idx + 1, rnext);
+                    if (idx + 1 < NCH * TI) load_half(idx + 1, rnext);
                 }
                 if (m < a.M) {
 #pragma unroll
                     for (int j = 0; j < H; ++j)
-                        ep.template apply_with<E, PH1>(m, e_n0 + wn * TJ * 16 + (j0 + j) * 16 + 4 * fq, acc[idx >> 1][j0 + j], bj[j0 + j], rcur[j]);
+                        ep.template apply_with<E, PH1>(m, e_n0 + wn * TJ * 16 + (j0 + j) * 16 + 4 * fq, acc[idx / NCH][j0 + j], bj[j0 + j], rcur[j]);
                 }
                 if constexpr (PLAIN) {
 #pragma unroll
@@ -324,17 +399,20 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         over |= ep.over;
 #ifdef TG_DEBUG_STAMPS
         if (it == 0) tg_epi_end = __builtin_readcyclecounter();
+        { const unsigned long long t = __builtin_readcyclecounter(); tg_all_epi += t - tg_mark; tg_mark = t; ++tg_tiles; }
 #endif
         if (!more) break;
         mt = mt2; nt = nt2;
     }
-    if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
+    range_publish(a.status, a.status ? a.status + 1 : nullptr, over);
 #ifdef TG_DEBUG_STAMPS
     if (blockIdx.x == (gridDim.x * 3) / 4 && (threadIdx.x == 0 || threadIdx.x == 256)) {
         for (int i = 0; i < 7; ++i) tg_stamps[grp][i] = tg_d[i];
         // epilogue | entry..loop end ; first tile's start-up | gap between the first tile's epilogue end and the second tile's first K step
         tg_stamps[grp][7] = ((tg_epi_end - tg_loop_end) << 32) | ((tg_loop_end - tg_entry) & 0xffffffffull);
         tg_stamps[grp][8] = ((tg_loop_begin - tg_p0) << 32) | ((tg_next_begin > tg_epi_end ? tg_next_begin - tg_epi_end : 0) & 0xffffffffull);
+        tg_stamps[grp][9] = tg_all_loop; tg_stamps[grp][10] = tg_all_epi; tg_stamps[grp][11] = tg_all_gap; tg_stamps[grp][12] = tg_tiles;
+        tg_stamps[grp][13] = __builtin_readcyclecounter() - tg_entry;
     }
 #endif
 }
@@ -361,7 +439,13 @@ template <bool WINDOWED, int TI, int TJ>
 static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream) {
     using Cfg = TgCfg<TI, TJ>;
     { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, gemm_f16x2_tg_kernel<WINDOWED, TI, TJ>, Cfg::LDS_BYTES)) return rc; }
-    hipLaunchKernelGGL((gemm_f16x2_tg_kernel<WINDOWED, TI, TJ>), grid, dim3(512), Cfg::LDS_BYTES, stream, a, ga);
+    Bf16x3Args b = a;
+    b.fdS = FastDivU((unsigned)(a.Sphases > 0 ? a.Sphases : 1));
+    b.fdS2 = FastDivU((unsigned)(a.S2phases > 0 ? a.S2phases : 1));
+    const int ntn = a.N / Cfg::BM, ntm = a.Mpad / Cfg::BM;
+    TgSched sd;
+    sd.gantn = FastDivU((unsigned)((ga > 0 ? ga : 1) * ntn)); sd.ntn = FastDivU((unsigned)ntn); sd.ntm = FastDivU((unsigned)ntm); sd.ga = FastDivU((unsigned)(ga > 0 ? ga : 1));
+    hipLaunchKernelGGL((gemm_f16x2_tg_kernel<WINDOWED, TI, TJ>), grid, dim3(512), Cfg::LDS_BYTES, stream, b, ga, sd);
     AT_CHECK_HIP(hipGetLastError());
 #ifdef TG_DEBUG_STAMPS
     {
@@ -369,7 +453,7 @@ static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream)
         if (printed < 12) {
             ++printed;
             (void)hipStreamSynchronize(stream);
-            unsigned long long hbuf[2][10];
+            unsigned long long hbuf[2][16];
             (void)hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(tg_stamps), sizeof(hbuf));
             const double nk = a.K / 32;
             for (int g = 0; g < 2; ++g) {
@@ -378,6 +462,9 @@ static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream)
                              hbuf[g][4] / nk, hbuf[g][5] / nk, hbuf[g][6] / nk);
                 std::fprintf(stderr, "    first tile: entry -> end of K loop %llu cycles (%d K steps), epilogue %llu; start-up (first issue -> first K step) %llu; epilogue end -> next tile's first K step %llu\n",
                              hbuf[g][7] & 0xffffffffull, (int)nk, hbuf[g][7] >> 32, hbuf[g][8] >> 32, hbuf[g][8] & 0xffffffffull);
+                const double nt_ = (double)(hbuf[g][12] ? hbuf[g][12] : 1);
+                std::fprintf(stderr, "    all %llu tiles of this workgroup, per tile: K loop %.0f  epilogue %.0f  start (wait for first chunks + barriers) %.0f; workgroup lifetime %llu cycles\n",
+                             hbuf[g][12], hbuf[g][9] / nt_, hbuf[g][10] / nt_, hbuf[g][11] / nt_, hbuf[g][13]);
             }
         }
     }
@@ -387,7 +474,7 @@ static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream)
 
 int launch_gemm_f16x2_tg(const Bf16x3Args& a, hipStream_t stream) {
     // 256 x 256 tiles when they fill the chip, else 128 x 128 (4 x as many workgroups, two per CU): same arithmetic per element
-    static const long long min_tiles = std::getenv("AUDIOTOKEN_F16X2_TG_MIN_TILES") ? std::atoll(std::getenv("AUDIOTOKEN_F16X2_TG_MIN_TILES")) : 256;
+    const long long min_tiles = 256;
     const bool big = a.N % 256 == 0 && (long long)a.batch * (a.Mpad / 256) * (a.N / 256) >= min_tiles;
     const int bm = big ? 256 : 128;
     const int ntn = a.N / bm, mtn = a.batch * (a.Mpad / bm);

@@ -44,6 +44,7 @@ struct at_hubert {
     bool finalized = false;
     std::map<std::string, HostTensor> staged;
     std::vector<float*> allocs;
+    int* range_tab = nullptr;   // device, {flag, census} per HSite, zeroed at the start of every encode (at_hubert_range_report reads it)
     const float* conv_w[7] = {};
     const float *gn_g = nullptr, *gn_b = nullptr, *fp_ln_g = nullptr, *fp_ln_b = nullptr, *fp_w = nullptr, *fp_b = nullptr;
     const float *pos_w = nullptr, *pos_b = nullptr, *enc_ln_g = nullptr, *enc_ln_b = nullptr;
@@ -129,8 +130,12 @@ Plan make_plan(int B, int N) {
     return p;
 }
 
+// Sites of the handle's range table (gemm_bf16x3.h, launch_range_combine): where activations become fp16 pieces
+enum HSite { HS_CONV0 = 0, HS_FE_CONV, HS_X_IN, HS_QKV_KV, HS_ATTENTION, HS_FFN_HIDDEN, HS_OTHER, H_NSITES };
+static const char* const kHSiteNames[H_NSITES] = {"conv0_out", "feature_convs", "layer_input", "qkv_kv", "attention", "ffn_hidden", "other"};
 struct SplitCtx {
-    int scheme; int* status;
+    int scheme; int* tab;
+    int* site(int k) const { return tab ? tab + 2 * k : nullptr; }
     float act_scale() const { return scheme == XB_SCHEME_F16X2 ? XB_F16_ACT_SCALE : 1.0f; }
 };
 
@@ -170,13 +175,13 @@ int split_weights(at_hubert* h, int scheme) {
 int linear_split(const SplitCtx& c, const float* X, int K, const piece_t* xs, piece_t* xs_w, const LayerW& L, int w, const float* bias, float* C, int N,
                  long long M, long long Mpad, int epi, const float* R, int ldc, piece_t* S, hipStream_t stream) {
     if (X) {
-        if (int rc = launch_split_blocked(X, K, M, Mpad, K, xs_w, stream, c.scheme, c.act_scale(), c.status)) return rc;
+        if (int rc = launch_split_blocked(X, K, M, Mpad, K, xs_w, stream, c.scheme, c.act_scale(), c.site(HS_X_IN))) return rc;
         xs = xs_w;
     }
     Bf16x3Args a;
     a.A = xs; a.W = L.ws[c.scheme][w]; a.bias = bias; a.M = (int)M; a.N = N; a.K = K; a.Mpad = (int)Mpad;
     a.epi = epi; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc; a.alpha = 1.0f; a.S = S; a.Spad = (int)Mpad;
-    a.scheme = c.scheme; a.status = c.status;
+    a.scheme = c.scheme; a.status = c.site(w == HW_1 ? HS_FFN_HIDDEN : HS_OTHER);
     if (c.scheme == XB_SCHEME_F16X2) { a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[w]); a.split_scale = XB_F16_ACT_SCALE; }
     return launch_gemm_bf16x3(a, stream);
 }
@@ -307,7 +312,6 @@ int at_hubert_finalize(at_hubert_t* h) {
     h->staged.clear();
     {
         h->arith = ARITH_F16X2;
-        if (const char* e = std::getenv("AUDIOTOKEN_BF16X3")) if (std::atoi(e) == 0) h->arith = ARITH_F32;   // round-1 switch, kept
         if (const char* e = std::getenv("AUDIOTOKEN_SEMANTIC_ARITH")) {
             const std::string v(e);
             AT_REQUIRE(v == "f32" || v == "bf16x3" || v == "f16x2", "AUDIOTOKEN_SEMANTIC_ARITH must be f32, bf16x3 or f16x2");
@@ -316,6 +320,11 @@ int at_hubert_finalize(at_hubert_t* h) {
     }
     if (h->arith != ARITH_F32)
         if (int rc = split_weights(h, h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
+    if (!host_only_test() && !h->range_tab) {
+        AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, 64 * sizeof(int)));
+        h->allocs.push_back(reinterpret_cast<float*>(h->range_tab));
+        AT_CHECK_HIP(hipMemset(h->range_tab, 0, 64 * sizeof(int)));
+    }
     h->finalized = true;
     return 0;
 }
@@ -387,7 +396,8 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
     Profiler& prof = h->prof;
     if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), (hipStream_t)stream_));
     const bool split = h->arith != ARITH_F32;
-    const SplitCtx sc{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, reinterpret_cast<int*>(status_dev)};
+    AT_CHECK_HIP(hipMemsetAsync(h->range_tab, 0, 64 * sizeof(int), (hipStream_t)stream_));
+    const SplitCtx sc{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, h->range_tab};
 
     // ---- conv feature encoder (7 valid strided convs, GroupNorm after the first, GELU) ----------------------
     float* bufs[2] = {ws + p.off_a, ws + p.off_b};
@@ -398,13 +408,13 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         // output, every conv's GELU epilogue writes the next conv's input the same way, the last one writes fp32 features
         piece_t* sb[2] = {reinterpret_cast<piece_t*>(ws + p.off_sb), reinterpret_cast<piece_t*>(ws + p.off_sa)};   // [i & 1]
         if (int rc = launch_hub_conv0_gn_gelu(wav, h->conv_w[0], h->gn_g, h->gn_b, ws + p.off_part, ws + p.off_ss, nullptr, B, N, p.L[1], stream,
-                                              sb[1], p.Lp[1], sc.scheme, sc.act_scale(), sc.status))
+                                              sb[1], p.Lp[1], sc.scheme, sc.act_scale(), sc.site(HS_CONV0)))
             return rc;
         for (int i = 1; i < 7; ++i) {
             Bf16x3Args a;
             a.A = sb[i & 1]; a.W = h->conv_ws[sc.scheme][i]; a.M = p.L[i + 1]; a.Mpad = p.Mp[i]; a.N = kCd; a.K = kKs[i] * kCd;
             a.batch = B; a.stride = kSt[i]; a.cblocks = kCd / 16; a.Lp = p.Lp[i];
-            a.scheme = sc.scheme; a.status = sc.status;
+            a.scheme = sc.scheme; a.status = sc.site(HS_FE_CONV);
             if (sc.scheme == XB_SCHEME_F16X2) { a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->conv_wscale[i]); a.split_scale = XB_F16_ACT_SCALE; }
             if (i < 6) { a.epi = XB_EPI_GELU_SPLIT; a.S = sb[(i + 1) & 1]; a.Spad = p.Lp[i + 1]; a.Sphases = kSt[i + 1]; }
             else { a.epi = XB_EPI_GELU; a.C = bufs[6 & 1]; a.ldc = kCd; }
@@ -434,8 +444,8 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
     piece_t* xs = reinterpret_cast<piece_t*>(ws + p.off_xs);
     piece_t* bigs = reinterpret_cast<piece_t*>(ws + p.off_bigs);
     piece_t* kvs = reinterpret_cast<piece_t*>(ws + p.off_kvs);
-    static const bool attn_kvp = !(std::getenv("AUDIOTOKEN_ATTN_KVP") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_KVP")) == 0);
-    const int attn_arith = (std::getenv("AUDIOTOKEN_ATTN_X3") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_X3")) == 0) ? 0 : h->arith;
+    const bool attn_kvp = true;   // k / v as pieces from the projection's epilogue whenever the arithmetic is f16x2
+    const int attn_arith = h->arith;   // attention follows the linear layers' arithmetic (0: the fp32-MFMA kernel)
     const long long Mpad = (long long)p.Mpad;
     float* big = ws + p.off_big;
     prof.begin("projection_posconv", 20, stream);
@@ -462,11 +472,11 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         // output projection's operand pieces (as in w2vbert.hip)
         const bool kvp = split && attn_arith == ARITH_F16X2 && sc.scheme == XB_SCHEME_F16X2 && attn_kvp;
         if (kvp) {
-            if (int rc = launch_split_blocked(x, kHid, M, Mpad, kHid, xs, stream, sc.scheme, sc.act_scale(), sc.status)) return rc;
+            if (int rc = launch_split_blocked(x, kHid, M, Mpad, kHid, xs, stream, sc.scheme, sc.act_scale(), sc.site(HS_X_IN))) return rc;
             Bf16x3Args qa;
             qa.A = xs; qa.W = L.ws[sc.scheme][HW_QKV]; qa.bias = L.bqkv; qa.M = (int)M; qa.N = 3 * kHid; qa.K = kHid; qa.Mpad = (int)Mpad;
             qa.epi = XB_EPI_QKV; qa.C = big; qa.ldc = 3 * kHid; qa.S = kvs; qa.Spad = (int)Mpad; qa.qkv_hid = kHid;
-            qa.scheme = sc.scheme; qa.status = sc.status; qa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[HW_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
+            qa.scheme = sc.scheme; qa.status = sc.site(HS_QKV_KV); qa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[HW_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
             if (int rc = launch_gemm_bf16x3(qa, stream)) return rc;
         } else if (split) {
             if (int rc = linear_split(sc, x, kHid, nullptr, xs, L, HW_QKV, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream)) return rc;
@@ -476,7 +486,7 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         prof.end(stream);
         prof.begin("attention", 1, stream);
         const bool ctx_as_pieces = split && attn_arith > 0;
-        if (int rc = launch_relpos_attention(big, fmask, nullptr, ctx_as_pieces ? nullptr : t1, B, T, stream, kHeads, attn_arith, sc.status,
+        if (int rc = launch_relpos_attention(big, fmask, nullptr, ctx_as_pieces ? nullptr : t1, B, T, stream, kHeads, attn_arith, sc.site(HS_ATTENTION),
                                              ctx_as_pieces ? xs : nullptr, Mpad, kvp ? kvs : nullptr)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
@@ -498,6 +508,8 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         if (int rc = launch_layernorm(x, L.ln2_g, L.ln2_b, nullptr, x, M, kHid, stream)) return rc;
         prof.end(stream);
     }
+    if (status_dev)   // every site's range verdict of this call -> the caller's status word
+        if (int rc = launch_range_combine(h->range_tab, (int)H_NSITES, reinterpret_cast<int*>(status_dev), stream)) return rc;
     if (hidden_out) AT_CHECK_HIP(hipMemcpyAsync(hidden_out, x, (size_t)M * kHid * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (tokens) {
         prof.begin("kmeans", 3, stream);
@@ -507,6 +519,25 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         prof.end(stream);
     }
     return 0;
+}
+
+// The measured fp16 headroom of the LAST encode of this handle (see at_w2vbert_range_report)
+int at_hubert_range_report(at_hubert_t* h, float* max_scaled, int cap) {
+    AT_REQUIRE(h && h->finalized && h->range_tab && max_scaled && cap >= (int)H_NSITES, "at_hubert_range_report: bad arguments");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    int host[2 * H_NSITES];
+    AT_CHECK_HIP(hipDeviceSynchronize());
+    AT_CHECK_HIP(hipMemcpy(host, h->range_tab, sizeof(host), hipMemcpyDeviceToHost));
+    for (int k = 0; k < (int)H_NSITES; ++k) { float f; std::memcpy(&f, &host[2 * k + 1], sizeof(f)); max_scaled[k] = f; }
+    return (int)H_NSITES;
+}
+int at_hubert_range_sites(char* names, size_t cap) {
+    std::string s;
+    for (int k = 0; k < (int)H_NSITES; ++k) { s += kHSiteNames[k]; s += "\n"; }
+    if (!names || cap < s.size() + 1) return -(int)(s.size() + 1);
+    std::memcpy(names, s.c_str(), s.size() + 1);
+    return (int)H_NSITES;
 }
 
 int at_hubert_profile(at_hubert_t* h, int enable) {

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __r
     __syncthreads();
     const int nf = T0 - t0 < C0_FRAMES ? T0 - t0 : C0_FRAMES;
     float* orow = out + ((long long)b * T0 + t0) * 512 + cg * 4;
-    bool over = false;
+    RangeMax over;
     for (int f = sub; f < nf; f += 2) {
         float xv[10];
 #pragma unroll
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __r
         }
     }
     if constexpr (SC::RANGE_CHECK)
-        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
+        range_publish(status, status ? status + 1 : nullptr, over);
 }
 
 int launch_hub_conv0_gn_gelu(const float* wav, const float* w, const float* gamma, const float* beta, float* part, float* ss, float* out,

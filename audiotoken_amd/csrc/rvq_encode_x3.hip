@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 1) void rvq_encode_x3_kernel(const float* __re
     PT* qx_lds = reinterpret_cast<PT*>(qx_lds_raw);
     const float sa = SC::RANGE_CHECK ? act_scale : 1.0f;
     const float rs = SC::RANGE_CHECK ? 1.0f / (act_scale * cb_scale) : 1.0f;
-    bool over = false;
+    RangeMax over;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const long long row_base = (long long)blockIdx.x * QX_ROWS + wave * 32;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void rvq_encode_x3_kernel(const float* __re
         }
     }
     if constexpr (SC::RANGE_CHECK)
-        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
+        range_publish(status, status ? status + 1 : nullptr, over);
 }
 
 template <class SC>

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512, 1) void seanet_down64x3_kernel(Down64Args a) {
     const int total_tiles = a.B * tiles_per_clip;   // < 2^31: checked by the launcher
     const float sa = SC::RANGE_CHECK ? a.act_scale : 1.0f, sw = SC::RANGE_CHECK ? a.w_scale : 1.0f;
     const float rs = SC::RANGE_CHECK ? 1.0f / (a.act_scale * a.w_scale) : 1.0f;
-    bool over = false;
+    RangeMax over;
 
     // ---- weights -> pieces in registers, once: wr[p][ks] = split(W[16w + r16][32 ks + 8 q .. +7] * sw) ------------------------------
     V8 wr[NP][16];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512, 1) void seanet_down64x3_kernel(Down64Args a) {
         __syncthreads();   // buffer buf ^ 1 is complete, buffer buf is free
     }
     if constexpr (SC::RANGE_CHECK)
-        if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
+        range_publish(a.status, a.status ? a.status + 1 : nullptr, over);
 }
 
 int launch_seanet_down64x3(const Down64Args& a, hipStream_t stream) {

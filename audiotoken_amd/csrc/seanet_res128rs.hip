@@ -50,7 +50,7 @@ __global__ __launch_bounds__(512, 1) void seanet_res128rs_kernel(Res64Args a) {
     const int total_tiles = a.B * tiles_per_clip;        // < 2^30: checked by the launcher
     const float sa = a.act_scale;
     const float rs3 = 1.0f / (a.act_scale * a.w3_scale), rst = 1.0f / (a.act_scale * a.wt_scale);
-    bool over = false;
+    RangeMax over;
 
     // ---- this wave's weights -> two fp16 pieces in 96 registers (MFMA A operand: row r16, k = 32 ks + 8 q .. + 7) ---------------------------
     // C wave: wreg[p][ks] = W3 row 16 w + r16, K step ks (12). T wave: wreg[p][6 n + ks] = [W1 | Wsc] row 32 w + 16 n + r16, K step ks (6).
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512, 1) void seanet_res128rs_kernel(Res64Args a) {
         __syncthreads();
         xb_prev = xb_cur; xb_cur = xb_next;
     }
-    if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
+    range_publish(a.status, a.status ? a.status + 1 : nullptr, over);
 }
 
 int launch_seanet_res128rs(const Res64Args& a, hipStream_t stream) {

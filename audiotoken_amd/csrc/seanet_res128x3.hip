@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
     const int L = a.L;
     const int tiles_per_clip = (L + RX_TT - 1) / RX_TT;
     const int total_tiles = a.B * tiles_per_clip;   // < 2^30: checked by the launcher
-    bool over = false;                               // fp16 range check of the f16x2 piece output
+    RangeMax over;                               // fp16 range check of the f16x2 piece output
 
     // ---- weights -> 3 bf16 pieces in registers, once per workgroup (MFMA A operand: row r16, k = 32 ks + 8 q .. + 7) -------------
     V8 w3p[NP][12], wtp[NP][2][6];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void seanet_res128x3_kernel(Res64Args a) {
             }
         }
     }
-    if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
+    range_publish(a.status, a.status ? a.status + 1 : nullptr, over);
 }
 
 // index 0 of plane i = padded row i = time i - 5 = reflect of time 5 - i (plane (5 - i) % 5, index (5 - i) / 5 + 1)

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void seanet_res64x3_kernel(Res64Args a) {
     PT* Hs = Xr + NP * RY_XP;            // split(ELU(conv3 + b3))
     const float sa = SC::RANGE_CHECK ? a.act_scale : 1.0f;
     const float rs3 = SC::RANGE_CHECK ? 1.0f / (a.act_scale * a.w3_scale) : 1.0f, rst = SC::RANGE_CHECK ? 1.0f / (a.act_scale * a.wt_scale) : 1.0f;
-    bool over = false;
+    RangeMax over;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int L = a.L;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void seanet_res64x3_kernel(Res64Args a) {
         }
     }
     if constexpr (SC::RANGE_CHECK)
-        if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
+        range_publish(a.status, a.status ? a.status + 1 : nullptr, over);
 }
 
 int launch_seanet_res64x3(const Res64Args& a, hipStream_t stream) {

@@ -36,9 +36,9 @@ constexpr int SX_WAV = 88;                 // waveform segment: Wv[s] = wav[|t0 
 
 // 4 consecutive channels * scale -> the NP pieces at element offset `off` (piece stride ps); returns the scheme's range verdict
 template <class SC>
-__device__ __forceinline__ bool sx_store4(typename SC::T* base, int off, int ps, const f4& v, float scale) {
+__device__ __forceinline__ float sx_store4(typename SC::T* base, int off, int ps, const f4& v, float scale) {
     typename SC::V4 p[SC::NP];
-    const bool over = split4<SC>(v, scale, p);
+    const float over = split4<SC>(v, scale, p);
 #pragma unroll
     for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(base + i * ps + off) = p[i];
     return over;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
     const float sa = SC::RANGE_CHECK ? a.act_scale : 1.0f;
     const float sw3 = SC::RANGE_CHECK ? a.w3_scale : 1.0f, swt = SC::RANGE_CHECK ? a.wt_scale : 1.0f, swd = SC::RANGE_CHECK ? a.wd_scale : 1.0f;
     const float rs3 = 1.0f / (sa * sw3), rst = 1.0f / (sa * swt), rsd = 1.0f / (sa * swd);
-    bool over = false;
+    RangeMax over;
     float* B0s = Wv + 2 * SX_WAV;                    // conv0 bias [32]  (Wv: two segments, alternating tiles)
     float* Bs = B0s + 32;                            // b3 [16] | bt [32] | bd [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
         __syncthreads();   // x0 of the next tile complete; Rs and Hs free
     }
     if constexpr (SC::RANGE_CHECK)
-        if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
+        range_publish(a.status, a.status ? a.status + 1 : nullptr, over);
 }
 
 template <class SC>

@@ -5,14 +5,15 @@
 
 namespace at {
 
-template <class SC>
+// FASTDIV: the caller filled a.fdS / a.fdS2 (the two-group kernel's launcher does)
+template <class SC, bool FASTDIV = false>
 struct XbEpilogue {
     typedef typename SC::T PT;
     const Bf16x3Args& a;
     const int clip;
     float* Cb;
     const float* Rb;
-    bool over = false;
+    RangeMax over;
 
     __device__ XbEpilogue(const Bf16x3Args& args, int clip_) : a(args), clip(clip_) {
         Cb = a.C ? a.C + (long long)clip * a.M * a.ldc : nullptr;
@@ -20,14 +21,15 @@ struct XbEpilogue {
     }
 
     // split outputs: [pieces][batch][blocks][phases][pad][16]; output row m lives in plane m % phases at index m / phases + front
-    __device__ __forceinline__ void write_split(__bf16* S_, int pad, int phases, int front, int blocks, int block0, int m, int n, const f4& v) {
+    template <bool FD = false>
+    __device__ __forceinline__ void write_split(__bf16* S_, int pad, int phases, int front, int blocks, int block0, int m, int n, const f4& v, const FastDivU* fd = nullptr) {
         PT* S = reinterpret_cast<PT*>(S_);
         const int nb = blocks > 0 ? blocks : a.N / 16;
         const long long s_clip = (long long)pad * phases * nb * 16;   // elements of one clip of one piece
         const long long psS = s_clip * a.batch;
         typename SC::V4 p[SC::NP];
         over |= split4<SC>(v, a.split_scale, p);
-        const int sq = m / phases, sp = m - sq * phases;
+        const int sq = FD ? (int)fd->div((unsigned)m) : m / phases, sp = m - sq * phases;
         PT* d = S + clip * s_clip + (((long long)(block0 + (n >> 4)) * phases + sp) * pad + sq + front) * 16 + (n & 15);
 #pragma unroll
         for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(d + i * psS) = p[i];
@@ -49,6 +51,17 @@ struct XbEpilogue {
         if constexpr (SC::RANGE_CHECK) v *= a.acc_scale;
         v += bias4;
         finish_quad<E, true, PH1>(m, n, v, res4);
+    }
+    // the value of a plain (fp32 row-major) output quad: the statement sequence of apply_with<E> + finish_quad<E, true> for E = LINEAR / GELU, for
+    // callers that address C / R themselves (the two-group kernel's row-layout epilogue: tile base in scalar registers + 32-bit lane offsets)
+    template <int E>
+    __device__ __forceinline__ f4 plain_value(f4 v, const f4& bias4, const f4& res4) const {
+        if constexpr (SC::RANGE_CHECK) v *= a.acc_scale;
+        v += bias4;
+        if constexpr (E == XB_EPI_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        v *= a.alpha;
+        v += res4;
+        return v;
     }
     // phases == 1: [pieces][batch][blocks][pad][16]
     __device__ __forceinline__ void write_split_ph1(__bf16* S_, int pad, int front, int blocks, int block0, int m, int n, const f4& v) {
@@ -73,9 +86,9 @@ struct XbEpilogue {
     template <int E, bool HAVE_RES, bool PH1 = false>
     __device__ __forceinline__ void finish_quad(int m, int n, f4 v, const f4& res4) {
         if constexpr (E == XB_EPI_RAW_ELU_SPLIT2) {
-            write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, v);
+            write_split<FASTDIV>(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, v, &a.fdS);
             const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
-            write_split(a.S2, a.S2pad, a.S2phases, a.S2front, a.S2blocks, a.S2block0, m, n, e);
+            write_split<FASTDIV>(a.S2, a.S2pad, a.S2phases, a.S2front, a.S2blocks, a.S2block0, m, n, e, &a.fdS2);
         } else if constexpr (E == XB_EPI_SWISH_SPLIT || E == XB_EPI_GELU_SPLIT || E == XB_EPI_ELU_SPLIT) {
             f4 w;
 #pragma unroll
@@ -84,7 +97,7 @@ struct XbEpilogue {
                      : E == XB_EPI_ELU_SPLIT ? elu1(v[k])
                                              : v[k] * sigmoidf_(v[k]);   // v_exp_f32 + v_rcp_f32 (~1 ulp each), as the fp32 GEMM's epilogue (the correctly rounded reciprocal cost 5 more instructions per value)
             if constexpr (PH1) write_split_ph1(a.S, a.Spad, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
-            else write_split(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
+            else write_split<FASTDIV>(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w, &a.fdS);
         } else if constexpr (E == XB_EPI_QKV) {
             if (n < a.qkv_hid) {
                 *reinterpret_cast<f4*>(Cb + (long long)m * a.ldc + n) = v;
@@ -112,7 +125,7 @@ struct XbEpilogue {
 
     __device__ __forceinline__ void finish() {
         if constexpr (SC::RANGE_CHECK)
-            if (over && a.status) atomicOr(a.status, XB_STATUS_F16_OVERFLOW);
+            range_publish(a.status, a.status ? a.status + 1 : nullptr, over);
     }
 };
 

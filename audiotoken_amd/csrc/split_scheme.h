@@ -37,6 +37,33 @@ struct SchemeF16x2 {
 template <class SC>
 struct SchemeNoCheck : SC { static constexpr bool RANGE_CHECK = false; };
 
+// Range bookkeeping of the fp16 scheme. A split writer keeps the running maximum of |x * scale| over everything it splits (one v_max3 per value
+// pair; `over |= split4(...)` reads as before) and publishes it ONCE at the end of the kernel: bit XB_STATUS_F16_OVERFLOW of *status when the maximum
+// does not fit fp16 (65504; an infinity fails it — a NaN can only descend from one, or from a NaN in the caller's input), and, when the launch has a
+// census word, the maximum itself (atomicMax on the float's bits: non-negative floats order like integers) — the per-site headroom that
+// at_*_range_report() returns: how close real activations come to the fp16 range is measured, not assumed.
+struct RangeMax {
+    float m = 0.f;
+    __device__ __forceinline__ RangeMax& operator|=(float quad_max) { m = fmaxf(m, quad_max); return *this; }
+    __device__ __forceinline__ RangeMax& operator|=(const RangeMax& o) { m = fmaxf(m, o.m); return *this; }
+    __device__ __forceinline__ bool overflow() const { return !(m <= 65504.0f); }
+};
+// one atomic per WAVE at most: butterfly maximum over the wave's active lanes (an inactive lane contributes 0), then the first active lane
+// publishes — and only when it raises the census word (after the first waves of a launch most are already below it)
+__device__ __forceinline__ void range_publish(int* status, int* census, const RangeMax& r) {
+    float m = r.m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (lane == __builtin_amdgcn_readfirstlane(lane)) {
+        if (status && !(m <= 65504.0f)) atomicOr(status, XB_STATUS_F16_OVERFLOW);
+        if (census) {
+            const int bits = __float_as_int(m);   // m >= 0 (or +inf); a NaN cannot come out of fmaxf unless every operand was one
+            if (bits > __atomic_load_n(census, __ATOMIC_RELAXED)) atomicMax(census, bits);
+        }
+    }
+}
+
 // a -> NP pieces: p[0] = round(a), p[1] = round(a - p[0]), ... (every subtraction is exact)
 template <class SC>
 __device__ __forceinline__ void split_n(float a, typename SC::T (&p)[SC::NP]) {
@@ -46,10 +73,9 @@ __device__ __forceinline__ void split_n(float a, typename SC::T (&p)[SC::NP]) {
         a -= (float)p[i];
     }
 }
-// four values * scale -> NP pieces of four; returns true when a value does not fit the scheme's range (two v_max3 and one compare per
-// call; an infinity fails it — a NaN can only descend from one, or from a NaN in the caller's input)
+// four values * scale -> NP pieces of four; returns max |v * scale| of the four for the caller's RangeMax (0 for a scheme without a range check)
 template <class SC>
-__device__ __forceinline__ bool split4(const f4& v, float scale, typename SC::V4 (&p)[SC::NP]) {
+__device__ __forceinline__ float split4(const f4& v, float scale, typename SC::V4 (&p)[SC::NP]) {
     if constexpr (SC::NP == 2) {
         // the fp16 scheme written on value PAIRS so that it compiles to the packed forms (v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32: three
         // instructions per value instead of five; the element-wise form below left half of the pairs to scalar code). Same arithmetic: the scale
@@ -57,8 +83,8 @@ __device__ __forceinline__ bool split4(const f4& v, float scale, typename SC::V4
         typedef float f2 __attribute__((ext_vector_type(2)));
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const f2 a = f2{v[0], v[1]} * scale, b = f2{v[2], v[3]} * scale;
-        bool over = false;
-        if constexpr (SC::RANGE_CHECK) over = !(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(b[0]), fabsf(b[1]))) <= 65504.0f);
+        float over = 0.f;
+        if constexpr (SC::RANGE_CHECK) over = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(b[0]), fabsf(b[1])));
         const h2 ah = __builtin_convertvector(a, h2), bh = __builtin_convertvector(b, h2);
         const f2 ar = a - __builtin_convertvector(ah, f2), br = b - __builtin_convertvector(bh, f2);
         const h2 al = __builtin_convertvector(ar, h2), bl = __builtin_convertvector(br, h2);
@@ -66,11 +92,8 @@ __device__ __forceinline__ bool split4(const f4& v, float scale, typename SC::V4
         p[1] = typename SC::V4{al[0], al[1], bl[0], bl[1]};
         return over;
     } else {
-        bool over = false;
-        if constexpr (SC::RANGE_CHECK) {
-            const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * scale;
-            over = !(m <= 65504.0f);
-        }
+        float over = 0.f;
+        if constexpr (SC::RANGE_CHECK) over = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * fabsf(scale);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float x = v[k] * scale;
@@ -84,11 +107,11 @@ __device__ __forceinline__ bool split4(const f4& v, float scale, typename SC::V4
 }
 
 // pieces of the 4 consecutive columns col .. col + 3 (col % 4 == 0) of row `row`, into K-blocked pieces [NP][K/16][rows_pad][16]
-// (piece_stride = rows_pad * K elements); one 8-byte store per piece. Returns true when a value does not fit the scheme's range.
+// (piece_stride = rows_pad * K elements); one 8-byte store per piece. Returns max |v * scale| (split4).
 template <class SC>
-__device__ __forceinline__ bool store_pieces4(typename SC::T* out, long long piece_stride, long long rows_pad, long long row, int col, const f4& v, float scale) {
+__device__ __forceinline__ float store_pieces4(typename SC::T* out, long long piece_stride, long long rows_pad, long long row, int col, const f4& v, float scale) {
     typename SC::V4 p[SC::NP];
-    const bool over = split4<SC>(v, scale, p);
+    const float over = split4<SC>(v, scale, p);
     typename SC::T* d = out + ((long long)(col >> 4) * rows_pad + row) * 16 + (col & 15);
 #pragma unroll
     for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(d + i * piece_stride) = p[i];

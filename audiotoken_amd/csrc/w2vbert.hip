@@ -62,6 +62,7 @@ struct at_w2vbert {
     bool finalized = false;
     std::map<std::string, HostTensor> staged;
     std::vector<float*> allocs;
+    int* range_tab = nullptr;   // device, {flag, census} per WSite, zeroed at the start of every encode (at_w2vbert_range_report reads it)
     const float *window = nullptr, *melw = nullptr;
     double* dft64 = nullptr;  // [520][400] DFT matrix in double (see dft_f64_kernel)
     const float *fp_ln_g = nullptr, *fp_ln_b = nullptr, *fp_w = nullptr, *fp_b = nullptr;
@@ -180,8 +181,12 @@ int split_weights(at_w2vbert* h, int scheme) {
 }
 
 // One split-operand GEMM of the conformer: C / S = epi(A . W^T) with A given as pieces (gemm_bf16x3.hip)
+// Sites of the handle's range table (gemm_bf16x3.h, launch_range_combine): where activations become fp16 pieces. The same site in every layer.
+enum WSite { WS_LN_FFN1 = 0, WS_FFN1_HIDDEN, WS_LN_ATTN, WS_QKV_KV, WS_ATTENTION, WS_LN_CONV, WS_DWCONV, WS_LN_FFN2, WS_FFN2_HIDDEN, WS_OTHER, W_NSITES };
+static const char* const kWSiteNames[W_NSITES] = {"ln_ffn1", "ffn1_hidden", "ln_attn", "qkv_kv", "attention", "ln_conv", "dwconv_out", "ln_ffn2", "ffn2_hidden", "other"};
 struct SplitCtx {
-    int scheme; int* status;
+    int scheme; int* tab;
+    int* site(int k) const { return tab ? tab + 2 * k : nullptr; }
     float act_scale() const { return scheme == XB_SCHEME_F16X2 ? XB_F16_ACT_SCALE : 1.0f; }
 };
 int gemm_split(const SplitCtx& c, const piece_t* A, const LayerW& L, int w, const float* bias, int N, int K, long long M, long long Mpad, int epi,
@@ -189,7 +194,7 @@ int gemm_split(const SplitCtx& c, const piece_t* A, const LayerW& L, int w, cons
     Bf16x3Args a;
     a.A = A; a.W = L.ws[c.scheme][w]; a.bias = bias; a.M = (int)M; a.N = N; a.K = K; a.Mpad = (int)Mpad;
     a.epi = epi; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc; a.alpha = alpha; a.S = S; a.Spad = (int)Mpad;
-    a.scheme = c.scheme; a.status = c.status;
+    a.scheme = c.scheme; a.status = c.site(w == W_1A ? WS_FFN1_HIDDEN : w == W_2A ? WS_FFN2_HIDDEN : WS_OTHER);
     if (c.scheme == XB_SCHEME_F16X2) { a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[w]); a.split_scale = XB_F16_ACT_SCALE; }
     return launch_gemm_bf16x3(a, stream);
 }
@@ -350,7 +355,6 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
     h->staged.clear();
     {
         h->arith = ARITH_F16X2;
-        if (const char* e = std::getenv("AUDIOTOKEN_BF16X3")) if (std::atoi(e) == 0) h->arith = ARITH_F32;   // round-1 switch, kept
         if (const char* e = std::getenv("AUDIOTOKEN_SEMANTIC_ARITH")) {
             const std::string v(e);
             AT_REQUIRE(v == "f32" || v == "bf16x3" || v == "f16x2", "AUDIOTOKEN_SEMANTIC_ARITH must be f32, bf16x3 or f16x2");
@@ -359,6 +363,11 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
     }
     if (h->arith != ARITH_F32)
         if (int rc = split_weights(h, h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
+    if (!host_only_test() && !h->range_tab) {
+        AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, 64 * sizeof(int)));
+        h->allocs.push_back(reinterpret_cast<float*>(h->range_tab));
+        AT_CHECK_HIP(hipMemset(h->range_tab, 0, 64 * sizeof(int)));
+    }
     h->finalized = true;
     return 0;
 }
@@ -455,9 +464,9 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     Profiler& prof = h->prof;
     if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
     const bool split = h->arith != ARITH_F32;
-    const SplitCtx sc{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, reinterpret_cast<int*>(status_dev)};
-    // attention follows the linear layers' arithmetic; $AUDIOTOKEN_ATTN_X3=0 keeps the fp32-MFMA attention kernel
-    const int attn_arith = (std::getenv("AUDIOTOKEN_ATTN_X3") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_X3")) == 0) ? 0 : h->arith;
+    AT_CHECK_HIP(hipMemsetAsync(h->range_tab, 0, 64 * sizeof(int), stream));
+    const SplitCtx sc{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, h->range_tab};
+    const int attn_arith = h->arith;   // attention follows the linear layers' arithmetic (0: the fp32-MFMA kernel)
 
     // ---- log-mel front-end (reference processors.py) -------------------------------------------
     double* frames = reinterpret_cast<double*>(ws + p.off_frames);
@@ -485,7 +494,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     piece_t* t1s = reinterpret_cast<piece_t*>(ws + p.off_t1s);
     piece_t* bigs = reinterpret_cast<piece_t*>(ws + p.off_bigs);
     piece_t* kvs = reinterpret_cast<piece_t*>(ws + p.off_kvs);
-    static const bool attn_kvp = !(std::getenv("AUDIOTOKEN_ATTN_KVP") && std::atoi(std::getenv("AUDIOTOKEN_ATTN_KVP")) == 0);
+    const bool attn_kvp = true;   // k / v as pieces from the projection's epilogue whenever the arithmetic is f16x2
     prof.begin("feature_projection", 2, stream);
     if (int rc = launch_layernorm(feats, h->fp_ln_g, h->fp_ln_b, nullptr, t1, M, kFeat, stream)) return rc;
     if (int rc = linear(t1, kFeat, h->fp_w, h->fp_b, x, kHid, M, EPI_NONE, 1.f, nullptr, amask, kHid, stream)) return rc;
@@ -500,7 +509,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             // written only to be re-read by a split pass.
             const float as = sc.act_scale();
             prof.begin("layernorm", 1, stream);
-            if (int rc = launch_layernorm_split(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            if (int rc = launch_layernorm_split(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_FFN1), stream)) return rc;
             prof.end(stream);
             prof.begin("ffn", 2, stream);
             if (int rc = gemm_split(sc, t1s, L, W_1A, L.b1a, kFfn, kHid, M, Mpad, XB_EPI_SWISH_SPLIT, 1.f, nullptr, nullptr, kFfn, bigs, stream)) return rc;
@@ -508,17 +517,17 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             prof.end(stream);
 
             prof.begin("layernorm", 1, stream);
-            if (int rc = launch_layernorm_split(x, L.ln_att_g, L.ln_att_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            if (int rc = launch_layernorm_split(x, L.ln_att_g, L.ln_att_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_ATTN), stream)) return rc;
             prof.end(stream);
             prof.begin("attn_proj", 1, stream);
             // f16x2: the projection's epilogue writes k and v directly as fp16 pieces (q stays fp32 for the rel-pos table); the attention kernel
-            // then stages K / V tiles without splitting them ($AUDIOTOKEN_ATTN_KVP=0: the kernel splits the fp32 rows itself)
+            // then stages K / V tiles without splitting them
             const bool kvp = attn_arith == ARITH_F16X2 && sc.scheme == XB_SCHEME_F16X2 && attn_kvp;
             if (kvp) {
                 Bf16x3Args qa;
                 qa.A = t1s; qa.W = L.ws[sc.scheme][W_QKV]; qa.bias = L.bqkv; qa.M = (int)M; qa.N = 3 * kHid; qa.K = kHid; qa.Mpad = (int)Mpad;
                 qa.epi = XB_EPI_QKV; qa.C = big; qa.ldc = 3 * kHid; qa.S = kvs; qa.Spad = (int)Mpad; qa.qkv_hid = kHid;
-                qa.scheme = sc.scheme; qa.status = sc.status; qa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[W_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
+                qa.scheme = sc.scheme; qa.status = sc.site(WS_QKV_KV); qa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[W_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
                 if (int rc = launch_gemm_bf16x3(qa, stream)) return rc;
             } else if (int rc = gemm_split(sc, t1s, L, W_QKV, L.bqkv, 3 * kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, big, nullptr, 3 * kHid, nullptr, stream)) {
                 return rc;
@@ -526,10 +535,10 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             prof.end(stream);
             prof.begin("attention", 1, stream);
             if (attn_arith > 0) {
-                if (int rc = launch_relpos_attention(big, amask, L.dist, nullptr, B, T, stream, 16, attn_arith, sc.status, t1s, Mpad, kvp ? kvs : nullptr)) return rc;
+                if (int rc = launch_relpos_attention(big, amask, L.dist, nullptr, B, T, stream, 16, attn_arith, sc.site(WS_ATTENTION), t1s, Mpad, kvp ? kvs : nullptr)) return rc;
             } else {
                 if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, 0, nullptr)) return rc;
-                if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream, sc.scheme, as, sc.status)) return rc;
+                if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream, sc.scheme, as, sc.site(WS_ATTENTION))) return rc;
             }
             prof.end(stream);
             prof.begin("attn_proj", 1, stream);
@@ -537,16 +546,16 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             prof.end(stream);
 
             prof.begin("layernorm", 1, stream);
-            if (int rc = launch_layernorm_split(x, L.ln_conv_g, L.ln_conv_b, amask, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            if (int rc = launch_layernorm_split(x, L.ln_conv_g, L.ln_conv_b, amask, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_CONV), stream)) return rc;
             prof.end(stream);
             prof.begin("conv_module", 3, stream);
             if (int rc = gemm_split(sc, t1s, L, W_PW1, nullptr, 2 * kHid, kHid, M, Mpad, XB_EPI_GLU, 1.f, big, nullptr, kHid, nullptr, stream)) return rc;
-            if (int rc = launch_dwconv_ln_swish(big, L.dw, L.ln_dw_g, L.ln_dw_b, nullptr, B, T, stream, t1s, Mpad, sc.scheme, as, sc.status)) return rc;
+            if (int rc = launch_dwconv_ln_swish(big, L.dw, L.ln_dw_g, L.ln_dw_b, nullptr, B, T, stream, t1s, Mpad, sc.scheme, as, sc.site(WS_DWCONV))) return rc;
             if (int rc = gemm_split(sc, t1s, L, W_PW2, nullptr, kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, x, x, kHid, nullptr, stream)) return rc;
             prof.end(stream);
 
             prof.begin("layernorm", 1, stream);
-            if (int rc = launch_layernorm_split(x, L.ln_ffn2_g, L.ln_ffn2_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.status, stream)) return rc;
+            if (int rc = launch_layernorm_split(x, L.ln_ffn2_g, L.ln_ffn2_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_FFN2), stream)) return rc;
             prof.end(stream);
             prof.begin("ffn", 2, stream);
             if (int rc = gemm_split(sc, t1s, L, W_2A, L.b2a, kFfn, kHid, M, Mpad, XB_EPI_SWISH_SPLIT, 1.f, nullptr, nullptr, kFfn, bigs, stream)) return rc;
@@ -568,7 +577,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
         if (int rc = linear(t1, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, 1.f, nullptr, nullptr, 3 * kHid, stream)) return rc;
         prof.end(stream);
         prof.begin("attention", 1, stream);
-        if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, attn_arith, sc.status)) return rc;
+        if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, attn_arith, sc.site(WS_ATTENTION))) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
         if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) return rc;
@@ -586,6 +595,8 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
         if (int rc = launch_layernorm(x, L.ln_fin_g, L.ln_fin_b, nullptr, x, M, kHid, stream)) return rc;
         prof.end(stream);
     }
+    if (status_dev)   // every site's range verdict of this call -> the caller's status word
+        if (int rc = launch_range_combine(h->range_tab, (int)W_NSITES, reinterpret_cast<int*>(status_dev), stream)) return rc;
     if (hidden_out) AT_CHECK_HIP(hipMemcpyAsync(hidden_out, x, (size_t)M * kHid * sizeof(float), hipMemcpyDeviceToDevice, stream));
 
     if (tokens) {
@@ -597,6 +608,26 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
         prof.end(stream);
     }
     return 0;
+}
+
+// The measured fp16 headroom of the LAST encode of this handle: per site (at_w2vbert_range_sites) the largest |x * scale| a split writer saw over all
+// layers (0: the site did not run on the fp16 scheme); the scheme overflows at 65504. Synchronises the device.
+int at_w2vbert_range_report(at_w2vbert_t* h, float* max_scaled, int cap) {
+    AT_REQUIRE(h && h->finalized && h->range_tab && max_scaled && cap >= (int)W_NSITES, "at_w2vbert_range_report: bad arguments");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    int host[2 * W_NSITES];
+    AT_CHECK_HIP(hipDeviceSynchronize());
+    AT_CHECK_HIP(hipMemcpy(host, h->range_tab, sizeof(host), hipMemcpyDeviceToHost));
+    for (int k = 0; k < (int)W_NSITES; ++k) { float f; std::memcpy(&f, &host[2 * k + 1], sizeof(f)); max_scaled[k] = f; }
+    return (int)W_NSITES;
+}
+int at_w2vbert_range_sites(char* names, size_t cap) {
+    std::string s;
+    for (int k = 0; k < (int)W_NSITES; ++k) { s += kWSiteNames[k]; s += "\n"; }
+    if (!names || cap < s.size() + 1) return -(int)(s.size() + 1);
+    std::memcpy(names, s.c_str(), s.size() + 1);
+    return (int)W_NSITES;
 }
 
 /* ---- operator-level entry points for the parity tests ---------------------------------------------------- */

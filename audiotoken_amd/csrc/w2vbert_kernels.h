@@ -11,7 +11,7 @@ int launch_fbank_normalize(const float* logmel, const float* fmask, float* stats
                            hipStream_t stream);
 int launch_layernorm(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, long long rows, int D,
                      hipStream_t stream);
-// arith: 0 = fp32-MFMA kernel, 1 = bf16x3, 2 = f16x2 (attention_bf16x3.hip), -1 = the default ($AUDIOTOKEN_ATTN_X3=0 -> 0, else
+// arith: 0 = fp32-MFMA kernel, 1 = bf16x3, 2 = f16x2 (attention_bf16x3.hip), -1 = the default (
 // $AUDIOTOKEN_SEMANTIC_ARITH, else f16x2); status: device word for the fp16 range check (nullable)
 // ctx_pieces != nullptr (split arithmetic only): the context is written as operand pieces [NP][hid/16][rows_pad][16] instead of fp32 ctx
 // kv_pieces != nullptr (f16x2 only): k and v are read as the row-major fp16 pieces [which][piece][rows_pad][hid] the q / k / v projection wrote

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
     __shared__ __attribute__((aligned(16))) PT tile[NP][LNS_D / 16][LNS_ROWS][16];   // 64 KB (two pieces) / 96 KB (three)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long r0 = (long long)blockIdx.x * LNS_ROWS;
-    bool over = false;
+    RangeMax over;
     // all rows of the wave are loaded before the first is reduced (one row at a time left 4 KB per wave in flight: 3.5 TB/s, 70 % of the wave
     // cycles waiting); 8 rows per workgroup instead of 16 puts four workgroups on a CU: 16.0 -> 13.7 ms per semantic_m step (4 rows: no further gain)
     f4 vall[LNS_RW][4];
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
                 *reinterpret_cast<const u4_*>(&tile[pi][kb][lr][(ch & 1) * 8]);
     }
     if constexpr (SC::RANGE_CHECK)
-        if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
+        range_publish(status, status ? status + 1 : nullptr, over);
 }
 
 int launch_layernorm_split(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, __bf16* out, long long rows, long long rows_pad,
@@ -427,7 +427,7 @@ int launch_layernorm_split(const float* x, const float* gamma, const float* beta
 // each 16-key tile — exactly the B-operand fragment of the P.V MFMA, so P never leaves registers.
 // qkv layout: [B*T][3072] = [q | k | v], head h at columns h*64.
 // ------------------------------------------------------------------------------------------------------
-constexpr bool kAttnX3Default = true;   // split-bf16 attention kernel (attention_bf16x3.hip); $AUDIOTOKEN_ATTN_X3 overrides
+constexpr bool kAttnX3Default = true;   // split-bf16 attention kernel (attention_bf16x3.hip)
 constexpr int ATT_QB = 128, ATT_KB = 64, ATT_D = 64;
 constexpr float ATT_SCALE2 = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e): scores live in the exp2 domain (p = v_exp_f32(s - m))
 constexpr int ATT_QE_LD = 81;   // 73 buckets padded to an odd stride
@@ -660,7 +660,6 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_kernel(const float* _
 }
 
 static int default_attention_arith() {
-    if (const char* e = std::getenv("AUDIOTOKEN_ATTN_X3")) if (std::atoi(e) == 0) return 0;
     if (const char* e = std::getenv("AUDIOTOKEN_SEMANTIC_ARITH")) {
         const std::string v(e);
         return v == "f32" ? 0 : v == "bf16x3" ? 1 : 2;
@@ -746,7 +745,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_swish_kernel(const float* __res
     __syncthreads();
     const f4 gm = reinterpret_cast<const f4*>(gamma)[tid];
     const f4 bt = reinterpret_cast<const f4*>(beta)[tid];
-    bool over = false;
+    RangeMax over;
     (void)over;
 #pragma unroll
     for (int i = 0; i < DW_TT; ++i) {
@@ -766,7 +765,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_swish_kernel(const float* __res
     }
     if constexpr (!std::is_void<SC>::value)
         if constexpr (SC::RANGE_CHECK)
-            if (over && status) atomicOr(status, XB_STATUS_F16_OVERFLOW);
+            range_publish(status, status ? status + 1 : nullptr, over);
 }
 
 int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,

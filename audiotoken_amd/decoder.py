@@ -29,6 +29,7 @@ class AcousticDecoder(torch.nn.Module):
         self.device = self._h.device
         self._ws: Optional[torch.Tensor] = None
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.fallback_batches = 0    # batches `verified` repeated without the f16x2 kernels (fp16 range overflow)
 
     def last_status(self) -> int:
         """0 = ok, 1 = a bounded wait inside the persistent LSTM kernel gave up (synchronises the device)."""
@@ -43,20 +44,33 @@ class AcousticDecoder(torch.nn.Module):
             logger.error(f"persistent LSTM hand-off timed out in the decoder (status {status}): waveform discarded; "
                          "decoding again with per-step LSTM launches (option persistent_lstm=0) from now on")
             self.set_option("persistent_lstm", 0)
+        saved = {}
         if status & 2:
+            self.fallback_batches += 1
             logger.error(f"fp16 range overflow in the decoder's f16x2 kernels (LSTM input projection, residual blocks, transposed convs; status {status}): "
-                         "waveform discarded; decoding again without them (options ih_f16x2=0, res_f16x2=0, up_f16x2=0) from now on")
-            self.set_option("ih_f16x2", 0)
-            self.set_option("res_f16x2", 0)
-            self.set_option("up_f16x2", 0)
-        wav = self.forward(tokens)
-        if self.last_status() != 0:
-            raise _cabi.HipLibraryError("acoustic decode failed twice (LSTM status non-zero with per-step launches)")
+                         "waveform discarded; decoding THIS batch again without them (options ih_f16x2=0, res_f16x2=0, up_f16x2=0)")
+            for opt in ("ih_f16x2", "res_f16x2", "up_f16x2"):
+                saved[opt] = self.get_option(opt)
+                self.set_option(opt, 0)
+        try:
+            wav = self.forward(tokens)
+            if self.last_status() != 0:
+                raise _cabi.HipLibraryError("acoustic decode failed twice (status non-zero on the fallback kernels)")
+        finally:
+            for opt, v in saved.items():
+                self.set_option(opt, v)
         return wav
 
     def set_option(self, name: str, value: int) -> None:
         """Kernel-selection switches of the library (results are bit-identical either way; used by the parity tests)."""
         _cabi.check(self._h.lib.at_encodec_set_option(self._h.handle, name.encode(), int(value)), f"at_encodec_set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        return int(self._h.lib.at_encodec_get_option(self._h.handle, name.encode()))
+
+    def range_report(self):
+        """{site: largest |x * scale| its split writers saw in the LAST decode} (see AcousticEncoder.range_report)."""
+        return _cabi.range_report(self._h.lib, "encodec", self._h.handle)
 
     @torch.no_grad()
     def forward(self, input_batch: torch.Tensor) -> torch.Tensor:

@@ -105,6 +105,7 @@ class AcousticEncoder(torch.nn.Module):
             raise ValueError(f"bandwidth {config.bandwidth} needs {self.n_q} codebooks, checkpoint has {self._h.n_codebooks}")
         self._ws: Optional[torch.Tensor] = None
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.fallback_batches = 0    # batches `verified` repeated on the bf16x3 kernels (fp16 range overflow)
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes:
@@ -142,10 +143,21 @@ class AcousticEncoder(torch.nn.Module):
         convs, LSTM input projection) (synchronises the device)."""
         return int(self._status.item())
 
+    def range_report(self) -> Dict[str, float]:
+        """{site: largest |x * scale| its split writers saw in the LAST call}: the measured headroom of the two-piece fp16 arithmetic, which
+        overflows at 65504 (0.0: the site did not run on that scheme). Synchronises the device."""
+        return _cabi.range_report(self._h.lib, "encodec", self._h.handle)
+
+    RANGE_OPTIONS = ("ih_f16x2", "chain_f16x2", "res_f16x2", "rvq_f16x2", "fin_f16x2")
+
     def verified(self, codes: torch.Tensor, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Product-path guard, called where the caller synchronises anyway (tokens leaving the device): if the persistent LSTM
-        reported a hand-off time-out for the call that produced `codes` (another process on the GPU, a partitioned device: not all
-        256 workgroups resident), log it and repeat the batch with the per-step LSTM launches, which need no co-residency."""
+        """Product-path guard, called where the caller synchronises anyway (tokens leaving the device). The status word of the call that
+        produced `codes` decides:
+        * bit 0, the persistent LSTM's hand-off timed out (another process on the GPU, a partitioned device: not all 256 workgroups
+          resident): a property of the MACHINE — log it, switch to the per-step LSTM launches for the rest of the handle's life and repeat;
+        * bit 1, an activation exceeded the fp16 range of the f16x2 kernels: a property of THIS BATCH — repeat it on the bf16x3 kernels (fp32
+          exponent range), count it in ``fallback_batches`` and switch back: the next batch runs on f16x2 again (round 2 switched the
+          handle for good, so one outlier batch halved the throughput of the rest of a run)."""
         status = self.last_status()
         if status == 0:
             return codes
@@ -153,15 +165,21 @@ class AcousticEncoder(torch.nn.Module):
             logger.error(f"persistent LSTM hand-off timed out (status {status}): the tokens of this batch were discarded; "
                          "re-encoding with per-step LSTM launches (option persistent_lstm=0) from now on")
             self.set_option("persistent_lstm", 0)
+        saved = {}
         if status & 2:
+            self.fallback_batches += 1
             logger.error(f"an activation exceeded the fp16 range of the f16x2 kernels (SEANet convs, LSTM input projection, final conv, RVQ search; status {status}): "
-                         "the tokens of this batch were discarded; re-encoding with the bf16x3 kernels "
-                         "(options chain_f16x2=0, ih_f16x2=0, res_f16x2=0, rvq_f16x2=0, fin_f16x2=0) from now on")
-            for opt in ("ih_f16x2", "chain_f16x2", "res_f16x2", "rvq_f16x2", "fin_f16x2"):
+                         f"the tokens of this batch were discarded; re-encoding THIS batch with the bf16x3 kernels (fallback batch #{self.fallback_batches})")
+            for opt in self.RANGE_OPTIONS:
+                saved[opt] = self.get_option(opt)
                 self.set_option(opt, 0)
-        codes = self.forward(input_batch, attention_mask)
-        if self.last_status() != 0:
-            raise _cabi.HipLibraryError("acoustic encode failed twice (LSTM status non-zero with per-step launches)")
+        try:
+            codes = self.forward(input_batch, attention_mask)
+            if self.last_status() != 0:
+                raise _cabi.HipLibraryError("acoustic encode failed twice (status non-zero on the fallback kernels)")
+        finally:
+            for opt, v in saved.items():
+                self.set_option(opt, v)
         return codes
 
     @torch.no_grad()
@@ -285,6 +303,7 @@ class Wav2VecBertEncoder(torch.nn.Module):
             raise ValueError(f"checkpoint has {self.n_layers} conformer layers, output_layer={self.output_layer} needs that many")
         self._ws: Optional[torch.Tensor] = None
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.fallback_batches = 0    # batches `verified` repeated with arith=bf16x3 (fp16 range overflow)
 
     def __del__(self):
         h = self.__dict__.pop("handle", None)
@@ -306,18 +325,28 @@ class Wav2VecBertEncoder(torch.nn.Module):
         """0 = ok; bit 1 (2) = an activation overflowed the fp16 range of the f16x2 arithmetic (synchronises the device)."""
         return int(self._status.item())
 
+    def range_report(self) -> Dict[str, float]:
+        """{site: largest |x * scale| its split writers saw in the LAST call, over all layers}; the f16x2 arithmetic overflows at 65504."""
+        return _cabi.range_report(self.lib, "w2vbert", self.handle)
+
     def verified(self, tokens: torch.Tensor, input_batch: torch.Tensor, mask: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
-        """Product-path guard, called where the caller synchronises anyway: if the call that produced `tokens` reported an fp16
-        range overflow, log it, switch the linear layers to the bf16x3 arithmetic (full fp32 exponent range) and repeat the batch."""
+        """Product-path guard, called where the caller synchronises anyway: if the call that produced `tokens` reported an fp16 range
+        overflow, log it, repeat THIS batch with the bf16x3 arithmetic (full fp32 exponent range), count it in ``fallback_batches`` and
+        switch back — the next batch runs on f16x2 again."""
         status = self.last_status()
         if status == 0:
             return tokens
+        self.fallback_batches += 1
         logger.error(f"semantic_m encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
-                     "the tokens of this batch were discarded; re-encoding with arith=bf16x3 from now on")
+                     f"the tokens of this batch were discarded; re-encoding THIS batch with arith=bf16x3 (fallback batch #{self.fallback_batches})")
+        saved = self.get_option("arith")
         self.set_option("arith", "bf16x3")
-        tokens = self.forward(input_batch, mask, **kw)
-        if self.last_status() != 0:
-            raise _cabi.HipLibraryError("semantic_m encode failed twice (status non-zero with bf16x3 arithmetic)")
+        try:
+            tokens = self.forward(input_batch, mask, **kw)
+            if self.last_status() != 0:
+                raise _cabi.HipLibraryError("semantic_m encode failed twice (status non-zero with bf16x3 arithmetic)")
+        finally:
+            self.set_option("arith", saved)
         return tokens
 
     def _workspace(self, nbytes: int) -> torch.Tensor:

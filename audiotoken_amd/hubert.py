@@ -94,6 +94,7 @@ class HubertEncoder(torch.nn.Module):
             raise ValueError(f"checkpoint has too few transformer layers for output_layer={self.output_layer}")
         self._ws: Optional[torch.Tensor] = None
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.fallback_batches = 0
 
     def __del__(self):
         h = self.__dict__.pop("handle", None)
@@ -115,17 +116,26 @@ class HubertEncoder(torch.nn.Module):
         """0 = ok; bit 1 (2) = an activation overflowed the fp16 range of the f16x2 arithmetic (synchronises the device)."""
         return int(self._status.item())
 
+    def range_report(self) -> Dict[str, float]:
+        """{site: largest |x * scale| its split writers saw in the LAST call}; the f16x2 arithmetic overflows at 65504."""
+        return _cabi.range_report(self.lib, "hubert", self.handle)
+
     def verified(self, tokens: torch.Tensor, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Product-path guard (see Wav2VecBertEncoder.verified): on an fp16 range overflow repeat the batch with arith=bf16x3."""
+        """Product-path guard (see Wav2VecBertEncoder.verified): on an fp16 range overflow repeat THIS batch with arith=bf16x3, then switch back."""
         status = self.last_status()
         if status == 0:
             return tokens
+        self.fallback_batches += 1
         logger.error(f"semantic_s encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
-                     "the tokens of this batch were discarded; re-encoding with arith=bf16x3 from now on")
+                     f"the tokens of this batch were discarded; re-encoding THIS batch with arith=bf16x3 (fallback batch #{self.fallback_batches})")
+        saved = self.get_option("arith")
         self.set_option("arith", "bf16x3")
-        tokens = self.forward(input_batch, attention_mask)
-        if self.last_status() != 0:
-            raise _cabi.HipLibraryError("semantic_s encode failed twice (status non-zero with bf16x3 arithmetic)")
+        try:
+            tokens = self.forward(input_batch, attention_mask)
+            if self.last_status() != 0:
+                raise _cabi.HipLibraryError("semantic_s encode failed twice (status non-zero with bf16x3 arithmetic)")
+        finally:
+            self.set_option("arith", saved)
         return tokens
 
     @torch.no_grad()

@@ -41,8 +41,6 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
-# Linear layers of the two semantic tokenizers run as exact 3-way bf16 splits (6 bf16 MFMAs per fp32-equivalent step) unless disabled
-BF16X3 = os.environ.get("AUDIOTOKEN_BF16X3", "1") != "0"
 BF16X3_GROUPS = ("ffn", "attn_proj", "feature_extractor")   # feature_extractor: HuBERT only (its six 512->512 convs)
 # acoustic kernel groups that execute as exact 3-way bf16 splits (library defaults; same switches as csrc/encodec.hip)
 BF16X3_ACOUSTIC = os.environ.get("AUDIOTOKEN_BF16X3_ACOUSTIC", "1") != "0"

@@ -74,7 +74,11 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
                               int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream,
                               uint32_t* status_dev);
 
-/* Options (they select kernels or bound memory; all but the "*_x3" ones leave the results bit-identical):
+/* Options (they select kernels or bound memory; all but the "*_x3" / "*_f16x2" ones leave the results bit-identical). The product runs the
+ * defaults; the others exist as the per-batch range fallback of AcousticEncoder.verified ("*_f16x2" = 0: three bf16 pieces, fp32 exponent range), as
+ * the machine fallback ("persistent_lstm" = 0) and as the A/B twins the parity tests compare against (fp32 kernels, unfused GEMM paths). Environment
+ * switches are limited to $AUDIOTOKEN_BF16X3_ACOUSTIC, $AUDIOTOKEN_X3_KERNELS (A/B masks of tools/ab_x3.sh), $AUDIOTOKEN_LSTM_STEPWISE and
+ * $AUDIOTOKEN_SUBBATCH: round 2's per-option variables were removed.
  *   "persistent_lstm" 1/0 — whole-sequence persistent LSTM kernel (default on) or one launch per time step;
  *   "fused_stage0", "fused_res64", "fused_res128", "fused_down64", "fused_dectail" 1/0 — fused SEANet kernels (default on)
  *   or the GEMM path;
@@ -83,17 +87,17 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
  *   operand (default on; $AUDIOTOKEN_X3_KERNELS bit mask, bits 3, 2, 1, 0, 4, 5, 6, 7, 8 in that order; 0 = the fp32-MFMA kernels:
  *   same tokens, embeddings differ in the last bits);
  *   "ih_f16x2", "chain_f16x2" 1/0 — the two LSTM input projections (encoder and decoder) / the encoder's stage-2 strided conv, 256-channel block
- *   and stage-3 strided conv (the GEMM chain) as two-piece fp16 operand splits, three MFMA products (default on, $AUDIOTOKEN_IH_F16X2 /
- *   $AUDIOTOKEN_CHAIN_F16X2) or as the three-piece bf16 splits, six products; see csrc/gemm_bf16x3.h;
+ *   and stage-3 strided conv (the GEMM chain) as two-piece fp16 operand splits, three MFMA products (default on)
+ *   or as the three-piece bf16 splits, six products; see csrc/gemm_bf16x3.h;
  *   "res_f16x2", "rvq_f16x2" 1/0 — the fused SEANet kernels of the encoder (stage 0, the 64- and 128-channel residual blocks, the stage-1 strided conv) /
- *   the RVQ search on the same two-piece fp16 scheme (default on, $AUDIOTOKEN_RES_F16X2 / $AUDIOTOKEN_RVQ_F16X2) or on three bf16 pieces;
+ *   the RVQ search on the same two-piece fp16 scheme (default on) or on three bf16 pieces;
  *   "res128_rs" 1/0 — the 128-channel block on the fp16 scheme as the role-split kernel (csrc/seanet_res128rs.hip, default) or as
  *   csrc/seanet_res128x3.hip; bit-identical results;
  *   "up_f16x2" 1/0 — the decoder's first three transposed convs as two-tap windowed split GEMMs on the fp16 scheme (default on) or as fp32-MFMA GEMMs;
- *   "fin_f16x2" 1/0 — the encoder's final k = 7 conv as a windowed split GEMM on the two-piece fp16 scheme (default on, $AUDIOTOKEN_FIN_F16X2) or on
+ *   "fin_f16x2" 1/0 — the encoder's final k = 7 conv as a windowed split GEMM on the two-piece fp16 scheme (default on) or on
  *   the fp32 MFMA;
  *   "lstm_f16x2" 1/0 — the persistent LSTM's recurrent product on the two-piece fp16 scheme (h in (-1, 1) always fits: no range check) or on
- *   three bf16 pieces (default on, $AUDIOTOKEN_LSTM_F16X2; needs "lstm_x3" = 1);
+ *   three bf16 pieces (default on; needs "lstm_x3" = 1);
  *   "lstm_spin_limit" n >= 0 — polls of a hand-off flag before a workgroup of the persistent LSTM gives up and the status word of the
  *   *_checked entry points becomes 1 (default 2^18, i.e. 0.1-0.3 s; 0 makes the first unready poll give up — used by the tests);
  *   "subbatch" n >= 1 — clips per pass through the conv stack (default 256 or $AUDIOTOKEN_SUBBATCH): bounds
@@ -196,6 +200,18 @@ int at_hubert_profile(at_hubert_t* h, int enable);
 int at_hubert_profile_read(at_hubert_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups);
 
 /* ---- operator-level entry points (the kernels behind the models; used by the parity tests) ------------- */
+
+/* Measured fp16 headroom of the LAST encode / decode of a handle (round 3). Every place where activations are split into fp16 pieces (a "site":
+ * a fused SEANet kernel's staging, a GEMM epilogue that writes the next layer's operand, LayerNorm -> pieces, the attention kernel ...) records the
+ * largest |x * scale| it saw; the two-piece fp16 arithmetic overflows at 65504 (status bit 1). at_*_range_sites: newline-separated site names
+ * (returns the count, or -(bytes needed)); at_*_range_report: max_scaled[k] per site (0 = the site did not run on the fp16 scheme), returns the
+ * count. Synchronises the device. */
+int at_encodec_range_sites(char* names, size_t cap);
+int at_encodec_range_report(at_encodec_t* h, float* max_scaled, int cap);
+int at_w2vbert_range_sites(char* names, size_t cap);
+int at_w2vbert_range_report(at_w2vbert_t* h, float* max_scaled, int cap);
+int at_hubert_range_sites(char* names, size_t cap);
+int at_hubert_range_report(at_hubert_t* h, float* max_scaled, int cap);
 
 /* Windowed fp32 GEMM: out[b][m][n] = act(alpha*(sum_kk A(b,m,kk)*W[n][kk] + bias[n])) (+ R[b][m][n]) with
  * A(b,m,kk) = pro(X[b][m*stride + kk/Cin - pad_left][kk%Cin]); rows outside [0,Tin) reflect (pad_mode=1) or are

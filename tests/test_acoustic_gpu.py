@@ -312,7 +312,8 @@ def test_role_split_res128_is_bit_identical(encoders):
 
 def test_fp16_range_overflow_is_reported_and_recovered(enc_weights):
     """A waveform far outside [-1, 1] (x 3e4) overflows the fp16 range of the two-piece kernels: the status word must say so (bit 1) and
-    AcousticEncoder.verified must hand back the tokens of the three-bf16-piece kernels (full fp32 exponent range), equal to the oracle's or explained."""
+    AcousticEncoder.verified must hand back the tokens of the three-bf16-piece kernels (full fp32 exponent range), equal to the oracle's or explained.
+    The fallback is PER BATCH: the options are restored, the next (ordinary) batch runs on f16x2 again with a clean status, and the count is kept."""
     from audiotoken_amd.configs import AcousticEncoderConfig
     from audiotoken_amd.encoder import AcousticEncoder
     enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=enc_weights)
@@ -322,10 +323,42 @@ def test_fp16_range_overflow_is_reported_and_recovered(enc_weights):
     x = wav.cuda()
     codes = enc(x, None)
     assert enc.last_status() & 2, "the range overflow was not reported"
+    before = {o: enc.get_option(o) for o in F16X2_OPTIONS}
     codes = enc.verified(codes, x, None)
-    assert enc.last_status() == 0
-    assert all(enc.get_option(o) == 0 for o in F16X2_OPTIONS if o != "lstm_f16x2")
+    assert enc.last_status() == 0 and enc.fallback_batches == 1
+    assert {o: enc.get_option(o) for o in F16X2_OPTIONS} == before, "the range fallback must not outlive the batch"
     P.assert_rvq_equal_or_explained(codes, ref, margins, P.RVQ_TIE, "after the range-overflow fallback")
+    quiet = (x / 3e4).contiguous()
+    c2 = enc(quiet, None)
+    assert enc.last_status() == 0 and enc.verified(c2, quiet, None) is c2 and enc.fallback_batches == 1
+
+
+def test_both_fallbacks_together(enc_weights):
+    """The option combination AcousticEncoder.verified can actually produce: the range fallback (every "*_f16x2" option of RANGE_OPTIONS off:
+    three bf16 pieces) WHILE the machine fallback is active (persistent_lstm = 0: one launch per LSTM step). Round 2 tested all-on, all-off and
+    bf16x3 triples but not this pair. Tokens against the oracle, and against the default path on an ordinary batch."""
+    from audiotoken_amd.configs import AcousticEncoderConfig
+    from audiotoken_amd.encoder import AcousticEncoder
+    enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=enc_weights)
+    wav = torch.from_numpy(W.synth_waveform(5, 24000 + 320 * 2, 24000, seed=29))
+    x = wav.cuda()
+    default = enc(x, None).clone()
+    assert enc.last_status() == 0
+    try:
+        enc.set_option("persistent_lstm", 0)
+        for o in AcousticEncoder.RANGE_OPTIONS:
+            enc.set_option(o, 0)
+        both = enc(x, None).clone()
+        assert enc.last_status() == 0
+    finally:
+        enc.set_option("persistent_lstm", 1)
+        for o in AcousticEncoder.RANGE_OPTIONS:
+            enc.set_option(o, 1)
+    w = W.synth_encodec_weights(seed=0)
+    ref, margins = R.acoustic_encode(w, wav, 8, return_margins=True)
+    P.assert_rvq_equal_or_explained(both, ref, margins, P.RVQ_TIE, "range fallback + per-step LSTM")
+    P.assert_rvq_equal_or_explained(default, ref, margins, P.RVQ_TIE, "default path, same batch")
+    assert torch.equal(enc(x, None), default), "the options were not restored"
 
 
 def test_forced_lstm_timeout_is_reported_and_recovered(enc_weights):

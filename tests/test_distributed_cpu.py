@@ -43,3 +43,87 @@ def test_shard_indices_partition(n, world):
     flat = [i for p in parts for i in p]
     assert flat == list(range(n))                      # contiguous blocks in rank order
     assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+# ---- encode_batch_files under torch.distributed (world 2, gloo) -------------------------------------------------------------------
+class _HashEncoder(torch.nn.Module):
+    """Stand-in encoder (no device): the token at frame t is a function of that frame's samples and of NOTHING else (not the batch row, not
+    the rank), so two runs produce identical files exactly when every segment reaches the encoder with the same content and in the same order
+    per file."""
+
+    def forward(self, x, m):
+        B, N = x.shape
+        T = -(-N // 320)
+        pad = torch.nn.functional.pad(x * m, (0, T * 320 - N)).reshape(B, T, 320)
+        a = (pad.abs().sum(-1) * 1000.0).round().to(torch.int64) % 1024
+        b = (pad[..., ::7].sum(-1).abs() * 1000.0).round().to(torch.int64) % 1024
+        return torch.stack([a, b], 1).to(torch.int16)
+
+
+def _write_inputs(d, sr=24000):
+    """7 WAV files of 1.2 .. 4.6 s (multi-chunk at chunk_size 1, ragged tails) + a tar of two members."""
+    import io
+    import tarfile
+    import wave as wavmod
+    from audiotoken_amd import weights as W
+    names = []
+    for i in range(7):
+        x = W.synth_waveform(1, int(sr * (1.2 + 0.55 * i)) + 37 * i, sr, seed=50 + i)[0]
+        p = os.path.join(d, f"clip{i}.v{i}.wav")        # dots in the stem: save_audio_tokens keeps only the first part (reference quirk B.6)
+        with wavmod.open(p, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr)
+            f.writeframes((np.clip(x, -1, 1) * 32767).astype(np.int16).tobytes())
+        names.append(p)
+    tp = os.path.join(d, "bundle.tar")
+    with tarfile.open(tp, "w") as tar:
+        for j in range(2):
+            x = W.synth_waveform(1, sr * 2 + 999 * j, sr, seed=70 + j)[0]
+            buf = io.BytesIO()
+            with wavmod.open(buf, "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr)
+                f.writeframes((np.clip(x, -1, 1) * 32767).astype(np.int16).tobytes())
+            info = tarfile.TarInfo(f"member{j}.wav"); info.size = buf.tell(); buf.seek(0)
+            tar.addfile(info, buf)
+    names.append(tp)
+    return names
+
+
+def _encode_files(names, outdir, workers):
+    from audiotoken_amd import AudioToken, Tokenizers
+    tok = AudioToken(Tokenizers.acoustic, device="cpu", num_codebooks=2)
+    tok.encoder = _HashEncoder()
+    tok.load_encoder = lambda: None
+    tok.encode_batch_files(batch_size=3, outdir=outdir, chunk_size=1, num_workers=workers, audio_files=names)
+    return tok
+
+
+def _batch_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        names = sorted(os.path.join(tmp, "in", n) for n in os.listdir(os.path.join(tmp, "in")))
+        _encode_files(names, os.path.join(tmp, f"out_rank{rank}"), workers=2)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_encode_batch_files_world2_equals_world1(tmp_path):
+    """Reference core.py:198-289 under the clip/file sharding of SURVEY.md §8(e): with torch.distributed initialised (world 2) every rank takes a
+    contiguous block of FILES — all chunks of a file on one rank, so the reference's per-file append order (utils.py:214-217) survives — the two
+    ranks' file sets are disjoint and complete, and every token file is byte-identical to the single-process run."""
+    os.makedirs(tmp_path / "in")
+    names = sorted(_write_inputs(str(tmp_path / "in")))
+    _encode_files(names, str(tmp_path / "out_world1"), workers=0)
+    ref = {n: np.load(tmp_path / "out_world1" / n) for n in sorted(os.listdir(tmp_path / "out_world1"))}
+    assert len(ref) == 9 and all(v.dtype == np.int16 and v.shape[0] == 2 for v in ref.values())       # 7 files + 2 tar members
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_batch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got0 = {n: np.load(tmp_path / "out_rank0" / n) for n in os.listdir(tmp_path / "out_rank0")}
+    got1 = {n: np.load(tmp_path / "out_rank1" / n) for n in os.listdir(tmp_path / "out_rank1")}
+    assert not (set(got0) & set(got1)), "a file was encoded by both ranks"
+    assert set(got0) | set(got1) == set(ref), "the ranks' file sets do not cover the input"
+    assert abs(len(got0) - len(got1)) <= 3            # 8 inputs (7 wav + 1 tar of 2) in two contiguous blocks of 4
+    for n, v in {**got0, **got1}.items():
+        assert v.shape == ref[n].shape and np.array_equal(v, ref[n]), f"{n}: tokens differ from the single-process run"
+    # rank 0 owns the first block of the sorted inputs (bundle.tar -> its two members, clip0 .. clip2), rank 1 the rest
+    assert {"member0.npy", "member1.npy", "clip0.npy"} <= set(got0) and {"clip5.npy", "clip6.npy"} <= set(got1)

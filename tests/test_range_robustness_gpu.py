@@ -1,0 +1,116 @@
+"""GPU: the two-piece fp16 arithmetic on ranges it was not tuned on. The activation scale of the f16x2 kernels is a fixed
+power of two (16: overflow beyond |x| > 4094), so (1) the per-site CENSUS (at_*_range_report: the largest |x * scale| every split site saw) measures
+how close the synthetic-weight activations come to 65504; (2) LayerNorm gains / conv weights scaled x8 and x64 must still give the oracle's tokens —
+x8 without leaving f16x2 (zero fallback batches); (3) when a batch does overflow, the fallback is per batch (test_acoustic_gpu / test_semantic_gpu)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from audiotoken_amd import weights as W
+from tests import parity as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _headroom(rep):
+    live = {k: v for k, v in rep.items() if v > 0}
+    worst = max(live.values())
+    return live, math.log2(65504.0 / worst)
+
+
+def _scaled_w2vbert(gain, which):
+    """which = "operands": the gains / biases of the LayerNorms in front of the FFNs and of the conv module, and the value projection, times `gain`
+    — every split site's operands grow (LayerNorm outputs, FFN hidden, dwconv output, v, the attention context) while the softmax logits do not;
+    "all": every LayerNorm of every layer, the attention one included — q and k grow too, the logits with gain^2: the network itself becomes
+    ill-conditioned in fp32 (the oracle differs from its own float64 evaluation by 1e-2 in the quantised vectors at x8)."""
+    w = dict(W.synth_w2vbert_weights(n_layers=3, seed=9, with_vq=True))
+    g = np.float32(gain)
+    for k in list(w):
+        if not k.startswith("encoder.layers."):
+            continue
+        if "layer_norm" in k and (which == "all" or "self_attn_layer_norm" not in k) and "final_layer_norm" not in k:
+            w[k] = (w[k] * g).astype(np.float32)
+        if which == "operands" and ".self_attn.linear_v." in k:
+            w[k] = (w[k] * g).astype(np.float32)
+    return w
+
+
+@pytest.mark.parametrize("which,gain", [("operands", 1.0), ("operands", 8.0), ("operands", 64.0), ("all", 8.0)])
+def test_semantic_m_scaled_operands(cuda_device, which, gain):
+    """A 3-layer conformer whose GEMM operands are `gain` times larger than the synthetic weights make them (see _scaled_w2vbert). Tokens must equal
+    the oracle's on the same weights — at x1 and x8 on f16x2 itself (status 0, no fallback batch); the census shows the headroom shrinking by
+    log2(gain) bits. For "all" the bar is the measured one of tests/parity.py (a flip needs an oracle margin below twice the measured vector
+    difference, itself bounded by the oracle's own float32-vs-float64 difference)."""
+    from audiotoken_amd.configs import Wav2VecBertConfig
+    from audiotoken_amd.encoder import Wav2VecBertEncoder
+    from oracle import w2vbert_ref as R
+    w = _scaled_w2vbert(gain, which)
+    enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=3), device="cuda:0", quantize=True, weights=w)
+    wav = torch.from_numpy(W.synth_waveform(2, 48000, 16000, seed=41))
+    mask = torch.ones_like(wav)
+    x, m = wav.cuda(), mask.cuda()
+    toks, taps = enc(x, m, return_taps=True)
+    status = enc.last_status()
+    live, bits = _headroom(enc.range_report())
+    print(f"[range] semantic_m {which} x{gain:g}: status {status}, census {dict((k, round(v, 1)) for k, v in live.items())}, headroom {bits:.1f} bits")
+    assert set(live) >= {"ln_ffn1", "ffn1_hidden", "ln_attn", "qkv_kv", "attention", "ln_conv", "dwconv_out", "ln_ffn2", "ffn2_hidden"}
+    if gain <= 8.0:
+        assert status == 0 and bits > 0, "f16x2 must hold at x8"
+    if status != 0:
+        toks = enc.verified(toks, x, m)
+        assert enc.fallback_batches == 1 and enc.get_option("arith") == 2
+        _, taps = enc(x, m, return_taps=True)     # (taps of the f16x2 run are invalid after an overflow; not compared then)
+    wt = {k: torch.from_numpy(v) for k, v in w.items()}
+    ref, margins = R.semantic_m_encode(wt, wav, mask, 2, 3, return_margins=True)
+    feats, am = R.processor(wav, mask, 2)
+    valid = am.bool().unsqueeze(1)
+    if which == "all":
+        x_ref = R.layer_norm(R.encoder_hidden_state(wt, feats, am, 3), wt, None, 1024)
+        wt64 = {k: v.double() for k, v in wt.items()}
+        x_ref_exact = torch.nn.functional.layer_norm(R.encoder_hidden_state(wt64, feats.double(), am.double(), 3), (1024,)).float()
+        x_got = torch.nn.functional.layer_norm(taps["hidden"].cpu(), (1024,))
+        P.assert_tokens_equal_or_explained_by_delta(toks, ref, margins, x_got, x_ref, P.VQ_TIE, f"[range] semantic_m {which} x{gain:g}", valid, x_ref_exact)
+    else:
+        P.assert_tokens_equal_or_explained(toks, ref, margins, P.VQ_TIE, f"[range] semantic_m {which} x{gain:g}", valid)
+
+
+@pytest.mark.parametrize("gain", [1.0, 8.0, 64.0])
+def test_acoustic_conv_weight_scale(cuda_device, gain):
+    """The stage-1 strided conv's weight (weight_g of its weight-norm pair) times `gain`: every later activation of the SEANet encoder, the LSTM
+    input and the RVQ residual grow with it. Tokens equal the oracle's; x8 stays on f16x2."""
+    from audiotoken_amd.configs import AcousticEncoderConfig
+    from audiotoken_amd.encoder import AcousticEncoder
+    from oracle import encodec_ref as R
+    w = dict(W.synth_encodec_weights(seed=7, with_decoder=False))
+    key = "encoder.model.6.conv.conv.weight_g"     # ELU, conv 64 -> 128 k8 s4 (layer 5-6)
+    assert key in w
+    w[key] = (w[key] * np.float32(gain)).astype(np.float32)
+    enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=w)
+    wav = torch.from_numpy(W.synth_waveform(3, 48000, 24000, seed=42))
+    x = wav.cuda()
+    codes = enc(x, None)
+    status = enc.last_status()
+    live, bits = _headroom(enc.range_report())
+    print(f"[range] acoustic down1 x{gain:g}: status {status}, census {dict((k, round(v, 1)) for k, v in live.items())}, headroom {bits:.1f} bits")
+    assert set(live) >= {"stage0", "res1", "down1", "res2", "down2", "res3_conv", "res3_tail", "lstm_ih", "final_conv_in", "rvq"}
+    if gain <= 8.0:
+        assert status == 0 and bits > 0, "f16x2 must hold at x8"
+    codes = enc.verified(codes, x, None)
+    assert enc.fallback_batches == (0 if status == 0 else 1)
+    ref, margins = R.acoustic_encode(w, wav, 8, return_margins=True)
+    P.assert_rvq_equal_or_explained(codes, ref, margins, P.RVQ_TIE, f"[range] acoustic down1 x{gain:g}")
+
+
+def test_semantic_s_census(cuda_device):
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    w = W.synth_hubert_weights(3, 0, True)
+    enc = HubertEncoder(HubertEncoderConfig(output_layer=3), device="cuda:0", quantize=True, weights=w)
+    wav = hubert_processor(torch.from_numpy(W.synth_waveform(1, 32000, 16000, seed=43)))
+    enc(wav.cuda(), torch.ones_like(wav).cuda())
+    assert enc.last_status() == 0
+    live, bits = _headroom(enc.range_report())
+    print(f"[range] semantic_s: census {dict((k, round(v, 1)) for k, v in live.items())}, headroom {bits:.1f} bits")
+    assert set(live) >= {"conv0_out", "feature_convs", "layer_input", "qkv_kv", "attention", "ffn_hidden"} and bits > 0

@@ -237,7 +237,8 @@ def test_fp16_range_overflow_is_reported_and_recovered():
     toks = enc(wav, mask)
     assert enc.last_status() & 2, "the overflow must be visible in the status word"
     toks = enc.verified(toks, wav, mask)
-    assert enc.get_option("arith") == 1 and enc.last_status() == 0
+    assert enc.last_status() == 0 and enc.fallback_batches == 1
+    assert enc.get_option("arith") == 2, "the range fallback must not outlive the batch"
     assert torch.equal(toks, ref)
 
 

@@ -24,3 +24,4 @@ except Exception as e:
     print("bench parse failed", e); print(open("$out/bench.err").read()[-3000:])
 PY
 if [ -f audiotoken_amd/lib/libaudiotoken_hip_dbg.so ]; then bash tools/tg_stamps.sh run > $out/tg_stamps.txt 2>&1; head -60 $out/tg_stamps.txt; fi
+if [ -f audiotoken_amd/lib/libaudiotoken_hip_axdbg.so ]; then bash tools/ax_stamps.sh run > $out/ax_stamps.txt 2>&1; cat $out/ax_stamps.txt; fi
