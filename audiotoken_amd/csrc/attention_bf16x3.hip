@@ -292,14 +292,24 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mnew = fmaxf(mrun, mx);
         float rs = 0.f;
+        {
+            typedef float f2_ __attribute__((ext_vector_type(2)));
+            const f2_ m2 = {mnew, mnew};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(s[r] - mnew);
-            s[r] = p;
-            rs += p;
+            for (int r = 0; r < 16; r += 2) {   // the subtraction on value pairs (v_pk_add_f32); exp2 and the running sum stay in order
+                const f2_ d = f2_{s[r], s[r + 1]} - m2;
+                const float p0 = __builtin_amdgcn_exp2f(d[0]), p1 = __builtin_amdgcn_exp2f(d[1]);
+                s[r] = p0; s[r + 1] = p1;
+                rs += p0;
+                rs += p1;
+            }
         }
         rs += __shfl_xor(rs, 32);
-        if (__builtin_amdgcn_ballot_w64(mnew != mrun) != 0ull) {
+        {
+            // Unconditional rescale (round 3): alpha = exp2(0) = 1 exactly when the row maximum did not move, so the products are exact and the
+            // results equal the branchy form's bit for bit; the branch cost a 32-register copy of the output accumulators on BOTH paths (the
+            // compiler gave the rescaled values new registers), more vector-unit slots than the 16 packed multiplies — and this kernel is bound by
+            // vector-unit issue (tools/ax_stamps.sh: ~450 instructions per 32-key tile against 24 MFMAs).
             const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);   // exp2(-inf) = 0 on the first tile
             lrun = lrun * alpha + rs;
             mrun = mnew;
@@ -307,8 +317,6 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-        } else {
-            lrun += rs;
         }
         AX_T(6);
         // ---- P pieces (B operand of P.V: k-step ks uses registers 8ks .. 8ks+7 = keys 16ks + {0..3, 8..11} + 4hh) -----------------

@@ -281,9 +281,15 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         const int el = lane_id(), fr = el & 15, fq = el >> 4;
         // bias quads once per column tile; residual quads one row tile ahead of the stores (split_epilogue.h: inside apply() each load would sit
         // behind the previous quad's store)
-        auto epilogue = [&](auto mode, auto ph1) {
+        // FULL: every row of the tile is below M (all tiles but a clip's last m-tile): no per-row predicate. With the predicate every store sat
+        // behind a conditional branch, the compiler's wait-count pass gave up counting across them and put s_waitcnt vmcnt(0) in front of EVERY
+        // store — each one waited for the acknowledgement of the one before it (~1 k cycles x 32 stores per lane = the 31-50 k-cycle residual
+        // epilogues of the stamps); straight-line code keeps the stores in flight behind counted waits.
+        auto epilogue = [&](auto mode, auto ph1, auto full_, auto res_) {
             constexpr int E = decltype(mode)::value;
             constexpr bool PH1 = decltype(ph1)::value;
+            constexpr bool FULL = decltype(full_)::value;
+            constexpr bool RES = decltype(res_)::value;    // a residual operand exists (uniform; a per-load null check is a branch per load)
             constexpr bool PLAIN = E == XB_EPI_LINEAR || E == XB_EPI_GELU;
             // ROW LAYOUT (256 x 256 tiles; the modes whose outputs are row-major: fp32 C, the q rows and k / v row-major pieces of the fused
             // projection, GLU): in the MFMA layout a lane owns 4 consecutive columns of ONE row per 16 x 16 tile, so a wave-instruction touches 16
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
                     auto load_res = [&](int i) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k)
-                            res[i][k] = (rb && mrow0 + i * 16 + 2 * k < a.M) ? *reinterpret_cast<const f4*>(rb + (offR + (unsigned)(i * 8 + k) * stepR)) : f4{0.f, 0.f, 0.f, 0.f};
+                            res[i][k] = (RES && (FULL || mrow0 + i * 16 + 2 * k < a.M)) ? *reinterpret_cast<const f4*>(rb + (offR + (unsigned)(i * 8 + k) * stepR)) : f4{0.f, 0.f, 0.f, 0.f};
                     };
                     load_res(0);
 #pragma unroll
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
                         for (int k = 0; k < 8; ++k) {
                             const int row = 2 * k + rrow;
                             const f4 q = *reinterpret_cast<const f4*>(wl + row * 128 + ((rc ^ (row & 7)) << 2));
-                            if (mrow0 + i * 16 + 2 * k < a.M)
+                            if (FULL || mrow0 + i * 16 + 2 * k < a.M)
                                 *reinterpret_cast<f4*>(cb + (offC + (unsigned)(i * 8 + k) * stepC)) = ep.template plain_value<E>(q, bias4, res[i][k]);
                         }
                     }
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
                         for (int k = 0; k < 8; ++k) {
                             const int row = 2 * k + rrow, m = mrow0 + i * 16 + 2 * k;
                             const f4 q = *reinterpret_cast<const f4*>(wl + row * 128 + ((rc ^ (row & 7)) << 2));
-                            if (m < a.M) ep.template apply_with<E, false>(m, ncol, q, bias4, f4{0.f, 0.f, 0.f, 0.f});
+                            if (FULL || m < a.M) ep.template apply_with<E, false>(m, ncol, q, bias4, f4{0.f, 0.f, 0.f, 0.f});
                         }
                     }
                 }
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
                 const int m = mbase + (idx / NCH) * 16, j0 = (idx % NCH) * H;
 #pragma unroll
                 for (int j = 0; j < H; ++j)
-                    r[j] = (PLAIN && m < a.M) ? ep.load_residual(m, e_n0 + wn * TJ * 16 + (j0 + j) * 16 + 4 * fq) : f4{0.f, 0.f, 0.f, 0.f};
+                    r[j] = (PLAIN && RES && (FULL || m < a.M)) ? ep.load_residual(m, e_n0 + wn * TJ * 16 + (j0 + j) * 16 + 4 * fq) : f4{0.f, 0.f, 0.f, 0.f};
             };
             if constexpr (PLAIN) load_half(0, rcur);
 #pragma unroll
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
                 if constexpr (PLAIN) {
                     if (idx + 1 < NCH * TI) load_half(idx + 1, rnext);
                 }
-                if (m < a.M) {
+                if (FULL || m < a.M) {
 #pragma unroll
                     for (int j = 0; j < H; ++j)
                         ep.template apply_with<E, PH1>(m, e_n0 + wn * TJ * 16 + (j0 + j) * 16 + 4 * fq, acc[idx / NCH][j0 + j], bj[j0 + j], rcur[j]);
@@ -386,15 +392,26 @@ __global__ __launch_bounds__(512, (TI * TJ <= 8) ? 4 : 2) void gemm_f16x2_tg_ker
         using T_ = std::true_type;
         using F_ = std::false_type;
         const bool ph1 = a.Sphases == 1;   // the plain linear layers' piece outputs: no phase planes, no integer division per quad
+        const bool full = e_m0 + BM <= a.M;
+        const bool has_res = a.R != nullptr;
+        auto run = [&](auto mode, auto p1) {
+            constexpr int E_ = decltype(mode)::value;
+            if constexpr (E_ == XB_EPI_LINEAR || E_ == XB_EPI_GELU) {
+                if (has_res) { if (full) epilogue(mode, p1, T_{}, T_{}); else epilogue(mode, p1, F_{}, T_{}); }
+                else { if (full) epilogue(mode, p1, T_{}, F_{}); else epilogue(mode, p1, F_{}, F_{}); }
+            } else {
+                if (full) epilogue(mode, p1, T_{}, F_{}); else epilogue(mode, p1, F_{}, F_{});
+            }
+        };
         switch (a.epi) {
-            case XB_EPI_SWISH_SPLIT: if (ph1) epilogue(std::integral_constant<int, XB_EPI_SWISH_SPLIT>{}, T_{}); else epilogue(std::integral_constant<int, XB_EPI_SWISH_SPLIT>{}, F_{}); break;
-            case XB_EPI_GELU_SPLIT: if (ph1) epilogue(std::integral_constant<int, XB_EPI_GELU_SPLIT>{}, T_{}); else epilogue(std::integral_constant<int, XB_EPI_GELU_SPLIT>{}, F_{}); break;
-            case XB_EPI_ELU_SPLIT: epilogue(std::integral_constant<int, XB_EPI_ELU_SPLIT>{}, F_{}); break;
-            case XB_EPI_GLU: epilogue(std::integral_constant<int, XB_EPI_GLU>{}, F_{}); break;
-            case XB_EPI_GELU: epilogue(std::integral_constant<int, XB_EPI_GELU>{}, F_{}); break;
-            case XB_EPI_QKV: epilogue(std::integral_constant<int, XB_EPI_QKV>{}, F_{}); break;
-            case XB_EPI_RAW_ELU_SPLIT2: epilogue(std::integral_constant<int, XB_EPI_RAW_ELU_SPLIT2>{}, F_{}); break;
-            default: epilogue(std::integral_constant<int, XB_EPI_LINEAR>{}, F_{}); break;
+            case XB_EPI_SWISH_SPLIT: if (ph1) run(std::integral_constant<int, XB_EPI_SWISH_SPLIT>{}, T_{}); else run(std::integral_constant<int, XB_EPI_SWISH_SPLIT>{}, F_{}); break;
+            case XB_EPI_GELU_SPLIT: if (ph1) run(std::integral_constant<int, XB_EPI_GELU_SPLIT>{}, T_{}); else run(std::integral_constant<int, XB_EPI_GELU_SPLIT>{}, F_{}); break;
+            case XB_EPI_ELU_SPLIT: run(std::integral_constant<int, XB_EPI_ELU_SPLIT>{}, F_{}); break;
+            case XB_EPI_GLU: run(std::integral_constant<int, XB_EPI_GLU>{}, F_{}); break;
+            case XB_EPI_GELU: run(std::integral_constant<int, XB_EPI_GELU>{}, F_{}); break;
+            case XB_EPI_QKV: run(std::integral_constant<int, XB_EPI_QKV>{}, F_{}); break;
+            case XB_EPI_RAW_ELU_SPLIT2: run(std::integral_constant<int, XB_EPI_RAW_ELU_SPLIT2>{}, F_{}); break;
+            default: run(std::integral_constant<int, XB_EPI_LINEAR>{}, F_{}); break;
         }
         over |= ep.over;
 #ifdef TG_DEBUG_STAMPS
