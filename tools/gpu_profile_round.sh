@@ -2,13 +2,13 @@
 # Round evidence run on the GPU box: full bench, rocprofv3 kernel-trace stats of the same command, and the PMC passes (counters are
 # collected in their own runs, kernel-trace only) for the acoustic and the semantic_m workloads. Outputs under gpurun_out/<tag>/.
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-TAG=${1:-r02}
+TAG=${1:-r03_final}
 export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $O/stats_bench.json 2> $O/stats.err
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 cd $R
 bash tools/gpu_pmc_semantic.sh acoustic $TAG/pmc_acoustic > $O/pmc_acoustic.log 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copies the evidence of `tools/gpu_profile_round.sh <tag>` (merged back under gpurun_out/<tag>/) into profiles/<tag>_* and derives the PMC tables
-# and the traffic file bench.py reads:   bash tools/refresh_profiles.sh r02_final
-T=${1:-r02_final}; G=gpurun_out/$T
+# and the traffic file bench.py reads:   bash tools/refresh_profiles.sh r03_final
+T=${1:-r03_final}; G=gpurun_out/$T
 cp $G/bench.json profiles/${T}_bench.json
 cp $G/kernel_stats.csv profiles/${T}_kernel_stats.csv
 cp $G/pmc_acoustic/pmc_summary.csv profiles/${T}_acoustic_pmc_summary.csv
@@ -16,7 +16,8 @@ for w in ('acoustic', 'semantic_m'):
     tot = sum(int(r['launches']) * float(r['hbm_bytes_per_launch']) for r in rows if r['hbm_bytes_per_launch'] not in ('None', ''))
     print(w, 'encode calls in the PMC run', calls, '-> HBM GB per step', round(tot / calls / 1e9, 2))
 d = json.loads(open(f'profiles/{T}_bench.json').readline())
-print('acoustic', d['ms_per_step'], 'ms', d['value'], d['unit'], {k: v['ms_per_step'] for k, v in d['breakdown'].items()})
-for k in ('semantic_m', 'semantic_s', 'acoustic_decode', 'combined'):
-    print(k, {kk: d[k][kk] for kk in d[k] if kk in ('value', 'ms_per_step')})
+print('step', d['ms_per_step'], 'ms', d['value'], d['unit'], '(' + d['metric'] + ')')
+for k in ('acoustic', 'semantic_m', 'semantic_s', 'acoustic_decode'):
+    if k in d:
+        print(k, {kk: d[k][kk] for kk in d[k] if kk in ('value', 'ms_per_step')}, {g: v['ms_per_step'] for g, v in d[k].get('breakdown', {}).items()})
 PY
