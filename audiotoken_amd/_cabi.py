@@ -102,6 +102,8 @@ SIGNATURES = {
                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "at_op_conv_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                   C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "at_op_rvq_encode_split": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "at_op_rvq_encode": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
 }
 

@@ -1262,4 +1262,25 @@ int at_op_rvq_encode(const float* x, int64_t rows, int T, const float* codebooks
     return launch_rvq_encode(x, rows, T, codebooks, e2, n_q, codes, (hipStream_t)stream);
 }
 
+// The RVQ search with split dot products (rvq_encode_x3.hip) — what the product runs: scheme 1 = two fp16 pieces / three products (default, option
+// "rvq_f16x2"), 0 = three bf16 pieces / six products (its range fallback). The codebooks are split into `workspace` first, as finalize() does.
+int at_op_rvq_encode_split(const float* x, int64_t rows, int T, const float* codebooks, const float* e2, int n_q, int16_t* codes, int scheme,
+                           float cb_max_abs, void* workspace, size_t workspace_bytes, int32_t* status_dev, at_stream_t stream_) {
+    using namespace at;
+    AT_REQUIRE(x && codebooks && e2 && codes && workspace && T >= 1 && n_q >= 1, "at_op_rvq_encode_split: bad arguments");
+    AT_REQUIRE(scheme == XB_SCHEME_BF16X3 || scheme == XB_SCHEME_F16X2, "at_op_rvq_encode_split: scheme 0 (bf16x3) or 1 (f16x2)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long n = (long long)n_q * kCodes * kDim;
+    const int np = xb_pieces(scheme);
+    AT_REQUIRE(workspace_bytes >= (size_t)np * n * sizeof(piece_t) + 2 * sizeof(int), "at_op_rvq_encode_split: workspace too small (pieces * n_q * 1024 * 128 * 2 + 8 bytes)");
+    __bf16* pieces = reinterpret_cast<__bf16*>(workspace);
+    int* pair = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (size_t)np * n * sizeof(piece_t));   // {flag, census} of this call
+    const float cs = scheme == XB_SCHEME_F16X2 ? xb_weight_scale(cb_max_abs) : 1.0f;
+    AT_CHECK_HIP(hipMemsetAsync(pair, 0, 2 * sizeof(int), stream));
+    if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
+    if (int rc = launch_split_plain(codebooks, n, pieces, stream, scheme, cs)) return rc;
+    if (int rc = launch_rvq_encode_x3(x, rows, T, codebooks, pieces, n, e2, n_q, codes, stream, scheme, scheme == XB_SCHEME_F16X2 ? XB_F16_ACT_SCALE : 1.0f, cs, pair)) return rc;
+    return launch_range_combine(pair, 1, reinterpret_cast<int*>(status_dev), stream);
+}
+
 }  // extern "C"

@@ -253,6 +253,11 @@ int at_op_conv_split(const float* X, const float* W, const float* bias, float* C
                      float w_max_abs, void* workspace, size_t workspace_bytes, int32_t* status_dev, at_stream_t stream);
 int at_op_rvq_encode(const float* x, int64_t rows, int T, const float* codebooks, const float* e2, int n_q,
                      int16_t* codes, at_stream_t stream);
+/* The same search on the SPLIT kernel the product runs (csrc/rvq_encode_x3.hip): scheme 1 = two fp16 pieces / three products (default), 0 = three
+ * bf16 pieces / six products; cb_max_abs = max |codebook| (the fp16 scheme's power-of-two codebook scale); workspace >= pieces * n_q * 1024 * 128 * 2 + 8
+ * bytes; status_dev nullable (bit 1 = fp16 range overflow of the residual). */
+int at_op_rvq_encode_split(const float* x, int64_t rows, int T, const float* codebooks, const float* e2, int n_q, int16_t* codes, int scheme,
+                           float cb_max_abs, void* workspace, size_t workspace_bytes, int32_t* status_dev, at_stream_t stream);
 
 /* LayerNorm over the last dim (eps 1e-5); gamma/beta NULL = non-affine; rows with row_mask 0 are zeroed. */
 int at_op_layernorm(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, int64_t rows, int D,
