@@ -29,7 +29,6 @@ struct LstmSeqArgs {
     int n_groups;        // filled by the launcher
     long long h_bytes;   // filled by the launcher
     unsigned spin_limit = 1u << 18;   // polls of a hand-off flag before a workgroup gives up (~0.1-0.3 s; normal waits are microseconds)
-    int try_local = 0;                // lstm_seq_x3, filled by the launcher: verify same-XCD placement per group and exchange through that XCD's L2
     float w_scale_f16 = 0.f;          // lstm_seq_x3 only: > 0 = two-piece fp16 scheme with W_hh scaled by this power of two; 0 = three bf16 pieces
 };
 int launch_lstm_seq(const LstmSeqArgs& a, hipStream_t stream);

@@ -49,7 +49,6 @@ constexpr int LX_STATUS = 63;      // as lstm_seq.hip
 constexpr int LX_FLAGS = 128;      // flags[16 groups][32 words] (16 used)
 constexpr int LX_FLAG_STRIDE = 32;
 constexpr int LX_MAX_GROUPS = 16;
-constexpr int LX_XCC = 640;        // xcc[16 groups][16 slices]: XCC id + 1 of every workgroup (zeroed per launch), for the placement check
 
 __device__ __forceinline__ f4 lx_mfma(bf16x8 w, bf16x8 x, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0); }
 __device__ __forceinline__ f4 lx_mfma(f16x8 w, f16x8 x, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0); }
@@ -133,37 +132,6 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
     // the flag's way to the pollers, as in the flag-less variant; 5.45 ms); fetching xg / skip one step ahead (the HBM loads then delay the h tile
     // loads they are issued behind: 5.6-6.4 ms) and polling the flags through the scalar memory path (5.6 ms).
     constexpr bool FAST = SC::NP == 2, YG = FAST;
-    // ---- XCD-local hand-off (round 3) -------------------------------------------------------------------------------------------------
-    // Workgroup b runs on XCD b % 8 (round-robin dispatch) and group = b % n_groups: with 16 groups the 16 slices of a group share ONE XCD and
-    // its L2. The exchange of h and the flags then only has to be coherent at that L2 (cache bits sc0: miss in the CU's L1, hit in L2) instead of at
-    // the memory side (sc1: every hop a round trip beyond L2 — the ~1 us per hop of the stamps). Placement is a dispatch property, not a
-    // guarantee, so it is VERIFIED per launch: every workgroup publishes its XCC id (memory-side coherent), waits for the 16 ids of its group
-    // and uses the local protocol only if they are equal; otherwise (or if the wait gives up) the group keeps the memory-side protocol.
-    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.sync, 0, 1024 * 4, 0x00020000);
-    __shared__ int local_s;
-    if (FAST && a.try_local) {
-        if (wave == 0) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            xcc = (xcc & 0xfu) + 1u;
-            if (lane == 0) __hip_atomic_store(a.sync + LX_XCC + group * LX_SLICES + slice, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            int ok = 1;
-            for (;;) {
-                const unsigned f = __hip_atomic_load(a.sync + LX_XCC + group * LX_SLICES + (lane & (LX_SLICES - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__builtin_amdgcn_ballot_w64(f == 0u) == 0ull) { ok = __builtin_amdgcn_ballot_w64(f != xcc) == 0ull ? 1 : 0; break; }
-                if (++spins > a.spin_limit) { ok = 0; break; }
-            }
-            if (lane == 0) local_s = ok;
-        }
-        __syncthreads();
-    } else {
-        if (tid == 0) local_s = 0;
-        __syncthreads();
-    }
-    const bool local = local_s != 0;
-    auto steps = [&](auto auxc) -> void {
-    constexpr int AUX = decltype(auxc)::value;       // cache bits of the exchange: 1 = sc0 (XCD-local), 16 = sc1 (memory side)
     for (int t = 0; t < T; ++t) {
         LX_STAMP(0);
         f4 xg[NJ];
@@ -180,8 +148,7 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
                 unsigned spins = 0;
                 int give_up = 0;
                 for (;;) {
-                    const unsigned f = AUX == 16 ? __hip_atomic_load(flags + (lane & (LX_SLICES - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                 : (unsigned)__builtin_amdgcn_raw_buffer_load_b32(srsrc, (LX_FLAGS + group * LX_FLAG_STRIDE + (lane & (LX_SLICES - 1))) * 4, 0, AUX);
+                    const unsigned f = __hip_atomic_load(flags + (lane & (LX_SLICES - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__builtin_amdgcn_ballot_w64(f < target) == 0ull) break;
                     ++spins;
                     if (spins > a.spin_limit) { give_up = 1; break; }
@@ -201,7 +168,7 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
             u4 stage[NST];
             const int toff = (t - 1) * (LX_H * 4);
 #pragma unroll
-            for (int j = 0; j < NST; ++j) stage[j] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, g_off[j] + toff, 0, AUX);
+            for (int j = 0; j < NST; ++j) stage[j] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, g_off[j] + toff, 0, 16);   // aux 16 = sc1
 #pragma unroll
             for (int j = 0; j < NST; ++j) {
                 const f4 hv = {__uint_as_float(stage[j][0]), __uint_as_float(stage[j][1]), __uint_as_float(stage[j][2]), __uint_as_float(stage[j][3])};
@@ -271,13 +238,10 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
                 const int idx = lane + 64 * i, row = idx >> 3, c4 = idx & 7;
                 const u4 v = *reinterpret_cast<const u4*>(&Hx[row][c4 * 4]);
                 if (b0 + row < a.B)
-                    __builtin_amdgcn_raw_buffer_store_b128(v, hrsrc, (((b0 + row) * T + t) * LX_H + slice * 32 + c4 * 4) * 4, 0, AUX);   // write-through to L2 (sc0) / memory (sc1); < 2^31: launcher
+                    __builtin_amdgcn_raw_buffer_store_b128(v, hrsrc, (((b0 + row) * T + t) * LX_H + slice * 32 + c4 * 4) * 4, 0, 16);   // aux 16 = sc1: write-through; < 2^31: launcher
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                if (AUX == 16) __hip_atomic_store(flags + slice, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else __builtin_amdgcn_raw_buffer_store_b32((unsigned)(t + 1), srsrc, (LX_FLAGS + group * LX_FLAG_STRIDE + slice) * 4, 0, AUX);
-            }
+            if (lane == 0) __hip_atomic_store(flags + slice, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         LX_STAMP(5);
         if (YG) {
@@ -297,9 +261,6 @@ __global__ __launch_bounds__(512, 1) void lstm_seq_x3_kernel(LstmSeqArgs a, floa
             }
         }
     }
-    };
-    if (FAST && local) steps(std::integral_constant<int, 1>{});
-    else steps(std::integral_constant<int, 16>{});
 }
 
 // clips one launch can take: all workgroups must be resident (one per CU), 16 per group of 16 clips
@@ -349,9 +310,7 @@ int launch_lstm_seq_x3(const LstmSeqArgs& a_in, hipStream_t stream) {
     a.n_groups = (a.B + LX_CLIPS - 1) / LX_CLIPS;
     a.h_bytes = (long long)a.B * a.T * LX_H * 4;
     AT_REQUIRE(a.h_bytes < (1ll << 31), "lstm_seq_x3: h buffer exceeds the 2 GB buffer-descriptor range");
-    AT_CHECK_HIP(hipMemsetAsync(a.sync + LX_FLAGS, 0, (LX_MAX_GROUPS * LX_FLAG_STRIDE + LX_MAX_GROUPS * LX_SLICES) * sizeof(unsigned), stream));   // flags + XCC ids, every launch
-    static const int try_local = std::getenv("AUDIOTOKEN_LSTM_LOCAL") ? std::atoi(std::getenv("AUDIOTOKEN_LSTM_LOCAL")) : 1;
-    a.try_local = try_local;
+    AT_CHECK_HIP(hipMemsetAsync(a.sync + LX_FLAGS, 0, LX_MAX_GROUPS * LX_FLAG_STRIDE * sizeof(unsigned), stream));   // flags, every launch
     const int rc = a.w_scale_f16 > 0.f ? launch_lx<SchemeF16x2>(a, a.w_scale_f16, LX_H_SCALE, stream) : launch_lx<SchemeBf16x3>(a, 1.0f, 1.0f, stream);
 #ifdef LX_DEBUG_STAMPS
     if (rc == 0) lx_print_stamps(a.T, stream);

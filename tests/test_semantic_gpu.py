@@ -65,6 +65,8 @@ def test_layernorm(cuda_device, rows, D, affine, masked):
 
 
 def test_attention_matches_reference(cuda_device):
+    """at_op_relpos_attention runs the kernel the product runs by default — relpos_attention_x3_kernel<SchemeF16x2> (two fp16 pieces, three
+    products; $AUDIOTOKEN_SEMANTIC_ARITH selects another) — against the golden produced by the reference's own modeling_wav2vec2_bert.py:20-80."""
     lib = _cabi.load()
     g = np.load(os.path.join(G, "attention_a.npz"))
     w = W.synth_w2vbert_weights(n_layers=1, seed=int(g["weight_seed"]), with_vq=False)
@@ -90,7 +92,8 @@ def test_attention_matches_reference(cuda_device):
 
 @pytest.mark.parametrize("B,T", [(2, 1500), (1, 130), (3, 64)])
 def test_attention_long_vs_oracle(cuda_device, B, T):
-    """T spanning many key tiles (far-field bias constants) and ragged masks, against the oracle attention."""
+    """T spanning many key tiles (far-field bias constants) and ragged masks, against the oracle attention (the op entry runs the product's default
+    arithmetic: relpos_attention_x3_kernel<SchemeF16x2>; the fp32 / bf16x3 forms are compared in test_arith_options_agree)."""
     lib = _cabi.load()
     w = W.synth_w2vbert_weights(n_layers=1, seed=11, with_vq=False)
     p = "encoder.layers.0.self_attn"
