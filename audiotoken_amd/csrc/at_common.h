@@ -41,6 +41,17 @@ inline int set_max_dynamic_lds(LdsAttrFlags& f, K kernel, size_t bytes) {
     }
     return 0;
 }
+// compute units of the current device (per-device cache: a process may hold handles on several devices)
+inline int device_cus() {
+    static int cus[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
 // $AUDIOTOKEN_HOST_ONLY_TEST=1: the sanitizer build's CPU test (tests/test_asan_cpu.py) runs tensor staging and the host-side packing of
 // finalize() on a machine without a device; handles can then be created and the first real device call fails with an error code as usual
 inline bool host_only_test() {

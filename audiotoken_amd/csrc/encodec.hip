@@ -123,6 +123,7 @@ struct at_encodec {
     bool fused_res64 = true;        // 64-channel residual block in one kernel (seanet_res64.hip)
     bool fused_res128 = true;       // 128-channel residual block in one kernel (seanet_res128.hip)
     bool fused_down64 = true;       // stage-1 strided conv with register-stationary weights (seanet_down64.hip)
+    bool fused_stage1 = true;       // 64-channel block + stage-1 strided conv in one role-split kernel (seanet_res64down.hip; fp16 scheme, needs res64_x3 / down64_x3 / res_f16x2)
     bool down64_x3 = true;          // ... on the bf16 matrix cores with 3-way split operands (seanet_down64x3.hip); follows bf16x3
     bool down128_x3 = true;         // stage-2 strided conv as a windowed split-bf16 GEMM fed by seanet_res128x3's split epilogue; follows bf16x3
     const __bf16* down2_s = nullptr;
@@ -910,6 +911,21 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
             float* x = ws + p.off_x[s];
             float* r = ws + p.off_r[s];
             bool down2_gemm = false;
+            float* out = s < 3 ? ws + p.off_x[s + 1] : x4 + (long long)b0 * T * kH;
+            // stage 1 in one kernel (seanet_res64down.hip): the block output (the largest tensor of the path) stays in LDS
+            const bool stage1 = s == 1 && h->fused_stage1 && h->fused_res64 && h->fused_down64 && h->bf16x3 && h->res64_x3 && h->down64_x3 && h->res_f16x2 &&
+                                L % 4 == 0 && L >= 8;
+            if (stage1) {
+                ResDown64Args fa;
+                fa.x = x; fa.out = out; fa.w3 = h->res[1][0].w; fa.b3 = h->res[1][0].b; fa.wt = h->res[1][1].w; fa.bt = h->res[1][1].b;
+                fa.wd = h->down[1].w; fa.bd = h->down[1].b; fa.B = g; fa.L = L;
+                fa.act_scale = XB_F16_ACT_SCALE; fa.w3_scale = h->res_fs[1][0]; fa.wt_scale = h->res_fs[1][1]; fa.wd_scale = h->down_fs[1];
+                fa.status_res = rs(AS_RES1); fa.status_down = rs(AS_DOWN1);
+                prof.begin("res1_down1", 1, stream);
+                if (int rc = launch_seanet_res64down(fa, stream)) return rc;
+                prof.end(stream);
+                continue;
+            }
             if (s == 1 && h->fused_res64) {
                 // 64-channel block fused into one kernel: 256 B in + 256 B out per row (seanet_res64.hip)
                 Res64Args ra;
@@ -963,7 +979,6 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
                 if (int rc = resblock(h->res[s], x, ws + p.off_h[s], r, L, g, stream, EPI_ELU)) return rc;
                 prof.end(stream);
             }
-            float* out = s < 3 ? ws + p.off_x[s + 1] : x4 + (long long)b0 * T * kH;
             prof.begin(kDown[s], 1, stream);
             if (s == 1 && h->fused_down64 && L % 4 == 0) {
                 Down64Args da;
@@ -1058,6 +1073,7 @@ const BoolOption kBoolOptions[] = {
     {"fused_res64", &at_encodec::fused_res64},
     {"fused_res128", &at_encodec::fused_res128},
     {"fused_down64", &at_encodec::fused_down64},
+    {"fused_stage1", &at_encodec::fused_stage1},
     {"down64_x3", &at_encodec::down64_x3},
     {"rvq_x3", &at_encodec::rvq_x3},
     {"lstm_x3", &at_encodec::lstm_x3},

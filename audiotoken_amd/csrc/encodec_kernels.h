@@ -109,6 +109,20 @@ struct Down64Args {
 int launch_seanet_down64(const Down64Args& a, hipStream_t stream);
 // the same conv on the bf16 matrix cores with exact 3-way bf16 splits of both operands (seanet_down64x3.hip)
 int launch_seanet_down64x3(const Down64Args& a, hipStream_t stream);
+// Stage 1 in one role-split kernel (seanet_res64down.hip): the 64-channel block and the strided conv above, fp16 scheme only; the block output stays
+// in LDS. Bit-identical to launch_seanet_res64x3 + launch_seanet_down64x3 with scheme = XB_SCHEME_F16X2.
+struct ResDown64Args {
+    const float* x;         // [B][L][64]
+    float* out;             // [B][L/4][128]
+    const float *w3, *b3;   // block conv3 packed [32][3*64], [32]
+    const float *wt, *bt;   // block tail packed [64][32 + 64], summed bias [64]
+    const float *wd, *bd;   // strided conv packed [128][8*64], [128]
+    int B, L;
+    float act_scale = 1.0f, w3_scale = 1.0f, wt_scale = 1.0f, wd_scale = 1.0f;
+    int* status_res = nullptr;    // range {flag, census} pair of the block's own splits
+    int* status_down = nullptr;   // ... of the conv's operand (the block output)
+};
+int launch_seanet_res64down(const ResDown64Args& a, hipStream_t stream);
 // Decoder tail (seanet_dectail.hip): x [B][L][64] (ELU'd) -> transposed conv (64->32, k4 s2) -> resblock(32) -> ELU -> conv k7 -> wav [B][2L]
 struct DecTailArgs {
     const float* x;

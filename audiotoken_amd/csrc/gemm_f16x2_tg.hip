@@ -440,18 +440,6 @@ bool gemm_f16x2_tg_eligible(const Bf16x3Args& a) {
     return a.N % 128 == 0 && a.K % 32 == 0 && a.Mpad % 256 == 0;
 }
 
-// compute units of the current device (per-device cache: a process may hold handles on several devices)
-static int device_cus() {
-    static int cus[kMaxDevices] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
-    if (cus[dev] == 0) {
-        int n = 0;
-        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    return cus[dev];
-}
-
 template <bool WINDOWED, int TI, int TJ>
 static int launch_tg(const Bf16x3Args& a, int ga, dim3 grid, hipStream_t stream) {
     using Cfg = TgCfg<TI, TJ>;

@@ -47,10 +47,12 @@ BF16X3_ACOUSTIC = os.environ.get("AUDIOTOKEN_BF16X3_ACOUSTIC", "1") != "0"
 _X3_MASK = int(os.environ.get("AUDIOTOKEN_X3_KERNELS", "511"))
 ACOUSTIC_X3_GROUPS = tuple(g for bit, g in enumerate(("down1", "res2", "res1", "stage0_fused", "down2", "down3", "res3", "lstm_rec", "rvq"))
                            if BF16X3_ACOUSTIC and (_X3_MASK >> bit) & 1) + (("lstm_ih",) if BF16X3_ACOUSTIC else ())
+if "res1" in ACOUSTIC_X3_GROUPS and "down1" in ACOUSTIC_X3_GROUPS:
+    ACOUSTIC_X3_GROUPS += ("res1_down1",)   # the two in one kernel (option fused_stage1, seanet_res64down.hip)
 # kernel groups behind each option of the two-piece fp16 scheme (three MFMA products per multiply-add instead of six); the live
 # option values are read back from the handle (at_encodec_get_option)
 ACOUSTIC_F16X2_OPTIONS = {"chain_f16x2": ("down2", "res3", "down3"), "ih_f16x2": ("lstm_ih",), "lstm_f16x2": ("lstm_rec",),
-                          "res_f16x2": ("stage0_fused", "res1", "down1", "res2"), "rvq_f16x2": ("rvq",), "fin_f16x2": ("final_conv",)}
+                          "res_f16x2": ("stage0_fused", "res1", "down1", "res1_down1", "res2"), "rvq_f16x2": ("rvq",), "fin_f16x2": ("final_conv",)}
 
 
 def acoustic_f16x2_groups(enc):
@@ -144,6 +146,7 @@ def acoustic_flops_per_clip(N: int, n_q: int):
         g[f"down{s}"] = 2.0 * L[s + 1] * (2 * r * C) * (2 * C)
         C *= 2
     g["stage0_fused"] = g["conv0"] + g["res0"] + g["down0"]
+    g["res1_down1"] = g["res1"] + g["down1"]
     T = L[4]
     g["lstm_ih"] = 2.0 * T * 512 * 2048 * 2
     g["lstm_rec"] = 2.0 * T * 512 * 2048 * 2
@@ -164,6 +167,7 @@ def acoustic_bytes_per_clip(N: int, n_q: int):
         g[f"res{s}"] = 4.0 * L[s] * (C + C)
         g[f"down{s}"] = 4.0 * (L[s] * C + L[s + 1] * 2 * C)
         C *= 2
+    g["res1_down1"] = 4.0 * (L[1] * 64 + L[2] * 128)   # the block output stays on the CU
     T = L[4]
     g["lstm_ih"] = 4.0 * T * (512 + 2048) * 2
     g["lstm_rec"] = 4.0 * T * (2048 + 512 * 2) * 2
@@ -514,6 +518,9 @@ def setup_acoustic(args, rank, world, dev, dist):
     enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=num_codebooks_to_bandwidth(n_q)), device=str(dev), weights=weights)
     torch.cuda.synchronize()
     finalize_ms = (time.perf_counter() - t0) * 1e3
+    for kv in args.acoustic_option:
+        name, _, val = kv.partition("=")
+        enc.set_option(name, int(val))
     wav = S.acoustic_batch(B, N, dev, rank)        # rank r owns clips [r B, (r + 1) B) of the global batch
     mask = torch.ones_like(wav)
     enc._bench_inputs = (wav, mask)
@@ -550,7 +557,7 @@ def report_acoustic(wl, args, rank, world, dev, dist):
                   "products or three bf16 pieces / six products: see mfma_products_per_mac; conv0 on the fp32 MFMA)") if ACOUSTIC_X3_GROUPS else "f32",
         "config": {"workload": f"Tokenizers.acoustic encode, {B} clips x {args.seconds:g} s @24 kHz per GPU, num_codebooks={n_q} (BASELINE configs[1])",
                    "clips_per_gpu": B, "samples_per_clip": N, "frames_per_clip": T, "weights": "synthetic seed 0",
-                   "parallelism": f"clip-sharded x{world}, no data-path collective"},
+                   "parallelism": f"clip-sharded x{world}, no data-path collective", **({"options": list(args.acoustic_option)} if args.acoustic_option else {})},
         "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS, "acoustic", 3 if dom in f16_groups else 6), "breakdown": breakdown,
         "mfma_products_per_mac": {**{g: (3 if g in f16_groups else 6) for g in ACOUSTIC_X3_GROUPS}, "final_conv": 3 if "final_conv" in f16_groups else 1},
         "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)", "token_checksum": checksum,
@@ -738,6 +745,8 @@ def parse_args(argv=None):
     ap.add_argument("--sem-batch", type=int, default=64, help="semantic_m clips per GPU per step (BASELINE configs[3]: 512/8)")
     ap.add_argument("--sem-seconds", type=float, default=30.0)
     ap.add_argument("--sem-layers", type=int, default=19)
+    ap.add_argument("--acoustic-option", action="append", default=[], metavar="NAME=0|1",
+                    help="A/B tooling: set a kernel-selection option of the acoustic handle (at_encodec_set_option) before the run; echoed in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle check of the timed batches (rank 0, N = 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --workload selftest run on CPU (tests)")

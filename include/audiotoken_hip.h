@@ -81,7 +81,8 @@ int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* ma
  * $AUDIOTOKEN_SUBBATCH: round 2's per-option variables were removed.
  *   "persistent_lstm" 1/0 — whole-sequence persistent LSTM kernel (default on) or one launch per time step;
  *   "fused_stage0", "fused_res64", "fused_res128", "fused_down64", "fused_dectail" 1/0 — fused SEANet kernels (default on)
- *   or the GEMM path;
+ *   or the GEMM path; "fused_stage1" 1/0 — the 64-channel block and the stage-1 strided conv in ONE kernel (seanet_res64down.hip, default on;
+ *   needs "fused_res64", "fused_down64", "res64_x3", "down64_x3", "res_f16x2"; bit-identical to the two kernels it replaces);
  *   "stage0_x3", "res64_x3", "res128_x3", "down64_x3", "down128_x3", "down256_x3", "res256_x3", "lstm_x3", "rvq_x3" 1/0 — the fused kernels, the
  *   stage-2 / stage-3 convs + 256-channel block (as chained GEMMs) the LSTM recurrence and the RVQ search on the bf16 matrix cores with exact 3-way bf16 splits of every
  *   operand (default on; $AUDIOTOKEN_X3_KERNELS bit mask, bits 3, 2, 1, 0, 4, 5, 6, 7, 8 in that order; 0 = the fp32-MFMA kernels:

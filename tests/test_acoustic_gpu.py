@@ -310,6 +310,33 @@ def test_role_split_res128_is_bit_identical(encoders):
         enc.set_option("res128_rs", 1)
 
 
+def test_fused_stage1_is_bit_identical(encoders):
+    """seanet_res64down.hip (block role + conv role in one workgroup, the block output kept in LDS, the conv's causal context carried from tile to
+    tile) performs the products of seanet_res64x3_kernel + seanet_down64x3_kernel (fp16 scheme) in the same order per output element: embeddings and
+    codes must be IDENTICAL — at stage-1 lengths that are not multiples of 64 (partial last tile), below one tile, with several clips per workgroup
+    run and with runs that start inside a clip (B * tiles not a multiple of the grid), and the range census of both sites must still be reported."""
+    enc = encoders[8]
+    try:
+        for B, N, seed in ((5, 24000 + 320 * 7, 1), (3, 24000 * 3 + 320 * 5 + 13, 2), (2, 320 * 9, 3), (17, 320 * 40, 4), (1, 240000, 5), (300, 320 * 3, 6)):
+            wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=950 + seed)).cuda()
+            enc.set_option("fused_stage1", 1)
+            c1, e1 = enc(wav, None, return_embeddings=True)
+            assert enc.last_status() == 0
+            live1 = enc.range_report()
+            enc.set_option("fused_stage1", 0)
+            c0, e0 = enc(wav, None, return_embeddings=True)
+            assert enc.last_status() == 0
+            live0 = enc.range_report()
+            assert torch.equal(e1, e0), f"fused stage 1 differs at B={B} N={N}: max {(e1 - e0).abs().max().item():.3e}"
+            assert torch.equal(c1, c0)
+            if N % 8 == 0:   # stage-1 length N / 2 divisible by 4: the fused kernel (and seanet_down64x3) ran, else the GEMM path did in both passes
+                assert live1["res1"] > 0 and live1["down1"] > 0
+                # the census of the fused kernel also covers rows past a clip's end (clamped copies of its last row): never below the pair's
+                assert live1["res1"] >= live0["res1"] * 0.999 and live1["down1"] >= live0["down1"] * 0.999
+    finally:
+        enc.set_option("fused_stage1", 1)
+
+
 def test_fp16_range_overflow_is_reported_and_recovered(enc_weights):
     """A waveform far outside [-1, 1] (x 3e4) overflows the fp16 range of the two-piece kernels: the status word must say so (bit 1) and
     AcousticEncoder.verified must hand back the tokens of the three-bf16-piece kernels (full fp32 exponent range), equal to the oracle's or explained.

@@ -18,7 +18,8 @@ from collections import defaultdict
 GROUPS = {  # bench.py group -> kernel name prefix
     "lstm_rec": "at::lstm_seq",   # lstm_seq_kernel / lstm_seq_x3_kernel<..>
     "stage0_fused": "at::seanet_stage0",      # seanet_stage0_kernel / seanet_stage0x3_kernel, whichever ran
-    "res1": "at::seanet_res64",
+    "res1_down1": "at::seanet_res64down",
+    "res1": "at::seanet_res64x3",
     "down1": "at::seanet_down64",
     "res2": "at::seanet_res128",
     "rvq": "at::rvq_encode",

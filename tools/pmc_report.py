@@ -14,7 +14,7 @@ import json
 import sys
 
 GROUPS = {   # workload -> bench.py group -> kernel-name prefix (first match, most launches)
-    "acoustic": {"stage0_fused": "at::seanet_stage0", "res1": "at::seanet_res64", "down1": "at::seanet_down64", "res2": "at::seanet_res128",
+    "acoustic": {"stage0_fused": "at::seanet_stage0", "res1_down1": "at::seanet_res64down", "res1": "at::seanet_res64x3", "down1": "at::seanet_down64", "res2": "at::seanet_res128",
                  "lstm_rec": "at::lstm_seq", "rvq": "at::rvq_encode", "down3": "at::gemm_f16x2_tg_kernel<true", "lstm_ih": "at::gemm_f16x2_tg_kernel<false"},
     "semantic_m": {"ffn": "at::gemm_f16x2_tg_kernel<false", "attn_proj": "at::gemm_f16x2_tg_kernel<false", "conv_module": "at::gemm_f16x2_tg_kernel<false",
                    "attention": "at::relpos_attention_x3_kernel", "layernorm": "at::layernorm_split_kernel"},
