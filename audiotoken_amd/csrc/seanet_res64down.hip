@@ -108,6 +108,7 @@ __global__ __launch_bounds__(RD_THREADS, 1) void seanet_res64down_kernel(ResDown
     if (wave >= 8) {
         // =========================================== block role (seanet_res64x3.hip) ===========================================
         const int rw = wave - 8;
+        __builtin_amdgcn_s_setprio(2);   // this role's chain (conv3 -> h -> tail) is the critical path of every iteration
         const int cn = rw & 1, mh = rw >> 1;        // conv3: channel tile, row half
         const float rs3 = 1.0f / (a.act_scale * a.w3_scale), rst = 1.0f / (a.act_scale * a.wt_scale);
         RangeMax over_h, over_out;
@@ -163,20 +164,30 @@ __global__ __launch_bounds__(RD_THREADS, 1) void seanet_res64down_kernel(ResDown
             if (live) {
                 // h[32 mh .. + 31, 16 cn .. + 15] = ELU(conv3(ELU(x)) + b3): output row j uses x rows j, j+1, j+2; ks = (tap, 32 channels)
                 f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-                for (int ks = 0; ks < 6; ++ks) {
+                auto xread = [&](int ks, V8 (&xf)[NP][2]) {
                     const int tap = ks >> 1, chunk = (ks & 1) * 4 + q;
-                    V8 xa[NP][2];
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         const PT* src = Xe + (32 * mh + 16 * m + r16 + tap) * RD_LDX + chunk * 8;
 #pragma unroll
-                        for (int p = 0; p < NP; ++p) xa[p][m] = *reinterpret_cast<const V8*>(src + p * RD_XP);
+                        for (int p = 0; p < NP; ++p) xf[p][m] = *reinterpret_cast<const V8*>(src + p * RD_XP);
                     }
+                };
+                // this chain is the critical path of the iteration: the next K step's fragments are in flight during the MFMAs of the current one
+                V8 xa[NP][2], xb[NP][2];
+                xread(0, xa);
+#pragma unroll
+                for (int ks = 0; ks < 6; ks += 2) {
+                    xread(ks + 1, xb);
 #pragma unroll
                     for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
                         for (int m = 0; m < 2; ++m) acc[m] = SC::mfma16(w3p[SC::prod_w(t)][ks], xa[SC::prod_a(t)][m], acc[m]);
+                    if (ks + 2 < 6) xread(ks + 2, xa);
+#pragma unroll
+                    for (int t = 0; t < SC::NPROD; ++t)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m] = SC::mfma16(w3p[SC::prod_w(t)][ks + 1], xb[SC::prod_a(t)][m], acc[m]);
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
@@ -199,22 +210,23 @@ __global__ __launch_bounds__(RD_THREADS, 1) void seanet_res64down_kernel(ResDown
 #pragma unroll 1
                 for (int mp = 0; mp < 4; mp += 2) {
                     f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+                    V8 xf[3][NP][2];   // all three K steps' fragments up front
 #pragma unroll
-                    for (int ks = 0; ks < 3; ++ks) {
-                        V8 xf[NP][2];
+                    for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             const int row = 16 * (mp + m) + r16;
                             const PT* src = ks == 0 ? Hs + row * RD_LDH + q * 8 : Xr + (row + 2) * RD_LDX + ((ks - 1) * 4 + q) * 8;
                             const int ps = ks == 0 ? RD_HP : RD_XP;
 #pragma unroll
-                            for (int p = 0; p < NP; ++p) xf[p][m] = *reinterpret_cast<const V8*>(src + p * ps);
+                            for (int p = 0; p < NP; ++p) xf[ks][p][m] = *reinterpret_cast<const V8*>(src + p * ps);
                         }
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
                         for (int t = 0; t < SC::NPROD; ++t)
 #pragma unroll
-                            for (int m = 0; m < 2; ++m) acc[m] = SC::mfma16(wtp[SC::prod_w(t)][ks], xf[SC::prod_a(t)][m], acc[m]);
-                    }
+                            for (int m = 0; m < 2; ++m) acc[m] = SC::mfma16(wtp[SC::prod_w(t)][ks], xf[ks][SC::prod_a(t)][m], acc[m]);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         const int j = (mp + m) * 16 + r16;

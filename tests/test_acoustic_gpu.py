@@ -317,7 +317,7 @@ def test_fused_stage1_is_bit_identical(encoders):
     run and with runs that start inside a clip (B * tiles not a multiple of the grid), and the range census of both sites must still be reported."""
     enc = encoders[8]
     try:
-        for B, N, seed in ((5, 24000 + 320 * 7, 1), (3, 24000 * 3 + 320 * 5 + 13, 2), (2, 320 * 9, 3), (17, 320 * 40, 4), (1, 240000, 5), (300, 320 * 3, 6)):
+        for B, N, seed in ((5, 24000 + 320 * 7, 1), (3, 24000 * 3 + 320 * 5 + 13, 2), (2, 320 * 9, 3), (17, 320 * 40, 4), (1, 240000, 5), (300, 320 * 9, 6)):
             wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=950 + seed)).cuda()
             enc.set_option("fused_stage1", 1)
             c1, e1 = enc(wav, None, return_embeddings=True)
