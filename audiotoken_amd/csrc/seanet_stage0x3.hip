@@ -43,6 +43,15 @@ __device__ __forceinline__ float sx_store4(typename SC::T* base, int off, int ps
     for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(base + i * ps + off) = p[i];
     return over;
 }
+// Write / read swizzle of the x0 and r images: 16-byte chunk c of a row lives at c ^ bit. The 8-byte piece stores of the 16 lanes of a store group go to
+// 16 rows with one column; with rows 96 B apart, rows 4 apart share their 32 banks (ds_write_b64 banks repeat every 128 B: MI355X_MICROARCH.md, LDS)
+// — a 4-way conflict on every store of conv0 and of the block's tail (PMC, round 2: 41 % of this kernel's LDS cycles were conflict replays). Flipping
+// the chunk for every other group of 4 rows halves that (the other half needs an 8-byte-granular swizzle, which would split the 16-byte fragment
+// reads); the fragment reads stay conflict-free: their lane groups {0-3,12-15,20-27} see, per column, rows whose flipped and unflipped halves
+// cover disjoint bank octets.
+__device__ __forceinline__ int sx_swz(int col, int bit) { return col ^ ((bit & 1) << 3); }
+__device__ __forceinline__ int sx_xbit(int row) { return row >> 2; }                 // x0 image: row i
+__device__ __forceinline__ int sx_rbit(int row) { return row ^ (row >> 3); }         // r image: plane (row & 1) ^ bit 2 of the in-plane index (row >> 1)
 __device__ __forceinline__ f4 sx_elu4(const f4& v) { return f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)}; }
 
 // SC = operand scheme of the three split contractions (conv3, tail, strided conv; conv0 stays on the fp32 MFMA): three bf16 pieces / six products,
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nt ? w0f[1][0] : w0f[0][0], Wseg[a0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(nt ? w0f[1][1] : w0f[0][1], Wseg[a1], acc, 0, 0, 0);
             const f4 o = acc + *reinterpret_cast<const f4*>(B0s + nt * 16 + q * 4);
-            const int off = i * SX_LDX + nt * 16 + q * 4;
+            const int off = i * SX_LDX + sx_swz(nt * 16 + q * 4, sx_xbit(i));
             over |= sx_store4<SC>(X0e, off, SX_XP, sx_elu4(o), sa);
         }
     };
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) xf[ks][p] = *reinterpret_cast<const V8*>(X0e + p * SX_XP + (row + ks) * SX_LDX + q * 8);
+                for (int p = 0; p < NP; ++p) xf[ks][p] = *reinterpret_cast<const V8*>(X0e + p * SX_XP + (row + ks) * SX_LDX + sx_swz(q * 8, sx_xbit(row + ks)));
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
                 for (int nt = 0; nt < 2; ++nt) acc2[nt] = SC::mfma16(wtp[SC::prod_w(t)][nt], tf[SC::prod_a(t)], acc2[nt]);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-                over |= sx_store4<SC>(Rs, ((row & 1) * SX_RIDX + (row >> 1)) * SX_LDR + nt * 16 + q * 4, SX_RP,
+                over |= sx_store4<SC>(Rs, ((row & 1) * SX_RIDX + (row >> 1)) * SX_LDR + sx_swz(nt * 16 + q * 4, sx_rbit(row)), SX_RP,
                                       sx_elu4((acc2[nt] * rst + sc[nt]) + *reinterpret_cast<const f4*>(Bs + 16 + nt * 16 + q * 4)), sa);
         }
         __syncthreads();
@@ -228,8 +237,8 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
             if (tid < 16 * NP) {
                 const int p = tid >> 4, j = (tid >> 3) & 1, c = (tid & 7) * 4;   // j = 0 <-> t = -2 (copy of row 4); j = 1 <-> t = -1 (row 3)
                 const int src = 4 - j;
-                *reinterpret_cast<V4*>(Rs + p * SX_RP + ((j & 1) * SX_RIDX + (j >> 1)) * SX_LDR + c) =
-                    *reinterpret_cast<const V4*>(Rs + p * SX_RP + ((src & 1) * SX_RIDX + (src >> 1)) * SX_LDR + c);
+                *reinterpret_cast<V4*>(Rs + p * SX_RP + ((j & 1) * SX_RIDX + (j >> 1)) * SX_LDR + sx_swz(c, sx_rbit(j))) =
+                    *reinterpret_cast<const V4*>(Rs + p * SX_RP + ((src & 1) * SX_RIDX + (src >> 1)) * SX_LDR + sx_swz(c, sx_rbit(src)));
             }
             __syncthreads();
         }
@@ -243,7 +252,8 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
                 for (int om = 0; om < 2; ++om)
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
-                        rf[ks][p][om] = *reinterpret_cast<const V8*>(Rs + p * SX_RP + ((ks & 1) * SX_RIDX + om * 16 + r16 + (ks >> 1)) * SX_LDR + q * 8);
+                        rf[ks][p][om] = *reinterpret_cast<const V8*>(Rs + p * SX_RP + ((ks & 1) * SX_RIDX + om * 16 + r16 + (ks >> 1)) * SX_LDR +
+                                                                     sx_swz(q * 8, sx_rbit(2 * (om * 16 + r16 + (ks >> 1)) + (ks & 1))));
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
