@@ -58,6 +58,10 @@ SIGNATURES = {
     "at_w2vbert_create": (C.c_void_p, [C.c_int]),
     "at_w2vbert_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "at_w2vbert_finalize": (C.c_int, [C.c_void_p]),
+    "at_w2vbert_packed_bytes": (C.c_int64, [C.c_void_p]),
+    "at_w2vbert_packed_meta": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "at_w2vbert_export_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "at_w2vbert_import_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "at_w2vbert_destroy": (None, [C.c_void_p]),
     "at_w2vbert_num_layers": (C.c_int, [C.c_void_p]),
     "at_w2vbert_num_tokens": (C.c_int, [C.c_int, C.c_int]),
@@ -74,6 +78,10 @@ SIGNATURES = {
     "at_hubert_create": (C.c_void_p, [C.c_int]),
     "at_hubert_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "at_hubert_finalize": (C.c_int, [C.c_void_p]),
+    "at_hubert_packed_bytes": (C.c_int64, [C.c_void_p]),
+    "at_hubert_packed_meta": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "at_hubert_export_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "at_hubert_import_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "at_hubert_destroy": (None, [C.c_void_p]),
     "at_hubert_num_layers": (C.c_int, [C.c_void_p]),
     "at_hubert_num_tokens": (C.c_int, [C.c_int]),
@@ -191,3 +199,33 @@ def range_report(lib, model: str, handle) -> dict:
     check(getattr(lib, f"at_{model}_range_report")(handle, vals, 64) - n, f"at_{model}_range_report")
     keys = names.value.decode().split("\n")[:n]
     return {k: float(vals[i]) for i, k in enumerate(keys)}
+
+
+def export_packed(lib, model: str, handle, device):
+    """(meta: bytes, blob: uint8 device tensor) of a finalized handle (include/audiotoken_hip.h, at_*_export_packed): the model as ONE device blob
+    plus a small host record, for ``import_packed`` on another rank."""
+    import torch
+    n = getattr(lib, f"at_{model}_packed_meta")(handle, None, 0)
+    if n < 0:
+        raise HipLibraryError(f"at_{model}_packed_meta failed: {last_error()}")
+    buf = C.create_string_buffer(int(n))
+    if getattr(lib, f"at_{model}_packed_meta")(handle, buf, n) != n:
+        raise HipLibraryError(f"at_{model}_packed_meta failed: {last_error()}")
+    nbytes = getattr(lib, f"at_{model}_packed_bytes")(handle)
+    if nbytes < 0:
+        raise HipLibraryError(f"at_{model}_packed_bytes failed: {last_error()}")
+    blob = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        check(getattr(lib, f"at_{model}_export_packed")(handle, blob.data_ptr(), int(nbytes), current_stream_handle(device)), f"at_{model}_export_packed")
+        torch.cuda.current_stream(device).synchronize()
+    return buf.raw, blob
+
+
+def import_packed(lib, model: str, handle, meta: bytes, blob) -> None:
+    """Rebuild a finalized model on a FRESH handle from ``export_packed``'s pair (the blob is copied into the handle's own allocation)."""
+    import torch
+    assert blob.dtype == torch.uint8 and blob.is_cuda and blob.is_contiguous()
+    with torch.cuda.device(blob.device):
+        check(getattr(lib, f"at_{model}_import_packed")(handle, meta, len(meta), blob.data_ptr(), blob.numel(), current_stream_handle(blob.device)),
+              f"at_{model}_import_packed")
+

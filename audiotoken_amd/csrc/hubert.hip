@@ -16,6 +16,7 @@
 #include "at_common.h"
 #include "hubert_kernels.h"
 #include "gemm_bf16x3.h"
+#include "packed_model.h"
 #include <cstdlib>
 #include "w2vbert_kernels.h"
 
@@ -43,7 +44,9 @@ struct at_hubert {
     int device = 0;
     bool finalized = false;
     std::map<std::string, HostTensor> staged;
-    std::vector<float*> allocs;
+    DeviceArena arena;          // every device allocation of finalize(), in order (packed_model.h: export / import of the finalized model)
+    PackedHeader imp{};         // import_packed: the exporter's record (layer count, flags) while finalize is replayed
+    std::vector<int> split_seq; // the schemes whose weight pieces exist, in the order they were split (= their order in the arena)
     int* range_tab = nullptr;   // device, {flag, census} per HSite, zeroed at the start of every encode (at_hubert_range_report reads it)
     const float* conv_w[7] = {};
     const float *gn_g = nullptr, *gn_b = nullptr, *fp_ln_g = nullptr, *fp_ln_b = nullptr, *fp_w = nullptr, *fp_b = nullptr;
@@ -65,17 +68,30 @@ const HostTensor* find(const at_hubert* h, const std::string& name) {
     return it == h->staged.end() ? nullptr : &it->second;
 }
 const float* upload(at_hubert* h, const std::vector<float>& v) {
-    float* d = nullptr;
     const size_t n = (v.size() + 3) / 4 * 4;
-    if (hipMalloc((void**)&d, n * sizeof(float)) != hipSuccess) return nullptr;
+    float* d = static_cast<float*>(h->arena.alloc(n * sizeof(float)));
+    if (!d) return nullptr;
     if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    h->allocs.push_back(d);
     float mx = 0.f;
     for (float x : v) mx = std::fmax(mx, std::fabs(x));
+    h->arena.blocks.back().wmax = mx;
     h->wmax[d] = mx;
     return d;
 }
+// import_packed: the tensor's bytes are already in the blob — take the next slice and the recorded max |w|
+const float* reserve(at_hubert* h, size_t n_floats) {
+    float* d = static_cast<float*>(h->arena.alloc((n_floats + 3) / 4 * 4 * sizeof(float)));
+    if (d) h->wmax[d] = h->arena.blocks.back().wmax;
+    return d;
+}
 const float* take(at_hubert* h, const std::string& name, std::vector<int64_t> shape, bool& ok) {
+    if (h->arena.importing) {
+        size_t n = 1;
+        for (int64_t d : shape) n *= (size_t)d;
+        const float* d = reserve(h, n);
+        if (!d) ok = false;
+        return d;
+    }
     const HostTensor* t = find(h, name);
     if (!t) { set_error("missing tensor " + name); ok = false; return nullptr; }
     if (t->shape != shape) { set_error("bad shape for " + name); ok = false; return nullptr; }
@@ -144,9 +160,8 @@ int split_weights(at_hubert* h, int scheme) {
     if (h->split_done[scheme]) return 0;
     const int np = xb_pieces(scheme);
     auto one = [&](const float* src, int n, int k, const piece_t** dst, float* scale_out, int win_cblocks = 0, int win_stride = 1) -> int {
-        piece_t* d = nullptr;
-        AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)np * n * k * sizeof(piece_t)));
-        h->allocs.push_back(reinterpret_cast<float*>(d));
+        piece_t* d = static_cast<piece_t*>(h->arena.alloc((size_t)np * n * k * sizeof(piece_t)));
+        if (!d) return -1;
         float sc = 1.0f;
         if (scheme == XB_SCHEME_F16X2) {
             auto it = h->wmax.find(src);
@@ -154,7 +169,8 @@ int split_weights(at_hubert* h, int scheme) {
             sc = xb_weight_scale(it->second);
             *scale_out = sc;
         }
-        if (int rc = launch_split_blocked(src, k, n, n, k, d, nullptr, scheme, sc, nullptr, win_cblocks, win_stride)) return rc;
+        if (!h->arena.importing)   // import_packed: the pieces are in the blob
+            if (int rc = launch_split_blocked(src, k, n, n, k, d, nullptr, scheme, sc, nullptr, win_cblocks, win_stride)) return rc;
         *dst = d;
         return 0;
     };
@@ -168,6 +184,7 @@ int split_weights(at_hubert* h, int scheme) {
     }
     AT_CHECK_HIP(hipDeviceSynchronize());
     h->split_done[scheme] = true;
+    h->split_seq.push_back(scheme);
     return 0;
 }
 
@@ -221,12 +238,17 @@ int at_hubert_set_tensor(at_hubert_t* h, const char* name, const float* host_dat
     return 0;
 }
 
-int at_hubert_finalize(at_hubert_t* h) {
-    AT_REQUIRE(h && !h->finalized, "bad handle");
-    DeviceGuard guard(h->device);
-    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+// finalize(): staged host tensors -> device. With the arena in import mode (at_hubert_import_packed) the same code REPLAYS the allocation order over the
+// packed blob: no host tensor is read, nothing is uploaded or split — only the pointers and scales are rebuilt.
+static int finalize_impl(at_hubert* h) {
+    const bool imp = h->arena.importing;
     bool ok = true;
     for (int i = 0; i < 7; ++i) {
+        if (imp) {
+            h->conv_w[i] = reserve(h, (size_t)kCd * kKs[i] * (i == 0 ? 1 : kCd));
+            AT_REQUIRE(h->conv_w[i] != nullptr, "import_packed: feature-extractor weights");
+            continue;
+        }
         const std::string key = "feature_extractor.conv_layers." + std::to_string(i) + ".conv.weight";
         const HostTensor* t = find(h, key);
         const int cin = i == 0 ? 1 : kCd, k = kKs[i];
@@ -248,7 +270,10 @@ int at_hubert_finalize(at_hubert_t* h) {
     h->enc_ln_g = take(h, "encoder.layer_norm.weight", {kHid}, ok);
     h->enc_ln_b = take(h, "encoder.layer_norm.bias", {kHid}, ok);
     if (!ok) return -1;
-    {   // grouped positional conv: folded weight [768][48][128] -> per group [48 out][128 taps][48 in]
+    if (imp) {
+        h->pos_w = reserve(h, (size_t)kHid * kPosK * kGc);
+        AT_REQUIRE(h->pos_w != nullptr, "import_packed: positional conv");
+    } else {   // grouped positional conv: folded weight [768][48][128] -> per group [48 out][128 taps][48 in]
         const HostTensor* t = find(h, "encoder.pos_conv_embed.conv.weight");
         AT_REQUIRE(t && t->shape == (std::vector<int64_t>{kHid, kGc, kPosK}), "encoder.pos_conv_embed.conv.weight [768,48,128] (weight-norm folded) missing");
         std::vector<float> w((size_t)kHid * kPosK * kGc);
@@ -259,23 +284,28 @@ int at_hubert_finalize(at_hubert_t* h) {
         h->pos_w = upload(h, w);
         AT_REQUIRE(h->pos_w != nullptr, "device allocation failed");
     }
-    int nl = 0;
-    while (find(h, "encoder.layers." + std::to_string(nl) + ".layer_norm.weight")) ++nl;
+    int nl = imp ? h->imp.n_layers : 0;
+    while (!imp && find(h, "encoder.layers." + std::to_string(nl) + ".layer_norm.weight")) ++nl;
     for (int i = 0; i < nl; ++i) {
         const std::string p = "encoder.layers." + std::to_string(i);
         LayerW L{};
-        std::vector<float> w((size_t)3 * kHid * kHid), b((size_t)3 * kHid);
-        const char* nm[3] = {"q_proj", "k_proj", "v_proj"};
-        for (int j = 0; j < 3; ++j) {
-            const HostTensor* wt = find(h, p + ".attention." + nm[j] + ".weight");
-            const HostTensor* bt = find(h, p + ".attention." + nm[j] + ".bias");
-            AT_REQUIRE(wt && bt && wt->shape == (std::vector<int64_t>{kHid, kHid}) && bt->shape == (std::vector<int64_t>{kHid}),
-                       "attention projection tensors missing or mis-shaped");
-            std::memcpy(&w[(size_t)j * kHid * kHid], wt->data.data(), (size_t)kHid * kHid * sizeof(float));
-            std::memcpy(&b[(size_t)j * kHid], bt->data.data(), kHid * sizeof(float));
+        if (imp) {
+            L.wqkv = reserve(h, (size_t)3 * kHid * kHid);
+            L.bqkv = reserve(h, (size_t)3 * kHid);
+        } else {
+            std::vector<float> w((size_t)3 * kHid * kHid), b((size_t)3 * kHid);
+            const char* nm[3] = {"q_proj", "k_proj", "v_proj"};
+            for (int j = 0; j < 3; ++j) {
+                const HostTensor* wt = find(h, p + ".attention." + nm[j] + ".weight");
+                const HostTensor* bt = find(h, p + ".attention." + nm[j] + ".bias");
+                AT_REQUIRE(wt && bt && wt->shape == (std::vector<int64_t>{kHid, kHid}) && bt->shape == (std::vector<int64_t>{kHid}),
+                           "attention projection tensors missing or mis-shaped");
+                std::memcpy(&w[(size_t)j * kHid * kHid], wt->data.data(), (size_t)kHid * kHid * sizeof(float));
+                std::memcpy(&b[(size_t)j * kHid], bt->data.data(), kHid * sizeof(float));
+            }
+            L.wqkv = upload(h, w);
+            L.bqkv = upload(h, b);
         }
-        L.wqkv = upload(h, w);
-        L.bqkv = upload(h, b);
         AT_REQUIRE(L.wqkv && L.bqkv, "device allocation failed");
         L.wo = take(h, p + ".attention.out_proj.weight", {kHid, kHid}, ok);
         L.bo = take(h, p + ".attention.out_proj.bias", {kHid}, ok);
@@ -290,7 +320,13 @@ int at_hubert_finalize(at_hubert_t* h) {
         if (!ok) return -1;
         h->layers.push_back(L);
     }
-    if (const HostTensor* c = find(h, "kmeans.cluster_centers_")) {
+    if (imp) {
+        if (h->imp.flags & 1) {
+            h->centers = reserve(h, (size_t)kCenters * kHid);
+            h->c2 = reserve(h, kCenters);
+            AT_REQUIRE(h->centers && h->c2, "import_packed: k-means centres");
+        }
+    } else if (const HostTensor* c = find(h, "kmeans.cluster_centers_")) {
         AT_REQUIRE(c->shape.size() == 2 && c->shape[1] == kHid && c->shape[0] % 4 == 0, "kmeans.cluster_centers_ must be [C,768], C % 4 == 0");
         h->centers = upload(h, c->data);
         const int C = (int)c->shape[0];
@@ -310,7 +346,9 @@ int at_hubert_finalize(at_hubert_t* h) {
         AT_REQUIRE(h->centers && h->c2, "device allocation failed");
     }
     h->staged.clear();
-    {
+    if (imp) {
+        h->arith = h->imp.arith;
+    } else {
         h->arith = ARITH_F16X2;
         if (const char* e = std::getenv("AUDIOTOKEN_SEMANTIC_ARITH")) {
             const std::string v(e);
@@ -318,21 +356,64 @@ int at_hubert_finalize(at_hubert_t* h) {
             h->arith = v == "f32" ? ARITH_F32 : v == "bf16x3" ? ARITH_BF16X3 : ARITH_F16X2;
         }
     }
-    if (h->arith != ARITH_F32)
+    if (imp) {
+        // the exporter's splits in ITS order (flags bits 1-2 = count, bits 3.. = one bit per split: 1 = bf16x3). Normally one: the default scheme at
+        // finalize; two when the per-batch range fallback had run there (the other scheme is split lazily, and the handle's current arithmetic may be either)
+        const int n = (h->imp.flags >> 1) & 3;
+        for (int i = 0; i < n; ++i)
+            if (int rc = split_weights(h, ((h->imp.flags >> (3 + i)) & 1) ? XB_SCHEME_BF16X3 : XB_SCHEME_F16X2)) return rc;
+    } else if (h->arith != ARITH_F32) {
         if (int rc = split_weights(h, h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
-    if (!host_only_test() && !h->range_tab) {
+    }
+    if (!host_only_test() && !h->range_tab) {   // run-time state, not part of the packed model
         AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, 64 * sizeof(int)));
-        h->allocs.push_back(reinterpret_cast<float*>(h->range_tab));
         AT_CHECK_HIP(hipMemset(h->range_tab, 0, 64 * sizeof(int)));
     }
     h->finalized = true;
     return 0;
 }
 
+int at_hubert_finalize(at_hubert_t* h) {
+    AT_REQUIRE(h && !h->finalized, "bad handle");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    return finalize_impl(h);
+}
+
+// ---- the finalized model as one device blob (packed_model.h) ------------------------------------------------------------------------------
+static int packed_flags(const at_hubert* h) {
+    int f = (h->centers ? 1 : 0) | ((int)h->split_seq.size() << 1);
+    for (size_t i = 0; i < h->split_seq.size(); ++i) f |= (h->split_seq[i] == XB_SCHEME_BF16X3 ? 1 : 0) << (3 + i);
+    return f;
+}
+int64_t at_hubert_packed_bytes(at_hubert_t* h) {
+    if (!h || !h->finalized) { set_error("at_hubert_packed_bytes: model not finalized"); return -1; }
+    return (int64_t)h->arena.packed_bytes();
+}
+int64_t at_hubert_packed_meta(at_hubert_t* h, void* host_dst, int64_t cap) {
+    if (!h || !h->finalized) { set_error("at_hubert_packed_meta: model not finalized"); return -1; }
+    return packed_write_meta(h->arena, PACKED_MODEL_HUBERT, (int)h->layers.size(), packed_flags(h), h->arith, host_dst, cap);
+}
+int at_hubert_export_packed(at_hubert_t* h, void* device_dst, int64_t bytes, void* stream) {
+    AT_REQUIRE(h && h->finalized, "at_hubert_export_packed: model not finalized");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    return packed_export(h->arena, device_dst, bytes, (hipStream_t)stream);
+}
+int at_hubert_import_packed(at_hubert_t* h, const void* host_meta, int64_t meta_bytes, const void* device_src, int64_t bytes, void* stream) {
+    AT_REQUIRE(h && !h->finalized && h->staged.empty(), "at_hubert_import_packed needs a fresh handle (no set_tensor, no finalize)");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    if (int rc = packed_begin_import(h->arena, PACKED_MODEL_HUBERT, host_meta, meta_bytes, device_src, bytes, (hipStream_t)stream, &h->imp)) return rc;
+    if (int rc = finalize_impl(h)) { h->arena.importing = false; return rc; }
+    return packed_end_import(h->arena);
+}
+
 void at_hubert_destroy(at_hubert_t* h) {
     if (!h) return;
     DeviceGuard guard(h->device);   // restores the caller's current device
-    for (float* p : h->allocs) (void)hipFree(p);
+    h->arena.free_all();
+    if (h->range_tab) (void)hipFree(h->range_tab);
     delete h;
 }
 

@@ -26,6 +26,7 @@
 #include "w2vbert_kernels.h"
 #include <cstdlib>
 #include "gemm_bf16x3.h"
+#include "packed_model.h"
 
 namespace at {
 const char* last_error_cstr();
@@ -61,7 +62,9 @@ struct at_w2vbert {
     int device = 0;
     bool finalized = false;
     std::map<std::string, HostTensor> staged;
-    std::vector<float*> allocs;
+    DeviceArena arena;          // every device allocation of finalize(), in order (packed_model.h: export / import of the finalized model)
+    PackedHeader imp{};         // import_packed: the exporter's record (layer count, flags) while finalize is replayed
+    std::vector<int> split_seq; // the schemes whose weight pieces exist, in the order they were split (= their order in the arena)
     int* range_tab = nullptr;   // device, {flag, census} per WSite, zeroed at the start of every encode (at_w2vbert_range_report reads it)
     const float *window = nullptr, *melw = nullptr;
     double* dft64 = nullptr;  // [520][400] DFT matrix in double (see dft_f64_kernel)
@@ -83,18 +86,31 @@ const HostTensor* find(const at_w2vbert* h, const std::string& name) {
 
 // upload one packed tensor into its own device allocation (the model is ~1.8 GB: no second full host copy)
 const float* upload(at_w2vbert* h, const std::vector<float>& v) {
-    float* d = nullptr;
-    size_t n = (v.size() + 3) / 4 * 4;
-    if (hipMalloc((void**)&d, n * sizeof(float)) != hipSuccess) return nullptr;
+    const size_t n = (v.size() + 3) / 4 * 4;
+    float* d = static_cast<float*>(h->arena.alloc(n * sizeof(float)));
+    if (!d) return nullptr;
     if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    h->allocs.push_back(d);
     float mx = 0.f;
     for (float x : v) mx = std::fmax(mx, std::fabs(x));
+    h->arena.blocks.back().wmax = mx;
     h->wmax[d] = mx;
+    return d;
+}
+// import_packed: the tensor's bytes are already in the blob — take the next slice and the recorded max |w|
+const float* reserve(at_w2vbert* h, size_t n_floats) {
+    float* d = static_cast<float*>(h->arena.alloc((n_floats + 3) / 4 * 4 * sizeof(float)));
+    if (d) h->wmax[d] = h->arena.blocks.back().wmax;
     return d;
 }
 
 const float* take(at_w2vbert* h, const std::string& name, std::vector<int64_t> shape, bool& ok) {
+    if (h->arena.importing) {
+        size_t n = 1;
+        for (int64_t d : shape) n *= (size_t)d;
+        const float* d = reserve(h, n);
+        if (!d) ok = false;
+        return d;
+    }
     const HostTensor* t = find(h, name);
     if (!t) { set_error("missing tensor " + name); ok = false; return nullptr; }
     if (t->shape != shape) { set_error("bad shape for " + name); ok = false; return nullptr; }
@@ -161,9 +177,8 @@ int split_weights(at_w2vbert* h, int scheme) {
         const int ns[8] = {kFfn, kHid, kFfn, kHid, 3 * kHid, kHid, 2 * kHid, kHid}, ks[8] = {kHid, kFfn, kHid, kFfn, kHid, kHid, kHid, kHid};
         for (int j = 0; j < 8; ++j) {
             const int n = ns[j], k = ks[j];
-            piece_t* d = nullptr;
-            AT_CHECK_HIP(hipMalloc((void**)&d, (size_t)np * n * k * sizeof(piece_t)));
-            h->allocs.push_back(reinterpret_cast<float*>(d));
+            piece_t* d = static_cast<piece_t*>(h->arena.alloc((size_t)np * n * k * sizeof(piece_t)));
+            if (!d) return -1;
             float sc = 1.0f;
             if (scheme == XB_SCHEME_F16X2) {
                 auto it = h->wmax.find(src[j]);
@@ -171,12 +186,14 @@ int split_weights(at_w2vbert* h, int scheme) {
                 sc = xb_weight_scale(it->second);
                 L.wscale[j] = sc;
             }
-            if (int rc = launch_split_blocked(src[j], k, n, n, k, d, nullptr, scheme, sc, nullptr)) return rc;
+            if (!h->arena.importing)   // import_packed: the pieces are in the blob
+                if (int rc = launch_split_blocked(src[j], k, n, n, k, d, nullptr, scheme, sc, nullptr)) return rc;
             L.ws[scheme][j] = d;
         }
     }
     AT_CHECK_HIP(hipDeviceSynchronize());
     h->split_done[scheme] = true;
+    h->split_seq.push_back(scheme);
     return 0;
 }
 
@@ -225,15 +242,19 @@ int at_w2vbert_set_tensor(at_w2vbert_t* h, const char* name, const float* host_d
     return 0;
 }
 
-int at_w2vbert_finalize(at_w2vbert_t* h) {
-    AT_REQUIRE(h && !h->finalized, "bad handle");
-    DeviceGuard guard(h->device);
-    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+// finalize(): staged host tensors -> device. With the arena in import mode (at_w2vbert_import_packed) the same code REPLAYS the allocation order over
+// the packed blob: no host tensor is read, nothing is uploaded or split — only the pointers and scales are rebuilt.
+static int finalize_impl(at_w2vbert* h) {
+    const bool imp = h->arena.importing;
     bool ok = true;
     // ---- front-end tables --------------------------------------------------------------------
     h->window = take(h, "frontend.window", {kFrame}, ok);
     if (!ok) return -1;
-    {
+    if (imp) {
+        h->melw = reserve(h, (size_t)kMel * kImOff);
+        h->dft64 = static_cast<double*>(h->arena.alloc((size_t)kSpecLd * kFrame * sizeof(double)));
+        AT_REQUIRE(h->melw && h->dft64, "import_packed: front-end tables");
+    } else {
         const HostTensor* mf = find(h, "frontend.mel_filters");
         AT_REQUIRE(mf && mf->shape == (std::vector<int64_t>{257, kMel}), "frontend.mel_filters [257,80] missing");
         std::vector<float> m((size_t)kMel * kImOff, 0.f);
@@ -249,9 +270,9 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
                 d[(size_t)k * kFrame + t] = std::cos(ang);
                 d[(size_t)(kImOff + k) * kFrame + t] = -std::sin(ang);
             }
-        AT_CHECK_HIP(hipMalloc((void**)&h->dft64, d.size() * sizeof(double)));
+        h->dft64 = static_cast<double*>(h->arena.alloc(d.size() * sizeof(double)));
+        AT_REQUIRE(h->melw != nullptr && h->dft64 != nullptr, "device allocation failed (front-end tables)");
         AT_CHECK_HIP(hipMemcpy(h->dft64, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice));
-        AT_REQUIRE(h->melw != nullptr, "device allocation failed (front-end tables)");
     }
     // ---- feature projection ------------------------------------------------------------------
     h->fp_ln_g = take(h, "feature_projection.layer_norm.weight", {kFeat}, ok);
@@ -260,8 +281,8 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
     h->fp_b = take(h, "feature_projection.projection.bias", {kHid}, ok);
     if (!ok) return -1;
     // ---- conformer layers ----------------------------------------------------------------------
-    int nl = 0;
-    while (find(h, "encoder.layers." + std::to_string(nl) + ".ffn1_layer_norm.weight")) ++nl;
+    int nl = imp ? h->imp.n_layers : 0;
+    while (!imp && find(h, "encoder.layers." + std::to_string(nl) + ".ffn1_layer_norm.weight")) ++nl;
     for (int i = 0; i < nl; ++i) {
         const std::string p = "encoder.layers." + std::to_string(i);
         LayerW L{};
@@ -274,7 +295,12 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
         L.ln_att_g = take(h, p + ".self_attn_layer_norm.weight", {kHid}, ok);
         L.ln_att_b = take(h, p + ".self_attn_layer_norm.bias", {kHid}, ok);
         if (!ok) return -1;
-        {
+        if (imp) {
+            L.wqkv = reserve(h, (size_t)3 * kHid * kHid);
+            L.bqkv = reserve(h, (size_t)3 * kHid);
+            L.dist = reserve(h, (size_t)80 * 64);
+            AT_REQUIRE(L.wqkv && L.bqkv && L.dist, "import_packed: attention tensors");
+        } else {
             std::vector<float> w((size_t)3 * kHid * kHid), b((size_t)3 * kHid);
             const char* nm[3] = {"linear_q", "linear_k", "linear_v"};
             for (int j = 0; j < 3; ++j) {
@@ -299,7 +325,11 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
         L.ln_conv_g = take(h, p + ".conv_module.layer_norm.weight", {kHid}, ok);
         L.ln_conv_b = take(h, p + ".conv_module.layer_norm.bias", {kHid}, ok);
         if (!ok) return -1;
-        {
+        if (imp) {
+            L.pw1 = reserve(h, (size_t)2 * kHid * kHid);
+            L.dw = reserve(h, (size_t)31 * kHid);
+            AT_REQUIRE(L.pw1 && L.dw, "import_packed: conv-module tensors");
+        } else {
             const HostTensor* pw = find(h, p + ".conv_module.pointwise_conv1.weight");
             AT_REQUIRE(pw && pw->shape == (std::vector<int64_t>{2 * kHid, kHid, 1}), "pointwise_conv1 [2048,1024,1] missing");
             std::vector<float> w((size_t)2 * kHid * kHid);
@@ -334,7 +364,13 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
             it = it->first.compare(0, p.size() + 1, p + ".") == 0 ? h->staged.erase(it) : std::next(it);
     }
     // ---- VQ codebook (state-dict key _codebook.embed [1, 2048, 1024], reference audiotoken/utils.py:331-339) ---
-    if (const HostTensor* cb = find(h, "vq._codebook.embed")) {
+    if (imp) {
+        if (h->imp.flags & 1) {
+            h->codebook = reserve(h, (size_t)kCodes * kHid);
+            h->e2 = reserve(h, kCodes);
+            AT_REQUIRE(h->codebook && h->e2, "import_packed: code book");
+        }
+    } else if (const HostTensor* cb = find(h, "vq._codebook.embed")) {
         AT_REQUIRE((cb->shape == std::vector<int64_t>{1, kCodes, kHid}) || (cb->shape == std::vector<int64_t>{kCodes, kHid}),
                    "vq._codebook.embed must be [1,2048,1024]");
         h->codebook = upload(h, cb->data);
@@ -353,7 +389,9 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
         AT_REQUIRE(h->codebook && h->e2, "device allocation failed (codebook)");
     }
     h->staged.clear();
-    {
+    if (imp) {
+        h->arith = h->imp.arith;
+    } else {
         h->arith = ARITH_F16X2;
         if (const char* e = std::getenv("AUDIOTOKEN_SEMANTIC_ARITH")) {
             const std::string v(e);
@@ -361,22 +399,64 @@ int at_w2vbert_finalize(at_w2vbert_t* h) {
             h->arith = v == "f32" ? ARITH_F32 : v == "bf16x3" ? ARITH_BF16X3 : ARITH_F16X2;
         }
     }
-    if (h->arith != ARITH_F32)
+    if (imp) {
+        // the exporter's splits in ITS order (flags bits 1-2 = count, bits 3.. = one bit per split: 1 = bf16x3). Normally one: the default scheme at
+        // finalize; two when the per-batch range fallback had run there (the other scheme is split lazily, and the handle's current arithmetic may be either)
+        const int n = (h->imp.flags >> 1) & 3;
+        for (int i = 0; i < n; ++i)
+            if (int rc = split_weights(h, ((h->imp.flags >> (3 + i)) & 1) ? XB_SCHEME_BF16X3 : XB_SCHEME_F16X2)) return rc;
+    } else if (h->arith != ARITH_F32) {
         if (int rc = split_weights(h, h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
-    if (!host_only_test() && !h->range_tab) {
+    }
+    if (!host_only_test() && !h->range_tab) {   // run-time state, not part of the packed model
         AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, 64 * sizeof(int)));
-        h->allocs.push_back(reinterpret_cast<float*>(h->range_tab));
         AT_CHECK_HIP(hipMemset(h->range_tab, 0, 64 * sizeof(int)));
     }
     h->finalized = true;
     return 0;
 }
 
+int at_w2vbert_finalize(at_w2vbert_t* h) {
+    AT_REQUIRE(h && !h->finalized, "bad handle");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    return finalize_impl(h);
+}
+
+// ---- the finalized model as one device blob (packed_model.h) ------------------------------------------------------------------------------
+static int packed_flags(const at_w2vbert* h) {
+    int f = (h->codebook ? 1 : 0) | ((int)h->split_seq.size() << 1);
+    for (size_t i = 0; i < h->split_seq.size(); ++i) f |= (h->split_seq[i] == XB_SCHEME_BF16X3 ? 1 : 0) << (3 + i);
+    return f;
+}
+int64_t at_w2vbert_packed_bytes(at_w2vbert_t* h) {
+    if (!h || !h->finalized) { set_error("at_w2vbert_packed_bytes: model not finalized"); return -1; }
+    return (int64_t)h->arena.packed_bytes();
+}
+int64_t at_w2vbert_packed_meta(at_w2vbert_t* h, void* host_dst, int64_t cap) {
+    if (!h || !h->finalized) { set_error("at_w2vbert_packed_meta: model not finalized"); return -1; }
+    return packed_write_meta(h->arena, PACKED_MODEL_W2VBERT, (int)h->layers.size(), packed_flags(h), h->arith, host_dst, cap);
+}
+int at_w2vbert_export_packed(at_w2vbert_t* h, void* device_dst, int64_t bytes, void* stream) {
+    AT_REQUIRE(h && h->finalized, "at_w2vbert_export_packed: model not finalized");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    return packed_export(h->arena, device_dst, bytes, (hipStream_t)stream);
+}
+int at_w2vbert_import_packed(at_w2vbert_t* h, const void* host_meta, int64_t meta_bytes, const void* device_src, int64_t bytes, void* stream) {
+    AT_REQUIRE(h && !h->finalized && h->staged.empty(), "at_w2vbert_import_packed needs a fresh handle (no set_tensor, no finalize)");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    if (int rc = packed_begin_import(h->arena, PACKED_MODEL_W2VBERT, host_meta, meta_bytes, device_src, bytes, (hipStream_t)stream, &h->imp)) return rc;
+    if (int rc = finalize_impl(h)) { h->arena.importing = false; return rc; }
+    return packed_end_import(h->arena);
+}
+
 void at_w2vbert_destroy(at_w2vbert_t* h) {
     if (!h) return;
     DeviceGuard guard(h->device);   // restores the caller's current device (destroy runs from garbage collection in Python)
-    for (float* p : h->allocs) (void)hipFree(p);
-    if (h->dft64) (void)hipFree(h->dft64);
+    h->arena.free_all();
+    if (h->range_tab) (void)hipFree(h->range_tab);
     delete h;
 }
 
@@ -508,9 +588,11 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             // FFN GEMM's swish epilogue, the attention kernel's context and the depthwise-conv kernel's output — so no fp32 activation is
             // written only to be re-read by a split pass.
             const float as = sc.act_scale();
-            prof.begin("layernorm", 1, stream);
-            if (int rc = launch_layernorm_split(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_FFN1), stream)) return rc;
-            prof.end(stream);
+            if (li == 0) {   // layers > 0: the previous layer's final LayerNorm wrote these pieces in the same pass (launch_layernorm2_split below)
+                prof.begin("layernorm", 1, stream);
+                if (int rc = launch_layernorm_split(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_FFN1), stream)) return rc;
+                prof.end(stream);
+            }
             prof.begin("ffn", 2, stream);
             if (int rc = gemm_split(sc, t1s, L, W_1A, L.b1a, kFfn, kHid, M, Mpad, XB_EPI_SWISH_SPLIT, 1.f, nullptr, nullptr, kFfn, bigs, stream)) return rc;
             if (int rc = gemm_split(sc, bigs, L, W_1B, L.b1b, kHid, kFfn, M, Mpad, XB_EPI_LINEAR, 0.5f, x, x, kHid, nullptr, stream)) return rc;
@@ -562,7 +644,14 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             if (int rc = gemm_split(sc, bigs, L, W_2B, L.b2b, kHid, kFfn, M, Mpad, XB_EPI_LINEAR, 0.5f, x, x, kHid, nullptr, stream)) return rc;
             prof.end(stream);
             prof.begin("layernorm", 1, stream);
-            if (int rc = launch_layernorm(x, L.ln_fin_g, L.ln_fin_b, nullptr, x, M, kHid, stream)) return rc;
+            if (li + 1 < n_layers) {
+                // final_layer_norm of this layer and ffn1_layer_norm of the next in ONE pass over the residual stream: x = LN(x) as fp32 rows and
+                // t1s = split(LN'(x)) (bit-identical to the two launches; saves one read of x per layer)
+                const LayerW& Ln = h->layers[li + 1];
+                if (int rc = launch_layernorm2_split(x, L.ln_fin_g, L.ln_fin_b, x, Ln.ln_ffn1_g, Ln.ln_ffn1_b, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_FFN1), stream)) return rc;
+            } else if (int rc = launch_layernorm(x, L.ln_fin_g, L.ln_fin_b, nullptr, x, M, kHid, stream)) {
+                return rc;
+            }
             prof.end(stream);
             continue;
         }

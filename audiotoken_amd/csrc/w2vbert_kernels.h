@@ -26,6 +26,8 @@ int launch_relpos_attention_x3(const float* qkv, const float* amask, const float
 int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,
                            hipStream_t stream, __bf16* pieces = nullptr, long long rows_pad = 0, int scheme = 0, float scale = 1.0f, int* status = nullptr);
 // LayerNorm(1024) written as operand pieces [NP][64][rows_pad][16] of `scheme` (times `scale`); y != nullptr: also as fp32 [rows][1024]
+int launch_layernorm2_split(const float* x, const float* gamma, const float* beta, float* y, const float* gamma2, const float* beta2, __bf16* out, long long rows,
+                            long long rows_pad, int D, int scheme, float scale, int* status, hipStream_t stream);
 int launch_layernorm_split(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, __bf16* out, long long rows, long long rows_pad,
                            int D, int scheme, float scale, int* status, hipStream_t stream);
 int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,

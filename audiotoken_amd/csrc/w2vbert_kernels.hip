@@ -313,10 +313,14 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, cons
 constexpr int LNS_ROWS = 8, LNS_D = 1024;    // rows per workgroup: 2 per wave (32 KB of LDS with two pieces: four workgroups per CU)
 constexpr int LNS_RW = LNS_ROWS / 4;          // rows per wave
 
-template <class SC, bool WRITE_Y>
+// DOUBLE: two LayerNorms back to back — y = LN(x; gamma, beta) is written as fp32 rows (WRITE_Y) and the pieces are split(LN(y; gamma2, beta2)). That is the
+// conformer's final_layer_norm followed by the next layer's ffn1_layer_norm (w2vbert.hip): one pass over the residual stream instead of two (y is not read
+// back). Each LayerNorm reduces exactly as layernorm_kernel / the single form do (same lane mapping, same sums): bit-identical to the two launches.
+template <class SC, bool WRITE_Y, bool DOUBLE = false>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ row_mask, float* __restrict__ y, typename SC::T* __restrict__ out,
-                                                              long long rows, long long rows_pad, float scale, int* __restrict__ status) {
+                                                              long long rows, long long rows_pad, float scale, int* __restrict__ status,
+                                                              const float* __restrict__ gamma2 = nullptr, const float* __restrict__ beta2 = nullptr) {
     typedef typename SC::T PT;
     typedef typename SC::V4 V4;
     constexpr int NP = SC::NP;
@@ -346,40 +350,53 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
         f4 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = vall[rr][j];
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-        const float mean = s / (float)LNS_D;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f4 d = v[j] - mean;
-            q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
-        const float rstd = 1.0f / sqrtf(q / (float)LNS_D + 1e-5f);
-        const float shift = -rstd * mean;
         const bool zero = row >= rows || (row_mask && row_mask[row] == 0.f);
+        // v -> LayerNorm(v; g, bb) in place (torch's CPU operation order, as layernorm_kernel)
+        auto normalize = [&](const float* g_, const float* b_) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+            const float mean = s / (float)LNS_D;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f4 d = v[j] - mean;
+                q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+            const float rstd = 1.0f / sqrtf(q / (float)LNS_D + 1e-5f);
+            const float shift = -rstd * mean;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = lane + 64 * j;           // float4 index: columns 4c .. 4c + 3 = k-block c / 4, quarter c % 4
+                f4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = fmaf(v[j][k], rstd, shift);
+                if (g_) {
+                    const f4 g = reinterpret_cast<const f4*>(g_)[c];
+                    const f4 bb = reinterpret_cast<const f4*>(b_)[c];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = fmaf(o[k], g[k], bb[k]);
+                }
+                if (zero) o = f4{0.f, 0.f, 0.f, 0.f};
+                v[j] = o;
+            }
+        };
+        normalize(gamma, beta);
+        if constexpr (WRITE_Y)
+            if (row < rows) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) reinterpret_cast<f4*>(y + row * LNS_D)[lane + 64 * j] = v[j];
+            }
+        if constexpr (DOUBLE) normalize(gamma2, beta2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = lane + 64 * j;           // float4 index: columns 4c .. 4c + 3 = k-block c / 4, quarter c % 4
-            f4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = fmaf(v[j][k], rstd, shift);
-            if (gamma) {
-                const f4 g = reinterpret_cast<const f4*>(gamma)[c];
-                const f4 bb = reinterpret_cast<const f4*>(beta)[c];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = fmaf(o[k], g[k], bb[k]);
-            }
-            if (zero) o = f4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (WRITE_Y)
-                if (row < rows) reinterpret_cast<f4*>(y + row * LNS_D)[c] = o;
+            const int c = lane + 64 * j;
             V4 p[NP];
-            over |= split4<SC>(o, scale, p);
+            over |= split4<SC>(v[j], scale, p);
 #pragma unroll
             for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(&tile[i][c >> 2][lr][(c & 3) * 4]) = p[i];
         }
@@ -400,17 +417,32 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
         range_publish(status, status ? status + 1 : nullptr, over);
 }
 
+// y = LN(x; gamma, beta) as fp32 rows (y == x allowed: a wave reads its rows first) and out = split(LN(y; gamma2, beta2)): layernorm_split_kernel<.., DOUBLE>
+int launch_layernorm2_split(const float* x, const float* gamma, const float* beta, float* y, const float* gamma2, const float* beta2, __bf16* out, long long rows,
+                            long long rows_pad, int D, int scheme, float scale, int* status, hipStream_t stream) {
+    AT_REQUIRE(D == LNS_D && rows_pad >= rows && rows_pad % LNS_ROWS == 0 && out && y, "layernorm2_split: D must be 1024, rows_pad a multiple of 8");
+    const unsigned blocks = (unsigned)(rows_pad / LNS_ROWS);
+    if (scheme == XB_SCHEME_F16X2)
+        hipLaunchKernelGGL((layernorm_split_kernel<SchemeF16x2, true, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, (const float*)nullptr, y,
+                           reinterpret_cast<_Float16*>(out), rows, rows_pad, scale, status, gamma2, beta2);
+    else
+        hipLaunchKernelGGL((layernorm_split_kernel<SchemeBf16x3, true, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, (const float*)nullptr, y, out, rows,
+                           rows_pad, scale, status, gamma2, beta2);
+    AT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_layernorm_split(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, __bf16* out, long long rows, long long rows_pad,
                            int D, int scheme, float scale, int* status, hipStream_t stream) {
     AT_REQUIRE(D == LNS_D && rows_pad >= rows && rows_pad % LNS_ROWS == 0 && out, "layernorm_split: D must be 1024, rows_pad a multiple of 8");
     const unsigned blocks = (unsigned)(rows_pad / LNS_ROWS);
     if (scheme == XB_SCHEME_F16X2) {
         _Float16* o = reinterpret_cast<_Float16*>(out);
-        if (y) hipLaunchKernelGGL((layernorm_split_kernel<SchemeF16x2, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, o, rows, rows_pad, scale, status);
-        else hipLaunchKernelGGL((layernorm_split_kernel<SchemeF16x2, false>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, o, rows, rows_pad, scale, status);
+        if (y) hipLaunchKernelGGL((layernorm_split_kernel<SchemeF16x2, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, o, rows, rows_pad, scale, status, (const float*)nullptr, (const float*)nullptr);
+        else hipLaunchKernelGGL((layernorm_split_kernel<SchemeF16x2, false>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, o, rows, rows_pad, scale, status, (const float*)nullptr, (const float*)nullptr);
     } else {
-        if (y) hipLaunchKernelGGL((layernorm_split_kernel<SchemeBf16x3, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, out, rows, rows_pad, scale, status);
-        else hipLaunchKernelGGL((layernorm_split_kernel<SchemeBf16x3, false>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, out, rows, rows_pad, scale, status);
+        if (y) hipLaunchKernelGGL((layernorm_split_kernel<SchemeBf16x3, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, out, rows, rows_pad, scale, status, (const float*)nullptr, (const float*)nullptr);
+        else hipLaunchKernelGGL((layernorm_split_kernel<SchemeBf16x3, false>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, out, rows, rows_pad, scale, status, (const float*)nullptr, (const float*)nullptr);
     }
     AT_CHECK_HIP(hipGetLastError());
     return 0;

@@ -46,6 +46,28 @@ def broadcast_weights(weights: Optional[Dict[str, np.ndarray]], device: torch.de
     return out
 
 
+def broadcast_packed(packed, device: torch.device, dist=None, src: int = 0):
+    """Rank ``src`` holds ``(meta: bytes, blob: uint8 tensor)`` of a finalized model (``encoder.export_packed()``); every rank returns the pair, the blob
+    on ``device``. Two collectives: the sizes, then meta and blob as uint8 tensors — the blob goes device to device (backend "nccl" = RCCL over xGMI),
+    never through the host, and the receivers rebuild the model over it with ``Encoder(packed=...)`` instead of re-reading, re-folding, re-uploading
+    and re-splitting the checkpoint on every rank."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return packed
+    rank = dist.get_rank()
+    sizes = torch.tensor([len(packed[0]), packed[1].numel()] if rank == src else [0, 0], dtype=torch.int64, device=device)
+    dist.broadcast(sizes, src=src)
+    n_meta, n_blob = int(sizes[0].item()), int(sizes[1].item())
+    if rank == src:
+        meta_t = torch.frombuffer(bytearray(packed[0]), dtype=torch.uint8).to(device)
+        blob = packed[1].to(device)
+    else:
+        meta_t = torch.empty(n_meta, dtype=torch.uint8, device=device)
+        blob = torch.empty(n_blob, dtype=torch.uint8, device=device)
+    dist.broadcast(meta_t, src=src)
+    dist.broadcast(blob, src=src)
+    return bytes(meta_t.cpu().numpy().tobytes()), blob
+
+
 def gather_scalars(values: Sequence[float], device: torch.device, dist=None) -> List[List[float]]:
     """All-gather a few per-rank scalars (benchmark reporting only)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

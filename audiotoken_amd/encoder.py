@@ -264,7 +264,9 @@ class Wav2VecBertEncoder(torch.nn.Module):
     """Drop-in for reference ``Wav2VecBertEncoder`` with ``quantize=True`` (audiotoken/encoder.py:111-186)."""
 
     def __init__(self, config=None, device: str = "cuda:0", quantize: bool = True,
-                 weights: Optional[Union[str, Dict[str, np.ndarray]]] = None):
+                 weights: Optional[Union[str, Dict[str, np.ndarray]]] = None, packed=None):
+        """``packed`` = ``(meta, blob)`` from another rank's ``export_packed()`` (``distributed.broadcast_packed``): the finalized model is rebuilt
+        over that device blob — no checkpoint is read, nothing is uploaded or split here (``weights`` is ignored)."""
         super().__init__()
         from .configs import Wav2VecBertConfig
         config = config or Wav2VecBertConfig()
@@ -274,6 +276,13 @@ class Wav2VecBertEncoder(torch.nn.Module):
         self.lib = _cabi.load()
         self.device_index = _device_index(device)
         self.device = torch.device("cuda", self.device_index)
+        if packed is not None:
+            self.handle = self.lib.at_w2vbert_create(self.device_index)
+            if not self.handle:
+                raise _cabi.HipLibraryError(f"at_w2vbert_create failed: {_cabi.last_error()}")
+            _cabi.import_packed(self.lib, "w2vbert", self.handle, packed[0], packed[1].to(self.device))
+            self._finish_init()
+            return
         if weights is None:
             weights = config.weights
         if weights is None:
@@ -298,6 +307,13 @@ class Wav2VecBertEncoder(torch.nn.Module):
         for name, arr in tensors.items():
             _cabi.set_tensor(self.lib, self.lib.at_w2vbert_set_tensor, self.handle, name, arr)
         _cabi.check(self.lib.at_w2vbert_finalize(self.handle), "at_w2vbert_finalize")
+        self._finish_init()
+
+    def export_packed(self):
+        """(meta bytes, uint8 device blob): this finalized model for ``Wav2VecBertEncoder(packed=...)`` on the other ranks of a node."""
+        return _cabi.export_packed(self.lib, "w2vbert", self.handle, self.device)
+
+    def _finish_init(self) -> None:
         self.n_layers = self.lib.at_w2vbert_num_layers(self.handle)
         if self.n_layers < self.output_layer:
             raise ValueError(f"checkpoint has {self.n_layers} conformer layers, output_layer={self.output_layer} needs that many")

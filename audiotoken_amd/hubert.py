@@ -68,7 +68,8 @@ class HubertEncoder(torch.nn.Module):
     """Drop-in for reference ``HubertEncoder`` (audiotoken/encoder.py:60-108)."""
 
     def __init__(self, config: HubertEncoderConfig = None, device: str = "cuda:0", quantize: bool = True,
-                 weights: Optional[Union[str, Dict[str, np.ndarray]]] = None):
+                 weights: Optional[Union[str, Dict[str, np.ndarray]]] = None, packed=None):
+        """``packed`` = ``(meta, blob)`` from another rank's ``export_packed()``: the finalized model is rebuilt over that device blob (``weights`` is ignored)."""
         super().__init__()
         config = config or HubertEncoderConfig()
         self.config = config
@@ -77,6 +78,13 @@ class HubertEncoder(torch.nn.Module):
         self.lib = _cabi.load()
         self.device_index = _device_index(device)
         self.device = torch.device("cuda", self.device_index)
+        if packed is not None:
+            self.handle = self.lib.at_hubert_create(self.device_index)
+            if not self.handle:
+                raise _cabi.HipLibraryError(f"at_hubert_create failed: {_cabi.last_error()}")
+            _cabi.import_packed(self.lib, "hubert", self.handle, packed[0], packed[1].to(self.device))
+            self._finish_init()
+            return
         if weights is None:
             weights = config.weights
         if weights is None:
@@ -90,6 +98,13 @@ class HubertEncoder(torch.nn.Module):
         for name, arr in fold_hubert_weights(weights, self.output_layer).items():
             _cabi.set_tensor(self.lib, self.lib.at_hubert_set_tensor, self.handle, name, arr)
         _cabi.check(self.lib.at_hubert_finalize(self.handle), "at_hubert_finalize")
+        self._finish_init()
+
+    def export_packed(self):
+        """(meta bytes, uint8 device blob): this finalized model for ``HubertEncoder(packed=...)`` on the other ranks of a node."""
+        return _cabi.export_packed(self.lib, "hubert", self.handle, self.device)
+
+    def _finish_init(self) -> None:
         if self.lib.at_hubert_num_layers(self.handle) < self.output_layer:
             raise ValueError(f"checkpoint has too few transformer layers for output_layer={self.output_layer}")
         self._ws: Optional[torch.Tensor] = None

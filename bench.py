@@ -289,8 +289,13 @@ def run_hubert(args, rank, world, dev, dist):
     nl, B, secs = 11, args.hub_batch, args.sem_seconds
     N = int(round(secs * 16000))
     weights = W.synth_hubert_weights(n_layers=nl, seed=0, with_kmeans=True) if rank == 0 else None
-    weights = broadcast_weights(weights, dev, dist)
-    enc = HubertEncoder(HubertEncoderConfig(output_layer=nl), device=str(dev), quantize=True, weights=weights)
+    enc = HubertEncoder(HubertEncoderConfig(output_layer=nl), device=str(dev), quantize=True, weights=weights) if rank == 0 else None
+    if world > 1:   # the finalized model travels as one device blob (as semantic_m)
+        from audiotoken_amd.distributed import broadcast_packed
+        packed = broadcast_packed(enc.export_packed() if rank == 0 else None, dev, dist)
+        if rank != 0:
+            enc = HubertEncoder(HubertEncoderConfig(output_layer=nl), device=str(dev), quantize=True, packed=packed)
+        del packed
     del weights
     from audiotoken_amd import synthetic as S
     wav = S.semantic_s_batch(B, N, dev, rank)
@@ -670,14 +675,32 @@ def setup_semantic(args, rank, world, dev, dist):
     nl = args.sem_layers
     B, secs = args.sem_batch, args.sem_seconds
     N = int(round(secs * 16000))
+    # weights: rank 0 generates, finalizes (fold, upload, split on its device) and exports the finalized model as ONE device blob; the other ranks
+    # receive it by one RCCL broadcast and rebuild the handle over it (at_w2vbert_import_packed): no D2H copy, no second host pass
     weights = W.synth_w2vbert_weights(n_layers=nl, seed=0, with_vq=True) if rank == 0 else None
+    enc, packed, export_ms = None, None, 0.0
     t0 = time.perf_counter()
-    weights = broadcast_weights(weights, dev, dist)
-    bcast_ms = (time.perf_counter() - t0) * 1e3
-    t0 = time.perf_counter()
-    enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=nl), device=str(dev), quantize=True, weights=weights)
-    torch.cuda.synchronize()
+    if rank == 0:
+        enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=nl), device=str(dev), quantize=True, weights=weights)
+        torch.cuda.synchronize()
     finalize_ms = (time.perf_counter() - t0) * 1e3
+    bcast_ms = 0.0
+    if world > 1:
+        from audiotoken_amd.distributed import broadcast_packed
+        t0 = time.perf_counter()
+        if rank == 0:
+            packed = enc.export_packed()
+        export_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        packed = broadcast_packed(packed, dev, dist)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+        if rank != 0:
+            t0 = time.perf_counter()
+            enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=nl), device=str(dev), quantize=True, packed=packed)
+            torch.cuda.synchronize()
+            finalize_ms = (time.perf_counter() - t0) * 1e3    # import: one D2D copy + pointer rebuild
+        del packed
     wav = S.semantic_m_batch(B, N, dev, rank)
     mask = torch.ones_like(wav)
     enc._bench_inputs = (wav, mask)
@@ -686,7 +709,7 @@ def setup_semantic(args, rank, world, dev, dist):
     enc.enable_profile(False)
     fallback, status = settle_status(enc, call, "semantic_m")
     return {"name": "semantic_m", "enc": enc, "call": call, "wav": wav, "mask": mask, "weights": weights if rank == 0 else None, "audio_s": B * secs, "B": B, "N": N, "nl": nl,
-            "secs": secs, "broadcast_ms": bcast_ms, "finalize_ms": finalize_ms, "fallback_batches_per_step": fallback, "fallback_status": status}
+            "secs": secs, "broadcast_ms": bcast_ms, "finalize_ms": finalize_ms, "export_ms": export_ms, "fallback_batches_per_step": fallback, "fallback_status": status}
 
 
 def report_semantic(wl, args, rank, world, dev, dist):
@@ -713,7 +736,8 @@ def report_semantic(wl, args, rank, world, dev, dist):
     res = {
         "value": round(world * B * secs / (ms * 1e-3), 2), "unit": "audio-s/s", "ms_per_step": round(ms, 3),
         "median_ms_per_step": round(median(wl["per_step_ms"]), 3), "rank_ms": rank_ms,
-        "broadcast_ms": round(wl["broadcast_ms"], 1), "finalize_ms": round(wl["finalize_ms"], 1),
+        "broadcast_ms": round(wl["broadcast_ms"], 1), "finalize_ms": round(max_over_ranks(wl["finalize_ms"], dev, dist), 1), "export_ms": round(wl["export_ms"], 1),
+        "startup_note": "finalize_ms = max over ranks (rank 0: checkpoint -> device; others: import of the broadcast blob); broadcast_ms = the packed device blob over RCCL",
         "dtype": {0: "f32", 1: "f32 (linear layers: three bf16 pieces per operand, six MFMA products, fp32 accumulate)",
                   2: "f32 (linear layers: two fp16 pieces per operand, three MFMA products, fp32 accumulate)"}[arith],
         "config": {"workload": f"Tokenizers.semantic_m encode, {B} clips x {secs:g} s @16 kHz per GPU, {nl} conformer layers, VQ 2048x1024 (BASELINE configs[3] per-GPU share)",

@@ -139,6 +139,21 @@ at_w2vbert_t* at_w2vbert_create(int device_id);
  * tables of reference processors.py:66-78: "frontend.window" [400], "frontend.mel_filters" [257,80]. */
 int at_w2vbert_set_tensor(at_w2vbert_t* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
 int at_w2vbert_finalize(at_w2vbert_t* h);
+/* The finalized model as ONE device blob, for start-up at N > 1 (weights cross xGMI once): one rank reads, folds, uploads and splits
+ * the checkpoint and exports; the others import what one RCCL broadcast delivered — no D2H copy, no second host pass over 1.8 GB, no split kernels.
+ * (The reference has no counterpart: audiotoken/core.py:66 is single-device; every process would call from_pretrained itself.)
+ *   packed_bytes(h)                       size of the blob of a finalized handle (-1: not finalized)
+ *   packed_meta(h, host_dst, cap)         the host-side record (block sizes, max |w| per tensor, layer count, arithmetic): returns its size, writes it
+ *                                         when cap is large enough (call with NULL / 0 first)
+ *   export_packed(h, device_dst, bytes, stream)   concatenate the handle's device allocations into device_dst (stream-ordered D2D copies)
+ *   import_packed(h, meta, meta_bytes, device_src, bytes, stream)   on a FRESH handle (create only): copy the blob into one allocation owned by the handle
+ *                                         and rebuild the model over it; the handle is finalized afterwards, device_src may be freed. Fails (-1,
+ *                                         at_last_error) when the record does not match this build's allocation order / sizes.
+ * Both sides must be the same build of this library on the same architecture; the blob is not a file format. */
+int64_t at_w2vbert_packed_bytes(at_w2vbert_t* h);
+int64_t at_w2vbert_packed_meta(at_w2vbert_t* h, void* host_dst, int64_t cap);
+int at_w2vbert_export_packed(at_w2vbert_t* h, void* device_dst, int64_t bytes, void* stream);
+int at_w2vbert_import_packed(at_w2vbert_t* h, const void* host_meta, int64_t meta_bytes, const void* device_src, int64_t bytes, void* stream);
 void at_w2vbert_destroy(at_w2vbert_t* h);
 int at_w2vbert_num_layers(const at_w2vbert_t* h);
 
@@ -182,6 +197,11 @@ at_hubert_t* at_hubert_create(int device_id);
  * "encoder.pos_conv_embed.conv.weight" [768,48,128]; "kmeans.cluster_centers_" [1000,768] (optional "kmeans.c2" [1000]). */
 int at_hubert_set_tensor(at_hubert_t* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
 int at_hubert_finalize(at_hubert_t* h);
+/* the finalized model as one device blob: as at_w2vbert_packed_bytes / _packed_meta / _export_packed / _import_packed above */
+int64_t at_hubert_packed_bytes(at_hubert_t* h);
+int64_t at_hubert_packed_meta(at_hubert_t* h, void* host_dst, int64_t cap);
+int at_hubert_export_packed(at_hubert_t* h, void* device_dst, int64_t bytes, void* stream);
+int at_hubert_import_packed(at_hubert_t* h, const void* host_meta, int64_t meta_bytes, const void* device_src, int64_t bytes, void* stream);
 void at_hubert_destroy(at_hubert_t* h);
 int at_hubert_num_layers(const at_hubert_t* h);
 /* T = chained floor((L - k)/s) + 1 over the 7 feature-extractor convs (HF modeling_hubert.py:664-677). */

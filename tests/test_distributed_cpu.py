@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from audiotoken_amd.distributed import broadcast_weights, gather_scalars, shard_indices
+from audiotoken_amd.distributed import broadcast_packed, broadcast_weights, gather_scalars, shard_indices
 
 
 def _worker(rank, world, port, tmp):
@@ -25,6 +25,10 @@ def _worker(rank, world, port, tmp):
         mine = shard_indices(11, rank, world)
         allv = gather_scalars([float(len(mine)), float(sum(mine))], torch.device("cpu"), dist)
         assert sum(v[0] for v in allv) == 11 and sum(v[1] for v in allv) == sum(range(11))
+        # the finalized model as (host record, one blob): every rank ends with rank 0's bytes (blob on the device given; CPU tensors here)
+        meta0, blob0 = bytes(range(200)) * 3, torch.arange(100003, dtype=torch.int64).to(torch.uint8)
+        meta, blob = broadcast_packed((meta0, blob0) if rank == 0 else None, torch.device("cpu"), dist)
+        assert meta == meta0 and blob.dtype == torch.uint8 and torch.equal(blob, blob0)
         np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array(mine))
     finally:
         dist.destroy_process_group()
