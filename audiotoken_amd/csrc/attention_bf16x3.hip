@@ -62,11 +62,16 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
     constexpr float S_SCALE2 = AX_SCALE2 / (XS * XS);
     RangeMax over;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    PT* Ks = reinterpret_cast<PT*>(smem_raw);                    // [NP][32 keys][72]
-    PT* Vt = Ks + AX_K_ELEMS;                                    // [NP][64 d][40], keys permuted inside each 16-group
-    float* QE = reinterpret_cast<float*>(Vt + AX_V_ELEMS);       // [128 queries][81]: log2(e)/8 * q.E[bucket]
-    float* kb = QE + AX_QB * AX_QE_LD;                           // [32] additive key bias: 0 / finfo.min (padded) / -inf (beyond T)
-    int* kb_any = reinterpret_cast<int*>(kb + AX_KB);
+    // KVP: the K / V tile, its key bias and its any-masked flag are DOUBLE-buffered (tile kt + 1 is written while tile kt is consumed: one barrier per
+    // tile instead of two — the first one cost ~280 of ~3500 cycles per tile, tools/ax_stamps.sh). Two workgroups per CU must still fit 160 KB, so the
+    // rel-pos table keeps only the 73 buckets that are read (row stride 75 instead of the 80 columns the MFMA tiles produce + 1): 81 680 B.
+    constexpr int NBUF = KVP ? 2 : 1;
+    constexpr int QE_LD = KVP ? 75 : AX_QE_LD;
+    constexpr int AX_KV_ELEMS = AX_K_ELEMS + AX_V_ELEMS;
+    PT* Ks0 = reinterpret_cast<PT*>(smem_raw);                   // [NBUF][ K [NP][32 keys][72] | V ]
+    float* QE = reinterpret_cast<float*>(Ks0 + NBUF * AX_KV_ELEMS);   // [128 queries][QE_LD]: log2(e)/8 * q.E[bucket]
+    float* kb0 = QE + AX_QB * QE_LD;                             // [NBUF][32] additive key bias: 0 / finfo.min (padded) / -inf (beyond T)
+    int* kb_any0 = reinterpret_cast<int*>(kb0 + NBUF * AX_KB);   // [NBUF]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, hh = lane >> 5;
     // 1-D grid, XCD-aware: workgroups g and g + 8 share an XCD (round-robin dispatch; speed only), so XCD x takes a contiguous range of
@@ -110,9 +115,10 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[c][e], qf[i][c][e], acc, 0, 0, 0);
-                float* dst = QE + (wave * 32 + i * 16 + r16) * AX_QE_LD + bt * 16 + qd * 4;
+                float* dst = QE + (wave * 32 + i * 16 + r16) * QE_LD + bt * 16 + qd * 4;
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) dst[reg] = AX_SCALE2 * acc[reg];
+                for (int reg = 0; reg < 4; ++reg)
+                    if (bt * 16 + qd * 4 + reg < QE_LD) dst[reg] = AX_SCALE2 * acc[reg];
             }
         }
     }
@@ -186,16 +192,11 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
         const int rr = kt * AX_KB + (tid & 31);
         am = amask[rowbase + (rr < T ? rr : T - 1)];
     };
-    prefetch(0);
-#ifdef AX_DEBUG_STAMPS
-    unsigned long long ax_d[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long ax_begin = __builtin_readcyclecounter();
-#endif
-    for (int kt = 0; kt < nkt; ++kt) {
+    // registers (tile kt's prefetch) -> LDS buffer `buf`: K / V pieces or fp32 rows split here, the key bias and its any-masked flag
+    auto stage = [&](int kt, int buf) {
         const int r0 = kt * AX_KB;
-        AX_T(0);
-        __syncthreads();   // previous tile fully consumed (also orders the QE stores before first use)
-        AX_T(1);
+        PT* Ks = Ks0 + buf * AX_KV_ELEMS;
+        PT* Vt = Ks + AX_K_ELEMS;
         if constexpr (KVP) {
             PT* kd = Ks + sk_key * AX_KLD + sk_d;
             PT* vd = Vt + sk_key * AX_VROW + sk_d;
@@ -230,19 +231,42 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
                 for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(vd + 8 * u + i * 64 * AX_VLD) = p4[i];
             }
         }
-        {
-            if (tid < AX_KB) {
-                const int rr = r0 + tid;
-                const float kbv = rr < T ? (am != 0.f ? 0.f : FMIN) : -INFINITY;
-                kb[tid] = kbv;
-                const unsigned long long anyb = __builtin_amdgcn_ballot_w64(kbv != 0.f);
-                if (tid == 0) kb_any[0] = anyb != 0ull ? 1 : 0;
-            }
+        if (tid < AX_KB) {
+            const int rr = r0 + tid;
+            const float kbv = rr < T ? (am != 0.f ? 0.f : FMIN) : -INFINITY;
+            kb0[buf * AX_KB + tid] = kbv;
+            const unsigned long long anyb = __builtin_amdgcn_ballot_w64(kbv != 0.f);
+            if (tid == 0) kb_any0[buf] = anyb != 0ull ? 1 : 0;
+        }
+    };
+    prefetch(0);
+    if constexpr (KVP) {   // prologue of the double-buffered form: tile 0 staged, tile 1 in flight
+        stage(0, 0);
+        if (nkt > 1) prefetch(1);
+        __syncthreads();   // (also orders the QE stores before first use)
+    }
+#ifdef AX_DEBUG_STAMPS
+    unsigned long long ax_d[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long ax_begin = __builtin_readcyclecounter();
+#endif
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int r0 = kt * AX_KB;
+        const int cur = KVP ? (kt & 1) : 0;
+        const PT* Ks = Ks0 + cur * AX_KV_ELEMS;
+        const PT* Vt = Ks + AX_K_ELEMS;
+        const float* kb = kb0 + cur * AX_KB;
+        AX_T(0);
+        if constexpr (!KVP) __syncthreads();   // previous tile fully consumed (also orders the QE stores before first use)
+        AX_T(1);
+        if constexpr (KVP) {
+            if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);   // the other buffer was last read before the barrier that ended the previous iteration
+        } else {
+            stage(kt, 0);
         }
         AX_T(2);
-        __syncthreads();
+        if constexpr (!KVP) __syncthreads();
         AX_T(3);
-        if (kt + 1 < nkt) prefetch(kt + 1);
+        if (kt + (KVP ? 2 : 1) < nkt) prefetch(kt + (KVP ? 2 : 1));
         AX_T(4);
         // ---- S^T = K . Q^T: lane holds s[r] = q_lq . k_(r0 + 8*(r/4) + 4*hh + r%4) ------------------------------------------------
         f16v s;
@@ -261,8 +285,8 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
         const bool far_left = (r0 + AX_KB - 1) - wl_min <= -64;
         const bool far_right = r0 - wl_max >= 8;
         const bool plain = far_left || far_right || !relpos;
-        const bool masked = __builtin_amdgcn_readfirstlane(kb_any[0]) != 0;
-        const float* qe = QE + (wave * 32 + l32) * AX_QE_LD;
+        const bool masked = __builtin_amdgcn_readfirstlane(kb_any0[cur]) != 0;
+        const float* qe = QE + (wave * 32 + l32) * QE_LD;
         const float c_far = relpos ? (far_left ? qe[0] : qe[72]) : 0.f;
         float mx = -INFINITY;
         if (plain && !masked) {
@@ -363,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
 #pragma unroll
                 for (int t = 0; t < SC::NPROD; ++t) oacc[dt] = SC::mfma(vf[SC::prod_a(t)], pp[SC::prod_w(t)][ks], oacc[dt]);
             }
+        if constexpr (KVP) __syncthreads();   // the next tile's buffer is complete and this one is free
         AX_T(8);
         AX_ACC(0, 0, 1); AX_ACC(1, 1, 2); AX_ACC(2, 2, 3); AX_ACC(3, 3, 4); AX_ACC(4, 4, 5); AX_ACC(5, 5, 6); AX_ACC(6, 6, 7); AX_ACC(7, 7, 8);
     }
@@ -396,7 +421,7 @@ static int launch_ax(const float* qkv, const float* amask, const float* dist_emb
                      __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces) {
     const long long nblk = (long long)((T + AX_QB - 1) / AX_QB) * heads * B;
     dim3 grid((unsigned)((nblk + 7) / 8 * 8));
-    constexpr size_t lds = KVP ? (size_t)(ax_k_elems<SC::NP>() + SC::NP * AX_KB * 96) * 2 + (size_t)(AX_QB * AX_QE_LD + AX_KB + 4) * 4 : ax_lds_bytes<SC::NP>();
+    constexpr size_t lds = KVP ? (size_t)2 * (ax_k_elems<SC::NP>() + SC::NP * AX_KB * 96) * 2 + (size_t)(AX_QB * 75 + 2 * AX_KB + 4) * 4 : ax_lds_bytes<SC::NP>();
     { static LdsAttrFlags lds_attr; if (int rc = set_max_dynamic_lds(lds_attr, relpos_attention_x3_kernel<SC, KVP>, lds)) return rc; }
     hipLaunchKernelGGL((relpos_attention_x3_kernel<SC, KVP>), grid, dim3(256), lds, stream, qkv, amask, dist_emb, ctx, T, heads * 64, status,
                        reinterpret_cast<typename SC::T*>(ctx_pieces), rows_pad, heads, B, reinterpret_cast<const typename SC::T*>(kv_pieces));
