@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
     prefetch(0);
     if constexpr (KVP) {   // prologue of the double-buffered form: tile 0 staged, tile 1 in flight
         stage(0, 0);
-        if (nkt > 1) prefetch(1);
+        prefetch(1);
         __syncthreads();   // (also orders the QE stores before first use)
     }
 #ifdef AX_DEBUG_STAMPS
@@ -259,14 +259,18 @@ __global__ __launch_bounds__(256, 2) void relpos_attention_x3_kernel(const float
         if constexpr (!KVP) __syncthreads();   // previous tile fully consumed (also orders the QE stores before first use)
         AX_T(1);
         if constexpr (KVP) {
-            if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);   // the other buffer was last read before the barrier that ended the previous iteration
+            // the other buffer was last read before the barrier that ended the previous iteration. Unconditional: past the last tile the stores land in
+            // a buffer nobody reads and the loads are clipped by the buffer descriptors (zeros) — no branch, so the LDS stores and the loads of the next
+            // tiles are scheduled among this tile's MFMAs instead of in a block of their own
+            stage(kt + 1, cur ^ 1);
         } else {
             stage(kt, 0);
         }
         AX_T(2);
         if constexpr (!KVP) __syncthreads();
         AX_T(3);
-        if (kt + (KVP ? 2 : 1) < nkt) prefetch(kt + (KVP ? 2 : 1));
+        if constexpr (KVP) prefetch(kt + 2);
+        else if (kt + 1 < nkt) prefetch(kt + 1);
         AX_T(4);
         // ---- S^T = K . Q^T: lane holds s[r] = q_lq . k_(r0 + 8*(r/4) + 4*hh + r%4) ------------------------------------------------
         f16v s;
