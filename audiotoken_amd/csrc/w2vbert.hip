@@ -74,6 +74,7 @@ struct at_w2vbert {
     int arith = ARITH_F16X2;   // linear layers: ARITH_* ($AUDIOTOKEN_SEMANTIC_ARITH = f32 | bf16x3 | f16x2; option "arith")
     bool split_done[2] = {false, false};
     std::map<const float*, float> wmax;   // max |w| of every uploaded tensor (the fp16 scheme's weight scales)
+    bool dwconv_stream = true;  // option "dwconv_stream": depthwise conv + LayerNorm + swish on the streaming kernel (dwconv_stream.hip)
     Profiler prof;
 };
 
@@ -506,6 +507,7 @@ int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value) {
         h->arith = value;
         return 0;
     }
+    if (n == "dwconv_stream") { h->dwconv_stream = value != 0; return 0; }
     set_error("at_w2vbert_set_option: unknown option " + n);
     return -1;
 }
@@ -513,6 +515,7 @@ int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value) {
 int at_w2vbert_get_option(const at_w2vbert_t* h, const char* name) {
     if (!h || !name) return -1;
     if (std::string(name) == "arith") return h->arith;
+    if (std::string(name) == "dwconv_stream") return h->dwconv_stream ? 1 : 0;
     return -1;
 }
 
@@ -632,7 +635,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             prof.end(stream);
             prof.begin("conv_module", 3, stream);
             if (int rc = gemm_split(sc, t1s, L, W_PW1, nullptr, 2 * kHid, kHid, M, Mpad, XB_EPI_GLU, 1.f, big, nullptr, kHid, nullptr, stream)) return rc;
-            if (int rc = launch_dwconv_ln_swish(big, L.dw, L.ln_dw_g, L.ln_dw_b, nullptr, B, T, stream, t1s, Mpad, sc.scheme, as, sc.site(WS_DWCONV))) return rc;
+            if (int rc = (h->dwconv_stream ? launch_dwconv_stream : launch_dwconv_ln_swish)(big, L.dw, L.ln_dw_g, L.ln_dw_b, nullptr, B, T, stream, t1s, Mpad, sc.scheme, as, sc.site(WS_DWCONV))) return rc;
             if (int rc = gemm_split(sc, t1s, L, W_PW2, nullptr, kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, x, x, kHid, nullptr, stream)) return rc;
             prof.end(stream);
 
@@ -674,7 +677,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
         prof.begin("conv_module", 4, stream);
         if (int rc = launch_layernorm(x, L.ln_conv_g, L.ln_conv_b, amask, t1, M, kHid, stream)) return rc;
         if (int rc = linear(t1, kHid, L.pw1, nullptr, big, 2 * kHid, M, EPI_GLU, 1.f, nullptr, nullptr, kHid, stream)) return rc;
-        if (int rc = launch_dwconv_ln_swish(big, L.dw, L.ln_dw_g, L.ln_dw_b, t1, B, T, stream)) return rc;
+        if (int rc = (h->dwconv_stream ? launch_dwconv_stream : launch_dwconv_ln_swish)(big, L.dw, L.ln_dw_g, L.ln_dw_b, t1, B, T, stream, nullptr, 0, 0, 1.0f, nullptr)) return rc;
         if (int rc = linear(t1, kHid, L.pw2, nullptr, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) return rc;
         prof.end(stream);
         prof.begin("ffn", 4, stream);
@@ -736,6 +739,12 @@ int at_op_dwconv_ln_swish(const float* g, const float* w31x1024, const float* ga
                           at_stream_t stream) {
     AT_REQUIRE(g && w31x1024 && gamma && beta && out && B >= 1 && T >= 1, "bad arguments");
     return launch_dwconv_ln_swish(g, w31x1024, gamma, beta, out, B, T, (hipStream_t)stream);
+}
+
+int at_op_dwconv_stream(const float* g, const float* w31x1024, const float* gamma, const float* beta, float* out, int B, int T,
+                        at_stream_t stream) {
+    AT_REQUIRE(g && w31x1024 && gamma && beta && out && B >= 1 && T >= 1, "bad arguments");
+    return launch_dwconv_stream(g, w31x1024, gamma, beta, out, B, T, (hipStream_t)stream);
 }
 
 int at_op_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, int64_t rows, int D, int C, at_stream_t stream) {

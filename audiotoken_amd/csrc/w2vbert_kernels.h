@@ -23,6 +23,10 @@ int launch_relpos_attention(const float* qkv, const float* amask, const float* d
 int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
                                int scheme, int* status, __bf16* ctx_pieces = nullptr, long long rows_pad = 0, const __bf16* kv_pieces = nullptr);
 // pieces != nullptr: the output is written as the K-blocked operand pieces [NP][64][rows_pad][16] of `scheme` (times `scale`) instead of fp32
+// the same op as a streaming kernel: one channel per thread walking along time, 16 waves per CU, every input row read once (dwconv_stream.hip);
+// bit-identical to launch_dwconv_ln_swish
+int launch_dwconv_stream(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T, hipStream_t stream,
+                         __bf16* pieces = nullptr, long long rows_pad = 0, int scheme = 0, float scale = 1.0f, int* status = nullptr);
 int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, const float* beta, float* out, int B, int T,
                            hipStream_t stream, __bf16* pieces = nullptr, long long rows_pad = 0, int scheme = 0, float scale = 1.0f, int* status = nullptr);
 // LayerNorm(1024) written as operand pieces [NP][64][rows_pad][16] of `scheme` (times `scale`); y != nullptr: also as fp32 [rows][1024]

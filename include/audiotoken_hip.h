@@ -180,7 +180,9 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
 /* Options. "arith": arithmetic of the eight linear layers per conformer layer — 0 = f32-input MFMA; 1 = "bf16x3": exact 3-way bf16
  * operand splits, six products on the bf16 matrix cores; 2 = "f16x2" (default, also $AUDIOTOKEN_SEMANTIC_ARITH=f32|bf16x3|f16x2): two fp16
  * pieces per operand, three products, operands pre-scaled by powers of two (fp32-class accuracy: csrc/gemm_bf16x3.h). Weights are split
- * for a scheme the first time it is selected. at_w2vbert_get_option returns the current value (or -1). */
+ * for a scheme the first time it is selected. "dwconv_stream" 1/0 (default 1): the conv module's depthwise conv + LayerNorm + swish as the streaming
+ * kernel (csrc/dwconv_stream.hip: one channel per thread walking along time) or the register-stationary one — bit-identical results, the option is
+ * the A/B twin the tests compare. at_w2vbert_get_option returns the current value (or -1). */
 int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value);
 int at_w2vbert_get_option(const at_w2vbert_t* h, const char* name);
 int at_w2vbert_profile(at_w2vbert_t* h, int enable);
@@ -293,6 +295,9 @@ int at_op_relpos_attention(const float* qkv, const float* attn_mask, const float
  * g [B*T][1024], w [31][1024]. */
 int at_op_dwconv_ln_swish(const float* g, const float* w31x1024, const float* gamma, const float* beta, float* out, int B, int T,
                           at_stream_t stream);
+/* the same op on the streaming kernel (csrc/dwconv_stream.hip); bit-identical to at_op_dwconv_ln_swish */
+int at_op_dwconv_stream(const float* g, const float* w31x1024, const float* gamma, const float* beta, float* out, int B, int T,
+                        at_stream_t stream);
 
 /* VQ assign from precomputed dots [rows][C]: argmax_n -sqrt(max(|x|^2 + e2[n] - 2 dots, 0)), first index. */
 int at_op_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, int64_t rows, int D, int C, at_stream_t stream);

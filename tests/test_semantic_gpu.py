@@ -137,6 +137,46 @@ def test_dwconv_ln_swish(cuda_device):
     assert (out.cpu().reshape(B, T, 1024) - ref).abs().max().item() < 5e-5
 
 
+@pytest.mark.parametrize("B,T", [(2, 77), (1, 8), (3, 5), (1, 1500), (5, 333), (64, 40)])
+def test_dwconv_stream_is_bit_identical(cuda_device, B, T):
+    """dwconv_stream.hip (one channel per thread walking along time, LayerNorm moments reduced over the register-stationary kernel's tree through LDS)
+    against dwconv_ln_swish_kernel: the outputs must be IDENTICAL — T below one 8-row iteration, not a multiple of it, several time segments per clip
+    (B = 1: 256 segments), one segment per clip (B = 64), inputs with large and tiny rows."""
+    lib = _cabi.load()
+    g = torch.from_numpy(prng.irwin_hall(f"dws.g{B}.{T}", (B, T, 1024), 1.0, 4))
+    g[0, : min(T, 3)] *= 1e3
+    g[-1, -1] *= 1e-6
+    w = torch.from_numpy(prng.uniform("dws.w", (31, 1024), -0.3, 0.3, 4))
+    gm = torch.from_numpy(prng.uniform("dws.gm", (1024,), 0.5, 1.5, 4))
+    bt = torch.from_numpy(prng.uniform("dws.bt", (1024,), -0.5, 0.5, 4))
+    gd, wd, gmd, btd = g.cuda(), w.cuda(), gm.cuda(), bt.cuda()
+    outs = []
+    for fn in (lib.at_op_dwconv_ln_swish, lib.at_op_dwconv_stream):
+        out = torch.full((B * T, 1024), float("nan"), device="cuda")
+        _cabi.check(fn(gd.data_ptr(), wd.data_ptr(), gmd.data_ptr(), btd.data_ptr(), out.data_ptr(), B, T, _stream(cuda_device)), "dwconv op")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert not torch.isnan(outs[1]).any()
+    diff = (outs[0] != outs[1]).sum().item()
+    assert diff == 0, f"{diff} of {outs[0].numel()} elements differ, max {(outs[0] - outs[1]).abs().max().item():.3e}"
+
+
+def test_dwconv_stream_option_keeps_tokens(enc3):
+    """The whole encoder with the streaming kernel (default) and with the register-stationary one: identical tokens and hidden states."""
+    enc, w = enc3
+    wav = torch.from_numpy(W.synth_waveform(3, 16000 * 3 + 123, 16000, seed=77)).cuda()
+    mask = torch.ones_like(wav)
+    mask[2, 30000:] = 0
+    try:
+        assert enc.get_option("dwconv_stream") == 1
+        t1 = enc(wav, mask)
+        enc.set_option("dwconv_stream", 0)
+        t0 = enc(wav, mask)
+        assert torch.equal(t1, t0)
+    finally:
+        enc.set_option("dwconv_stream", 1)
+
+
 def test_conformer_matches_hf_golden(enc3):
     enc, w = enc3
     g = np.load(os.path.join(G, "conformer_a.npz"))
