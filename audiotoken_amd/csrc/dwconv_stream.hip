@@ -32,11 +32,14 @@ constexpr int DS_C = 1024;
 __device__ __forceinline__ float ds_quad_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); }
 __device__ __forceinline__ float ds_quad_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)); }
 
-// the moment reduction over 1024 channels of DS_RB rows: v[i] = this thread's (channel's) term; leaves the four group totals of every row in red
-// (ds_total). sq / red: LDS scratch [DS_RB][256] / [DS_RB][4]. Two workgroup barriers. The 8 x 4 (row, 256-channel group) butterflies are done by ONE
-// wave each — lane = quad, exactly the register-stationary kernel's wave — two per wave: the LDS pipe carries ~16 operations per wave here instead of
-// the ~100 of a form in which every thread reduces its own copy (measured: that form made the kernel LDS-instruction-bound, 0.63 ms per launch).
-__device__ __forceinline__ void ds_reduce(float (&v)[DS_RB], float (*sq)[256], float (*red)[4], int c, int lane) {
+// The moment reduction over 1024 channels of DS_RB rows: v[i] = this thread's (channel's) term. sq: LDS scratch [DS_RB][256]. Two workgroup barriers.
+// The four (256-channel group) butterflies of a row are done by ONE wave — lane = quad, exactly the register-stationary kernel's wave — which also forms
+// the row's statistic once, for the 1024 threads that would otherwise each recompute it (a form in which every thread reduced its own copy made the
+// kernel LDS-instruction-bound: 0.63 ms per launch; with per-thread 1 / sqrt it was vector-bound: 0.40 ms):
+//   SECOND = false: stat[r][0] = mean = total / 1024
+//   SECOND = true:  stat[r][1] = rstd = 1 / sqrt(total / 1024 + 1e-5), stat[r][2] = shift = -rstd * mean
+template <bool SECOND>
+__device__ __forceinline__ void ds_reduce(float (&v)[DS_RB], float (*sq)[256], float (*stat)[4], int c, int lane) {
 #pragma unroll
     for (int i = 0; i < DS_RB; ++i) {
         float p = v[i] + ds_quad_xor1(v[i]);      // (x + y) and (z + w)
@@ -44,21 +47,28 @@ __device__ __forceinline__ void ds_reduce(float (&v)[DS_RB], float (*sq)[256], f
         if ((lane & 3) == 0) sq[i][c >> 2] = p;
     }
     __syncthreads();
-    const int wave = c >> 6, r = wave & 7;
+    const int wave = c >> 6;
+    if (wave < DS_RB) {   // wave r reduces row r
+        float t[4];
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
-        const int grp = 2 * (wave >> 3) + gg;
-        float t = sq[r][grp * 64 + lane];
+        for (int grp = 0; grp < 4; ++grp) t[grp] = sq[wave][grp * 64 + lane];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
-        if (lane == 0) red[r][grp] = t;
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) t[grp] += __shfl_xor(t[grp], off);
+        if (lane == 0) {
+            const float total = (t[0] + t[1]) + (t[2] + t[3]);
+            if (!SECOND) {
+                stat[wave][0] = total * (1.0f / 1024.0f);
+            } else {
+                const float vr = total * (1.0f / 1024.0f);
+                const float rstd = 1.0f / sqrtf(vr + 1e-5f);
+                stat[wave][1] = rstd;
+                stat[wave][2] = -rstd * stat[wave][0];
+            }
+        }
     }
     __syncthreads();
-}
-// ... the total of row i after ds_reduce (re-read from LDS where it is needed instead of living in 8 registers across the next phase)
-__device__ __forceinline__ float ds_total(const float (*red)[4], int i) {
-    const f4 r = *reinterpret_cast<const f4*>(red[i]);   // one 16-byte LDS read
-    return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
 }  // namespace
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(1024, 1) void dwconv_stream_kernel(const float* __r
                                                                 float* __restrict__ out, int T, int seg_len, void* __restrict__ pieces, long long rows_pad,
                                                                 float scale, int* __restrict__ status) {
     __shared__ float sq[DS_RB][256];
-    __shared__ __attribute__((aligned(16))) float red_s[DS_RB][4], red_q[DS_RB][4];
+    __shared__ __attribute__((aligned(16))) float stat[DS_RB][4];   // per row: mean, rstd, shift
     __shared__ __attribute__((aligned(16))) float otile[DS_RB][DS_C];   // pieces only: the 8 output rows, re-read as float4 per channel quad
     const int c = threadIdx.x, lane = c & 63;
     const int b = blockIdx.y;
@@ -117,11 +127,10 @@ __global__ __launch_bounds__(1024, 1) void dwconv_stream_kernel(const float* __r
         float term[DS_RB];
 #pragma unroll
         for (int i = 0; i < DS_RB; ++i) term[i] = acc[i];
-        ds_reduce(term, sq, red_s, c, lane);
+        ds_reduce<false>(term, sq, stat, c, lane);
 #pragma unroll
         for (int i = 0; i < DS_RB; ++i) {
-            const float mean = ds_total(red_s, i) * (1.0f / 1024.0f);
-            const float d = acc[i] - mean;
+            const float d = acc[i] - stat[i][0];
             // quad term (dx*dx + dy*dy) + (dz*dz + dw*dw) as fma(dx, dx, dy * dy) + fma(dz, dz, dw * dw): the odd channel supplies the rounded
             // product, the even channel forms the fma. ds_reduce's first step adds lane ^ 1, so the odd lane hands it 0 (f + 0 is exact): the pair sum
             // is f, the quad sum f_xy + f_zw
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(1024, 1) void dwconv_stream_kernel(const float* __r
             const float f = __builtin_fmaf(d, d, ds_quad_xor1(m));   // even lanes: fma(d_even, d_even, d_odd * d_odd)
             term[i] = (lane & 1) ? 0.f : f;
         }
-        ds_reduce(term, sq, red_q, c, lane);
+        ds_reduce<true>(term, sq, stat, c, lane);
         // ---- normalise, swish, store -------------------------------------------------------------------------------------------------
         // gamma / beta of this channel are re-read per iteration (opaque pointers: not hoisted) — two registers this 128-register kernel needs elsewhere
         const float* gp = gamma;
@@ -139,11 +148,7 @@ __global__ __launch_bounds__(1024, 1) void dwconv_stream_kernel(const float* __r
 #pragma unroll
         for (int i = 0; i < DS_RB; ++i) {
             const int t = tb + i;
-            const float mean = ds_total(red_s, i) * (1.0f / 1024.0f);
-            const float vr = ds_total(red_q, i) * (1.0f / 1024.0f);
-            const float rstd = 1.0f / sqrtf(vr + 1e-5f);
-            const float shift = -rstd * mean;
-            const float o = swishf_(fmaf(fmaf(acc[i], rstd, shift), gm, bt));
+            const float o = swishf_(fmaf(fmaf(acc[i], stat[i][1], stat[i][2]), gm, bt));
             if constexpr (std::is_void<SC>::value) {
                 if (t < t_end) out[(base + t) * DS_C + c] = o;
             } else {
