@@ -20,7 +20,7 @@ i, n = 0, len(rows)
 while i < n:
     # a conformer layer starts at a layernorm_split launch followed by two <false, 4, 8> GEMMs
     if "layernorm_split_kernel" in names[i] and i + 14 < n and "gemm_f16x2_tg_kernel<false, 4, 8>" in names[i + 1] and "gemm_f16x2_tg_kernel<false, 4, 8>" in names[i + 2] \
-            and "relpos_attention" in names[i + 5] and "dwconv_ln_swish" in names[i + 9]:
+            and "relpos_attention" in names[i + 5] and "dwconv" in names[i + 9]:
         idx = [i + 1, i + 2, i + 4, i + 6, i + 8, i + 10, i + 12, i + 13]
         if all("gemm_f16x2_tg_kernel<false, 4, 8>" in names[j] for j in idx):
             for k, j in enumerate(idx):
