@@ -18,6 +18,12 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
+def collective_device(device: torch.device, dist) -> torch.device:
+    """Where a collective's tensors live: the rank's device under RCCL ("nccl"); host memory under gloo (the CPU tests, and bench.py's
+    ``--shared-device`` rehearsal of the N > 1 path on a one-GPU box, where every rank drives cuda:0 and RCCL cannot be used)."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else device
+
+
 def broadcast_weights(weights: Optional[Dict[str, np.ndarray]], device: torch.device, dist=None, src: int = 0):
     """Rank ``src`` holds the weight dict; every rank returns an identical dict.
 
@@ -30,11 +36,12 @@ def broadcast_weights(weights: Optional[Dict[str, np.ndarray]], device: torch.de
     dist.broadcast_object_list(meta, src=src)
     layout = meta[0]
     total = int(sum(int(np.prod(s)) for _, s in layout))
+    cdev = collective_device(device, dist)
     if rank == src:
         flat = torch.from_numpy(np.concatenate([np.asarray(weights[k], dtype=np.float32).reshape(-1) for k, _ in layout]))
-        flat = flat.to(device)
+        flat = flat.to(cdev)
     else:
-        flat = torch.empty(total, dtype=torch.float32, device=device)
+        flat = torch.empty(total, dtype=torch.float32, device=cdev)
     dist.broadcast(flat, src=src)
     host = flat.cpu().numpy()
     out: Dict[str, np.ndarray] = {}
@@ -54,25 +61,26 @@ def broadcast_packed(packed, device: torch.device, dist=None, src: int = 0):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return packed
     rank = dist.get_rank()
-    sizes = torch.tensor([len(packed[0]), packed[1].numel()] if rank == src else [0, 0], dtype=torch.int64, device=device)
+    cdev = collective_device(device, dist)   # gloo (tests / one-GPU rehearsal): the blob is staged through the host; RCCL: device to device
+    sizes = torch.tensor([len(packed[0]), packed[1].numel()] if rank == src else [0, 0], dtype=torch.int64, device=cdev)
     dist.broadcast(sizes, src=src)
     n_meta, n_blob = int(sizes[0].item()), int(sizes[1].item())
     if rank == src:
-        meta_t = torch.frombuffer(bytearray(packed[0]), dtype=torch.uint8).to(device)
-        blob = packed[1].to(device)
+        meta_t = torch.frombuffer(bytearray(packed[0]), dtype=torch.uint8).to(cdev)
+        blob = packed[1].to(cdev)
     else:
-        meta_t = torch.empty(n_meta, dtype=torch.uint8, device=device)
-        blob = torch.empty(n_blob, dtype=torch.uint8, device=device)
+        meta_t = torch.empty(n_meta, dtype=torch.uint8, device=cdev)
+        blob = torch.empty(n_blob, dtype=torch.uint8, device=cdev)
     dist.broadcast(meta_t, src=src)
     dist.broadcast(blob, src=src)
-    return bytes(meta_t.cpu().numpy().tobytes()), blob
+    return bytes(meta_t.cpu().numpy().tobytes()), blob.to(device)
 
 
 def gather_scalars(values: Sequence[float], device: torch.device, dist=None) -> List[List[float]]:
     """All-gather a few per-rank scalars (benchmark reporting only)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [list(values)]
-    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    t = torch.tensor(list(values), dtype=torch.float64, device=collective_device(device, dist))
     outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, t)
     return [o.tolist() for o in outs]

@@ -411,7 +411,8 @@ def pipelined_pcie(enc_call, host_in: torch.Tensor, dev, iters: int):
 def max_over_ranks(x: float, dev, dist) -> float:
     if dist is None:
         return x
-    t = torch.tensor([x], device=dev, dtype=torch.float64)
+    from audiotoken_amd.distributed import collective_device
+    t = torch.tensor([x], device=collective_device(dev, dist), dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -774,6 +775,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-timing oracle check of the timed batches (rank 0, N = 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --workload selftest run on CPU (tests)")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="rehearsal of the N > 1 path on a ONE-GPU box: every rank drives cuda:0 (needs --backend gloo: RCCL cannot put two ranks on "
+                         "one device); the collectives go through host memory, the numbers are not a measurement")
     return ap.parse_args(argv)
 
 
@@ -796,6 +800,9 @@ def main(argv=None):
         dev = torch.device("cpu")
     else:
         assert torch.cuda.is_available(), "bench.py needs a HIP device"
+        if args.shared_device:
+            assert args.backend == "gloo", "--shared-device needs --backend gloo"
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     rank, world, dist = init_ranks(args.backend, dev)
