@@ -213,6 +213,27 @@ def test_tokens_vs_oracle_ragged(enc3):
     assert same[valid].all(), "token ids at valid positions must be bit-identical"
 
 
+@pytest.mark.parametrize("N", [4000, 10480, 10800, 880], ids=["T11", "T32", "T33", "T2"])
+def test_tokens_vs_oracle_short_clips(enc3, N):
+    """Clips shorter than one attention key tile (32 frames), exactly one, one plus a frame, and two frames: the double-buffered K / V prologue with a
+    single tile, the depthwise-conv kernel below its 8-row iteration and with more time segments than rows, the LayerNorm / GEMM padding rows.
+    Token ids at valid positions must equal the oracle's."""
+    enc, w = enc3
+    B = 3
+    wave = W.synth_waveform(B, N, 16000, seed=131 + N)
+    mask = np.ones((B, N), dtype=np.float32)
+    mask[1, N // 2:] = 0
+    wave = wave * mask
+    toks = enc(torch.from_numpy(wave).cuda(), torch.from_numpy(mask).cuda(), 2)
+    assert enc.last_status() == 0
+    ref = R.semantic_m_encode(w, torch.from_numpy(wave), torch.from_numpy(mask), 2, 3)
+    feats, am = R.processor(torch.from_numpy(wave), torch.from_numpy(mask), 2)
+    valid = am.bool().unsqueeze(1)
+    assert toks.shape == ref.shape
+    same = (toks.cpu() == ref)
+    assert same[valid].all(), f"N={N}: {int((~same[valid]).sum())} token ids differ at valid positions"
+
+
 def test_encode_batch_files_semantic_m(tmp_path):
     """Files -> 2 s chunks -> zero padding + mask -> 19-layer HIP encoder -> trimmed .npy, against the oracle run on the
     same padded chunks (reference core.py:198-289 + datasets.py:75-105 semantics incl. the sample mask)."""
