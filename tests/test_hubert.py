@@ -64,3 +64,23 @@ def test_gpu_api_semantic_s(cuda_device):
     same = (out == ref).float().mean().item()
     print(f"semantic_s tokens equal to oracle: {same:.4f}")
     assert same == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1200, 4000, 10640], ids=["T3", "T12", "T33"])
+def test_gpu_short_clips_vs_oracle(cuda_device, N):
+    """Clips of 3, 12 and 33 frames (below / just above one attention key tile): ids equal the oracle's, or the oracle's own top-2 centre margin
+    explains them (tests/parity.py)."""
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    nl = 3
+    w = W.synth_hubert_weights(nl, 5, True)
+    enc = HubertEncoder(HubertEncoderConfig(output_layer=nl), device="cuda:0", quantize=True, weights=w)
+    wav = W.synth_waveform(2, N, 16000, seed=300 + N)
+    norm = hubert_processor(torch.from_numpy(wav))
+    mask = torch.ones_like(norm)
+    toks = enc(norm.cuda(), mask.cuda())
+    assert enc.last_status() == 0
+    ref = R.semantic_s_encode(w, norm, mask, nl)
+    assert toks.shape == ref.shape and toks.shape[-1] == W.hubert_num_frames(N)
+    assert torch.equal(toks.cpu(), ref), f"N={N}: {int((toks.cpu() != ref).sum())} ids differ"
