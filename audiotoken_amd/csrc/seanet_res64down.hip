@@ -6,7 +6,8 @@
 // ROLE-SPLIT, 12 waves = 3 per SIMD at 168 registers each:
 //   waves 8..11 (block role):  conv3 -> h -> tail -> ELU -> split -> R pieces in LDS, one 64-row tile per iteration
 //   waves 0..7  (conv role):   16 output channels each, the 16 outputs of the PREVIOUS tile from its R pieces (16 K steps x 3 products), and the
-//                              staging of the NEXT tile's input: split(ELU(x)) / split(x) into the other X buffer (loads one more tile ahead)
+//                              staging of the NEXT tile's input, half a tile at a time: split(ELU(x)) / split(x) into the other X buffer while the
+//                              other half's loads fly (one float4 per thread in flight)
 // One iteration = two workgroup barriers (h ready / R ready + next X staged); the conv waves cut their 16 K steps in two at the first one. The
 // block role's chain conv3 -> h -> tail is the critical path of an iteration (one workgroup per CU: nothing else hides its latency), so everything
 // that is not on it — half of the vector work (the input ELUs and splits) — runs in the eight conv waves, whose matrix work is shorter.
