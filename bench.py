@@ -754,6 +754,23 @@ def report_semantic(wl, args, rank, world, dev, dist):
     }
     if "vq" in breakdown and breakdown["vq"]["ms_per_step"] > 0:
         res["argmin"] = argmin_entry("vq", breakdown["vq"]["ms_per_step"], flops["vq"] * B, (4.0 * T * 1024 + 2.0 * T) * B, 1)
+    # the §8(d) wall for this tokenizer as for the acoustic one: pinned host waveform + sample mask -> H2D on a copy stream during the previous encode ->
+    # encode -> D2H tokens; all ranks at once, max over ranks. Beside the sub-object's `value`, never as it.
+    try:
+        host = torch.stack([wl["wav"].cpu(), wl["mask"].cpu()]).pin_memory()
+        if dist is not None:
+            dist.barrier()
+        pp = pipelined_pcie(lambda d: enc(d[0], d[1]), host, dev, max(5, min(args.steps, 10)))
+        med = max_over_ranks(pp["median_ms"], dev, dist)
+        res["pcie_inclusive"] = {"value": round(world * B * secs / (med * 1e-3), 2), "unit": "audio-s/s", "median_ms_per_step": round(med, 3),
+                                 "mean_ms_per_step": round(max_over_ranks(pp["mean_ms"], dev, dist), 3), "iters": pp["iters"],
+                                 "note": "pinned host waveforms + sample masks -> H2D on a copy stream during the previous encode -> encode -> D2H tokens; "
+                                         "median over batches; all ranks run it concurrently, max over ranks"}
+        del host
+    except Exception as e:  # pragma: no cover - informational only
+        res["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
+        if dist is not None:
+            raise
     return res
 
 
