@@ -2,12 +2,12 @@
 //   waveform -> conv0 (1->32, k7) -> residual block (ELU, k3 32->16, ELU, k1 16->32, + k1 shortcut) -> ELU -> strided conv (32->64, k4 s2)
 // with the three 32/16-channel contractions as exact 3-way bf16 splits on v_mfma_f32_16x16x32_bf16 (six per 32-wide K step;
 // arithmetic and accuracy: gemm_bf16x3.hip). conv0 (K = 7 taps) stays on the fp32 MFMA exactly as in the fp32 kernel.
-// Tile = 62 input samples (31 outputs): 64 rows of the block = 4 MFMA row tiles, one per wave (conv3 + tail per wave on its own rows,
+// Tile = 60 input samples (30 outputs; SX_ADV below): 64 rows of the block = 4 MFMA row tiles, one per wave (conv3 + tail per wave on its own rows,
 // no barrier in between); the strided conv is split over the OUTPUT channels instead (wave = 16 channels, all 32 output slots), so a
 // wave's weights are 132 registers of bf16 pieces and 65 KB of LDS per workgroup put TWO workgroups on a CU — one splits / applies
 // ELUs (vector work) while the other multiplies; a bf16 MFMA leaves half of its cycles to vector issue.
 // LDS (bf16 pieces, rows padded by 16 B so that fragment reads of 16 consecutive rows are conflict-free with linear addresses):
-//   X0e = split(ELU(x0)), X0r = split(x0): [3][80 rows][32 + 8]   row i <-> time t0 - 4 + i
+//   X0e = split(ELU(x0)): [pieces][66 rows][32 + 16]   row i <-> time t0 - 4 + i (64 rows from conv0 + 2 zero rows)
 //   Hs  = split(ELU(conv3 + b3)):          [3][64][16 + 8]        row j <-> time t0 - 2 + j
 //   Rs  = split(ELU(block output)):        [3][2 planes][34][32 + 8]: row j in plane j & 1 at j >> 1, so that the stride-2 rows of
 //         the strided conv's fragment reads are consecutive.
@@ -25,9 +25,14 @@ namespace at {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SX_ADV = 62;                 // input samples per tile
-constexpr int SX_UO = 31;                  // outputs per tile
-constexpr int SX_XROWS = 80;               // x0 rows written (5 MFMA row tiles; 66 used)
+// Tile = 60 input samples (30 outputs): the block needs x0 rows 0 .. ADV + 3 = 64 rows = exactly FOUR MFMA row tiles of conv0, 8 (row tile, channel
+// tile) units = two per wave. (Rounds 1-2: 62 samples / 31 outputs needed 66 rows = five row tiles, 10 units: waves 0 and 1 ran three units while
+// waves 2 and 3 waited at the barrier after two, and 14 of the 80 rows were never used — a third of the conv0 phase for one more output per tile.)
+// Rows 64, 65 of the x0 image (read by conv3 rows 62, 63, whose results only feed the two masked output slots) are zeroed once per workgroup.
+constexpr int SX_ADV = 60;                 // input samples per tile
+constexpr int SX_UO = 30;                  // outputs per tile
+constexpr int SX_XUNITS = 8;               // conv0 units: 4 row tiles x 2 channel tiles
+constexpr int SX_XROWS = 66;               // x0 rows: 64 written by conv0 + 2 zero rows
 constexpr int SX_ROWS = 64;                // h / r rows
 constexpr int SX_RIDX = 34;                // r rows per parity plane (the masked 32nd output reads rows 62..65)
 constexpr int SX_LDX = 48, SX_LDH = 24, SX_LDR = 48;   // x0 / r rows + 32 B (conflict-free fragment reads, see seanet_res128x3.hip); h rows keep + 16 B (two workgroups per CU)
@@ -80,6 +85,10 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
     const int total_tiles = a.B * tiles_per_clip;   // < 2^30: checked by the launcher
 
     // ---- weights -> registers, once per workgroup ------------------------------------------------------------------
+    for (int e = tid; e < NP * 2 * SX_LDX; e += 256) {   // x0 rows 64, 65 of every piece: zeros (see SX_ADV)
+        const int p = e / (2 * SX_LDX), r = e - p * (2 * SX_LDX);
+        X0e[p * SX_XP + 64 * SX_LDX + r] = (PT)0.f;
+    }
     if (tid < 32) B0s[tid] = a.b0[tid];
     if (tid < 16) Bs[tid] = a.b3[tid];
     if (tid < 32) Bs[16 + tid] = a.bsc0[tid];   // Wsc . b0 + (b1 + bsc)
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
         w = w > N - 1 ? N - 1 : w;
         return a.wav[(long long)b * N + w];
     };
-    // ---- B: conv0 of a tile at time |t0 - 4 + i| on the fp32 MFMA (as seanet_stage0.hip) -> split raw and ELU copies. 10 units of
+    // ---- B: conv0 of a tile at time |t0 - 4 + i| on the fp32 MFMA (as seanet_stage0.hip) -> split ELU copy. 8 units of
     //      (row tile, channel tile) over the 4 waves. Only the first tile of a clip needs the reflect index map ------------------------
     // waveform-segment indices of the two K = 4 tap groups of x0 row i (time t0 - 4 + i): only the first tile of a clip needs the reflect maps
     auto tap_index = [&](int t0, int i, int& a0, int& a1) {
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256, SC::NP == 2 ? 3 : 2) void seanet_stage0x3_kern
     auto conv0_tile = [&](int tile, const float* Wseg) {
         if (tile >= total_tiles) return;
         const int t0 = (tile % tiles_per_clip) * SX_ADV;
-        for (int unit = wave; unit < 10; unit += 4) {
+        for (int unit = wave; unit < SX_XUNITS; unit += 4) {
             const int mt = unit >> 1, nt = unit & 1;
             const int i = mt * 16 + r16;
             int a0, a1;
