@@ -71,6 +71,9 @@ struct at_w2vbert {
     const float *fp_ln_g = nullptr, *fp_ln_b = nullptr, *fp_w = nullptr, *fp_b = nullptr;
     std::vector<LayerW> layers;
     const float *codebook = nullptr, *e2 = nullptr;
+    const piece_t* cb_s[2] = {};   // the code book as operand pieces, per scheme (the VQ score GEMM on the split kernel; option "vq_split")
+    float cb_scale = 1.f;
+    bool vq_split = true;
     int arith = ARITH_F16X2;   // linear layers: ARITH_* ($AUDIOTOKEN_SEMANTIC_ARITH = f32 | bf16x3 | f16x2; option "arith")
     bool split_done[2] = {false, false};
     std::map<const float*, float> wmax;   // max |w| of every uploaded tensor (the fp16 scheme's weight scales)
@@ -191,6 +194,20 @@ int split_weights(at_w2vbert* h, int scheme) {
                 if (int rc = launch_split_blocked(src[j], k, n, n, k, d, nullptr, scheme, sc, nullptr)) return rc;
             L.ws[scheme][j] = d;
         }
+    }
+    if (h->codebook) {   // the VQ score GEMM dots = LN(x) . E^T [M x 1024] x [1024 x 2048]
+        piece_t* d = static_cast<piece_t*>(h->arena.alloc((size_t)np * kCodes * kHid * sizeof(piece_t)));
+        if (!d) return -1;
+        float sc = 1.0f;
+        if (scheme == XB_SCHEME_F16X2) {
+            auto it = h->wmax.find(h->codebook);
+            AT_REQUIRE(it != h->wmax.end(), "code book maximum not recorded");
+            sc = xb_weight_scale(it->second);
+            h->cb_scale = sc;
+        }
+        if (!h->arena.importing)
+            if (int rc = launch_split_blocked(h->codebook, kHid, kCodes, kCodes, kHid, d, nullptr, scheme, sc, nullptr)) return rc;
+        h->cb_s[scheme] = d;
     }
     AT_CHECK_HIP(hipDeviceSynchronize());
     h->split_done[scheme] = true;
@@ -508,6 +525,7 @@ int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value) {
         return 0;
     }
     if (n == "dwconv_stream") { h->dwconv_stream = value != 0; return 0; }
+    if (n == "vq_split") { h->vq_split = value != 0; return 0; }
     set_error("at_w2vbert_set_option: unknown option " + n);
     return -1;
 }
@@ -516,6 +534,7 @@ int at_w2vbert_get_option(const at_w2vbert_t* h, const char* name) {
     if (!h || !name) return -1;
     if (std::string(name) == "arith") return h->arith;
     if (std::string(name) == "dwconv_stream") return h->dwconv_stream ? 1 : 0;
+    if (std::string(name) == "vq_split") return h->vq_split ? 1 : 0;
     return -1;
 }
 
@@ -694,8 +713,20 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     if (tokens) {
         // non-affine LayerNorm (reference encoder.py:138-143,176) then nearest code (encoder.py:180-181)
         prof.begin("vq", 3, stream);
-        if (int rc = launch_layernorm(x, nullptr, nullptr, nullptr, t1, M, kHid, stream)) return rc;
-        if (int rc = linear(t1, kHid, h->codebook, nullptr, big, kCodes, M, EPI_NONE, 1.f, nullptr, nullptr, kCodes, stream)) return rc;
+        if (split && h->vq_split && h->cb_s[sc.scheme]) {
+            // the score GEMM on the split kernel: the LayerNorm writes its fp32 rows (|x|^2 of the distance) and the operand pieces in one pass. Non-affine
+            // LayerNorm output is bounded by sqrt(1024) = 32: x 16 cannot leave the fp16 range, so this site has no range word.
+            if (int rc = launch_layernorm_split(x, nullptr, nullptr, nullptr, t1, t1s, M, Mpad, kHid, sc.scheme, sc.act_scale(), nullptr, stream)) return rc;
+            Bf16x3Args va;
+            va.A = t1s; va.W = h->cb_s[sc.scheme]; va.bias = nullptr; va.M = (int)M; va.N = kCodes; va.K = kHid; va.Mpad = (int)Mpad;
+            va.epi = XB_EPI_LINEAR; va.C = big; va.ldc = kCodes; va.R = nullptr; va.ldr = kCodes; va.alpha = 1.f;
+            va.scheme = sc.scheme; va.status = nullptr;
+            if (sc.scheme == XB_SCHEME_F16X2) { va.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->cb_scale); va.split_scale = XB_F16_ACT_SCALE; }
+            if (int rc = launch_gemm_bf16x3(va, stream)) return rc;
+        } else {
+            if (int rc = launch_layernorm(x, nullptr, nullptr, nullptr, t1, M, kHid, stream)) return rc;
+            if (int rc = linear(t1, kHid, h->codebook, nullptr, big, kCodes, M, EPI_NONE, 1.f, nullptr, nullptr, kCodes, stream)) return rc;
+        }
         if (int rc = launch_vq_argmax(t1, big, h->e2, tokens, M, kHid, kCodes, stream)) return rc;
         prof.end(stream);
     }

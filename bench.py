@@ -753,7 +753,8 @@ def report_semantic(wl, args, rank, world, dev, dist):
         "fallback_batches": wl["fallback_batches_per_step"] * args.steps, "fallback_status": wl["fallback_status"],
     }
     if "vq" in breakdown and breakdown["vq"]["ms_per_step"] > 0:
-        res["argmin"] = argmin_entry("vq", breakdown["vq"]["ms_per_step"], flops["vq"] * B, (4.0 * T * 1024 + 2.0 * T) * B, 1)
+        vq_products = {0: 1, 1: 6, 2: 3}[arith] if enc.get_option("vq_split") == 1 else 1   # the score GEMM on the split kernel (option vq_split) or the fp32 MFMA
+        res["argmin"] = argmin_entry("vq", breakdown["vq"]["ms_per_step"], flops["vq"] * B, (4.0 * T * 1024 + 2.0 * T) * B, vq_products)
     # the §8(d) wall for this tokenizer as for the acoustic one: pinned host waveform + sample mask -> H2D on a copy stream during the previous encode ->
     # encode -> D2H tokens; all ranks at once, max over ranks. Beside the sub-object's `value`, never as it.
     try:

@@ -182,7 +182,8 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
  * pieces per operand, three products, operands pre-scaled by powers of two (fp32-class accuracy: csrc/gemm_bf16x3.h). Weights are split
  * for a scheme the first time it is selected. "dwconv_stream" 1/0 (default 1): the conv module's depthwise conv + LayerNorm + swish as the streaming
  * kernel (csrc/dwconv_stream.hip: one channel per thread walking along time) or the register-stationary one — bit-identical results, the option is
- * the A/B twin the tests compare. at_w2vbert_get_option returns the current value (or -1). */
+ * the A/B twin the tests compare. "vq_split" 1/0 (default 1): the VQ score GEMM (LayerNorm output x code book) on the split kernel with the handle's
+ * arithmetic, or on the fp32 MFMA (always with "arith" = 0). at_w2vbert_get_option returns the current value (or -1). */
 int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value);
 int at_w2vbert_get_option(const at_w2vbert_t* h, const char* name);
 int at_w2vbert_profile(at_w2vbert_t* h, int enable);

@@ -177,6 +177,26 @@ def test_dwconv_stream_option_keeps_tokens(enc3):
         enc.set_option("dwconv_stream", 1)
 
 
+def test_vq_split_option_keeps_tokens(enc3):
+    """The VQ score GEMM (non-affine LayerNorm output x code book) on the split kernel (default, option vq_split) and on the fp32 MFMA: the same tokens —
+    both are fp32-grade dot products, the argmax only moves where two codes tie to ~1e-6 (none in this batch; the bench batch's pinned checksum and the
+    oracle comparisons of tests/test_fullsize_gpu.py cover the size)."""
+    enc, w = enc3
+    wav = torch.from_numpy(W.synth_waveform(4, 16000 * 3 + 777, 16000, seed=78)).cuda()
+    mask = torch.ones_like(wav)
+    mask[1, 25000:] = 0
+    try:
+        assert enc.get_option("vq_split") == 1
+        t1 = enc(wav, mask)
+        enc.set_option("vq_split", 0)
+        t0 = enc(wav, mask)
+        valid = (t1 >= 0)
+        assert torch.equal(t1, t0), f"{int((t1 != t0).sum())} of {t1.numel()} ids differ between the split and the fp32 score GEMM"
+        assert valid.all()
+    finally:
+        enc.set_option("vq_split", 1)
+
+
 def test_conformer_matches_hf_golden(enc3):
     enc, w = enc3
     g = np.load(os.path.join(G, "conformer_a.npz"))
