@@ -188,6 +188,8 @@ __device__ __forceinline__ float gelu_erf(float y) {
     const float e = (p * t) * __expf(-x * x);        // erfc(|y| / sqrt 2)
     return 0.5f * y * (y < 0.0f ? e : 2.0f - e);
 }
-__device__ __forceinline__ float swishf_(float x) { return x / (1.0f + expf(-x)); }
+// swish of the conformer conv module's depthwise-conv kernels: x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (~1 ulp each) like the GEMM's swish and GLU
+// epilogues (until late in round 3: ocml expf + a correctly rounded division, ~30 more vector instructions per value in a vector-bound kernel)
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 
 }  // namespace at
