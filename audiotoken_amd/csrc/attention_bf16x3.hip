@@ -448,12 +448,17 @@ static int launch_ax(const float* qkv, const float* amask, const float* dist_emb
 }
 
 int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
-                               int scheme, int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces) {
+                               int scheme, int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces, int w8) {
     AT_REQUIRE(B >= 1 && T >= 1 && heads >= 1 && heads <= 64, "relpos_attention_x3: bad shape");
     AT_REQUIRE((long long)T * 3 * heads * 64 * 4 < (1ll << 31), "relpos_attention_x3: one clip's qkv rows exceed the buffer-descriptor range");
     AT_REQUIRE(ctx_pieces == nullptr || rows_pad >= (long long)B * T, "relpos_attention_x3: rows_pad too small");
     AT_REQUIRE(kv_pieces == nullptr || (scheme == XB_SCHEME_F16X2 && rows_pad >= (long long)B * T && (long long)T * heads * 64 * 2 < (1ll << 31)),
                "relpos_attention_x3: pre-split k / v need the fp16 scheme and rows_pad");
+    if (scheme == XB_SCHEME_F16X2 && kv_pieces) {
+        static const int w8_default = []() { const char* e = std::getenv("AUDIOTOKEN_ATTN_W8"); return (e && e[0] == '0') ? 0 : 1; }();
+        if ((w8 < 0 ? w8_default : w8) != 0 && relpos_attention_w8_eligible(T, heads, rows_pad, B, dist_emb != nullptr))
+            return launch_relpos_attention_w8(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, kv_pieces);
+    }
     if (scheme == XB_SCHEME_F16X2 && kv_pieces) return launch_ax<SchemeF16x2, true>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, kv_pieces);
     if (scheme == XB_SCHEME_F16X2) return launch_ax<SchemeF16x2, false>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, nullptr);
     return launch_ax<SchemeBf16x3, false>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, nullptr);

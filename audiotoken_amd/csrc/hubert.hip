@@ -57,6 +57,7 @@ struct at_hubert {
     float conv_wscale[7] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     int arith = ARITH_F16X2;   // linear layers + conv chain: ARITH_* ($AUDIOTOKEN_SEMANTIC_ARITH = f32 | bf16x3 | f16x2; option "arith")
     bool split_done[2] = {false, false};
+    int attn_w8 = -1;          // option "attn_w8" (as at_w2vbert): the round-4 attention kernel (attention_f16x2_w8.hip) or its round-3 twin
     std::map<const float*, float> wmax;   // max |w| of every uploaded tensor
     Profiler prof;
 };
@@ -443,6 +444,7 @@ int at_hubert_set_option(at_hubert_t* h, const char* name, int value) {
         h->arith = value;
         return 0;
     }
+    if (n == "attn_w8") { h->attn_w8 = value < 0 ? -1 : (value != 0); return 0; }
     set_error("at_hubert_set_option: unknown option " + n);
     return -1;
 }
@@ -450,6 +452,7 @@ int at_hubert_set_option(at_hubert_t* h, const char* name, int value) {
 int at_hubert_get_option(const at_hubert_t* h, const char* name) {
     if (!h || !name) return -1;
     if (std::string(name) == "arith") return h->arith;
+    if (std::string(name) == "attn_w8") return h->attn_w8;
     return -1;
 }
 
@@ -568,7 +571,7 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         prof.begin("attention", 1, stream);
         const bool ctx_as_pieces = split && attn_arith > 0;
         if (int rc = launch_relpos_attention(big, fmask, nullptr, ctx_as_pieces ? nullptr : t1, B, T, stream, kHeads, attn_arith, sc.site(HS_ATTENTION),
-                                             ctx_as_pieces ? xs : nullptr, Mpad, kvp ? kvs : nullptr)) return rc;
+                                             ctx_as_pieces ? xs : nullptr, Mpad, kvp ? kvs : nullptr, h->attn_w8)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
         if (split) {

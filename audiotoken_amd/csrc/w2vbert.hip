@@ -78,6 +78,7 @@ struct at_w2vbert {
     bool split_done[2] = {false, false};
     std::map<const float*, float> wmax;   // max |w| of every uploaded tensor (the fp16 scheme's weight scales)
     bool dwconv_stream = true;  // option "dwconv_stream": depthwise conv + LayerNorm + swish on the streaming kernel (dwconv_stream.hip)
+    int attn_w8 = -1;           // option "attn_w8": 1 / 0 = the 8-wave 64-key LDS-DMA attention (attention_f16x2_w8.hip) / its round-3 twin; -1 = $AUDIOTOKEN_ATTN_W8, default 1
     Profiler prof;
 };
 
@@ -526,6 +527,7 @@ int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value) {
     }
     if (n == "dwconv_stream") { h->dwconv_stream = value != 0; return 0; }
     if (n == "vq_split") { h->vq_split = value != 0; return 0; }
+    if (n == "attn_w8") { h->attn_w8 = value < 0 ? -1 : (value != 0); return 0; }
     set_error("at_w2vbert_set_option: unknown option " + n);
     return -1;
 }
@@ -535,6 +537,7 @@ int at_w2vbert_get_option(const at_w2vbert_t* h, const char* name) {
     if (std::string(name) == "arith") return h->arith;
     if (std::string(name) == "dwconv_stream") return h->dwconv_stream ? 1 : 0;
     if (std::string(name) == "vq_split") return h->vq_split ? 1 : 0;
+    if (std::string(name) == "attn_w8") return h->attn_w8;
     return -1;
 }
 
@@ -639,7 +642,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             prof.end(stream);
             prof.begin("attention", 1, stream);
             if (attn_arith > 0) {
-                if (int rc = launch_relpos_attention(big, amask, L.dist, nullptr, B, T, stream, 16, attn_arith, sc.site(WS_ATTENTION), t1s, Mpad, kvp ? kvs : nullptr)) return rc;
+                if (int rc = launch_relpos_attention(big, amask, L.dist, nullptr, B, T, stream, 16, attn_arith, sc.site(WS_ATTENTION), t1s, Mpad, kvp ? kvs : nullptr, h->attn_w8)) return rc;
             } else {
                 if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, 0, nullptr)) return rc;
                 if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream, sc.scheme, as, sc.site(WS_ATTENTION))) return rc;
@@ -764,6 +767,17 @@ int at_op_relpos_attention(const float* qkv, const float* attn_mask, const float
                            at_stream_t stream) {
     AT_REQUIRE(qkv && attn_mask && dist_emb80 && ctx && B >= 1 && T >= 1, "bad arguments");
     return launch_relpos_attention(qkv, attn_mask, dist_emb80, ctx, B, T, (hipStream_t)stream);
+}
+
+int at_op_relpos_attention_kvp(const float* qkv, const float* attn_mask, const float* dist_emb80, float* ctx, int B, int T, int heads, int w8,
+                               void* kv_workspace, size_t kv_workspace_bytes, int32_t* status_dev, at_stream_t stream) {
+    AT_REQUIRE(qkv && attn_mask && ctx && kv_workspace && B >= 1 && T >= 1 && heads >= 1 && heads <= 64, "bad arguments");
+    const long long rows = (long long)B * T, rows_pad = (rows + 255) / 256 * 256;
+    const int hid = heads * 64;
+    AT_REQUIRE(kv_workspace_bytes >= (size_t)4 * rows_pad * hid * 2, "kv workspace too small: 4 * ceil256(B * T) * heads * 64 * 2 bytes");
+    if (int rc = launch_kv_rowmajor_split(qkv, static_cast<__bf16*>(kv_workspace), rows, rows_pad, hid, status_dev, (hipStream_t)stream)) return rc;
+    return launch_relpos_attention(qkv, attn_mask, dist_emb80, ctx, B, T, (hipStream_t)stream, heads, 2, status_dev, nullptr, rows_pad,
+                                   static_cast<const __bf16*>(kv_workspace), w8);
 }
 
 int at_op_dwconv_ln_swish(const float* g, const float* w31x1024, const float* gamma, const float* beta, float* out, int B, int T,

@@ -292,6 +292,13 @@ int at_op_layernorm(const float* x, const float* gamma, const float* beta, const
 int at_op_relpos_attention(const float* qkv, const float* attn_mask, const float* dist_emb80, float* ctx, int B, int T,
                            at_stream_t stream);
 
+/* The same attention on the path the product runs (ref audiotoken/modeling_wav2vec2_bert.py:46-73; HF HubertAttention with dist_emb80 = NULL): k / v are
+ * first written as the row-major fp16 pieces the fused q / k / v projection's epilogue produces (into kv_workspace: 4 * ceil256(B * T) * heads * 64 * 2
+ * bytes), then w8 = 1 runs csrc/attention_f16x2_w8.hip (8-wave workgroups, 64-key tiles, LDS-DMA staging), w8 = 0 its round-3 twin
+ * (csrc/attention_bf16x3.hip <SchemeF16x2, KVP>), w8 = -1 the default. status_dev nullable (bit 1 = fp16 range overflow; {flag, census} pair). */
+int at_op_relpos_attention_kvp(const float* qkv, const float* attn_mask, const float* dist_emb80, float* ctx, int B, int T, int heads, int w8,
+                               void* kv_workspace, size_t kv_workspace_bytes, int32_t* status_dev, at_stream_t stream);
+
 /* Conformer conv middle (HF modeling_wav2vec2_bert.py:212-222): causal depthwise k31 -> LayerNorm -> swish;
  * g [B*T][1024], w [31][1024]. */
 int at_op_dwconv_ln_swish(const float* g, const float* w31x1024, const float* gamma, const float* beta, float* out, int B, int T,

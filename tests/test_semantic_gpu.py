@@ -119,6 +119,90 @@ def test_attention_long_vs_oracle(cuda_device, B, T):
     assert err < 1e-4
 
 
+def _attention_kvp(lib, dev, qkv, mask, de, B, T, heads, w8):
+    """at_op_relpos_attention_kvp: k / v as the row-major fp16 pieces the fused projection writes, then the product's attention kernel
+    (w8 = 1: attention_f16x2_w8.hip, w8 = 0: its round-3 twin)."""
+    hid = heads * 64
+    rows_pad = (B * T + 255) // 256 * 256
+    ws = torch.full((4 * rows_pad * hid,), float("nan"), dtype=torch.float16, device="cuda")   # padding rows stay NaN: must never reach a result
+    ctx = torch.full((B * T, hid), float("nan"), device="cuda")
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    _cabi.check(lib.at_op_relpos_attention_kvp(qkv.data_ptr(), mask.data_ptr(), _cabi.ptr(de), ctx.data_ptr(), B, T, heads, w8,
+                                               ws.data_ptr(), ws.numel() * 2, status.data_ptr(), _stream(dev)), "at_op_relpos_attention_kvp")
+    torch.cuda.synchronize()
+    assert int(status[0].item()) == 0
+    return ctx
+
+
+@pytest.mark.parametrize("w8", [1, 0], ids=["w8", "r3"])
+def test_attention_kvp_matches_reference(cuda_device, w8):
+    """The kernels the product runs (pre-split k / v) against the golden produced by the reference's own modeling_wav2vec2_bert.py:20-80."""
+    lib = _cabi.load()
+    g = np.load(os.path.join(G, "attention_a.npz"))
+    w = W.synth_w2vbert_weights(n_layers=1, seed=int(g["weight_seed"]), with_vq=False)
+    B, T = int(g["B"]), int(g["T"])
+    x = torch.from_numpy(prng.irwin_hall("attn.x", (B, T, 1024), 1.0, int(g["x_seed"])))
+    p = "encoder.layers.0.self_attn"
+    wq = torch.cat([torch.from_numpy(w[f"{p}.linear_{n}.weight"]) for n in "qkv"])
+    bq = torch.cat([torch.from_numpy(w[f"{p}.linear_{n}.bias"]) for n in "qkv"])
+    qkv = F.linear(x, wq, bq).reshape(B * T, 3072).cuda().contiguous()
+    de = torch.zeros(80, 64)
+    de[:73] = torch.from_numpy(w[f"{p}.distance_embedding.weight"])
+    mask, ded = torch.from_numpy(g["mask"]).reshape(-1).cuda(), de.cuda()
+    ctx = _attention_kvp(lib, cuda_device, qkv, mask, ded, B, T, 16, w8)
+    out = F.linear(ctx.cpu().reshape(B, T, 1024), torch.from_numpy(w[f"{p}.linear_out.weight"]), torch.from_numpy(w[f"{p}.linear_out.bias"]))
+    err = (out - torch.from_numpy(g["out"])).abs().max().item()
+    print(f"attention kvp w8={w8}: max abs err after out-proj {err:.3e}")
+    assert err < 1e-4
+
+
+@pytest.mark.parametrize("w8", [1, 0], ids=["w8", "r3"])
+@pytest.mark.parametrize("B,T", [(2, 1500), (1, 130), (3, 64), (2, 257), (1, 1), (2, 1499)])
+def test_attention_kvp_long_vs_oracle(cuda_device, B, T, w8):
+    """Many key tiles (far-field constants on both sides, near-diagonal gathers, a last tile cut by T), ragged masks (one clip padded from 2/3 on,
+    i.e. tiles that are wholly and partly masked) — against the oracle attention."""
+    lib = _cabi.load()
+    w = W.synth_w2vbert_weights(n_layers=1, seed=11, with_vq=False)
+    p = "encoder.layers.0.self_attn"
+    x = torch.from_numpy(prng.irwin_hall("attn.long", (B, T, 1024), 1.0, 2))
+    mask = torch.ones(B, T)
+    if B > 1:
+        mask[1, T * 2 // 3:] = 0
+    add = ((1.0 - mask[:, None, None, :]) * torch.finfo(torch.float32).min).expand(B, 1, T, T)
+    ref = R.relpos_attention(w, p, x, add)
+    wq = torch.cat([torch.from_numpy(w[f"{p}.linear_{n}.weight"]) for n in "qkv"])
+    bq = torch.cat([torch.from_numpy(w[f"{p}.linear_{n}.bias"]) for n in "qkv"])
+    qkv = F.linear(x, wq, bq).reshape(B * T, 3072).cuda().contiguous()
+    de = torch.zeros(80, 64)
+    de[:73] = torch.from_numpy(w[f"{p}.distance_embedding.weight"])
+    md, ded = mask.reshape(-1).cuda(), de.cuda()
+    ctx = _attention_kvp(lib, cuda_device, qkv, md, ded, B, T, 16, w8)
+    out = F.linear(ctx.cpu().reshape(B, T, 1024), torch.from_numpy(w[f"{p}.linear_out.weight"]), torch.from_numpy(w[f"{p}.linear_out.bias"]))
+    err = (out - ref).abs().max().item()
+    print(f"attention kvp w8={w8} B={B} T={T}: max abs err {err:.3e}")
+    assert err < 1e-4
+
+
+@pytest.mark.parametrize("w8", [1, 0], ids=["w8", "r3"])
+def test_attention_kvp_no_relpos_12_heads(cuda_device, w8):
+    """HuBERT's use of the kernel (HF HubertAttention: 12 heads x 64, no position bias, additive finfo.min key mask) against torch fp32; logits up to ~ +-20
+    and one head with a spiked key so that the running maximum jumps inside a later tile (the rescale path)."""
+    lib = _cabi.load()
+    B, T, heads = 2, 700, 12
+    hid = heads * 64
+    qkv = torch.from_numpy(prng.irwin_hall("attn.h12", (B * T, 3 * hid), 1.0, 7)) * 1.5
+    qkv[400, hid:hid + 64] *= 6.0          # key 400 of clip 0, head 0
+    mask = torch.ones(B, T)
+    mask[1, 500:] = 0
+    q, k, v = (qkv[:, i * hid:(i + 1) * hid].reshape(B, T, heads, 64).transpose(1, 2) for i in range(3))
+    logits = (q @ k.transpose(-1, -2)) * 0.125 + ((1.0 - mask[:, None, None, :]) * torch.finfo(torch.float32).min)
+    ref = (torch.softmax(logits, dim=-1) @ v).transpose(1, 2).reshape(B * T, hid)
+    ctx = _attention_kvp(lib, cuda_device, qkv.cuda().contiguous(), mask.reshape(-1).cuda(), None, B, T, heads, w8)
+    err = (ctx.cpu() - ref).abs().max().item()
+    print(f"attention kvp w8={w8} 12 heads no rel-pos: max abs err {err:.3e} (max |logit| {logits[logits > -1e30].abs().max().item():.1f})")
+    assert err < 2e-5
+
+
 def test_dwconv_ln_swish(cuda_device):
     lib = _cabi.load()
     B, T = 2, 77
