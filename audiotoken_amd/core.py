@@ -142,10 +142,13 @@ class AudioToken:
                     logger.error(f"Skipping {file_path}: {e}")
                     self.skipped_files.append((file_path, str(e)))
                     return []
+            def skipped(name, why):   # an undecodable archive member: recorded and skipped like an undecodable file
+                logger.error(f"Skipping {name}: {why}")
+                self.skipped_files.append((name, why))
             if file_path.endswith(TAR_EXTS):
-                return background(lambda: iterate_tar(file_path, sr, chunk_size)) if num_workers > 0 else iterate_tar(file_path, sr, chunk_size)
+                return background(lambda: iterate_tar(file_path, sr, chunk_size, skipped)) if num_workers > 0 else iterate_tar(file_path, sr, chunk_size, skipped)
             if file_path.endswith(ZIP_EXTS):
-                return background(lambda: iterate_zip(file_path, sr, chunk_size)) if num_workers > 0 else iterate_zip(file_path, sr, chunk_size)
+                return background(lambda: iterate_zip(file_path, sr, chunk_size, skipped)) if num_workers > 0 else iterate_zip(file_path, sr, chunk_size, skipped)
             logger.error(f"File {file_path} not supported for processing. Only {AUDIO_EXTS + TAR_EXTS + ZIP_EXTS} supported")
             self.skipped_files.append((file_path, "unsupported extension"))
             return []

@@ -332,10 +332,11 @@ enum AcSite { AS_STAGE0 = 0, AS_RES1, AS_DOWN1, AS_RES2, AS_DOWN2, AS_RES3_CONV,
               AS_DEC_LSTM_IH, AS_DEC_UP, AS_DEC_RES, AC_NSITES };
 static const char* const kAcSiteNames[AC_NSITES] = {"stage0", "res1", "down1", "res2", "down2", "res3_conv", "res3_tail", "lstm_ih", "final_conv_in", "rvq",
                                                    "dec_lstm_ih", "dec_up", "dec_res"};
-// status word of the *_checked entry points: bit 0 = an LSTM hand-off wait gave up (sync[63]), bit 1 = fp16 range overflow at any site
+// status word of the *_checked entry points: bit 0 = an LSTM hand-off wait gave up (sync[63]), bit 1 = fp16 range overflow at any site, bit 2 = a NaN /
+// infinity reached the RVQ search (XB_STATUS_NONFINITE)
 __global__ void status_combine_kernel(const unsigned* sync, const int* range_tab, int nsites, unsigned* out) {
     unsigned v = sync[63] ? 1u : 0u;
-    for (int k = 0; k < nsites; ++k) v |= (unsigned)range_tab[2 * k] & (unsigned)XB_STATUS_F16_OVERFLOW;
+    for (int k = 0; k < nsites; ++k) v |= (unsigned)range_tab[2 * k] & (unsigned)(XB_STATUS_F16_OVERFLOW | XB_STATUS_NONFINITE);
     out[0] = v;
 }
 int launch_status_combine(const unsigned* sync, const int* range_tab, unsigned* out, hipStream_t stream) {

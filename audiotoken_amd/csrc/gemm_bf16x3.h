@@ -16,6 +16,9 @@ namespace at {
 enum { XB_SCHEME_BF16X3 = 0, XB_SCHEME_F16X2 = 1 };
 constexpr float XB_F16_ACT_SCALE = 16.0f;
 constexpr int XB_STATUS_F16_OVERFLOW = 2;
+// a NaN / infinity reached a quantiser (RVQ, VQ, k-means): the range bookkeeping's fmaxf drops NaNs, so a NaN that does not descend from a flagged overflow
+// (a NaN in the caller's waveform) is caught where every activation ends up — |x|^2 of the vectors that are quantised
+constexpr int XB_STATUS_NONFINITE = 4;
 // 16-bit storage of one operand piece (bf16 bits or fp16 bits, by scheme)
 typedef __bf16 piece_t;
 inline int xb_pieces(int scheme) { return scheme == XB_SCHEME_F16X2 ? 2 : 3; }

@@ -322,7 +322,7 @@ static int launch_scheme(const Bf16x3Args& a, hipStream_t stream) {
 
 __global__ void range_combine_kernel(const int* tab, int nsites, int* out) {
     int v = 0;
-    for (int k = 0; k < nsites; ++k) v |= tab[2 * k] & XB_STATUS_F16_OVERFLOW;
+    for (int k = 0; k < nsites; ++k) v |= tab[2 * k] & (XB_STATUS_F16_OVERFLOW | XB_STATUS_NONFINITE);
     if (v) atomicOr(out, v);
 }
 int launch_range_combine(const int* range_tab, int nsites, int* status_out, hipStream_t stream) {

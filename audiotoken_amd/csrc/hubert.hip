@@ -406,8 +406,23 @@ int at_hubert_import_packed(at_hubert_t* h, const void* host_meta, int64_t meta_
     DeviceGuard guard(h->device);
     AT_REQUIRE(guard.ok, "cannot select the handle's device");
     if (int rc = packed_begin_import(h->arena, PACKED_MODEL_HUBERT, host_meta, meta_bytes, device_src, bytes, (hipStream_t)stream, &h->imp)) return rc;
-    if (int rc = finalize_impl(h)) { h->arena.importing = false; return rc; }
-    return packed_end_import(h->arena);
+    int rc = finalize_impl(h);
+    if (!rc) rc = packed_end_import(h->arena);
+    if (rc) {
+        // a failed import leaves an EMPTY handle that can only be destroyed (or imported into again): not a half-built model that reports `finalized`
+        h->finalized = false;
+        h->arena.importing = false;
+        h->layers.clear();
+        h->split_seq.clear();
+        h->split_done[0] = h->split_done[1] = false;
+        h->wmax.clear();
+        h->centers = h->c2 = nullptr;
+        for (int s = 0; s < 2; ++s)
+            for (int j = 0; j < 7; ++j) h->conv_ws[s][j] = nullptr;
+        h->arena.free_all();
+        if (h->range_tab) { (void)hipFree(h->range_tab); h->range_tab = nullptr; }
+    }
+    return rc;
 }
 
 void at_hubert_destroy(at_hubert_t* h) {
@@ -599,7 +614,7 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         prof.begin("kmeans", 3, stream);
         if (int rc = launch_layernorm(x, nullptr, nullptr, nullptr, t1, M, kHid, stream)) return rc;
         if (int rc = linear(t1, kHid, h->centers, nullptr, big, kCenters, M, EPI_NONE, nullptr, nullptr, kCenters, stream)) return rc;
-        if (int rc = launch_vq_argmax(t1, big, h->c2, tokens, M, kHid, kCenters, stream)) return rc;
+        if (int rc = launch_vq_argmax(t1, big, h->c2, tokens, M, kHid, kCenters, stream, reinterpret_cast<int*>(status_dev))) return rc;
         prof.end(stream);
     }
     return 0;

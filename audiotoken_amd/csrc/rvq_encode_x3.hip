@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256, 1) void rvq_encode_x3_kernel(const float* __re
     const float sa = SC::RANGE_CHECK ? act_scale : 1.0f;
     const float rs = SC::RANGE_CHECK ? 1.0f / (act_scale * cb_scale) : 1.0f;
     RangeMax over;
+    bool nonfinite = false;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const long long row_base = (long long)blockIdx.x * QX_ROWS + wave * 32;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256, 1) void rvq_encode_x3_kernel(const float* __re
             p += __shfl_xor(p, 16);
             p += __shfl_xor(p, 32);
             s2[i] = p;
+            nonfinite |= valid[i] && !(p <= 3.0e38f);   // |residual|^2: a NaN / infinity anywhere in the encoder ends up here
         }
         float best[2] = {-INFINITY, -INFINITY};
         int bidx[2] = {0, 0};
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(256, 1) void rvq_encode_x3_kernel(const float* __re
     }
     if constexpr (SC::RANGE_CHECK)
         range_publish(status, status ? status + 1 : nullptr, over);
+    if (status && nonfinite) atomicOr(status, XB_STATUS_NONFINITE);
 }
 
 template <class SC>

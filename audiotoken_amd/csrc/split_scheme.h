@@ -39,7 +39,8 @@ struct SchemeNoCheck : SC { static constexpr bool RANGE_CHECK = false; };
 
 // Range bookkeeping of the fp16 scheme. A split writer keeps the running maximum of |x * scale| over everything it splits (one v_max3 per value
 // pair; `over |= split4(...)` reads as before) and publishes it ONCE at the end of the kernel: bit XB_STATUS_F16_OVERFLOW of *status when the maximum
-// does not fit fp16 (65504; an infinity fails it — a NaN can only descend from one, or from a NaN in the caller's input), and, when the launch has a
+// does not fit fp16 (65504; an infinity fails it — fmaxf drops a NaN, which can only descend from an infinity that was flagged where it arose, or from a NaN in
+// the caller's input: XB_STATUS_NONFINITE, raised by the quantisers, covers that), and, when the launch has a
 // census word, the maximum itself (atomicMax on the float's bits: non-negative floats order like integers) — the per-site headroom that
 // at_*_range_report() returns: how close real activations come to the fp16 range is measured, not assumed.
 struct RangeMax {

@@ -467,8 +467,22 @@ int at_w2vbert_import_packed(at_w2vbert_t* h, const void* host_meta, int64_t met
     DeviceGuard guard(h->device);
     AT_REQUIRE(guard.ok, "cannot select the handle's device");
     if (int rc = packed_begin_import(h->arena, PACKED_MODEL_W2VBERT, host_meta, meta_bytes, device_src, bytes, (hipStream_t)stream, &h->imp)) return rc;
-    if (int rc = finalize_impl(h)) { h->arena.importing = false; return rc; }
-    return packed_end_import(h->arena);
+    int rc = finalize_impl(h);
+    if (!rc) rc = packed_end_import(h->arena);
+    if (rc) {
+        // a failed import leaves an EMPTY handle that can only be destroyed (or imported into again): not a half-built model that reports `finalized`
+        h->finalized = false;
+        h->arena.importing = false;
+        h->layers.clear();
+        h->split_seq.clear();
+        h->split_done[0] = h->split_done[1] = false;
+        h->wmax.clear();
+        h->codebook = h->e2 = nullptr;
+        h->cb_s[0] = h->cb_s[1] = nullptr;
+        h->arena.free_all();
+        if (h->range_tab) { (void)hipFree(h->range_tab); h->range_tab = nullptr; }
+    }
+    return rc;
 }
 
 void at_w2vbert_destroy(at_w2vbert_t* h) {
@@ -730,7 +744,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             if (int rc = launch_layernorm(x, nullptr, nullptr, nullptr, t1, M, kHid, stream)) return rc;
             if (int rc = linear(t1, kHid, h->codebook, nullptr, big, kCodes, M, EPI_NONE, 1.f, nullptr, nullptr, kCodes, stream)) return rc;
         }
-        if (int rc = launch_vq_argmax(t1, big, h->e2, tokens, M, kHid, kCodes, stream)) return rc;
+        if (int rc = launch_vq_argmax(t1, big, h->e2, tokens, M, kHid, kCodes, stream, reinterpret_cast<int*>(status_dev))) return rc;
         prof.end(stream);
     }
     return 0;

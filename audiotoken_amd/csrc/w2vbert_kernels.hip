@@ -820,7 +820,7 @@ int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, c
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict__ x, const float* __restrict__ dots,
                                                         const float* __restrict__ e2, int16_t* __restrict__ out, long long rows,
-                                                        int D, int C) {
+                                                        int D, int C, int* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -831,6 +831,7 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) x2 += __shfl_xor(x2, off);
+    if (status && lane == 0 && !(x2 <= 3.0e38f)) atomicOr(status, XB_STATUS_NONFINITE);   // a NaN / infinity anywhere upstream ends up in these rows
     float best = -INFINITY;
     int bidx = 0;
     for (int c = lane; c < (C >> 2); c += 64) {   // increasing n per lane: strict > keeps the first index
@@ -853,9 +854,9 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
 }
 
 int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,
-                     hipStream_t stream) {
+                     hipStream_t stream, int* status) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(vq_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, dots, e2, out, rows, D, C);
+    hipLaunchKernelGGL(vq_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, dots, e2, out, rows, D, C, status);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -106,6 +106,7 @@ class AcousticEncoder(torch.nn.Module):
         self._ws: Optional[torch.Tensor] = None
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.fallback_batches = 0    # batches `verified` repeated on the bf16x3 kernels (fp16 range overflow)
+        self.nonfinite_batches = 0   # batches whose activations held a NaN / infinity at the quantiser (status bit 2)
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes:
@@ -161,6 +162,15 @@ class AcousticEncoder(torch.nn.Module):
         status = self.last_status()
         if status == 0:
             return codes
+        if status & 4:
+            # a NaN / infinity reached the quantiser (a non-finite sample in the waveform, as a rule): no kernel choice changes that. The reference emits
+            # arbitrary ids for such input without a diagnostic; here it is at least logged and counted. The ids are returned as they are.
+            self.nonfinite_batches += 1
+            logger.error(f"acoustic encode: a NaN or an infinity reached the quantiser (status {status}); check the input waveform. "
+                         f"The token ids of this batch are meaningless (non-finite batch #{self.nonfinite_batches})")
+            status &= ~4
+            if status == 0:
+                return codes
         if status & 1:
             logger.error(f"persistent LSTM hand-off timed out (status {status}): the tokens of this batch were discarded; "
                          "re-encoding with per-step LSTM launches (option persistent_lstm=0) from now on")
@@ -175,7 +185,7 @@ class AcousticEncoder(torch.nn.Module):
                 self.set_option(opt, 0)
         try:
             codes = self.forward(input_batch, attention_mask)
-            if self.last_status() != 0:
+            if self.last_status() & ~4 != 0:   # (bit 2, non-finite input, is not something a repeat can clear)
                 raise _cabi.HipLibraryError("acoustic encode failed twice (status non-zero on the fallback kernels)")
         finally:
             for opt, v in saved.items():
@@ -320,6 +330,7 @@ class Wav2VecBertEncoder(torch.nn.Module):
         self._ws: Optional[torch.Tensor] = None
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.fallback_batches = 0    # batches `verified` repeated with arith=bf16x3 (fp16 range overflow)
+        self.nonfinite_batches = 0
 
     def __del__(self):
         h = self.__dict__.pop("handle", None)
@@ -352,6 +363,15 @@ class Wav2VecBertEncoder(torch.nn.Module):
         status = self.last_status()
         if status == 0:
             return tokens
+        if status & 4:
+            # a NaN / infinity reached the quantiser (a non-finite sample in the waveform, as a rule): no kernel choice changes that. The reference emits
+            # arbitrary ids for such input without a diagnostic; here it is at least logged and counted. The ids are returned as they are.
+            self.nonfinite_batches += 1
+            logger.error(f"semantic_m encode: a NaN or an infinity reached the quantiser (status {status}); check the input waveform. "
+                         f"The token ids of this batch are meaningless (non-finite batch #{self.nonfinite_batches})")
+            status &= ~4
+            if status == 0:
+                return tokens
         self.fallback_batches += 1
         logger.error(f"semantic_m encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
                      f"the tokens of this batch were discarded; re-encoding THIS batch with arith=bf16x3 (fallback batch #{self.fallback_batches})")
@@ -359,7 +379,7 @@ class Wav2VecBertEncoder(torch.nn.Module):
         self.set_option("arith", "bf16x3")
         try:
             tokens = self.forward(input_batch, mask, **kw)
-            if self.last_status() != 0:
+            if self.last_status() & ~4 != 0:   # (bit 2, non-finite input, is not something a repeat can clear)
                 raise _cabi.HipLibraryError("semantic_m encode failed twice (status non-zero with bf16x3 arithmetic)")
         finally:
             self.set_option("arith", saved)

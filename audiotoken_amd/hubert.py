@@ -110,6 +110,7 @@ class HubertEncoder(torch.nn.Module):
         self._ws: Optional[torch.Tensor] = None
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.fallback_batches = 0
+        self.nonfinite_batches = 0
 
     def __del__(self):
         h = self.__dict__.pop("handle", None)
@@ -140,6 +141,15 @@ class HubertEncoder(torch.nn.Module):
         status = self.last_status()
         if status == 0:
             return tokens
+        if status & 4:
+            # a NaN / infinity reached the quantiser (a non-finite sample in the waveform, as a rule): no kernel choice changes that. The reference emits
+            # arbitrary ids for such input without a diagnostic; here it is at least logged and counted. The ids are returned as they are.
+            self.nonfinite_batches += 1
+            logger.error(f"semantic_s encode: a NaN or an infinity reached the quantiser (status {status}); check the input waveform. "
+                         f"The token ids of this batch are meaningless (non-finite batch #{self.nonfinite_batches})")
+            status &= ~4
+            if status == 0:
+                return tokens
         self.fallback_batches += 1
         logger.error(f"semantic_s encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
                      f"the tokens of this batch were discarded; re-encoding THIS batch with arith=bf16x3 (fallback batch #{self.fallback_batches})")
@@ -147,7 +157,7 @@ class HubertEncoder(torch.nn.Module):
         self.set_option("arith", "bf16x3")
         try:
             tokens = self.forward(input_batch, attention_mask)
-            if self.last_status() != 0:
+            if self.last_status() & ~4 != 0:   # (bit 2, non-finite input, is not something a repeat can clear)
                 raise _cabi.HipLibraryError("semantic_s encode failed twice (status non-zero with bf16x3 arithmetic)")
         finally:
             self.set_option("arith", saved)

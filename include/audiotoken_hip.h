@@ -69,7 +69,12 @@ int at_encodec_encode(at_encodec_t* h, const float* wav, const float* mask, int 
 /* Same as at_encodec_encode, plus a device uint32 status word (stream-ordered): 0 on success; bit 0 (1) = a bounded wait inside the
  * persistent LSTM kernel gave up (the call still terminates); bit 1 (2) = an activation did not fit the fp16 range of an f16x2 kernel ("chain_f16x2",
  * "ih_f16x2", "res_f16x2", "rvq_f16x2", "fin_f16x2"). In both cases the codes are invalid and the caller repeats the batch on the safe path (options
- * persistent_lstm = 0 / chain_f16x2 = ih_f16x2 = res_f16x2 = rvq_f16x2 = fin_f16x2 = 0). */
+ * persistent_lstm = 0 / chain_f16x2 = ih_f16x2 = res_f16x2 = rvq_f16x2 = fin_f16x2 = 0). Bit 2 (4) = a NaN or an infinity reached the RVQ search (a
+ * non-finite sample in `wav`, as a rule): repeating does not help; the reference emits arbitrary codes for such input without a diagnostic.
+ * THREADING: a handle carries per-call bookkeeping (the range table the status word is combined from, zeroed at the start of every call), so the
+ * *_checked / range_report calls of ONE handle must be issued on one stream at a time — two concurrent calls on the same handle (an encode and a
+ * decode included) can clear each other's flags. Use one handle per stream. The same holds for at_w2vbert_* and at_hubert_* handles and for the
+ * handle-less at_op_*_split entry points (one range pair per device). */
 int at_encodec_encode_checked(at_encodec_t* h, const float* wav, const float* mask, int B, int N, int n_q, int16_t* codes,
                               int* T_out, float* emb_out, void* workspace, size_t workspace_bytes, at_stream_t stream,
                               uint32_t* status_dev);
@@ -173,7 +178,8 @@ int at_w2vbert_encode(at_w2vbert_t* h, const float* wav, const float* mask, int 
                       size_t workspace_bytes, at_stream_t stream);
 /* Same as at_w2vbert_encode, plus a device int32 status word (stream-ordered: zeroed at the start of the call, final when the call's work
  * has completed): bit 1 (value 2) = an activation did not fit the fp16 range of the "f16x2" arithmetic (|x| > 65504 / 16) — the
- * tokens are then invalid and the caller should repeat the batch after at_w2vbert_set_option(h, "arith", 1). */
+ * tokens are then invalid and the caller should repeat the batch after at_w2vbert_set_option(h, "arith", 1); bit 2 (value 4) = a NaN or an
+ * infinity reached the quantiser (a non-finite sample in `wav`): repeating does not help. One stream per handle (see at_encodec_encode_checked). */
 int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* mask, int B, int N, int pad_to_multiple_of, int n_layers,
                               int16_t* tokens, int* T_out, float* features_out, float* attn_mask_out, float* hidden_out, void* workspace,
                               size_t workspace_bytes, at_stream_t stream, int32_t* status_dev);
@@ -222,6 +228,36 @@ int at_hubert_set_option(at_hubert_t* h, const char* name, int value);
 int at_hubert_get_option(const at_hubert_t* h, const char* name);
 int at_hubert_profile(at_hubert_t* h, int enable);
 int at_hubert_profile_read(at_hubert_t* h, char* names, size_t names_cap, float* total_ms, int* launches, int max_groups);
+
+/* ---- input side of encode_batch_files: what the reference does through torchaudio / ffmpeg ------------------------------- */
+/* FLAC (RFC 9639), host code: replaces the StreamReader decode of reference audiotoken/utils.py:71-101 for '.flac' members of AUDIO_EXTS. `data` = the whole
+ * file in host memory. at_flac_info: STREAMINFO fields (md5_16 nullable: the MD5 of the decoded little-endian PCM, for the caller to verify).
+ * at_flac_decode: planar int32 samples out[c * cap_samples_per_channel + i], every frame's CRC-8 / CRC-16 verified; returns samples per channel or a
+ * negative code. Thread-safe (no handle, no device). */
+int at_flac_info(const uint8_t* data, size_t n, int* sample_rate, int* channels, int* bits_per_sample, int64_t* total_samples, uint8_t* md5_16);
+int64_t at_flac_decode(const uint8_t* data, size_t n, int32_t* out, int64_t cap_samples_per_channel);
+
+/* Raw PCM on the device -> the batch the encoders take, in one launch: sample format conversion, the per-chunk resampling of reference
+ * audiotoken/utils.py:82-98 (torchaudio Resample defaults), the segmentation / zero padding / mask of reference audiotoken/datasets.py:75-105.
+ * One descriptor per output row (built on the host from headers and lengths only; the array lives in device memory):
+ *   pcm        device pointer to the decoded file's mono samples in format `fmt`
+ *   table      device pointer to the resampling table of (orig, new): float32 [n][2 width + o] (audiotoken_amd/audio_io.py: resample_table) followed by
+ *              int32 [n][2] = the non-zero tap range [lo, hi) of every phase; NULL = the file is at the model's rate
+ *   chunk_off / chunk_len   the streamed chunk (chunk_size seconds at the SOURCE rate) this row is cut from: every chunk is resampled on its own
+ *   out_start / valid_len   the row = samples [out_start, out_start + valid_len) of the resampled chunk, then padding up to seg_len
+ *   scale      multiplies integer samples (1 / 32768 for 16-bit WAV, 1 / 2^31 for 24 / 32-bit WAV, 1 / 2^(bits - 1) for FLAC); u8: (x - 128) * scale
+ *   o, n, width   orig / g, new / g, half kernel width (o == n when table is NULL)
+ * segments [nseg][seg_len] float32, masks [nseg][seg_len] float32 (1 = sample exists; nullable). Stream-ordered, no allocation. */
+enum { AT_PCM_S16 = 0, AT_PCM_S32 = 1, AT_PCM_F32 = 2, AT_PCM_U8 = 3 };
+typedef struct at_segment_desc {
+    const void* pcm;
+    const float* table;
+    int64_t chunk_off;
+    int32_t chunk_len, out_start, valid_len, fmt;
+    float scale;
+    int32_t o, n, width;
+} at_segment_desc;
+int at_segments_from_pcm(const at_segment_desc* descs_dev, int nseg, int seg_len, float pad_value, float* segments, float* masks, at_stream_t stream);
 
 /* ---- operator-level entry points (the kernels behind the models; used by the parity tests) ------------- */
 

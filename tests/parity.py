@@ -60,12 +60,20 @@ def assert_rvq_equal_or_explained(got, ref, margins, tie, what):
 # that position, which no second implementation (another BLAS build of the reference included) reproduces.
 FLOAT_TOL = 1e-3
 NOISE_FACTOR = 4.0
+# NOT the contract's bar: this second explanation exists for two STRESS suites only (inputs / weights on which the reference itself is ill-conditioned).
+# Tests of BASELINE workloads, golden vectors and bench batches use assert_tokens_equal_or_explained (equal, or an oracle near-tie < 1e-3) and nothing else;
+# the guard below makes that a property of the code, not of a reviewer's attention.
+DELTA_HELPER_ALLOWED_IN = ("test_edge_inputs_gpu.py", "test_range_robustness_gpu.py", "test_parity_helpers_cpu.py")
 
 
 def assert_tokens_equal_or_explained_by_delta(got, ref, margins, x_got, x_ref, tie, what, valid=None, x_ref_exact=None):
     """got / ref / margins [B, 1, T]; x_got / x_ref [B, T, D] = the vectors that were quantised (HIP path / oracle); x_ref_exact = the oracle's
     vectors with a float64 front-end (optional). A differing id must have an oracle margin < tie, or <= 2 ||x_got - x_ref||_2 at its position with
     max |x_got - x_ref| <= max(FLOAT_TOL, NOISE_FACTOR max |x_ref - x_ref_exact|) there. Prints the counts."""
+    import inspect
+    import os
+    caller = os.path.basename(inspect.stack()[1].filename)
+    assert caller in DELTA_HELPER_ALLOWED_IN, f"assert_tokens_equal_or_explained_by_delta is a stress-test bar only (called from {caller})"
     got, ref = got.cpu().long(), ref.cpu().long()
     mism = (got != ref)[:, 0]                                   # [B, T]
     if valid is not None:

@@ -68,10 +68,13 @@ def test_edge_acoustic(acoustic, name):
 
 @pytest.mark.parametrize("name", CASES)
 def test_edge_semantic_m(semantic_m, name):
-    """The reference normalises every mel bin by its variance over time, (x - mean) / sqrt(var + 1e-7) (processors.py:128-135,242). When a bin
+    """The reference normalises every mel bin by its variance over time, (x - mean) / sqrt(var + 1e-7) (processors.py:117-135,192-207,242). When a bin
     is constant over time — silence, DC (removed per frame), a square wave whose period divides the 160-sample hop — the result is the one-ulp
-    summation noise of the reference's own fp32 mean amplified ~3000 x; the HIP path computes those statistics in float64 (exact zero). That
-    noise is not reproducible by construction, so those inputs are SKIPPED with the measured variance, not thresholded."""
+    summation noise of the reference's own fp32 mean amplified ~3000 x; the HIP path computes those statistics in float64 (exact zero). That noise is
+    not reproducible by construction, so on those inputs the build's tokens are NOT asserted against the oracle's. They are still real
+    inputs (gaps in recordings), so what the build emits there is pinned instead: status 0, ids in range, bit-identical on a repeat, independent of the
+    clip's position in a batch and of its batch mates — and the agreement with the oracle is printed, without a threshold, so the size of the
+    divergence is on record."""
     from oracle import w2vbert_ref as R
     w, enc = semantic_m
     wav = torch.from_numpy(edge_wave(name, 32000, 16000))[None]
@@ -81,7 +84,19 @@ def test_edge_semantic_m(semantic_m, name):
     assert enc.last_status() == 0, "an edge input left the fp16 range of the f16x2 kernels"
     assert int(toks.min()) >= 0 and int(toks.max()) < 2048
     if vmin < 1e-6:
-        pytest.skip(f"semantic_m {name}: a mel bin is constant over time (min per-bin variance {vmin:.2e}): the reference output is its own rounding noise")
+        again = enc(wav.cuda(), mask.cuda())
+        assert enc.last_status() == 0 and torch.equal(again, toks), f"semantic_m {name}: a repeat of the same call gave different tokens"
+        mates = torch.from_numpy(W.synth_waveform(2, 32000, 16000, seed=977))
+        batch = torch.cat([mates[:1], wav, mates[1:]]).cuda()
+        in_batch = enc(batch, torch.ones_like(batch))
+        assert enc.last_status() == 0 and torch.equal(in_batch[1:2], toks), f"semantic_m {name}: tokens depend on the batch position / batch mates"
+        wt = {k: torch.from_numpy(v) for k, v in w.items()}
+        ref = R.semantic_m_encode(wt, wav, mask, 2, 3)
+        same = (toks.cpu() == ref)
+        print(f"[edge] semantic_m {name}: a mel bin is constant over time (min per-bin variance {vmin:.2e}): the reference output is its own rounding noise; "
+              f"the build's tokens are deterministic and batch-independent; {int(same.sum())} of {same.numel()} ids ({same.float().mean().item():.3f}) "
+              f"happen to equal the fp32 oracle's (information, not a bar)")
+        return
     wt = {k: torch.from_numpy(v) for k, v in w.items()}
     ref, margins = R.semantic_m_encode(wt, wav, mask, 2, 3, return_margins=True)
     feats, am = R.processor(wav, mask, 2)

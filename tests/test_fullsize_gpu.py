@@ -198,13 +198,12 @@ def test_bench_batch_semantic_m_vs_oracle(cuda_device, w2vbert_19):
     checksum = S.token_checksum(toks)
     print(f"[parity-at-size] semantic_m bench batch token_checksum {checksum} (pinned {S.PINNED_CHECKSUMS['semantic_m']})")
     wt = {k: torch.from_numpy(v) for k, v in w.items()}
-    n_differ = n_bad = n_ids = 0
+    n_differ = n_bad = n_ids = n_padded = 0
     for i in (1, 22, 43, 63):
         ref, margins = R.semantic_m_encode(wt, wav[i:i + 1].cpu(), mask[i:i + 1].cpu(), 2, 19, return_margins=True)
-        _, am = R.processor(wav[i:i + 1].cpu(), mask[i:i + 1].cpu(), 2)
-        valid = am.bool().unsqueeze(1)
-        n, bad, _ = P.explain_token_mismatches(toks[i:i + 1], ref, margins, P.VQ_TIE, valid)
-        n_differ += n; n_bad += bad; n_ids += int(valid.sum())
+        # every position, padded ones included: the reference's trim persists ceil(sec * 50) tokens per chunk
+        n, bad, _ = P.explain_token_mismatches(toks[i:i + 1], ref, margins, P.VQ_TIE)
+        n_differ += n; n_bad += bad; n_ids += ref.numel()
     # ragged rows: the reference zeroes nothing itself — the harness right-pads with zeros and mask 0 (datasets.py:98-103)
     wav2, mask2 = wav.clone(), mask.clone()
     for i, cut in ((3, 300000), (40, 123456)):
@@ -215,13 +214,12 @@ def test_bench_batch_semantic_m_vs_oracle(cuda_device, w2vbert_19):
     for i in (3, 40):
         ref, margins = R.semantic_m_encode(wt, wav2[i:i + 1].cpu(), mask2[i:i + 1].cpu(), 2, 19, return_margins=True)
         _, am = R.processor(wav2[i:i + 1].cpu(), mask2[i:i + 1].cpu(), 2)
-        valid = am.bool().unsqueeze(1)
-        n, bad, _ = P.explain_token_mismatches(toks2[i:i + 1], ref, margins, P.VQ_TIE, valid)
-        n_differ += n; n_bad += bad; n_ids += int(valid.sum())
+        n, bad, _ = P.explain_token_mismatches(toks2[i:i + 1], ref, margins, P.VQ_TIE)
+        n_differ += n; n_bad += bad; n_ids += ref.numel(); n_padded += int((~am.bool()).sum())
     # rows the ragged edit did not touch are unchanged (batch independence at size)
     keep = [i for i in range(64) if i not in (3, 40)]
     assert torch.equal(toks2[keep], toks[keep])
-    _report("semantic_m bench batch, 4 full + 2 ragged of 64 clips, 19 layers", n_ids, n_differ, n_bad)
+    _report(f"semantic_m bench batch, 4 full + 2 ragged of 64 clips, 19 layers, ALL positions ({n_padded}+ of them padded)", n_ids, n_differ, n_bad)
     assert n_bad == 0
     assert checksum == S.PINNED_CHECKSUMS["semantic_m"], f"semantic_m token_checksum moved: {checksum} != pinned {S.PINNED_CHECKSUMS['semantic_m']}"
 

@@ -33,7 +33,7 @@ def test_read_audio_and_chunks(tmp_path):
     stereo = np.stack([x, -x], 1)
     wavfile.write(str(tmp_path / "s.wav"), sr, stereo.astype(np.float32))
     assert float(A.read_audio(tmp_path / "s.wav", sr).abs().max()) < 1e-6       # mono mix of (x, -x)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(A.AudioDecodeError):                # lossy codecs: no decoder in this build
         A.load(tmp_path / "a.mp3")
 
 
@@ -132,7 +132,7 @@ def test_batch_files_sharding_logic(tmp_path, monkeypatch):
 
 
 def test_undecodable_files_are_skipped_visibly_and_bugs_propagate(tmp_path, monkeypatch):
-    """A file this build cannot decode (flac: no ffmpeg here; a stereo WAV; a damaged header) is skipped, but the caller can see it:
+    """A file this build cannot decode (a damaged FLAC; an mp3: no lossy decoder here; a stereo WAV; a damaged header) is skipped, but the caller can see it:
     ``AudioToken.skipped_files`` lists it and the run logs a summary. Any other exception (a bug in resampling / chunking) propagates, like
     the reference's dataset iterator (audiotoken/datasets.py __iter__) lets it."""
     from audiotoken_amd import AudioToken, Tokenizers
@@ -151,12 +151,14 @@ def test_undecodable_files_are_skipped_visibly_and_bugs_propagate(tmp_path, monk
 
     tok.encoder = Fake()
     monkeypatch.setattr(tok, "load_encoder", lambda: None)
-    files = [tmp_path / n for n in ("music.flac", "good.wav", "broken.wav", "stereo.wav", "notes.txt")]
+    (tmp_path / "song.mp3").write_bytes(b"ID3\x03\x00\x00")
+    files = [tmp_path / n for n in ("music.flac", "good.wav", "broken.wav", "stereo.wav", "notes.txt", "song.mp3")]
     tok.encode_batch_files(batch_size=2, outdir=tmp_path / "o", chunk_size=1, audio_files=files, num_workers=2)
     assert sorted(os.listdir(tmp_path / "o")) == ["good.npy"]
     skipped = {os.path.basename(p): why for p, why in tok.skipped_files}
-    assert set(skipped) == {"music.flac", "broken.wav", "stereo.wav", "notes.txt"}
-    assert "NotImplementedError" in skipped["music.flac"] and "mono" in skipped["stereo.wav"] and skipped["notes.txt"] == "unsupported extension"
+    assert set(skipped) == {"music.flac", "broken.wav", "stereo.wav", "notes.txt", "song.mp3"}
+    assert "flac" in skipped["music.flac"] and "mono" in skipped["stereo.wav"] and skipped["notes.txt"] == "unsupported extension"
+    assert "lossy-codec decoder" in skipped["song.mp3"]
     # a second run starts from an empty list
     tok.encode_batch_files(batch_size=2, outdir=tmp_path / "o2", chunk_size=1, audio_files=[tmp_path / "good.wav"], num_workers=0)
     assert tok.skipped_files == []

@@ -118,3 +118,39 @@ def test_semantic_s_census(cuda_device):
     live, bits = _headroom(enc.range_report())
     print(f"[range] semantic_s: census {dict((k, round(v, 1)) for k, v in live.items())}, headroom {bits:.1f} bits")
     assert set(live) >= {"conv0_out", "feature_convs", "layer_input", "qkv_kv", "attention", "ffn_hidden"} and bits > 0
+
+
+@pytest.mark.parametrize("tokenizer", ["acoustic", "semantic_m", "semantic_s"])
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")], ids=["nan", "inf"])
+def test_nonfinite_input_is_reported(cuda_device, tokenizer, bad):
+    """A NaN / infinity in the caller's waveform: the range bookkeeping's running maximum drops NaNs (fmaxf), so without a check such a batch would
+    finish with status 0. The quantisers (RVQ, VQ, k-means) raise status bit 2 when a vector they quantise is not finite; `verified` logs it, counts it
+    and returns the ids as they are (the reference emits arbitrary ids there without a diagnostic). A clean batch on the same handle reads 0 again."""
+    if tokenizer == "acoustic":
+        from audiotoken_amd.configs import AcousticEncoderConfig
+        from audiotoken_amd.encoder import AcousticEncoder
+        enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=W.synth_encodec_weights(seed=0, with_decoder=False))
+        wav = torch.from_numpy(W.synth_waveform(2, 24000, 24000, seed=5))
+    elif tokenizer == "semantic_m":
+        from audiotoken_amd.configs import Wav2VecBertConfig
+        from audiotoken_amd.encoder import Wav2VecBertEncoder
+        enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=2), device="cuda:0", quantize=True, weights=W.synth_w2vbert_weights(n_layers=2, seed=9, with_vq=True))
+        wav = torch.from_numpy(W.synth_waveform(2, 32000, 16000, seed=5))
+    else:
+        from audiotoken_amd.configs import HubertEncoderConfig
+        from audiotoken_amd.hubert import HubertEncoder
+        enc = HubertEncoder(HubertEncoderConfig(output_layer=2), device="cuda:0", weights=W.synth_hubert_weights(2, 0, True))
+        wav = torch.from_numpy(W.synth_waveform(2, 32000, 16000, seed=5))
+    mask = torch.ones_like(wav)
+    clean = enc(wav.cuda(), mask.cuda())
+    assert enc.last_status() == 0
+    dirty = wav.clone()
+    dirty[1, 12345] = bad
+    toks = enc(dirty.cuda(), mask.cuda())
+    status = enc.last_status()
+    print(f"[range] {tokenizer}: a {bad} sample in clip 1 -> status {status}")
+    assert status & 4, f"{tokenizer}: a non-finite input finished with status {status}"
+    out = enc.verified(toks, dirty.cuda(), mask.cuda())
+    assert enc.nonfinite_batches == 1 and out.shape == clean.shape
+    again = enc(wav.cuda(), mask.cuda())
+    assert enc.last_status() == 0 and torch.equal(again, clean)

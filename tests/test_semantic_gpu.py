@@ -313,8 +313,10 @@ def test_tokens_vs_oracle_ragged(enc3):
     feats, am = R.processor(torch.from_numpy(wave), torch.from_numpy(mask), 2)
     valid = am.bool().unsqueeze(1)
     same = (toks.cpu() == ref)
-    print(f"tokens equal: valid {same[valid].float().mean().item():.4f}, all {same.float().mean().item():.4f}")
-    assert same[valid].all(), "token ids at valid positions must be bit-identical"
+    # EVERY position is compared: the reference's save-time trim keeps ceil(sec * 50) tokens per streamed chunk, which includes
+    # positions whose frames are padding (token mask 0) — their ids reach the .npy files, so they are part of what "the same tokens" means
+    print(f"tokens equal: valid {same[valid].float().mean().item():.4f}, all {same.float().mean().item():.4f} ({int((~valid).sum())} padded positions compared too)")
+    assert same.all(), f"{int((~same).sum())} token ids differ ({int((~same[valid]).sum())} of them at valid positions)"
 
 
 @pytest.mark.parametrize("N", [4000, 10480, 10800, 880], ids=["T11", "T32", "T33", "T2"])
@@ -335,7 +337,8 @@ def test_tokens_vs_oracle_short_clips(enc3, N):
     valid = am.bool().unsqueeze(1)
     assert toks.shape == ref.shape
     same = (toks.cpu() == ref)
-    assert same[valid].all(), f"N={N}: {int((~same[valid]).sum())} token ids differ at valid positions"
+    print(f"N={N}: {same.numel()} ids compared, {int((~valid).sum())} of them at padded positions (persisted by the reference's trim: SURVEY.md App. B.7)")
+    assert same.all(), f"N={N}: {int((~same).sum())} token ids differ ({int((~same[valid]).sum())} at valid positions)"
 
 
 def test_encode_batch_files_semantic_m(tmp_path):
@@ -377,12 +380,11 @@ def test_encode_batch_files_semantic_m(tmp_path):
         margins = np.hstack([p[1] for p in pieces])
         valid = np.hstack([p[2] for p in pieces]) > 0
         assert got.dtype == np.int16 and got.shape == ref_all.shape, (got.shape, ref_all.shape)
-        # the trim keeps ceil(sec*50) tokens, which can include positions whose frames are padding (token mask 0): ids there are not
-        # part of the parity contract. Every VALID position must equal the oracle's id or sit on an oracle near-tie.
+        # the trim keeps ceil(sec*50) tokens, which can include positions whose frames are padding (token mask 0): the reference writes those ids to the
+        # file too, so EVERY id of the file must equal the oracle's or sit on an oracle near-tie
         from tests import parity as P
         n = P.assert_tokens_equal_or_explained(torch.from_numpy(got)[None], torch.from_numpy(ref_all)[None], torch.from_numpy(margins)[None],
-                                               P.VQ_TIE, f"{name}: {got.shape[1]} tokens ({int((~valid).sum())} padded positions excluded)",
-                                               torch.from_numpy(valid)[None])
+                                               P.VQ_TIE, f"{name}: all {got.shape[1]} tokens of the file ({int((~valid).sum())} of them at padded positions)")
         assert n <= 2
 
 
