@@ -29,6 +29,18 @@ from .logger import get_logger
 logger = get_logger(__name__, log_file=None, level="WARNING")
 
 
+def _in_flight(start, items, depth):
+    """``start(item)`` for up to ``depth`` items ahead of the consumer, results in order (``start`` returns immediately: it submits work elsewhere)."""
+    from collections import deque
+    pending = deque()
+    for it in items:
+        pending.append(start(it))
+        if len(pending) >= max(1, depth):
+            yield pending.popleft()
+    while pending:
+        yield pending.popleft()
+
+
 class AudioToken:
     def __init__(self, tokenizer: Tokenizers, device: str = "cpu", compile: bool = False, **kwargs):
         """Reference ``AudioToken.__init__`` (core.py:28-71). Supported kwargs: ``num_codebooks`` in {2,4,8,16}
@@ -123,12 +135,23 @@ class AudioToken:
                 out = checked.cpu()
         return out
 
-    def _chunk_stream(self, files, chunk_size: int, num_workers: int = 0):
-        """File -> streamed ``chunk_size``-second chunks -> segments (reference datasets.py:107-139). Decoding and resampling
-        run ``num_workers`` files ahead on a thread pool (prefetch.py); the segment order equals the sequential one."""
+    def _chunk_stream(self, files, chunk_size: int, num_workers: int = 0, worker_processes: bool = False):
+        """File -> streamed ``chunk_size``-second chunks -> segments (reference datasets.py:107-139). Decoding and resampling run ``num_workers`` files
+        ahead of the consumer — in SPAWNED worker processes for plain audio files when ``worker_processes`` (the reference's DataLoader workers,
+        core.py:259-267; the parent has the GPU initialised, so never forked), else on a thread pool; archives are streamed member by member by a
+        background thread either way (members are not random-access). The segment order equals the sequential one."""
         from .audio_io import AudioDecodeError, iterate_tar, iterate_zip, process_audio_chunks
         from .prefetch import background, ordered_map
         sr = self.model_config.model_sample_rate
+        pool = None
+        if worker_processes and num_workers > 0:
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            pool = ProcessPoolExecutor(max_workers=num_workers, mp_context=mp.get_context("spawn"))
+
+        def skipped(name, why):   # an undecodable file / archive member: recorded and skipped
+            logger.error(f"Skipping {name}: {why}")
+            self.skipped_files.append((name, why))
 
         def load(file_path: str):
             """One unit of host work: plain audio files are decoded completely; archives return a streaming source. A file that
@@ -136,15 +159,14 @@ class AudioToken:
             in ``self.skipped_files`` and reported at the end of the run — it must not abort a run whose earlier files have already been
             appended to. Any other exception propagates, as in the reference (datasets.py __iter__)."""
             if file_path.endswith(AUDIO_EXTS):
+                if pool is not None:
+                    from ._workers import decode_chunks
+                    return pool.submit(decode_chunks, file_path, sr, chunk_size)
                 try:
                     return list(process_audio_chunks(file_path, sr, chunk_size))
                 except AudioDecodeError as e:
-                    logger.error(f"Skipping {file_path}: {e}")
-                    self.skipped_files.append((file_path, str(e)))
+                    skipped(file_path, str(e))
                     return []
-            def skipped(name, why):   # an undecodable archive member: recorded and skipped like an undecodable file
-                logger.error(f"Skipping {name}: {why}")
-                self.skipped_files.append((name, why))
             if file_path.endswith(TAR_EXTS):
                 return background(lambda: iterate_tar(file_path, sr, chunk_size, skipped)) if num_workers > 0 else iterate_tar(file_path, sr, chunk_size, skipped)
             if file_path.endswith(ZIP_EXTS):
@@ -153,25 +175,45 @@ class AudioToken:
             self.skipped_files.append((file_path, "unsupported extension"))
             return []
 
-        for source in ordered_map(load, [str(f) for f in files], num_workers):
-            try:
-                for waveform, file_name in source:
-                    yield from iter_chunk(waveform, file_name, sample_rate=self.model_config.model_sample_rate, chunk_size=chunk_size,
-                                          model_token_rate=self.model_config.model_token_rate, pad_token=self.model_config.pad_token,
-                                          transform=self.transform_func)
-            finally:   # an exception in the consumer (or an abandoned run) must not leave an archive's producer thread and its handle behind
-                close = getattr(source, "close", None)
-                if close is not None:
-                    close()
+        def resolve(file_path, source):
+            if pool is not None and hasattr(source, "result"):      # a worker process's answer: numpy chunks, or the reason the file was skipped
+                kind, payload = source.result()
+                if kind == "skip":
+                    skipped(file_path, payload)
+                    return []
+                return [(torch.from_numpy(c), file_path) for c in payload]
+            return source
+
+        names = [str(f) for f in files]
+        try:
+            # with processes `load` only SUBMITS (the thread pool of ordered_map is not needed: in-line submission keeps num_workers futures in flight)
+            sources = ordered_map(lambda f: (f, load(f)), names, num_workers if pool is None else 0) if pool is None else _in_flight(lambda f: (f, load(f)), names, num_workers)
+            for file_path, source in sources:
+                source = resolve(file_path, source)
+                try:
+                    for waveform, file_name in source:
+                        yield from iter_chunk(waveform, file_name, sample_rate=self.model_config.model_sample_rate, chunk_size=chunk_size,
+                                              model_token_rate=self.model_config.model_token_rate, pad_token=self.model_config.pad_token,
+                                              transform=self.transform_func)
+                finally:   # an exception in the consumer (or an abandoned run) must not leave an archive's producer thread and its handle behind
+                    close = getattr(source, "close", None)
+                    if close is not None:
+                        close()
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=False, cancel_futures=True)
 
     def encode_batch_files(self, batch_size: int, outdir: os.PathLike, chunk_size: int = 30, num_workers: int = 12,
                            audio_files: Optional[List[os.PathLike]] = None, audio_dir: Optional[Union[os.PathLike, Path]] = None,
                            **dataloader_kwargs) -> None:
         """core.py:198-289. Files -> ``chunk_size``-second segments -> batches -> encoder -> per-row trimmed
-        ``<stem>.npy`` (append semantics as in the reference). ``num_workers`` files are decoded / resampled ahead of the
-        device on a thread pool, in order (the reference's DataLoader workers; 0 = inline). Under ``torch.distributed``
-        every rank takes a contiguous block of files (all chunks of a file stay on one rank, preserving the append
-        order)."""
+        ``<stem>.npy`` (append semantics as in the reference). ``num_workers`` files are decoded ahead of the device, in order (the reference's
+        DataLoader workers; 0 = inline). On a HIP device, for the tokenizers without a host-side transform (acoustic, semantic_m), the samples never become
+        float32 on the host: the DEVICE FEEDER (feeder.py) uploads the decoded PCM and converts / resamples / segments / pads in one kernel per batch
+        (``device_feeder=False`` keeps the reference's host data flow). Host path: a thread pool by default — the heavy work (file read, FLAC decode, the
+        resampling conv1d) releases the GIL — or spawned worker PROCESSES with ``worker_processes=True`` (the reference's arrangement; archives are always
+        streamed by a thread). Under ``torch.distributed`` every rank takes whole files, balanced by size (distributed.shard_by_size): all chunks of a file stay
+        on one rank, preserving the append order."""
         self.load_encoder()
         self.skipped_files = []
         assert audio_files or audio_dir, "Either audio_files or audio_dir must be provided"
@@ -183,8 +225,10 @@ class AudioToken:
             files = sorted(str(p) for ext in AUDIO_EXTS + TAR_EXTS + ZIP_EXTS for p in Path(audio_dir).rglob(f"*{ext}"))
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            from .distributed import shard_indices
-            files = [files[i] for i in shard_indices(len(files), dist.get_rank(), dist.get_world_size())]
+            # duration-aware: whole files by greedy LPT on their sizes (distributed.shard_by_size); every rank stats the same list and gets the same answer
+            from .distributed import shard_by_size
+            sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in files]
+            files = [files[i] for i in shard_by_size(sizes, dist.get_rank(), dist.get_world_size())]
         start_time = time.time()
         on_gpu = torch.device(self.device).type == "cuda"
         copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
@@ -202,25 +246,58 @@ class AudioToken:
                 ev.record(copy_stream)
             return ids, masks, file_pointers, ev
 
-        batches = batched(self._chunk_stream(files, chunk_size, num_workers), batch_size)
-        nxt = next(batches, None)
-        staged = upload(nxt) if nxt is not None else None
+        # Device feeder (feeder.py): decoding stays on the host, sample conversion / per-chunk resampling / segmentation / padding run in one HIP kernel per
+        # batch. For tokenizers without a host-side transform (acoustic, semantic_m); `device_feeder=False` keeps the host data flow of the reference.
+        use_feeder = on_gpu and self.transform_func is None and dataloader_kwargs.get("device_feeder", True)
+        self.feeder_timings = None
+        if use_feeder:
+            from .feeder import DeviceFeeder
+
+            def skipped(name, why):
+                logger.error(f"Skipping {name}: {why}")
+                self.skipped_files.append((name, why))
+            feeder = DeviceFeeder(self.device, self.model_config.model_sample_rate, chunk_size, self.model_config.model_token_rate,
+                                  self.model_config.pad_token, num_workers, skipped)
+            self.feeder_timings = feeder.timings
+            staged_iter = feeder.batches(files, batch_size)
+            stage_next = lambda: next(staged_iter, None)
+        else:
+            batches = batched(self._chunk_stream(files, chunk_size, num_workers, bool(dataloader_kwargs.get("worker_processes", False))), batch_size)
+
+            def stage_next():
+                b = next(batches, None)
+                return upload(b) if b is not None else None
+        # host seconds per stage of the loop (bench.py's files leg): `stage` = producing the next batch (decode wait + upload + descriptors, or the host
+        # chunk stream + collate + upload), `encode_call` = enqueueing the encode, `device_wait` = blocked on the device (the status read of verified / the
+        # first .cpu()), `save` = the per-row trim + append to the .npy files
+        rt = self.run_timings = {"stage_s": 0.0, "encode_call_s": 0.0, "device_wait_s": 0.0, "save_s": 0.0, "batches": 0, "rows": 0}
+        t0 = time.perf_counter()
+        staged = stage_next()
+        rt["stage_s"] += time.perf_counter() - t0
         while staged is not None:
             input_ids, attention_masks, file_pointers, ev = staged
+            t0 = time.perf_counter()
             if ev is not None:
                 torch.cuda.current_stream(self.device).wait_event(ev)
                 input_ids.record_stream(torch.cuda.current_stream(self.device))
                 attention_masks.record_stream(torch.cuda.current_stream(self.device))
             encoded_audio = self.encoder(input_ids, attention_masks)      # asynchronous on the device
-            nxt = next(batches, None)
-            staged = upload(nxt) if nxt is not None else None             # next batch's copy flies during this encode
+            t1 = time.perf_counter()
+            staged = stage_next()                                         # the next batch is decoded / uploaded / cut while this one encodes
+            t2 = time.perf_counter()
             if hasattr(self.encoder, "verified"):   # the saves below synchronise anyway: check the call's device status first
                 encoded_audio = self.encoder.verified(encoded_audio, input_ids, attention_masks)
+            encoded_audio = encoded_audio.cpu()     # ONE device-to-host copy per batch (a per-row .cpu() inside the save would synchronise B times)
+            t3 = time.perf_counter()
             for tokens_batch, file_pointer in zip(encoded_audio, file_pointers):
                 if audio_files is not None:
                     save_audio_tokens(tokens_batch, file_pointer, str(outdir))
                 else:
                     save_rel_audio_tokens(tokens_batch, file_pointer, str(outdir), str(audio_dir))
+            t4 = time.perf_counter()
+            rt["encode_call_s"] += t1 - t0; rt["stage_s"] += t2 - t1; rt["device_wait_s"] += t3 - t2; rt["save_s"] += t4 - t3
+            rt["batches"] += 1; rt["rows"] += len(file_pointers)
+        rt["total_s"] = time.time() - start_time
         logger.debug(f"Encoding batch files took: {time.time() - start_time:.2f}s")
         if self.skipped_files:
             logger.error(f"encode_batch_files: {len(self.skipped_files)} input(s) were skipped and have NO token file (AudioToken.skipped_files): "

@@ -595,7 +595,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     float* feats = features_out ? features_out : ws + p.off_feats;
     float* amask = attn_mask_out ? attn_mask_out : ws + p.off_amask;
     prof.begin("frontend", 5, stream);
-    if (int rc = launch_frame_prep(wav, mask, h->window, frames, fmask, B, N, F, stream)) return rc;
+    if (int rc = launch_frame_prep(wav, mask, h->window, frames, fmask, B, N, F, stream, reinterpret_cast<int*>(status_dev))) return rc;
     if (int rc = launch_dft_f64(frames, h->dft64, spec, BF, kSpecLd, stream)) return rc;
     {   // |X|^2 folded into the mel projection's prologue, log(max(., floor)) into its epilogue
         GemmArgs a;

@@ -5,7 +5,7 @@
 namespace at {
 
 int launch_frame_prep(const float* wav, const float* smask, const float* window, double* frames, float* fmask, int B, int N,
-                      int F, hipStream_t stream);
+                      int F, hipStream_t stream, int* status = nullptr);   // status: OR-ed with XB_STATUS_NONFINITE when a frame holds a NaN / infinity
 int launch_dft_f64(const double* frames, const double* dft, float* spec, long long M, int N, hipStream_t stream);
 int launch_fbank_normalize(const float* logmel, const float* fmask, float* stats, float* feats, float* amask, int B, int F, int Tp,
                            hipStream_t stream);

@@ -22,7 +22,7 @@ namespace at {
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void frame_prep_kernel(const float* __restrict__ wav, const float* __restrict__ smask,
                                                          const float* __restrict__ window, double* __restrict__ frames,
-                                                         float* __restrict__ fmask, int N, int F, long long total_frames) {
+                                                         float* __restrict__ fmask, int N, int F, long long total_frames, int* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const long long fid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (fid >= total_frames) return;
@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void frame_prep_kernel(const float* __restrict
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    // a NaN / infinity in the waveform: the log(max(., floor)) of the mel stage would launder it (fmaxf drops a NaN) where the reference's clamp keeps it,
+    // so it is flagged here, where every sample the model uses passes by (XB_STATUS_NONFINITE)
+    if (status && lane == 0 && !(fabs(sum) <= 1.0e300)) atomicOr(status, XB_STATUS_NONFINITE);
     const double mean = sum / 400.0;
     const unsigned long long ok = __ballot(all_valid);
     double* out = frames + fid * 400;
@@ -63,11 +66,11 @@ __global__ __launch_bounds__(256) void frame_prep_kernel(const float* __restrict
 }
 
 int launch_frame_prep(const float* wav, const float* smask, const float* window, double* frames, float* fmask, int B, int N,
-                      int F, hipStream_t stream) {
+                      int F, hipStream_t stream, int* status) {
     const long long total = (long long)B * F;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(frame_prep_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, wav, smask, window, frames,
-                       fmask, N, F, total);
+                       fmask, N, F, total, status);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -18,6 +18,23 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
+def shard_by_size(sizes: Sequence[int], rank: int, world: int) -> List[int]:
+    """Items owned by ``rank`` when the items have very different costs (audio files: bytes as the proxy for seconds): greedy longest-processing-time
+    assignment — items in decreasing size, each to the rank with the least work so far (ties: the lowest rank; equal sizes: the lower index first) —
+    which every rank computes identically from the same list. Whole items only, so all chunks of a file stay on one rank (the reference's per-file append
+    order, audiotoken/utils.py:214-217); a rank's items keep their original relative order. The reference balances dynamically (its DataLoader workers
+    pull files from a queue, audiotoken/datasets.py:107-139); contiguous blocks by COUNT left ranks idle behind a few long files. Worst case of LPT:
+    4/3 - 1/(3 world) of the optimum; with many files of bounded size the loads differ by at most the smallest file."""
+    order = sorted(range(len(sizes)), key=lambda i: (-int(sizes[i]), i))
+    load = [0] * world
+    owner = [0] * len(sizes)
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += max(int(sizes[i]), 1)
+    return [i for i in range(len(sizes)) if owner[i] == rank]
+
+
 def collective_device(device: torch.device, dist) -> torch.device:
     """Where a collective's tensors live: the rank's device under RCCL ("nccl"); host memory under gloo (the CPU tests, and bench.py's
     ``--shared-device`` rehearsal of the N > 1 path on a one-GPU box, where every rank drives cuda:0 and RCCL cannot be used)."""

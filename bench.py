@@ -492,6 +492,79 @@ def timed_region(workloads, steps, warmup, dist):
     return elapsed
 
 
+def run_files(args, rank, world, dev, dist, device_rates):
+    """files -> tokens: `AudioToken.encode_batch_files` end to end on generated WAV files (30 s, 16-bit PCM) — directory scan, decode (worker threads),
+    upload of the raw PCM, the device feeder's convert / resample / segment kernel, the encode, the status read, the per-file .npy writes — at the model's
+    sample rate and at a rate that needs resampling (48 k -> 24 k acoustic, 44.1 k -> 16 k semantic_m). Reported BESIDE `value` (never as it): audio-seconds
+    per wall-second of the whole call, its ratio to the device-resident rate of the same tokenizer measured in this run, and the host seconds per stage.
+    Runs on ALL ranks at once (every rank its own files), barrier-bracketed, max over ranks: this is the loop whose host side can bend the weak-scaling
+    curve — the real feeder, not pre-pinned tensors."""
+    import shutil
+    import tempfile
+    from scipy.io import wavfile
+    from audiotoken_amd import AudioToken, Tokenizers
+    from audiotoken_amd import weights as W
+    legs = []
+    root = tempfile.mkdtemp(prefix=f"audiotoken_files_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        plans = [("acoustic", Tokenizers.acoustic, 24000, 24000, args.files_acoustic, 256), ("acoustic", Tokenizers.acoustic, 48000, 24000, args.files_acoustic // 2, 256),
+                 ("semantic_m", Tokenizers.semantic_m, 16000, 16000, args.files_semantic, 64), ("semantic_m", Tokenizers.semantic_m, 44100, 16000, args.files_semantic // 2, 64)]
+        toks = {}
+        for name, which, src, dst, n_files, bs in plans:
+            if n_files <= 0:
+                continue
+            d = os.path.join(root, f"{name}_{src}")
+            os.makedirs(d)
+            base = W.synth_waveform(4, int(30 * src), src, seed=4242)          # four distinct clips, written with different gains
+            for i in range(n_files):
+                wavfile.write(os.path.join(d, f"clip{i:04d}.wav"), src, np.round(base[i % 4] * (12000 + 37 * i)).astype(np.int16))
+            if name not in toks:
+                if name == "acoustic":
+                    toks[name] = AudioToken(which, device=str(dev), num_codebooks=args.num_codebooks, weights=W.synth_encodec_weights(seed=0, with_decoder=False))
+                else:
+                    toks[name] = AudioToken(which, device=str(dev), weights=W.synth_w2vbert_weights(n_layers=args.sem_layers, seed=0, with_vq=True))
+                toks[name].load_encoder()
+            tok = toks[name]
+            if not device_rates.get(name):   # (--workload files alone) the device-resident rate of this tokenizer: the same batch shape, inputs in HBM
+                xb = torch.randn(bs, 30 * dst, device=dev) * 0.1
+                mb = torch.ones_like(xb)
+                tok.encoder(xb, mb)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    tok.encoder(xb, mb)
+                torch.cuda.synchronize()
+                device_rates[name] = round(2 * bs * 30.0 / (time.perf_counter() - t0), 1)
+                del xb, mb
+            out = os.path.join(root, f"out_{name}_{src}")
+            warm = sorted(os.path.join(d, f) for f in os.listdir(d))[:bs]
+            tok.encode_batch_files(batch_size=bs, outdir=out + "_warm", chunk_size=30, audio_files=warm, num_workers=args.files_workers)   # allocations, tables, worker threads
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            tok.encode_batch_files(batch_size=bs, outdir=out, chunk_size=30, audio_dir=d, num_workers=args.files_workers)
+            torch.cuda.synchronize()
+            el = max_over_ranks(time.perf_counter() - t0, dev, dist)
+            n_out = len(os.listdir(out))
+            rate = world * n_files * 30.0 / el
+            rt, ft = dict(tok.run_timings), dict(tok.feeder_timings or {})
+            legs.append({"tokenizer": name, "files_per_gpu": n_files, "file": f"30 s, 16-bit PCM WAV @ {src} Hz" + ("" if src == dst else f" (resampled to {dst} Hz on the device)"),
+                         "batch_size": bs, "num_workers": args.files_workers, "value": round(rate, 1), "unit": "audio-s/s", "seconds": round(el, 3), "token_files_written": n_out,
+                         "device_resident_rate": device_rates.get(name), "fraction_of_device_resident": round(rate / device_rates[name], 3) if device_rates.get(name) else None,
+                         "host_seconds": {k: round(v, 3) for k, v in rt.items() if k.endswith("_s")},
+                         "feeder_seconds": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ft.items()},
+                         "upload_GBps": round(ft.get("bytes_uploaded", 0) / el / 1e9, 2) if ft else None})
+            shutil.rmtree(d, ignore_errors=True)
+            shutil.rmtree(out, ignore_errors=True)
+        del toks
+        torch.cuda.empty_cache()
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return {"definition": "AudioToken.encode_batch_files end to end (scan, decode, upload, device feeder, encode, status read, .npy writes) on generated files; all ranks at "
+                          "once, max over ranks; reported beside `value`, never as it", "legs": legs}
+
+
 def settle_status(enc, call, name):
     """What the product path does at its synchronisation point (AcousticEncoder.verified / Wav2VecBertEncoder.verified): a non-zero device status
     word after the untimed first call means this batch does not fit the fast kernels (fp16 range of the f16x2 arithmetic, LSTM hand-off) — the
@@ -782,7 +855,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="all", choices=["all", "both", "acoustic", "semantic_m", "semantic_s", "selftest"])
+    ap.add_argument("--workload", default="all", choices=["all", "both", "acoustic", "semantic_m", "semantic_s", "selftest", "files"])
+    ap.add_argument("--files-acoustic", type=int, default=512, help="files leg: 30 s files per GPU for the acoustic tokenizer (half as many for the resampled leg; 0 = skip)")
+    ap.add_argument("--files-semantic", type=int, default=192, help="files leg: 30 s files per GPU for semantic_m")
+    ap.add_argument("--files-workers", type=int, default=8, help="files leg: decode-ahead workers (encode_batch_files num_workers)")
     ap.add_argument("--hub-batch", type=int, default=128, help="semantic_s clips per GPU per step (BASELINE configs[2]: 128)")
     ap.add_argument("--batch", type=int, default=256, help="acoustic clips per GPU per step (BASELINE configs[1]: 256)")
     ap.add_argument("--seconds", type=float, default=10.0)
@@ -892,6 +968,21 @@ def main(argv=None):
             if args.workload == "semantic_s" or dist is not None:
                 raise
             hub_err = f"{type(e).__name__}: {e}"
+    files = files_err = None
+    if args.workload in ("all", "files"):
+        try:
+            files = run_files(args, rank, world, dev, dist, {n: r["value"] / world for n, r in res.items()})
+        except Exception as e:
+            if args.workload == "files" or dist is not None:
+                raise
+            files_err = f"{type(e).__name__}: {e}"
+    if args.workload == "files":
+        if rank == 0:
+            print(json.dumps({"metric": "files -> tokens, audio-sec / wall-sec (encode_batch_files end to end)", "value": files["legs"][0]["value"] if files["legs"] else None,
+                              "unit": "audio-s/s", "n_gpus": world, "higher_is_better": True, "data": "synthetic", "files": files}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
     if not workloads:   # --workload semantic_s alone
         value, ms_per_step, rank_ms = hub["value"], hub["ms_per_step"], hub["ms_per_step"]
 
@@ -953,6 +1044,10 @@ def main(argv=None):
             out["semantic_s"] = hub
         elif hub_err:
             out["semantic_s"] = {"error": hub_err}
+        if files is not None:
+            out["files"] = files
+        elif files_err:
+            out["files"] = {"error": files_err}
         out["fallback_batches"] = sum(r.get("fallback_batches", 0) for r in (ac, sem, hub) if r is not None)
         print(json.dumps(out), flush=True)
     if dist is not None:

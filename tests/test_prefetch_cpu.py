@@ -163,3 +163,40 @@ def test_background_stops_when_garbage_collected_or_consumer_fails():
     assert b.join(3.0) and closed.wait(1.0)
     with pytest.raises(StopIteration):
         next(b)
+
+
+def test_worker_processes_give_the_sequential_result(tmp_path):
+    """encode_batch_files(worker_processes=True): plain files are decoded / resampled in SPAWNED worker processes (the reference's DataLoader workers,
+    core.py:259-267), archives by a background thread — same token files, same skip list as the inline run; an undecodable file inside the process pool
+    is reported, not fatal."""
+    import tarfile
+    import numpy as np
+    import torch
+    from scipy.io import wavfile
+    from audiotoken_amd import AudioToken, Tokenizers
+    from audiotoken_amd import weights as W
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    for i, (sr, secs) in enumerate([(24000, 2.3), (44100, 1.7), (16000, 3.1), (24000, 0.6)]):
+        wavfile.write(str(tmp_path / f"w{i}.wav"), sr, np.round(W.synth_waveform(1, int(sr * secs), sr, seed=40 + i)[0] * 20000).astype(np.int16))
+    (tmp_path / "bad.wav").write_bytes(b"RIFF\x00\x00")
+    with tarfile.open(tmp_path / "t.tar", "w") as tar:
+        tar.add(os.path.join(G, "flac_a.flac"), arcname="m/flac_a.flac")
+    files = [tmp_path / "w0.wav", tmp_path / "bad.wav", tmp_path / "w1.wav", tmp_path / "t.tar", tmp_path / "w2.wav", os.path.join(G, "flac_c.flac"), tmp_path / "w3.wav"]
+
+    class Fake(torch.nn.Module):
+        def forward(self, x, m):
+            return ((x * m).reshape(x.shape[0], 75, -1).abs().sum(-1) * 997).to(torch.int64).remainder(1024).to(torch.int16)[:, None, :].repeat(1, 2, 1)
+
+    outs = {}
+    for name, kw in (("inline", dict(num_workers=0)), ("procs", dict(num_workers=3, worker_processes=True)), ("threads", dict(num_workers=3))):
+        tok = AudioToken(Tokenizers.acoustic, device="cpu", num_codebooks=2)
+        tok.encoder = Fake()
+        tok.load_encoder = lambda: None
+        tok.encode_batch_files(batch_size=4, outdir=tmp_path / name, chunk_size=1, audio_files=files, **kw)
+        outs[name] = ({n: np.load(tmp_path / name / n) for n in sorted(os.listdir(tmp_path / name))}, [os.path.basename(p) for p, _ in tok.skipped_files])
+    ref, ref_skipped = outs["inline"]
+    assert sorted(ref) == ["flac_a.npy", "flac_c.npy", "w0.npy", "w1.npy", "w2.npy", "w3.npy"] and ref_skipped == ["bad.wav"]
+    for name in ("procs", "threads"):
+        got, skipped = outs[name]
+        assert skipped == ref_skipped and sorted(got) == sorted(ref)
+        assert all(np.array_equal(got[n], ref[n]) for n in ref), name
