@@ -162,14 +162,13 @@ class AcousticEncoder(torch.nn.Module):
         status = self.last_status()
         if status == 0:
             return codes
-        if status & 4:
+        if status & 4 and not status & 2:   # (with bit 1 set the infinity descends from the flagged fp16 overflow: the repeat below cures it)
             # a NaN / infinity reached the quantiser (a non-finite sample in the waveform, as a rule): no kernel choice changes that. The reference emits
             # arbitrary ids for such input without a diagnostic; here it is at least logged and counted. The ids are returned as they are.
             self.nonfinite_batches += 1
             logger.error(f"acoustic encode: a NaN or an infinity reached the quantiser (status {status}); check the input waveform. "
                          f"The token ids of this batch are meaningless (non-finite batch #{self.nonfinite_batches})")
-            status &= ~4
-            if status == 0:
+            if status & ~4 == 0:
                 return codes
         if status & 1:
             logger.error(f"persistent LSTM hand-off timed out (status {status}): the tokens of this batch were discarded; "
@@ -185,6 +184,9 @@ class AcousticEncoder(torch.nn.Module):
                 self.set_option(opt, 0)
         try:
             codes = self.forward(input_batch, attention_mask)
+            if self.last_status() & 4:          # still non-finite on the safe kernels: it came with the input, not from the fp16 range
+                self.nonfinite_batches += 1
+                logger.error(f"a NaN or an infinity reached the quantiser on the fallback kernels too (non-finite batch #{self.nonfinite_batches}): check the input waveform")
             if self.last_status() & ~4 != 0:   # (bit 2, non-finite input, is not something a repeat can clear)
                 raise _cabi.HipLibraryError("acoustic encode failed twice (status non-zero on the fallback kernels)")
         finally:
@@ -363,14 +365,13 @@ class Wav2VecBertEncoder(torch.nn.Module):
         status = self.last_status()
         if status == 0:
             return tokens
-        if status & 4:
+        if status & 4 and not status & 2:   # (with bit 1 set the infinity descends from the flagged fp16 overflow: the repeat below cures it)
             # a NaN / infinity reached the quantiser (a non-finite sample in the waveform, as a rule): no kernel choice changes that. The reference emits
             # arbitrary ids for such input without a diagnostic; here it is at least logged and counted. The ids are returned as they are.
             self.nonfinite_batches += 1
             logger.error(f"semantic_m encode: a NaN or an infinity reached the quantiser (status {status}); check the input waveform. "
                          f"The token ids of this batch are meaningless (non-finite batch #{self.nonfinite_batches})")
-            status &= ~4
-            if status == 0:
+            if status & ~4 == 0:
                 return tokens
         self.fallback_batches += 1
         logger.error(f"semantic_m encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
@@ -379,6 +380,9 @@ class Wav2VecBertEncoder(torch.nn.Module):
         self.set_option("arith", "bf16x3")
         try:
             tokens = self.forward(input_batch, mask, **kw)
+            if self.last_status() & 4:          # still non-finite on the safe kernels: it came with the input, not from the fp16 range
+                self.nonfinite_batches += 1
+                logger.error(f"a NaN or an infinity reached the quantiser on the fallback kernels too (non-finite batch #{self.nonfinite_batches}): check the input waveform")
             if self.last_status() & ~4 != 0:   # (bit 2, non-finite input, is not something a repeat can clear)
                 raise _cabi.HipLibraryError("semantic_m encode failed twice (status non-zero with bf16x3 arithmetic)")
         finally:

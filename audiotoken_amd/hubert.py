@@ -141,14 +141,13 @@ class HubertEncoder(torch.nn.Module):
         status = self.last_status()
         if status == 0:
             return tokens
-        if status & 4:
+        if status & 4 and not status & 2:   # (with bit 1 set the infinity descends from the flagged fp16 overflow: the repeat below cures it)
             # a NaN / infinity reached the quantiser (a non-finite sample in the waveform, as a rule): no kernel choice changes that. The reference emits
             # arbitrary ids for such input without a diagnostic; here it is at least logged and counted. The ids are returned as they are.
             self.nonfinite_batches += 1
             logger.error(f"semantic_s encode: a NaN or an infinity reached the quantiser (status {status}); check the input waveform. "
                          f"The token ids of this batch are meaningless (non-finite batch #{self.nonfinite_batches})")
-            status &= ~4
-            if status == 0:
+            if status & ~4 == 0:
                 return tokens
         self.fallback_batches += 1
         logger.error(f"semantic_s encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
@@ -157,6 +156,9 @@ class HubertEncoder(torch.nn.Module):
         self.set_option("arith", "bf16x3")
         try:
             tokens = self.forward(input_batch, attention_mask)
+            if self.last_status() & 4:          # still non-finite on the safe kernels: it came with the input, not from the fp16 range
+                self.nonfinite_batches += 1
+                logger.error(f"a NaN or an infinity reached the quantiser on the fallback kernels too (non-finite batch #{self.nonfinite_batches}): check the input waveform")
             if self.last_status() & ~4 != 0:   # (bit 2, non-finite input, is not something a repeat can clear)
                 raise _cabi.HipLibraryError("semantic_s encode failed twice (status non-zero with bf16x3 arithmetic)")
         finally:

@@ -154,3 +154,61 @@ def test_nonfinite_input_is_reported(cuda_device, tokenizer, bad):
     assert enc.nonfinite_batches == 1 and out.shape == clean.shape
     again = enc(wav.cuda(), mask.cuda())
     assert enc.last_status() == 0 and torch.equal(again, clean)
+
+
+OUTLIER_CHANNELS = (5, 261, 700, 1019)
+
+
+def test_semantic_m_per_channel_outliers(cuda_device):
+    """Real transformer checkpoints carry a few channels whose LayerNorm gains are 100-1000 x the median; uniform gains do not
+    model that. Here FOUR channels of every FFN-input LayerNorm (ffn1 / ffn2, gain and bias) of every layer are x 256: the split sites downstream see a
+    256-fold spread inside one operand row. Tokens must equal the oracle's on the same weights, on the f16x2 arithmetic itself (status 0, no fallback
+    batch) — the fixed activation scale (x 16, overflow at |x| > 4094) must hold without a per-site rescue — and the census shows what is left."""
+    from audiotoken_amd.configs import Wav2VecBertConfig
+    from audiotoken_amd.encoder import Wav2VecBertEncoder
+    from oracle import w2vbert_ref as R
+    w = dict(W.synth_w2vbert_weights(n_layers=3, seed=9, with_vq=True))
+    n = 0
+    for k in list(w):
+        if k.startswith("encoder.layers.") and ("ffn1_layer_norm" in k or "ffn2_layer_norm" in k):
+            v = w[k].copy()
+            v[list(OUTLIER_CHANNELS)] *= np.float32(256.0)
+            w[k] = v
+            n += 1
+    assert n == 3 * 2 * 2
+    enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=3), device="cuda:0", quantize=True, weights=w)
+    wav = torch.from_numpy(W.synth_waveform(2, 48000, 16000, seed=41))
+    mask = torch.ones_like(wav)
+    toks = enc(wav.cuda(), mask.cuda())
+    status = enc.last_status()
+    live, bits = _headroom(enc.range_report())
+    print(f"[range] semantic_m, 4 outlier channels x256 in every FFN LayerNorm: status {status}, census {dict((k, round(v, 1)) for k, v in live.items())}, headroom {bits:.1f} bits")
+    assert status == 0 and bits > 0, "four x256 channels must not leave the fp16 range"
+    toks = enc.verified(toks, wav.cuda(), mask.cuda())
+    assert enc.fallback_batches == 0
+    wt = {k: torch.from_numpy(v) for k, v in w.items()}
+    ref, margins = R.semantic_m_encode(wt, wav, mask, 2, 3, return_margins=True)
+    P.assert_tokens_equal_or_explained(toks, ref, margins, P.VQ_TIE, "[range] semantic_m per-channel outliers x256")
+
+
+def test_acoustic_per_channel_outliers(cuda_device):
+    """The same for the SEANet encoder: four output channels of the stage-1 strided conv (encoder.model.6: weight_g and bias) x 256."""
+    from audiotoken_amd.configs import AcousticEncoderConfig
+    from audiotoken_amd.encoder import AcousticEncoder
+    from oracle import encodec_ref as R
+    w = dict(W.synth_encodec_weights(seed=7, with_decoder=False))
+    for key in ("encoder.model.6.conv.conv.weight_g", "encoder.model.6.conv.conv.bias"):
+        v = w[key].copy()
+        v[[3, 40, 77, 120]] *= np.float32(256.0)
+        w[key] = v
+    enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=w)
+    wav = torch.from_numpy(W.synth_waveform(3, 48000, 24000, seed=42))
+    codes = enc(wav.cuda(), None)
+    status = enc.last_status()
+    live, bits = _headroom(enc.range_report())
+    print(f"[range] acoustic, 4 outlier channels x256 in encoder.model.6: status {status}, census {dict((k, round(v, 1)) for k, v in live.items())}, headroom {bits:.1f} bits")
+    codes = enc.verified(codes, wav.cuda(), None)
+    print(f"    fallback batches {enc.fallback_batches}")
+    ref, margins = R.acoustic_encode(w, wav, 8, return_margins=True)
+    P.assert_rvq_equal_or_explained(codes, ref, margins, P.RVQ_TIE, "[range] acoustic per-channel outliers x256")
+    assert status == 0 and enc.fallback_batches == 0, "four x256 channels must not leave the fp16 range"
