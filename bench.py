@@ -419,7 +419,7 @@ def max_over_ranks(x: float, dev, dist) -> float:
 
 def measured_traffic(group: str, workload: str = "acoustic"):
     """HBM bytes per launch of a kernel group from the committed rocprofv3 PMC passes (the newest profiles/r0N_*_traffic.json); None if that group was not profiled. PMC collection needs rocprofv3, so it cannot run inside the timed benchmark."""
-    for name in ("r03_final_traffic.json", "r02_final_traffic.json", "r02_v2_traffic.json", "r01_traffic.json"):
+    for name in ("r04_final_traffic.json", "r03_final_traffic.json", "r02_final_traffic.json", "r02_v2_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 doc = json.load(f)
@@ -1058,6 +1058,10 @@ def main(argv=None):
             out["semantic_s"] = hub
         elif hub_err:
             out["semantic_s"] = {"error": hub_err}
+        # what the launcher's environment was (VERDICT round 3, next #6c): the two variables that change multi-process GPU behaviour / the CPU baseline
+        out["env"] = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
+                      "torch_num_threads": torch.get_num_threads(), "host_cores": os.cpu_count(),
+                      "AUDIOTOKEN_overrides": {k: v for k, v in os.environ.items() if k.startswith("AUDIOTOKEN_")}}
         if args.stress_range:
             out["stress_range"] = ("semantic_m ran with one split site overflowing the fp16 range on every batch (--stress-range): its time includes the product's per-batch "
                                    "bf16x3 repeat; NOT a BASELINE measurement")

@@ -24,6 +24,8 @@ run sq_busy SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INS
 run sq_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_BUSY_CU_CYCLES
 cd $R
 python3 tools/collect_pmc.py $O/pmc_summary.csv $O/fetch $O/write $O/sq_busy $O/sq_lds > $O/collect.log 2>&1
+# per-ROLE traffic of the one GEMM kernel symbol (needs the per-dispatch rows: before the large CSVs are deleted)
+if [ "$W" = "semantic_m" ]; then python3 tools/gemm_roles_pmc.py $O/gemm_roles_traffic.json $O/fetch $O/write > $O/gemm_roles.log 2>&1; cat $O/gemm_roles.log; fi
 find $O -name "*.csv" -size +1M -delete
 find $O -name "*.db" -delete
 tail -3 $O/*.err | tail -40

@@ -2,7 +2,7 @@
 # Round evidence run on the GPU box: full bench, rocprofv3 kernel-trace stats of the same command, and the PMC passes (counters are
 # collected in their own runs, kernel-trace only) for the acoustic and the semantic_m workloads. Outputs under gpurun_out/<tag>/.
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -13,5 +13,7 @@ cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 cd $R
 bash tools/gpu_pmc_semantic.sh acoustic $TAG/pmc_acoustic > $O/pmc_acoustic.log 2>&1
 bash tools/gpu_pmc_semantic.sh semantic_m $TAG/pmc_semantic_m > $O/pmc_semantic_m.log 2>&1
+bash tools/gpu_pmc_semantic.sh semantic_s $TAG/pmc_semantic_s > $O/pmc_semantic_s.log 2>&1
+python3 tools/gemm_groups_from_trace.py $(find $O/stats -name "*kernel_trace.csv" | head -1) > $O/gemm_roles_from_trace.txt 2>&1
 find $O -name "*.csv" -size +1M -delete; find $O -name "*.db" -delete
 cut -c1-400 $O/bench.json

@@ -17,7 +17,9 @@ GROUPS = {   # workload -> bench.py group -> kernel-name prefix (first match, mo
     "acoustic": {"stage0_fused": "at::seanet_stage0", "res1_down1": "at::seanet_res64down", "res1": "at::seanet_res64x3", "down1": "at::seanet_down64", "res2": "at::seanet_res128",
                  "lstm_rec": "at::lstm_seq", "rvq": "at::rvq_encode", "down3": "at::gemm_f16x2_tg_kernel<true", "lstm_ih": "at::gemm_f16x2_tg_kernel<false"},
     "semantic_m": {"ffn": "at::gemm_f16x2_tg_kernel<false", "attn_proj": "at::gemm_f16x2_tg_kernel<false", "conv_module": "at::gemm_f16x2_tg_kernel<false",
-                   "attention": "at::relpos_attention_x3_kernel", "layernorm": "at::layernorm_split_kernel"},
+                   "attention": "at::relpos_attention", "layernorm": "at::layernorm_split_kernel"},
+    "semantic_s": {"ffn": "at::gemm_f16x2_tg_kernel<false", "attn_proj": "at::gemm_f16x2_tg_kernel<false", "attention": "at::relpos_attention",
+                   "feature_convs": "at::gemm_f16x2_tg_kernel<true", "positional_conv": "at::gemm_f32_kernel", "conv0": "at::hub_conv0"},
 }
 
 
@@ -66,6 +68,17 @@ def main():
             o = max(cands, key=lambda c: c["launches"])
             kernels[group] = {"kernel": o["kernel"], "traffic_bytes_per_launch": o["hbm_bytes_per_launch"], "mfma_pipe_busy_frac": o["mfma_pipe_busy_frac"],
                               "cycles_per_launch": o["cycles_per_launch"], "launches_in_pmc_run": o["launches"]}
+        if workload == "semantic_m":   # the one GEMM kernel symbol resolved by ROLE (tools/gemm_roles_pmc.py, per-dispatch counters of the same passes)
+            import os
+            rp = f"{prefix}_gemm_roles_traffic.json"
+            if os.path.exists(rp):
+                roles = json.load(open(rp))
+                for g, v in roles.get("groups", {}).items():
+                    if g in kernels:
+                        kernels[g]["traffic_bytes_per_launch_all_roles_average"] = kernels[g]["traffic_bytes_per_launch"]
+                        kernels[g]["traffic_bytes_per_launch"] = v["hbm_bytes_per_launch"]
+                        kernels[g]["role_resolved"] = v["roles"]
+                kernels["_gemm_roles"] = roles.get("roles", {})
         traffic[workload] = {"kernels": kernels}
         print(workload, json.dumps(kernels, indent=1)[:1500])
     with open(f"{prefix}_traffic.json", "w") as fh:

@@ -1,16 +1,19 @@
 #!/bin/bash
 # Copies the evidence of `tools/gpu_profile_round.sh <tag>` (merged back under gpurun_out/<tag>/) into profiles/<tag>_* and derives the PMC tables
 # and the traffic file bench.py reads:   bash tools/refresh_profiles.sh r03_final
-T=${1:-r03_final}; G=gpurun_out/$T
+T=${1:-r04_final}; G=gpurun_out/$T
 cp $G/bench.json profiles/${T}_bench.json
 cp $G/kernel_stats.csv profiles/${T}_kernel_stats.csv
 cp $G/pmc_acoustic/pmc_summary.csv profiles/${T}_acoustic_pmc_summary.csv
 cp $G/pmc_semantic_m/pmc_summary.csv profiles/${T}_semantic_m_pmc_summary.csv
-python3 tools/pmc_report.py profiles/$T acoustic=profiles/${T}_acoustic_pmc_summary.csv semantic_m=profiles/${T}_semantic_m_pmc_summary.csv > /dev/null
+[ -f $G/pmc_semantic_s/pmc_summary.csv ] && cp $G/pmc_semantic_s/pmc_summary.csv profiles/${T}_semantic_s_pmc_summary.csv
+[ -f $G/pmc_semantic_m/gemm_roles_traffic.json ] && cp $G/pmc_semantic_m/gemm_roles_traffic.json profiles/${T}_gemm_roles_traffic.json
+[ -f $G/gemm_roles_from_trace.txt ] && cp $G/gemm_roles_from_trace.txt profiles/${T}_gemm_roles_from_trace.txt
+python3 tools/pmc_report.py profiles/$T acoustic=profiles/${T}_acoustic_pmc_summary.csv semantic_m=profiles/${T}_semantic_m_pmc_summary.csv $( [ -f profiles/${T}_semantic_s_pmc_summary.csv ] && echo semantic_s=profiles/${T}_semantic_s_pmc_summary.csv ) > /dev/null
 python3 - "$T" <<'PY'
 import csv, json, sys
 T = sys.argv[1]
-for w in ('acoustic', 'semantic_m'):
+for w in ('acoustic', 'semantic_m'):   # (HBM GB per step)
     rows = list(csv.DictReader(open(f'profiles/{T}_{w}_pmc_derived.csv')))
     calls = [int(r['launches']) for r in rows if ('stage0' in r['kernel'] or 'fbank_stats' in r['kernel'])][0]
     tot = sum(int(r['launches']) * float(r['hbm_bytes_per_launch']) for r in rows if r['hbm_bytes_per_launch'] not in ('None', ''))
