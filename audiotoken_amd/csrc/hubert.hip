@@ -54,6 +54,9 @@ struct at_hubert {
     std::vector<LayerW> layers;
     const float *centers = nullptr, *c2 = nullptr;
     const piece_t* conv_ws[2][7] = {};   // conv weights of layers 1..6 as operand pieces, per scheme
+    const piece_t* pos_ws = nullptr;     // positional-conv weights as fp16 pieces in the per-K-step layout of hubert_posconv.hip (f16x2 scheme only)
+    float pos_wscale = 1.f;
+    bool posconv_split = true;           // option "posconv_split": the LDS-resident grouped conv kernel (hubert_posconv.hip) instead of 16 fp32 windowed GEMMs
     float conv_wscale[7] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     int arith = ARITH_F16X2;   // linear layers + conv chain: ARITH_* ($AUDIOTOKEN_SEMANTIC_ARITH = f32 | bf16x3 | f16x2; option "arith")
     bool split_done[2] = {false, false};
@@ -177,6 +180,16 @@ int split_weights(at_hubert* h, int scheme) {
     };
     for (int i = 1; i < 7; ++i)
         if (int rc = one(h->conv_w[i], kCd, kKs[i] * kCd, &h->conv_ws[scheme][i], &h->conv_wscale[i], kCd / 16, kSt[i])) return rc;   // window order
+    if (scheme == XB_SCHEME_F16X2) {   // the positional conv's weights in hubert_posconv.hip's layout ([group][K step][piece][k-block][48][16])
+        piece_t* d = static_cast<piece_t*>(h->arena.alloc(posconv_weight_pieces_bytes()));
+        if (!d) return -1;
+        auto it = h->wmax.find(h->pos_w);
+        AT_REQUIRE(it != h->wmax.end(), "weight maximum not recorded");
+        h->pos_wscale = xb_weight_scale(it->second);
+        if (!h->arena.importing)
+            if (int rc = launch_posconv_weight_split(h->pos_w, d, h->pos_wscale, nullptr)) return rc;
+        h->pos_ws = d;
+    }
     for (LayerW& L : h->layers) {
         const float* src[4] = {L.wqkv, L.wo, L.w1, L.w2};
         const int ns[4] = {3 * kHid, kHid, kFfn, kHid}, ks[4] = {kHid, kHid, kHid, kFfn};
@@ -417,6 +430,7 @@ int at_hubert_import_packed(at_hubert_t* h, const void* host_meta, int64_t meta_
         h->split_done[0] = h->split_done[1] = false;
         h->wmax.clear();
         h->centers = h->c2 = nullptr;
+        h->pos_ws = nullptr;
         for (int s = 0; s < 2; ++s)
             for (int j = 0; j < 7; ++j) h->conv_ws[s][j] = nullptr;
         h->arena.free_all();
@@ -460,6 +474,7 @@ int at_hubert_set_option(at_hubert_t* h, const char* name, int value) {
         return 0;
     }
     if (n == "attn_w8") { h->attn_w8 = value < 0 ? -1 : (value != 0); return 0; }
+    if (n == "posconv_split") { h->posconv_split = value != 0; return 0; }
     set_error("at_hubert_set_option: unknown option " + n);
     return -1;
 }
@@ -468,6 +483,7 @@ int at_hubert_get_option(const at_hubert_t* h, const char* name) {
     if (!h || !name) return -1;
     if (std::string(name) == "arith") return h->arith;
     if (std::string(name) == "attn_w8") return h->attn_w8;
+    if (std::string(name) == "posconv_split") return h->posconv_split ? 1 : 0;
     return -1;
 }
 
@@ -551,6 +567,10 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
     if (int rc = launch_hub_frame_mask(mask, fmask, B, N, T, stream)) return rc;
     if (int rc = launch_layernorm(feats, h->fp_ln_g, h->fp_ln_b, nullptr, t1, M, kCd, stream)) return rc;
     if (int rc = linear(t1, kCd, h->fp_w, h->fp_b, x, kHid, M, EPI_NONE, nullptr, fmask, kHid, stream)) return rc;
+    if (split && sc.scheme == XB_SCHEME_F16X2 && h->pos_ws && h->posconv_split) {
+        // all 16 groups in one launch on the split scheme, the input tile resident in LDS (hubert_posconv.hip)
+        if (int rc = launch_hubert_posconv(x, h->pos_ws, h->pos_b, pos, B, T, h->pos_wscale, sc.site(HS_X_IN), stream)) return rc;
+    } else
     for (int g = 0; g < kGroups; ++g) {   // pos[b][t][g*48 + co] = x + gelu(conv_g(x) + bias)
         GemmArgs a;
         a.X = x + g * kGc; a.x_bstride = (long long)T * kHid; a.Tin = T; a.Cin = kGc; a.ldx = kHid;

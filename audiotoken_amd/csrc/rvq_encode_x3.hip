@@ -221,7 +221,7 @@ int launch_rvq_encode_x3(const float* x, long long rows, int T, const float* cod
         AT_REQUIRE(act_scale > 0.f && cb_scale > 0.f, "two-piece fp16 RVQ needs its scales");
         return launch_rvq_scheme<SchemeF16x2>(x, rows, T, codebooks, cb_s, cb_piece, e2, n_q, codes, act_scale, cb_scale, status, stream);
     }
-    return launch_rvq_scheme<SchemeBf16x3>(x, rows, T, codebooks, cb_s, cb_piece, e2, n_q, codes, 1.f, 1.f, nullptr, stream);
+    return launch_rvq_scheme<SchemeBf16x3>(x, rows, T, codebooks, cb_s, cb_piece, e2, n_q, codes, 1.f, 1.f, status, stream);   // (status: the non-finite flag only)
 }
 
 }  // namespace at

@@ -84,3 +84,35 @@ def test_gpu_short_clips_vs_oracle(cuda_device, N):
     ref = R.semantic_s_encode(w, norm, mask, nl)
     assert toks.shape == ref.shape and toks.shape[-1] == W.hubert_num_frames(N)
     assert torch.equal(toks.cpu(), ref), f"N={N}: {int((toks.cpu() != ref).sum())} ids differ"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(3, 16000 * 6 + 77), (2, 10640), (1, 1200), (2, 82000)], ids=["T300", "T33", "T3", "T256"])
+def test_gpu_positional_conv_kernels_agree(cuda_device, B, N):
+    """The grouped positional convolution (HF HubertPositionalConvEmbedding: k 128, 16 groups, padding 64, last output dropped) on the LDS-resident split
+    kernel (csrc/hubert_posconv.hip, option posconv_split = 1, default) against the 16 windowed fp32-MFMA GEMMs it replaces (= 0): the layer-0 input they
+    produce agrees to fp32 rounding, ids are identical; tile seams (T = 300: two 256-row tiles), clips shorter than the 128 taps, ragged masks."""
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    w = W.synth_hubert_weights(2, 17, True)
+    enc = HubertEncoder(HubertEncoderConfig(output_layer=2), device="cuda:0", quantize=True, weights=w)
+    wav = hubert_processor(torch.from_numpy(W.synth_waveform(B, N, 16000, seed=400 + B)))
+    mask = torch.ones_like(wav)
+    if B > 1:
+        mask[1, N * 2 // 3:] = 0
+    x, m = wav.cuda(), mask.cuda()
+    assert enc.get_option("posconv_split") == 1
+    t1, h1 = enc(x, m, n_layers=0, return_hidden=True)
+    t1f = enc(x, m)
+    assert enc.last_status() == 0
+    enc.set_option("posconv_split", 0)
+    t0, h0 = enc(x, m, n_layers=0, return_hidden=True)
+    t0f = enc(x, m)
+    enc.set_option("posconv_split", 1)
+    err = (h1 - h0).abs().max().item()
+    print(f"positional conv B={B} T={h1.shape[1]}: max |split - fp32| at the encoder input {err:.2e} (max |h| {h0.abs().max().item():.2f})")
+    assert err < 2e-5
+    assert torch.equal(t1f, t0f)
+    ref, margins = R.semantic_s_encode(w, wav, mask, 2, return_margins=True)
+    from tests import parity as P
+    P.assert_tokens_equal_or_explained(t1f, ref, margins, P.VQ_TIE, f"positional conv (split kernel) B={B} N={N}")
