@@ -448,7 +448,7 @@ static int launch_ax(const float* qkv, const float* amask, const float* dist_emb
 }
 
 int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
-                               int scheme, int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces, int w8) {
+                               int scheme, int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces, int w8, const __bf16* dist_pieces, float dist_scale) {
     AT_REQUIRE(B >= 1 && T >= 1 && heads >= 1 && heads <= 64, "relpos_attention_x3: bad shape");
     AT_REQUIRE((long long)T * 3 * heads * 64 * 4 < (1ll << 31), "relpos_attention_x3: one clip's qkv rows exceed the buffer-descriptor range");
     AT_REQUIRE(ctx_pieces == nullptr || rows_pad >= (long long)B * T, "relpos_attention_x3: rows_pad too small");
@@ -456,8 +456,9 @@ int launch_relpos_attention_x3(const float* qkv, const float* amask, const float
                "relpos_attention_x3: pre-split k / v need the fp16 scheme and rows_pad");
     if (scheme == XB_SCHEME_F16X2 && kv_pieces) {
         static const int w8_default = []() { const char* e = std::getenv("AUDIOTOKEN_ATTN_W8"); return (e && e[0] == '0') ? 0 : 1; }();
-        if ((w8 < 0 ? w8_default : w8) != 0 && relpos_attention_w8_eligible(T, heads, rows_pad, B, dist_emb != nullptr))
-            return launch_relpos_attention_w8(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, kv_pieces);
+        // (the round-4 kernel builds its rel-pos table from PRE-SPLIT distance embeddings: with rel-pos it needs them)
+        if ((w8 < 0 ? w8_default : w8) != 0 && (dist_emb == nullptr || dist_pieces != nullptr) && relpos_attention_w8_eligible(T, heads, rows_pad, B, dist_emb != nullptr))
+            return launch_relpos_attention_w8(qkv, amask, dist_emb ? dist_pieces : nullptr, dist_scale, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, kv_pieces);
     }
     if (scheme == XB_SCHEME_F16X2 && kv_pieces) return launch_ax<SchemeF16x2, true>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, kv_pieces);
     if (scheme == XB_SCHEME_F16X2) return launch_ax<SchemeF16x2, false>(qkv, amask, dist_emb, ctx, B, T, stream, heads, status, ctx_pieces, rows_pad, nullptr);

@@ -67,6 +67,11 @@ constexpr int W8_QE_LD = 73;                    // the 73 buckets: odd stride, c
 constexpr int W8_LDS_MAX = 163840;              // the key-bias table of a clip must fit the LDS left beside the tiles and the rel-pos table
 constexpr float W8_SCALE2 = 0.125f * 1.4426950408889634f;
 constexpr float W8_P_LOG2 = 10.0f;              // probabilities are split as p * 2^10
+// Deferred rescale (cdna_hip_programming.md T13): when no query of the wave raises its running maximum by more than this (log2 domain), the maximum is
+// kept and O is not rescaled — the probabilities of the tile are then at most 2^(10 + 4) = 16384 (fp16 pieces hold 65504; the split keeps its 22 bits at any
+// magnitude, the row sum is fp32), and the 32-register multiply of O — pure vector work, which does not overlap with MFMAs on this chip — is skipped for all
+// but the first tiles of a query block. Exact algebra: the deferred factor cancels in O / l; only the rounding of exp2's argument moves.
+constexpr float W8_DEFER = 4.0f;
 
 static size_t w8_lds_bytes(int T, bool relpos) {
     const int nkt = (T + W8_KB - 1) / W8_KB;
@@ -98,7 +103,7 @@ __device__ __forceinline__ void w8_split_pair(float p0, float p1, unsigned& hi, 
 constexpr int W8_NQB = 1;
 template <bool RELPOS>
 __global__ __launch_bounds__(512 / W8_NQB, W8_NQB == 1 ? 2 : 1) void relpos_attention_w8_kernel(const float* __restrict__ qkv, const float* __restrict__ amask,
-                                                                     const float* __restrict__ dist_emb, float* __restrict__ ctx, int T, int hid,
+                                                                     const _Float16* __restrict__ dist_pieces, float dist_inv_scale, float* __restrict__ ctx, int T, int hid,
                                                                      int* __restrict__ status, _Float16* __restrict__ ctx_pieces, long long rows_pad,
                                                                      int nheads, int nclips, const _Float16* __restrict__ kv_pieces) {
     constexpr int NQB = W8_NQB;
@@ -170,39 +175,6 @@ __global__ __launch_bounds__(512 / W8_NQB, W8_NQB == 1 ? 2 : 1) void relpos_atte
     issue_v(0, 0);
     if (nkt > 1) issue_k(1, 1);
 
-    // ---- rel-pos table QE = log2(e)/8 * q . E^T on the fp32 MFMA, once per workgroup; wave w fills the rows of its own 64 queries ------------------
-    if constexpr (RELPOS) {
-        const int r16 = lane & 15, qd = lane >> 4;
-#pragma unroll 1
-        for (int half = 0; half < NQB; ++half) {
-            f4 qf[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int l = l0 + wave * QW + half * 32 + i * 16 + r16;
-                const int lc = l < T ? l : T - 1;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) qf[i][c] = *reinterpret_cast<const f4*>(qp + (rowbase + lc) * LD + c * 16 + qd * 4);
-            }
-#pragma unroll
-            for (int bt = 0; bt < 5; ++bt) {
-                f4 ef[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) ef[c] = *reinterpret_cast<const f4*>(dist_emb + (bt * 16 + r16) * 64 + c * 16 + qd * 4);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[c][e], qf[i][c][e], acc, 0, 0, 0);
-                    float* dst = QE + (wave * QW + half * 32 + i * 16 + r16) * W8_QE_LD + bt * 16 + qd * 4;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        if (bt * 16 + qd * 4 + reg < W8_QE_LD) dst[reg] = W8_SCALE2 * acc[reg];
-                }
-            }
-        }
-    }
     // ---- key bias of the whole clip + per-tile "any key masked" bits ---------------------------------------------------------------------------
     const float FMIN = -3.4028234663852886e38f;
     if (tid < 2) tmask[tid] = 0;
@@ -233,6 +205,36 @@ __global__ __launch_bounds__(512 / W8_NQB, W8_NQB == 1 ? 2 : 1) void relpos_atte
                 for (int k = 0; k < 4; ++k) { qpc[qb][i][ds][k] = pa[i][k]; qpc[qb][i][ds][4 + k] = pc[i][k]; }
         }
     }
+    // ---- rel-pos table QE[query][bucket] = log2(e)/8 * q . E[bucket] on the SAME fp16 MFMAs as the scores (round 4): E^T . Q^T is S^T with the 73 distance
+    // embeddings in the place of the keys — three 32-bucket row tiles x 4 k-steps x 3 products = 36 MFMAs per query block against 160 fp32 MFMAs of 32
+    // cycles each before (10 k cycles per SIMD and workgroup: 7 % of the kernel). The embeddings arrive pre-split (launch_dist_split: [piece][96][64] fp16
+    // times a power of two, rows >= 73 zero) and are read as fragments straight from L2; q pieces are the ones the scores use.
+    if constexpr (RELPOS) {
+        const float qe_scale = W8_SCALE2 * dist_inv_scale / XS;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            float* row = QE + (wave * QW + qb * 32 + l32) * W8_QE_LD;
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                f16v acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ds = 0; ds < 4; ++ds) {
+                    V8 ef[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) ef[p] = *reinterpret_cast<const V8*>(dist_pieces + (p * 96 + rt * 32 + l32) * 64 + ds * 16 + 8 * hh);
+#pragma unroll
+                    for (int t = 0; t < SC::NPROD; ++t) acc = SC::mfma(ef[SC::prod_a(t)], qpc[qb][SC::prod_w(t)][ds], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {   // lane holds buckets 32 rt + 8 (r / 4) + 4 hh + r % 4 of query l32
+                    const int bucket = rt * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+                    if (bucket < W8_QE_LD) row[bucket] = qe_scale * acc[r];
+                }
+            }
+        }
+    }
     f16v oacc[NQB][2];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb)
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(512 / W8_NQB, W8_NQB == 1 ? 2 : 1) void relpos_atte
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[qb][dt][r] = 0.f;
     float mrun[NQB], lrun[NQB], alpha[NQB];   // alpha: the rescale of O that the statistics of the current tile ask for
+    bool rescale[NQB];                        // wave-uniform: whether they ask for one at all (deferred rescale, W8_DEFER)
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) { mrun[qb] = -INFINITY; lrun[qb] = 0.f; alpha[qb] = 0.f; }
     const int wl_min = l0 + wave * QW, wl_max = wl_min + QW - 1;
@@ -335,7 +338,9 @@ __global__ __launch_bounds__(512 / W8_NQB, W8_NQB == 1 ? 2 : 1) void relpos_atte
         if (!RELPOS || far_left || far_right) mx = bias_pass(s, r0, 0, qe0, far_left ? c_left[qb] : c_right[qb], std::false_type{});
         else mx = bias_pass(s, r0, lq0 + 32 * qb, qe0 + qb * 32 * W8_QE_LD, 0.f, std::true_type{});
         mx = w8_pair_max(mx);
-        const float mnew = fmaxf(mrun[qb], mx);
+        const bool resc = __builtin_amdgcn_ballot_w64(mx > mrun[qb] + W8_DEFER) != 0ull;   // wave-uniform (mrun = -inf on the first tile: always)
+        rescale[qb] = resc;
+        const float mnew = resc ? fmaxf(mrun[qb], mx) : mrun[qb];
         const float sub = mnew - W8_P_LOG2;
         float rs = 0.f;
 #pragma unroll
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(512 / W8_NQB, W8_NQB == 1 ? 2 : 1) void relpos_atte
                 rs += p;
             }
         rs = w8_pair_sum(rs);
-        alpha[qb] = __builtin_amdgcn_exp2f(mrun[qb] - mnew);
+        alpha[qb] = resc ? __builtin_amdgcn_exp2f(mrun[qb] - mnew) : 1.0f;
         lrun[qb] = lrun[qb] * alpha[qb] + rs;
         mrun[qb] = mnew;
     };
@@ -361,9 +366,11 @@ __global__ __launch_bounds__(512 / W8_NQB, W8_NQB == 1 ? 2 : 1) void relpos_atte
             for (int e = 0; e < 8; ++e) f_mraw[qb] = fmaxf(f_mraw[qb], sa[k >> 1][8 * (k & 1) + e]);
         } else if (k == 4) {
             const float mx = w8_pair_max(fmaf(S_SCALE2, f_mraw[qb], f_cfar[qb]));
-            f_mnew[qb] = fmaxf(mrun[qb], mx);
+            const bool resc = __builtin_amdgcn_ballot_w64(mx > mrun[qb] + W8_DEFER) != 0ull;   // wave-uniform (mrun = -inf on the first tile: always)
+            rescale[qb] = resc;
+            f_mnew[qb] = resc ? fmaxf(mrun[qb], mx) : mrun[qb];
             f_bias2[qb] = (f_cfar[qb] - f_mnew[qb]) + W8_P_LOG2;
-            alpha[qb] = __builtin_amdgcn_exp2f(mrun[qb] - f_mnew[qb]);   // exp2(0) = 1 exactly when the maximum did not move, exp2(-inf) = 0 on the first tile
+            alpha[qb] = resc ? __builtin_amdgcn_exp2f(mrun[qb] - f_mnew[qb]) : 1.0f;   // exp2(0) = 1 exactly for a lane whose maximum did not move, exp2(-inf) = 0 on the first tile
         } else if (k < 21) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -504,10 +511,12 @@ __global__ __launch_bounds__(512 / W8_NQB, W8_NQB == 1 ? 2 : 1) void relpos_atte
         W8_T(4);
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb)
+            if (rescale[qb]) {      // (rare after the first tiles: W8_DEFER)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[qb][dt][r] *= alpha[qb];
+                    for (int r = 0; r < 16; ++r) oacc[qb][dt][r] *= alpha[qb];
+            }
         __builtin_amdgcn_sched_barrier(0);
         W8_T(5);
         // phase B: the MFMAs of P.V(i) beside the split of tile i's probabilities
@@ -557,27 +566,29 @@ bool relpos_attention_w8_eligible(int T, int heads, long long rows_pad, long lon
     return T >= 1 && T <= 4096 /* 64 tile bits */ && rows_pad * heads * 64 * 8 < (1ll << 32) /* one descriptor over the four planes */ && w8_lds_bytes(T, relpos) <= (size_t)W8_LDS_MAX && rows_pad >= B * T && (long long)T * heads * 64 * 2 < (1ll << 31);
 }
 
-int launch_relpos_attention_w8(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
-                               int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces) {
-    AT_REQUIRE(kv_pieces != nullptr && relpos_attention_w8_eligible(T, heads, rows_pad, B, dist_emb != nullptr),
+int launch_relpos_attention_w8(const float* qkv, const float* amask, const __bf16* dist_pieces, float dist_scale, float* ctx, int B, int T, hipStream_t stream,
+                               int heads, int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces) {
+    AT_REQUIRE(kv_pieces != nullptr && relpos_attention_w8_eligible(T, heads, rows_pad, B, dist_pieces != nullptr),
                "relpos_attention_w8: needs pre-split k / v and a clip whose key-bias table fits LDS (T <= 1728 with rel-pos)");
     const long long nblk = (long long)((T + W8_QB - 1) / W8_QB) * heads * B;
     dim3 grid((unsigned)((nblk + 7) / 8 * 8));
-    const size_t lds = w8_lds_bytes(T, dist_emb != nullptr);
+    const size_t lds = w8_lds_bytes(T, dist_pieces != nullptr);
     // (the attribute is the maximum over every T this process will use: set it to the kernel's ceiling once per device)
     const size_t lds_max = W8_LDS_MAX;
     int rc;
     const int hid = heads * 64;
     _Float16* cp = reinterpret_cast<_Float16*>(ctx_pieces);
     const _Float16* kp = reinterpret_cast<const _Float16*>(kv_pieces);
-    if (dist_emb) {
+    const _Float16* dp = reinterpret_cast<const _Float16*>(dist_pieces);
+    const float dinv = dist_pieces ? 1.0f / dist_scale : 1.0f;
+    if (dist_pieces) {
         static LdsAttrFlags lds_attr;
         rc = set_max_dynamic_lds(lds_attr, relpos_attention_w8_kernel<true>, lds_max);
-        if (!rc) hipLaunchKernelGGL((relpos_attention_w8_kernel<true>), grid, dim3(512 / W8_NQB), lds, stream, qkv, amask, dist_emb, ctx, T, hid, status, cp, rows_pad, heads, B, kp);
+        if (!rc) hipLaunchKernelGGL((relpos_attention_w8_kernel<true>), grid, dim3(512 / W8_NQB), lds, stream, qkv, amask, dp, dinv, ctx, T, hid, status, cp, rows_pad, heads, B, kp);
     } else {
         static LdsAttrFlags lds_attr;
         rc = set_max_dynamic_lds(lds_attr, relpos_attention_w8_kernel<false>, lds_max);
-        if (!rc) hipLaunchKernelGGL((relpos_attention_w8_kernel<false>), grid, dim3(512 / W8_NQB), lds, stream, qkv, amask, dist_emb, ctx, T, hid, status, cp, rows_pad, heads, B, kp);
+        if (!rc) hipLaunchKernelGGL((relpos_attention_w8_kernel<false>), grid, dim3(512 / W8_NQB), lds, stream, qkv, amask, dp, dinv, ctx, T, hid, status, cp, rows_pad, heads, B, kp);
     }
     if (rc) return rc;
     AT_CHECK_HIP(hipGetLastError());
@@ -597,6 +608,24 @@ int launch_relpos_attention_w8(const float* qkv, const float* amask, const float
         }
     }
 #endif
+    return 0;
+}
+
+// distance embeddings fp32 [80][64] (73 rows used) * scale -> fp16 pieces [2][96][64], rows >= 73 zero (the A operand of the rel-pos table's MFMAs)
+__global__ __launch_bounds__(256) void dist_split_kernel(const float* __restrict__ e, _Float16* __restrict__ out, float scale) {
+    const int q = blockIdx.x * 256 + threadIdx.x;      // one quad of one of 96 rows
+    if (q >= 96 * 16) return;
+    const int row = q >> 4, col = (q & 15) * 4;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < 73) v = *reinterpret_cast<const f4*>(e + row * 64 + col);
+    SchemeNoCheck<SchemeF16x2>::V4 p[2];
+    split4<SchemeNoCheck<SchemeF16x2>>(v, scale, p);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f16x4*>(out + (i * 96 + row) * 64 + col) = p[i];
+}
+int launch_dist_split(const float* dist_emb, __bf16* out, float scale, hipStream_t stream) {
+    hipLaunchKernelGGL(dist_split_kernel, dim3(6), dim3(256), 0, stream, dist_emb, reinterpret_cast<_Float16*>(out), scale);
+    AT_CHECK_HIP(hipGetLastError());
     return 0;
 }
 

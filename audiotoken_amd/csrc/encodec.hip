@@ -1184,21 +1184,25 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
     AT_REQUIRE(workspace_bytes >= p.total_floats * sizeof(float), "workspace too small");
     float* ws = (float*)workspace;
     float* z = ws + p.off_z;
+    Profiler& prof = h->prof;   // same HIP-event taps as the encoder (at_encodec_profile / at_encodec_profile_read)
+    prof.begin("dec_rvq_conv0", 2, stream);
     if (int rc = launch_rvq_decode(codes, B, K, T, h->codebooks, z, stream)) return rc;
     float* x0 = ws + p.off_x0;
     if (int rc = conv_gemm(h->dconv0, z, (long long)T * kDim, T, x0, (long long)T * kH, T, B, PRO_NONE, nullptr, 0, stream)) return rc;
+    prof.end(stream);
     float* y = ws + p.off_y;
-    Profiler noprof;
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);
     AT_CHECK_HIP(hipMemsetAsync(sync, 0, 1024 * sizeof(unsigned), stream));
     AT_CHECK_HIP(hipMemsetAsync(h->range_tab, 0, 64 * sizeof(int), stream));
     // every activation that is only consumed through ELU is stored already ELU'd (once per element, in the producer's
     // epilogue) so the transposed convs run the plain-linear GEMM path: y (LSTM + skip) and the block outputs of stages 0-2
-    if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, noprof,
+    if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
                            sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
                            (h->bf16x3 && h->ih_f16x2) ? h->dwih_f : nullptr, h->dwih_fs, h->range_tab + 2 * AS_DEC_LSTM_IH, h->lstm_f16x2 ? h->dwhh_fs : nullptr))
         return rc;
     const int Lout = p.L[4];
+    static const char* kUp[4] = {"dec_up0", "dec_up1", "dec_up2", "dec_up3"};
+    static const char* kDRes[4] = {"dec_res0", "dec_res1", "dec_res2", "dec_res3"};
     for (int b0 = 0; b0 < B; b0 += p.G) {
         const int g = (B - b0) < p.G ? (B - b0) : p.G;
         const float* in = y + (long long)b0 * T * kH;
@@ -1212,11 +1216,14 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
                 da.wu = h->dup[3].w; da.bu = h->dup[3].b; da.w3 = h->dres[3][0].w; da.b3 = h->dres[3][0].b;
                 da.wt = h->dres[3][1].w; da.bt = h->dres[3][1].b; da.wl = h->dlast.w; da.bl = h->dlast.b;
                 da.B = g; da.L = Li;
+                prof.begin("dec_tail", 1, stream);
                 if (int rc = launch_seanet_dectail(da, stream)) return rc;
+                prof.end(stream);
                 tail_done = true;
                 break;
             }
             float* u = ws + p.off_u[s];
+            prof.begin(kUp[s], 2, stream);
             // ConvTranspose1d(k = 2r, stride r) of the (already ELU'd) input, trimmed right by r, as one GEMM with N = r*Cout:
             // out[t][p*Cout + co] = x[t-1].W[:, co, p+r] + x[t].W[:, co, p]; [Li][r*Cout] is [Lo][Cout] in memory.
             if (s < 3 && h->bf16x3 && h->up_f16x2 && h->dup_f[s] && Li > 1) {
@@ -1234,7 +1241,9 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
             } else if (int rc = conv_gemm(h->dup[s], in, (long long)Li * Cin, Li, u, (long long)Lo * Co, Li, g, PRO_NONE, nullptr, 0, stream, 0)) {
                 return rc;
             }
+            prof.end(stream);
             float* r = ws + p.off_r[s];
+            prof.begin(kDRes[s], 1, stream);
             if ((Co == 64 && h->fused_res64) || (Co == 128 && h->fused_res128)) {
                 Res64Args ra;
                 ra.x = u; ra.out = r; ra.w3 = h->dres[s][0].w; ra.b3 = h->dres[s][0].b; ra.wt = h->dres[s][1].w; ra.bt = h->dres[s][1].b;
@@ -1251,11 +1260,15 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
                 // the last block's output goes to conv_last, which applies the ELU itself
                 if (int rc = resblock(h->dres[s], u, ws + p.off_h[s], r, Lo, g, stream, s < 3 ? EPI_ELU : EPI_NONE)) return rc;
             }
+            prof.end(stream);
             in = r;
             Cin = Co;
         }
-        if (!tail_done)
+        if (!tail_done) {
+            prof.begin("dec_tail", 1, stream);
             if (int rc = launch_conv_last(in, h->dlast.w, h->dlast.b, wav + (long long)b0 * Lout, g, Lout, stream)) return rc;
+            prof.end(stream);
+        }
     }
     if (status_dev) return launch_status_combine(sync, h->range_tab, status_dev, stream);   // LSTM hand-off + every range verdict of the call
     return 0;

@@ -52,6 +52,8 @@ struct LayerW {
     // wscale: the power of two the fp16 scheme multiplied that weight by (max |w s| in [2^14, 2^15))
     const piece_t* ws[2][8] = {};
     float wscale[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    const piece_t* dist_s = nullptr;   // the distance embeddings as fp16 pieces [2][96][64] (attention_f16x2_w8.hip's rel-pos table MFMAs; f16x2 scheme only)
+    float dist_scale = 1.f;
 };
 enum { W_1A = 0, W_1B, W_2A, W_2B, W_QKV, W_O, W_PW1, W_PW2 };
 // arithmetic of the linear layers: the fp32 MFMA, or operand splits on the 16-bit matrix cores (gemm_bf16x3.h)
@@ -194,6 +196,16 @@ int split_weights(at_w2vbert* h, int scheme) {
             if (!h->arena.importing)   // import_packed: the pieces are in the blob
                 if (int rc = launch_split_blocked(src[j], k, n, n, k, d, nullptr, scheme, sc, nullptr)) return rc;
             L.ws[scheme][j] = d;
+        }
+        if (scheme == XB_SCHEME_F16X2) {   // distance embeddings -> pieces for the attention kernel's rel-pos table
+            piece_t* d = static_cast<piece_t*>(h->arena.alloc((size_t)2 * 96 * 64 * sizeof(piece_t)));
+            if (!d) return -1;
+            auto it = h->wmax.find(L.dist);
+            AT_REQUIRE(it != h->wmax.end(), "distance embedding maximum not recorded");
+            L.dist_scale = xb_weight_scale(it->second);
+            if (!h->arena.importing)
+                if (int rc = launch_dist_split(L.dist, d, L.dist_scale, nullptr)) return rc;
+            L.dist_s = d;
         }
     }
     if (h->codebook) {   // the VQ score GEMM dots = LN(x) . E^T [M x 1024] x [1024 x 2048]
@@ -656,7 +668,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             prof.end(stream);
             prof.begin("attention", 1, stream);
             if (attn_arith > 0) {
-                if (int rc = launch_relpos_attention(big, amask, L.dist, nullptr, B, T, stream, 16, attn_arith, sc.site(WS_ATTENTION), t1s, Mpad, kvp ? kvs : nullptr, h->attn_w8)) return rc;
+                if (int rc = launch_relpos_attention(big, amask, L.dist, nullptr, B, T, stream, 16, attn_arith, sc.site(WS_ATTENTION), t1s, Mpad, kvp ? kvs : nullptr, h->attn_w8, L.dist_s, L.dist_scale)) return rc;
             } else {
                 if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, 0, nullptr)) return rc;
                 if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream, sc.scheme, as, sc.site(WS_ATTENTION))) return rc;
@@ -783,15 +795,23 @@ int at_op_relpos_attention(const float* qkv, const float* attn_mask, const float
     return launch_relpos_attention(qkv, attn_mask, dist_emb80, ctx, B, T, (hipStream_t)stream);
 }
 
-int at_op_relpos_attention_kvp(const float* qkv, const float* attn_mask, const float* dist_emb80, float* ctx, int B, int T, int heads, int w8,
+int at_op_relpos_attention_kvp(const float* qkv, const float* attn_mask, const float* dist_emb80, float dist_max_abs, float* ctx, int B, int T, int heads, int w8,
                                void* kv_workspace, size_t kv_workspace_bytes, int32_t* status_dev, at_stream_t stream) {
     AT_REQUIRE(qkv && attn_mask && ctx && kv_workspace && B >= 1 && T >= 1 && heads >= 1 && heads <= 64, "bad arguments");
     const long long rows = (long long)B * T, rows_pad = (rows + 255) / 256 * 256;
     const int hid = heads * 64;
-    AT_REQUIRE(kv_workspace_bytes >= (size_t)4 * rows_pad * hid * 2, "kv workspace too small: 4 * ceil256(B * T) * heads * 64 * 2 bytes");
+    const size_t kv_bytes = (size_t)4 * rows_pad * hid * 2, dist_bytes = (size_t)2 * 96 * 64 * 2;
+    AT_REQUIRE(kv_workspace_bytes >= kv_bytes + dist_bytes, "kv workspace too small: 4 * ceil256(B * T) * heads * 64 * 2 + 24576 bytes");
     if (int rc = launch_kv_rowmajor_split(qkv, static_cast<__bf16*>(kv_workspace), rows, rows_pad, hid, status_dev, (hipStream_t)stream)) return rc;
+    __bf16* dist_s = nullptr;
+    float dist_scale = 1.0f;
+    if (dist_emb80) {   // what finalize() does once per layer: the distance embeddings as fp16 pieces times a power of two
+        dist_s = reinterpret_cast<__bf16*>(static_cast<char*>(kv_workspace) + kv_bytes);
+        dist_scale = xb_weight_scale(dist_max_abs);
+        if (int rc = launch_dist_split(dist_emb80, dist_s, dist_scale, (hipStream_t)stream)) return rc;
+    }
     return launch_relpos_attention(qkv, attn_mask, dist_emb80, ctx, B, T, (hipStream_t)stream, heads, 2, status_dev, nullptr, rows_pad,
-                                   static_cast<const __bf16*>(kv_workspace), w8);
+                                   static_cast<const __bf16*>(kv_workspace), w8, dist_s, dist_scale);
 }
 
 int at_op_dwconv_ln_swish(const float* g, const float* w31x1024, const float* gamma, const float* beta, float* out, int B, int T,

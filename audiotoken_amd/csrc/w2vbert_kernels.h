@@ -18,15 +18,18 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, cons
 // (XB_EPI_QKV) instead of being split from the fp32 qkv rows by every query-tile workgroup; qkv then only supplies q
 int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
                             hipStream_t stream, int heads = 16, int arith = -1, int* status = nullptr, __bf16* ctx_pieces = nullptr, long long rows_pad = 0,
-                            const __bf16* kv_pieces = nullptr, int w8 = -1);
+                            const __bf16* kv_pieces = nullptr, int w8 = -1, const __bf16* dist_pieces = nullptr, float dist_scale = 1.0f);
 // the same attention with both products as operand splits on the 16-bit matrix cores (attention_bf16x3.hip); scheme = XB_SCHEME_*
 int launch_relpos_attention_x3(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
-                               int scheme, int* status, __bf16* ctx_pieces = nullptr, long long rows_pad = 0, const __bf16* kv_pieces = nullptr, int w8 = -1);
+                               int scheme, int* status, __bf16* ctx_pieces = nullptr, long long rows_pad = 0, const __bf16* kv_pieces = nullptr, int w8 = -1,
+                               const __bf16* dist_pieces = nullptr, float dist_scale = 1.0f);
 // round 4: the f16x2 attention with pre-split k / v as ONE 8-wave workgroup per CU, 64-key tiles and LDS-DMA staging (attention_f16x2_w8.hip);
 // launch_relpos_attention_x3 dispatches to it when kv_pieces != nullptr and w8 != 0 (w8 = -1: $AUDIOTOKEN_ATTN_W8, default 1)
 bool relpos_attention_w8_eligible(int T, int heads, long long rows_pad, long long B, bool relpos);
-int launch_relpos_attention_w8(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T, hipStream_t stream, int heads,
-                               int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces);
+// dist_pieces: the distance embeddings as fp16 pieces [2][96][64] * dist_scale (launch_dist_split; 24 576 bytes), NULL = no rel-pos bias (HuBERT)
+int launch_relpos_attention_w8(const float* qkv, const float* amask, const __bf16* dist_pieces, float dist_scale, float* ctx, int B, int T, hipStream_t stream,
+                               int heads, int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces);
+int launch_dist_split(const float* dist_emb, __bf16* out, float scale, hipStream_t stream);
 // fp32 qkv rows [rows][3 hid] -> row-major k / v pieces [which][piece][rows_pad][hid] * XB_F16_ACT_SCALE (what XB_EPI_QKV writes)
 int launch_kv_rowmajor_split(const float* qkv, __bf16* out, long long rows, long long rows_pad, int hid, int* status, hipStream_t stream);
 // pieces != nullptr: the output is written as the K-blocked operand pieces [NP][64][rows_pad][16] of `scheme` (times `scale`) instead of fp32

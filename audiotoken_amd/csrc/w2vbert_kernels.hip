@@ -703,10 +703,11 @@ static int default_attention_arith() {
 }
 
 int launch_relpos_attention(const float* qkv, const float* amask, const float* dist_emb, float* ctx, int B, int T,
-                            hipStream_t stream, int heads, int arith, int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces, int w8) {
+                            hipStream_t stream, int heads, int arith, int* status, __bf16* ctx_pieces, long long rows_pad, const __bf16* kv_pieces, int w8,
+                            const __bf16* dist_pieces, float dist_scale) {
     static const int dflt = default_attention_arith();
     if (arith < 0) arith = dflt;
-    if (arith > 0) return launch_relpos_attention_x3(qkv, amask, dist_emb, ctx, B, T, stream, heads, arith == 2 ? 1 : 0, status, ctx_pieces, rows_pad, kv_pieces, w8);
+    if (arith > 0) return launch_relpos_attention_x3(qkv, amask, dist_emb, ctx, B, T, stream, heads, arith == 2 ? 1 : 0, status, ctx_pieces, rows_pad, kv_pieces, w8, dist_pieces, dist_scale);
     AT_REQUIRE(ctx_pieces == nullptr && kv_pieces == nullptr, "relpos_attention: piece input / output needs the split kernels");
     dim3 grid((T + ATT_QB - 1) / ATT_QB, heads, B);
     const size_t lds = ATT_LDS_FLOATS * sizeof(float);

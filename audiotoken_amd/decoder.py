@@ -72,6 +72,13 @@ class AcousticDecoder(torch.nn.Module):
         """{site: largest |x * scale| its split writers saw in the LAST decode} (see AcousticEncoder.range_report)."""
         return _cabi.range_report(self._h.lib, "encodec", self._h.handle)
 
+    def enable_profile(self, on: bool) -> None:
+        """HIP-event taps per kernel group (bench.py only; off by default)."""
+        self._h.enable_profile(on)
+
+    def read_profile(self) -> Dict[str, tuple]:
+        return self._h.read_profile()
+
     @torch.no_grad()
     def forward(self, input_batch: torch.Tensor) -> torch.Tensor:
         assert input_batch.dim() == 3, "tokens must be [B, K, T]"

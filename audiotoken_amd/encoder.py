@@ -89,6 +89,20 @@ class _EncodecHandle:
         if h:
             self.lib.at_encodec_destroy(h)
 
+    # benchmark taps: HIP events recorded by the library on the launch stream, {group: (total ms, launches)}
+    def enable_profile(self, on: bool) -> None:
+        _cabi.check(self.lib.at_encodec_profile(self.handle, 1 if on else 0), "at_encodec_profile")
+
+    def read_profile(self) -> Dict[str, tuple]:
+        names = C.create_string_buffer(4096)
+        ms = (C.c_float * 64)()
+        ln = (C.c_int * 64)()
+        n = self.lib.at_encodec_profile_read(self.handle, names, 4096, ms, ln, 64)
+        if n < 0:
+            raise _cabi.HipLibraryError(f"at_encodec_profile_read failed: {_cabi.last_error()}")
+        keys = names.value.decode().split("\n")[:n]
+        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(keys)}
+
 
 class AcousticEncoder(torch.nn.Module):
     """Drop-in for reference ``AcousticEncoder`` (audiotoken/encoder.py:29-57)."""
@@ -220,17 +234,10 @@ class AcousticEncoder(torch.nn.Module):
 
     # ---- benchmark taps (HIP events recorded by the library on the launch stream) -----------------
     def enable_profile(self, on: bool) -> None:
-        _cabi.check(self._h.lib.at_encodec_profile(self._h.handle, 1 if on else 0), "at_encodec_profile")
+        self._h.enable_profile(on)
 
     def read_profile(self) -> Dict[str, tuple]:
-        names = C.create_string_buffer(4096)
-        ms = (C.c_float * 64)()
-        ln = (C.c_int * 64)()
-        n = self._h.lib.at_encodec_profile_read(self._h.handle, names, 4096, ms, ln, 64)
-        if n < 0:
-            raise _cabi.HipLibraryError(f"at_encodec_profile_read failed: {_cabi.last_error()}")
-        keys = names.value.decode().split("\n")[:n]
-        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(keys)}
+        return self._h.read_profile()
 
 
 # ======================================================================================================

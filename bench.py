@@ -155,6 +155,31 @@ def acoustic_flops_per_clip(N: int, n_q: int):
     return g, T
 
 
+def decode_work_per_clip(T: int, fused_tail: bool):
+    """Algorithmic FLOPs (2 per MAC) and compulsory HBM bytes (input read once + output written once, fp32 channels-last) of one clip of the
+    EnCodec decoder per kernel group of at_encodec_decode (reference call site audiotoken/decoder.py:66-76):
+    conv k7 128->512, 2-layer LSTM(512) + skip, four [ConvTranspose1d(C -> C/2, k = 2r, stride r) + residual block] stages with r = 8, 5, 4, 2,
+    conv k7 32->1. A transposed conv does L_in * C * (C/2) * 2r MACs."""
+    f = {"dec_rvq_conv0": 2.0 * T * 7 * 128 * 512, "lstm_ih": 2.0 * T * 512 * 2048 * 2, "lstm_rec": 2.0 * T * 512 * 2048 * 2}
+    b = {"dec_rvq_conv0": 4.0 * T * (128 + 512), "lstm_ih": 4.0 * T * (512 + 2048) * 2, "lstm_rec": 4.0 * T * (2048 + 512 * 2) * 2}
+    L, C = T, 512
+    for s, r in enumerate((8, 5, 4, 2)):
+        Lo, Co = L * r, C // 2
+        f[f"dec_up{s}"] = 2.0 * L * C * Co * 2 * r
+        b[f"dec_up{s}"] = 4.0 * (L * C + Lo * Co)
+        f[f"dec_res{s}"] = 2.0 * Lo * (3 * Co * (Co // 2) + (Co // 2) * Co + Co * Co)
+        b[f"dec_res{s}"] = 4.0 * Lo * 2 * Co
+        L, C = Lo, Co
+    last = 2.0 * L * 7 * 32
+    if fused_tail:   # stage 3 and the last conv in one kernel: 64-channel rows in, samples out
+        f["dec_tail"] = f["dec_up3"] + f["dec_res3"] + last
+        b["dec_tail"] = 4.0 * (L // 2 * 64 + L)
+    else:
+        f["dec_tail"] = last
+        b["dec_tail"] = 4.0 * (L * 32 + L)
+    return f, b
+
+
 def acoustic_bytes_per_clip(N: int, n_q: int):
     """Algorithmic (compulsory) HBM bytes per kernel group as launched today: each group reads its input
     activation once and writes its output once (fp32, channels-last)."""
@@ -736,8 +761,20 @@ def run_decode(args, rank, world, dev, dist):
     if hasattr(dec, "last_status"):
         assert dec.last_status() == 0, "persistent LSTM hand-off status non-zero: the timed decode is invalid"
     elapsed = max_over_ranks(elapsed, dev, dist)
+    prof = tapped_breakdown(dec, lambda: dec(codes), min(args.steps, 3))
+    flops, nbytes = decode_work_per_clip(T, bool(dec.get_option("fused_dectail")))
+    breakdown = {}
+    for k, (per, launches) in prof.items():
+        breakdown[k] = {"ms_per_step": round(per, 3), "launches_per_step": launches,
+                        "tflops": round(flops[k] * B / (per * 1e-3) / 1e12, 2) if per > 0 else None,
+                        "gbs": round(nbytes[k] * B / (per * 1e-3) / 1e9, 1) if per > 0 else None}
+    # kernel groups that run as two-piece fp16 operand splits (three MFMA products per multiply-add) under the decoder's options
+    split = tuple(g for opt, groups in {"up_f16x2": ("dec_up0", "dec_up1", "dec_up2"), "res_f16x2": ("dec_res0", "dec_res1", "dec_res2"),
+                                        "ih_f16x2": ("lstm_ih",), "lstm_f16x2": ("lstm_rec",)}.items() if BF16X3_ACOUSTIC and dec.get_option(opt) == 1 for g in groups)
     res = {"value": round(world * B * args.seconds * args.steps / elapsed, 2), "unit": "audio-s/s", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
            "config": {"workload": f"Tokenizers.acoustic decode, {B} clips x {args.seconds:g} s, num_codebooks={args.num_codebooks}"},
+           "roofline": roofline_of(breakdown, flops, nbytes, B, split, "acoustic_decode", 3), "breakdown": breakdown,
+           "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)",
            "checksum": float(out.double().abs().sum().item())}
     del dec
     torch.cuda.empty_cache()

@@ -329,10 +329,11 @@ int at_op_relpos_attention(const float* qkv, const float* attn_mask, const float
                            at_stream_t stream);
 
 /* The same attention on the path the product runs (ref audiotoken/modeling_wav2vec2_bert.py:46-73; HF HubertAttention with dist_emb80 = NULL): k / v are
- * first written as the row-major fp16 pieces the fused q / k / v projection's epilogue produces (into kv_workspace: 4 * ceil256(B * T) * heads * 64 * 2
+ * first written as the row-major fp16 pieces the fused q / k / v projection's epilogue produces and the distance embeddings as the fp16 pieces finalize()
+ * prepares per layer (dist_max_abs = max |dist_emb80|: their power-of-two scale), both into kv_workspace (4 * ceil256(B * T) * heads * 64 * 2 + 24576
  * bytes), then w8 = 1 runs csrc/attention_f16x2_w8.hip (8-wave workgroups, 64-key tiles, LDS-DMA staging), w8 = 0 its round-3 twin
  * (csrc/attention_bf16x3.hip <SchemeF16x2, KVP>), w8 = -1 the default. status_dev nullable (bit 1 = fp16 range overflow; {flag, census} pair). */
-int at_op_relpos_attention_kvp(const float* qkv, const float* attn_mask, const float* dist_emb80, float* ctx, int B, int T, int heads, int w8,
+int at_op_relpos_attention_kvp(const float* qkv, const float* attn_mask, const float* dist_emb80, float dist_max_abs, float* ctx, int B, int T, int heads, int w8,
                                void* kv_workspace, size_t kv_workspace_bytes, int32_t* status_dev, at_stream_t stream);
 
 /* Conformer conv middle (HF modeling_wav2vec2_bert.py:212-222): causal depthwise k31 -> LayerNorm -> swish;

@@ -124,10 +124,11 @@ def _attention_kvp(lib, dev, qkv, mask, de, B, T, heads, w8):
     (w8 = 1: attention_f16x2_w8.hip, w8 = 0: its round-3 twin)."""
     hid = heads * 64
     rows_pad = (B * T + 255) // 256 * 256
-    ws = torch.full((4 * rows_pad * hid,), float("nan"), dtype=torch.float16, device="cuda")   # padding rows stay NaN: must never reach a result
+    ws = torch.full((4 * rows_pad * hid + 2 * 96 * 64,), float("nan"), dtype=torch.float16, device="cuda")   # padding rows stay NaN: must never reach a result
     ctx = torch.full((B * T, hid), float("nan"), device="cuda")
     status = torch.zeros(2, dtype=torch.int32, device="cuda")
-    _cabi.check(lib.at_op_relpos_attention_kvp(qkv.data_ptr(), mask.data_ptr(), _cabi.ptr(de), ctx.data_ptr(), B, T, heads, w8,
+    dmax = float(de.abs().max().item()) if de is not None else 0.0
+    _cabi.check(lib.at_op_relpos_attention_kvp(qkv.data_ptr(), mask.data_ptr(), _cabi.ptr(de), dmax, ctx.data_ptr(), B, T, heads, w8,
                                                ws.data_ptr(), ws.numel() * 2, status.data_ptr(), _stream(dev)), "at_op_relpos_attention_kvp")
     torch.cuda.synchronize()
     assert int(status[0].item()) == 0

@@ -15,12 +15,12 @@ qkv = torch.randn(B * T, 3 * hid, device=dev)
 mask = torch.ones(B * T, device=dev)
 de = (torch.randn(80, 64, device=dev) * 0.5) if heads == 16 else None
 rows_pad = (B * T + 255) // 256 * 256
-ws = torch.zeros(4 * rows_pad * hid, dtype=torch.float16, device=dev)
+ws = torch.zeros(4 * rows_pad * hid + 2 * 96 * 64, dtype=torch.float16, device=dev)
 st = _cabi.current_stream_handle(dev)
 from ctypes import c_void_p
 outs = {}
 def run(w8, ctx):
-    _cabi.check(lib.at_op_relpos_attention_kvp(qkv.data_ptr(), mask.data_ptr(), _cabi.ptr(de), ctx.data_ptr(), B, T, heads, w8, ws.data_ptr(),
+    _cabi.check(lib.at_op_relpos_attention_kvp(qkv.data_ptr(), mask.data_ptr(), _cabi.ptr(de), float(de.abs().max()) if de is not None else 0.0, ctx.data_ptr(), B, T, heads, w8, ws.data_ptr(),
                                                ws.numel() * 2, None, st), "attn")
 for w8 in (1, 0):
     outs[w8] = torch.empty(B * T, hid, device=dev)
