@@ -166,6 +166,7 @@ struct at_encodec {
     bool res_f16x2 = true;
     float whh_fs[2] = {0.f, 0.f}, dwhh_fs[2] = {0.f, 0.f};   // W_hh scales of the fp16-scheme LSTM recurrence (option "lstm_f16x2")
     bool lstm_f16x2 = true;
+    bool lstm_pipe = true;          // batches of <= 80 clips: both LSTM layers in one pipelined launch (lstm_pipe.hip), same arithmetic
     bool ih_f16x2 = true;   // option "ih_f16x2": LSTM input projections on the fp16 scheme (three MFMA products instead of six)
     std::vector<void*> extra_allocs;
     int* range_tab = nullptr;   // device, {flag, census} per AcSite, zeroed at the start of every encode / decode (at_encodec_range_report reads it)
@@ -349,7 +350,9 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
               const float* x, float* xg, float* h0, float* h1, float* c, float* y, int B, int T, hipStream_t stream,
               Profiler& prof, unsigned* sync, bool persistent, int y_elu, const __bf16* const* wih_s = nullptr, __bf16* xs = nullptr,
               bool rec_x3 = false, unsigned spin_limit = 1u << 18, const piece_t* const* wih_f = nullptr, const float* wih_fs = nullptr,
-              int* range_status = nullptr, const float* whh_fs = nullptr) {
+              int* range_status = nullptr, const float* whh_fs = nullptr, float* xg2 = nullptr) {
+    // small batches: both layers in one pipelined launch after layer 1's projection (lstm_pipe.hip) — same arithmetic, ~half the dependent steps
+    const bool pipe = xg2 && persistent && rec_x3 && whh_fs && wih_f && wih_f[0] && wih_f[1] && wih_fs && xs && lstm_pipe_eligible(B, T);
     for (int layer = 0; layer < 2; ++layer) {
         const float* in = layer == 0 ? x : h0;
         float* hout = layer == 0 ? h0 : h1;
@@ -377,6 +380,16 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
             return rc;
         }
         prof.end(stream);
+        if (pipe) {
+            LstmPipeArgs q;
+            q.xg1 = xg; q.w_hh1 = whh[0]; q.b_hh1 = bhh[0]; q.w_ih2 = wih[1]; q.b_ih2 = bih[1]; q.w_hh2 = whh[1]; q.b_hh2 = bhh[1];
+            q.h1 = h0; q.xg2 = xg2; q.h2 = h1; q.y_out = y; q.skip = x; q.sync = sync; q.B = B; q.T = T; q.y_elu = y_elu; q.spin_limit = spin_limit;
+            q.ws_hh1 = whh_fs[0]; q.ws_ih2 = wih_fs[1]; q.ws_hh2 = whh_fs[1]; q.act_scale = XB_F16_ACT_SCALE;
+            prof.begin("lstm_rec", 1, stream);
+            if (int rc = launch_lstm_pipe(q, stream)) return rc;
+            prof.end(stream);
+            return 0;
+        }
         if (persistent) {
             // whole sequence in one persistent launch per 256-clip block (lstm_seq.hip)
             const int maxc = rec_x3 ? lstm_seq_x3_max_clips() : lstm_seq_max_clips();
@@ -409,11 +422,13 @@ int lstm_skip(const float* const wih[2], const float* const whh[2], const float*
     return 0;
 }
 
+constexpr int kPipeMaxClips = 80;   // lstm_pipe.hip: 5 groups of 16 clips x 48 workgroups on 256 CUs (the launcher checks the device)
+
 struct EncPlan {
     int L[5];        // lengths: L[0] = N, L[s+1] = ceil(L[s]/ratio)
     int G;           // sub-batch
     size_t off_x[4], off_h[4], off_r[4];  // per-stage sub-batch buffers (floats)
-    size_t off_x4, off_xg, off_h0, off_h1, off_c, off_y, off_emb, off_sync, off_xs;
+    size_t off_x4, off_xg, off_xg2, off_h0, off_h1, off_c, off_y, off_emb, off_sync, off_xs;
     int Mpf = 0, Lpf = 0;   // final conv as a windowed GEMM: padded output rows / operand rows per clip
     int Mp3, Lp3; size_t off_s3;   // stage-3 strided conv the same way, its input split by a separate pass or by the block's tail GEMM
     int Mpc, Lpc; size_t off_ac3, off_at3;   // 256-channel block as two split-bf16 GEMMs: pieces of ELU(x) (2 front rows) and of [h | x]
@@ -455,6 +470,7 @@ EncPlan make_plan(int B, int N, int sub) {
     const size_t T = p.L[4];
     p.off_x4 = take((size_t)B * T * kH);
     p.off_xg = take((size_t)B * T * 4 * kH);
+    p.off_xg2 = take(B <= kPipeMaxClips ? (size_t)B * T * 4 * kH : 0);   // layer-2 input gates of the pipelined LSTM launch (small batches)
     p.off_h0 = take((size_t)B * T * kH);
     p.off_h1 = take((size_t)B * T * kH);
     p.off_c = take((size_t)B * kH);
@@ -474,7 +490,7 @@ EncPlan make_plan(int B, int N, int sub) {
 struct DecPlan {
     int L[5];  // L[0] = T, L[s+1] = L[s]*ratio
     int G;
-    size_t off_z, off_x0, off_xg, off_h0, off_h1, off_c, off_y, off_sync, off_xs;
+    size_t off_z, off_x0, off_xg, off_xg2, off_h0, off_h1, off_c, off_y, off_sync, off_xs;
     size_t off_u[4], off_h[4], off_r[4];
     size_t off_ap;     // operand pieces of a transposed conv run as a windowed split GEMM: [2][G][Cin/16][Lpu][16] fp16 (one float per element)
     int Mpu[3], Lpu[3];   // per stage: padded output rows / operand rows per clip
@@ -491,6 +507,7 @@ DecPlan make_dec_plan(int B, int T, int sub) {
     p.off_z = take((size_t)B * T * kDim);
     p.off_x0 = take((size_t)B * T * kH);
     p.off_xg = take((size_t)B * T * 4 * kH);
+    p.off_xg2 = take(B <= kPipeMaxClips ? (size_t)B * T * 4 * kH : 0);
     p.off_h0 = take((size_t)B * T * kH);
     p.off_h1 = take((size_t)B * T * kH);
     p.off_c = take((size_t)B * kH);
@@ -1024,7 +1041,8 @@ static int encodec_encode_impl(at_encodec_t* h, const float* wav, const float* m
     unsigned* sync = reinterpret_cast<unsigned*>(ws + p.off_sync);   // zeroed at the start of the call (the conv stack's range status lives in it)
     if (int rc = lstm_skip(h->wih, h->whh, h->bih, h->bhh, x4, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
                            sync, h->persistent_lstm, 1, h->bf16x3 ? h->wih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
-                           (h->bf16x3 && h->ih_f16x2) ? h->wih_f : nullptr, h->wih_fs, h->range_tab + 2 * AS_LSTM_IH, h->lstm_f16x2 ? h->whh_fs : nullptr))
+                           (h->bf16x3 && h->ih_f16x2) ? h->wih_f : nullptr, h->wih_fs, h->range_tab + 2 * AS_LSTM_IH, h->lstm_f16x2 ? h->whh_fs : nullptr,
+                           (h->lstm_pipe && B <= kPipeMaxClips) ? ws + p.off_xg2 : nullptr))
         return rc;
     float* emb = emb_out ? emb_out : ws + p.off_emb;
     prof.begin("final_conv", 1, stream);
@@ -1092,6 +1110,7 @@ const BoolOption kBoolOptions[] = {
     {"res128_rs", &at_encodec::res128_rs},
     {"up_f16x2", &at_encodec::up_f16x2},
     {"lstm_f16x2", &at_encodec::lstm_f16x2},
+    {"lstm_pipe", &at_encodec::lstm_pipe},
     {"chain_f16x2", &at_encodec::chain_f16x2},
 };
 }  // namespace
@@ -1198,7 +1217,8 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
     // epilogue) so the transposed convs run the plain-linear GEMM path: y (LSTM + skip) and the block outputs of stages 0-2
     if (int rc = lstm_skip(h->dwih, h->dwhh, h->dbih, h->dbhh, x0, ws + p.off_xg, ws + p.off_h0, ws + p.off_h1, ws + p.off_c, y, B, T, stream, prof,
                            sync, h->persistent_lstm, 1, h->bf16x3 ? h->dwih_s : nullptr, reinterpret_cast<__bf16*>(ws + p.off_xs), h->bf16x3 && h->lstm_x3, h->lstm_spin_limit,
-                           (h->bf16x3 && h->ih_f16x2) ? h->dwih_f : nullptr, h->dwih_fs, h->range_tab + 2 * AS_DEC_LSTM_IH, h->lstm_f16x2 ? h->dwhh_fs : nullptr))
+                           (h->bf16x3 && h->ih_f16x2) ? h->dwih_f : nullptr, h->dwih_fs, h->range_tab + 2 * AS_DEC_LSTM_IH, h->lstm_f16x2 ? h->dwhh_fs : nullptr,
+                           (h->lstm_pipe && B <= kPipeMaxClips) ? ws + p.off_xg2 : nullptr))
         return rc;
     const int Lout = p.L[4];
     static const char* kUp[4] = {"dec_up0", "dec_up1", "dec_up2", "dec_up3"};

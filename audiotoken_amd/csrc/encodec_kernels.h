@@ -36,6 +36,30 @@ int lstm_seq_max_clips();
 // the same layer with the recurrent product as split-bf16 MFMAs: 16 workgroups of 32 hidden units per 16-clip group (lstm_seq_x3.hip)
 int launch_lstm_seq_x3(const LstmSeqArgs& a, hipStream_t stream);
 int lstm_seq_x3_max_clips();
+// Both layers in ONE persistent launch, layer 2 one step behind layer 1 (lstm_pipe.hip): three roles of workgroups per 16-clip group — layer 1,
+// layer 2's input gates W_ih2 h1_t (replaces the projection GEMM between the layers), layer 2. Two-piece fp16 scheme only; <= lstm_pipe_max_clips().
+struct LstmPipeArgs {
+    const float* xg1;    // [B][T][2048] layer-1 input-side gates incl. b_ih (the projection GEMM's output)
+    const float* w_hh1; const float* b_hh1;
+    const float* w_ih2; const float* b_ih2;   // fp32 [2048][512] gate-interleaved rows, as the recurrent weights
+    const float* w_hh2; const float* b_hh2;
+    float* h1;           // [B][T][512] layer-1 output (exchange buffer of roles A and X)
+    float* xg2;          // [B][T][2048] layer-2 input-side gates (exchange buffer of roles X and B)
+    float* h2;           // [B][T][512] layer-2 output
+    float* y_out;        // [B][T][512] h2 + skip
+    const float* skip;
+    unsigned* sync;      // as LstmSeqArgs
+    int B, T;
+    int y_elu;
+    int n_groups = 0;    // filled by the launcher
+    long long h_bytes = 0, xg_bytes = 0;
+    unsigned spin_limit = 1u << 18;
+    float ws_hh1 = 0.f, ws_ih2 = 0.f, ws_hh2 = 0.f;   // finalize-time power-of-two scales of the three weight matrices
+    float act_scale = 0.f;                            // activation scale of the projection GEMM this launch stands in for (XB_F16_ACT_SCALE)
+};
+int launch_lstm_pipe(const LstmPipeArgs& a, hipStream_t stream);
+int lstm_pipe_max_clips();
+bool lstm_pipe_eligible(int B, int T);
 // RVQ search with split dot products (rvq_encode_x3.hip); cb_s = codebooks as [3][n_cb * 1024][128] bf16 pieces, or with
 // scheme = XB_SCHEME_F16X2 as [2][n_cb * 1024][128] fp16 pieces of E * cb_scale (launch_split_plain with the same scheme / scale);
 // the fp16 scheme also needs the residual scale and the device status word that receives the range verdict

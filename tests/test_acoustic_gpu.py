@@ -146,6 +146,41 @@ def test_persistent_lstm_equals_stepwise(encoders, enc_weights):
     enc.set_option("lstm_x3", 1)
 
 
+def test_pipelined_lstm_equals_layerwise(encoders, enc_weights):
+    """lstm_pipe.hip (both LSTM layers in one launch, layer 2 one step behind layer 1, its input gates computed by a third role of
+    workgroups instead of the projection GEMM) against the layer-by-layer launches: the same products in the same order, so embeddings,
+    codes and decoded waveforms are bit-identical — full, ragged (B % 16 != 0) and maximal (80-clip) groups, and over repeats (the
+    hand-off protocol of three chained roles is a race if it is wrong)."""
+    from audiotoken_amd.configs import AcousticDecoderConfig
+    from audiotoken_amd.decoder import AcousticDecoder
+    enc = encoders[8]
+    assert enc.get_option("lstm_pipe") == 1
+    for B, N in ((5, 9600), (33, 6400), (80, 3200), (16, 24000)):
+        wav = torch.from_numpy(W.synth_waveform(B, N, 24000, seed=100 + B)).cuda()
+        c1, e1 = enc(wav, None, return_embeddings=True)
+        assert enc.last_status() == 0
+        enc.set_option("lstm_pipe", 0)
+        c0, e0 = enc(wav, None, return_embeddings=True)
+        enc.set_option("lstm_pipe", 1)
+        assert torch.equal(e0, e1), (B, (e0 - e1).abs().max().item())
+        assert torch.equal(c0, c1)
+        for _ in range(5):
+            c2, e2 = enc(wav, None, return_embeddings=True)
+            assert torch.equal(e2, e1) and enc.last_status() == 0
+    dec = AcousticDecoder(AcousticDecoderConfig(), device="cuda:0", weights=enc_weights)
+    g = torch.Generator().manual_seed(9)
+    for B, T in ((3, 25), (64, 75), (21, 40)):
+        codes = torch.randint(0, 1024, (B, 8, T), generator=g, dtype=torch.long).cuda()
+        w1 = dec(codes).clone()
+        assert dec.last_status() == 0
+        dec.set_option("lstm_pipe", 0)
+        w0 = dec(codes).clone()
+        dec.set_option("lstm_pipe", 1)
+        assert torch.equal(w0, w1), (B, T, (w0 - w1).abs().max().item())
+        for _ in range(5):
+            assert torch.equal(dec(codes), w1) and dec.last_status() == 0
+
+
 def test_fused_stage0_equals_unfused(encoders):
     """seanet_stage0_kernel (conv0 + resblock + strided conv fused) keeps the MFMA / tap order of the separate kernels:
     embeddings and codes must be bit-identical, including the reflect-padded clip start and a ragged last tile."""
