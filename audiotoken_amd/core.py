@@ -269,11 +269,19 @@ class AudioToken:
                 return upload(b) if b is not None else None
         # host seconds per stage of the loop (bench.py's files leg): `stage` = producing the next batch (decode wait + upload + descriptors, or the host
         # chunk stream + collate + upload), `encode_call` = enqueueing the encode, `device_wait` = blocked on the device (the status read of verified / the
-        # first .cpu()), `save` = the per-row trim + append to the .npy files
+        # first .cpu()), `save` = the per-row trim + append to the .npy files (of the batch BEFORE, while the device encodes the current one)
         rt = self.run_timings = {"stage_s": 0.0, "encode_call_s": 0.0, "device_wait_s": 0.0, "save_s": 0.0, "batches": 0, "rows": 0}
+        def save(tokens, pointers):
+            for tokens_batch, file_pointer in zip(tokens, pointers):
+                if audio_files is not None:
+                    save_audio_tokens(tokens_batch, file_pointer, str(outdir))
+                else:
+                    save_rel_audio_tokens(tokens_batch, file_pointer, str(outdir), str(audio_dir))
+
         t0 = time.perf_counter()
         staged = stage_next()
         rt["stage_s"] += time.perf_counter() - t0
+        pending = None    # (tokens on the host, file pointers) of the batch before: written while the device encodes the next one, in batch order
         while staged is not None:
             input_ids, attention_masks, file_pointers, ev = staged
             t0 = time.perf_counter()
@@ -283,20 +291,22 @@ class AudioToken:
                 attention_masks.record_stream(torch.cuda.current_stream(self.device))
             encoded_audio = self.encoder(input_ids, attention_masks)      # asynchronous on the device
             t1 = time.perf_counter()
-            staged = stage_next()                                         # the next batch is decoded / uploaded / cut while this one encodes
+            if pending is not None:
+                save(*pending)
+                pending = None
             t2 = time.perf_counter()
-            if hasattr(self.encoder, "verified"):   # the saves below synchronise anyway: check the call's device status first
-                encoded_audio = self.encoder.verified(encoded_audio, input_ids, attention_masks)
-            encoded_audio = encoded_audio.cpu()     # ONE device-to-host copy per batch (a per-row .cpu() inside the save would synchronise B times)
+            staged = stage_next()                                         # the next batch is decoded / uploaded / cut while this one encodes
             t3 = time.perf_counter()
-            for tokens_batch, file_pointer in zip(encoded_audio, file_pointers):
-                if audio_files is not None:
-                    save_audio_tokens(tokens_batch, file_pointer, str(outdir))
-                else:
-                    save_rel_audio_tokens(tokens_batch, file_pointer, str(outdir), str(audio_dir))
+            if hasattr(self.encoder, "verified"):   # the copy below synchronises anyway: check the call's device status first
+                encoded_audio = self.encoder.verified(encoded_audio, input_ids, attention_masks)
+            pending = (encoded_audio.cpu(), file_pointers)   # ONE device-to-host copy per batch (a per-row .cpu() inside the save would synchronise B times)
             t4 = time.perf_counter()
-            rt["encode_call_s"] += t1 - t0; rt["stage_s"] += t2 - t1; rt["device_wait_s"] += t3 - t2; rt["save_s"] += t4 - t3
+            rt["encode_call_s"] += t1 - t0; rt["save_s"] += t2 - t1; rt["stage_s"] += t3 - t2; rt["device_wait_s"] += t4 - t3
             rt["batches"] += 1; rt["rows"] += len(file_pointers)
+        if pending is not None:
+            t0 = time.perf_counter()
+            save(*pending)
+            rt["save_s"] += time.perf_counter() - t0
         rt["total_s"] = time.time() - start_time
         logger.debug(f"Encoding batch files took: {time.time() - start_time:.2f}s")
         if self.skipped_files:

@@ -530,12 +530,17 @@ def run_files(args, rank, world, dev, dist, device_rates):
     from audiotoken_amd import AudioToken, Tokenizers
     from audiotoken_amd import weights as W
     legs = []
-    root = tempfile.mkdtemp(prefix=f"audiotoken_files_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    # the largest leg holds files_acoustic x 1.44 MB (or half as many 48 kHz files of twice the size) at a time: RAM-backed /dev/shm when it has the room
+    # (x 2 margin, all ranks of the node at once), else the default temporary directory
+    need = 2 * world * max(args.files_acoustic * 1.45e6, args.files_semantic * 0.97e6, 1.0)
+    shm_ok = os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need
+    root = tempfile.mkdtemp(prefix=f"audiotoken_files_r{rank}_", dir="/dev/shm" if shm_ok else None)
     try:
-        # (128 x 30 s per acoustic batch: four batches per leg, so the pipeline's overlap — stage batch i + 1 while batch i encodes — is part of what is
-        # measured, not only one exposed first stage; measured on one box: batch 256 x 2 batches 55.5 k audio-s/s, batch 64 x 8 batches 45.7 k, the
-        # device-resident rate of the encoder itself falling from 84.7 k to 53.4 k at 64 clips)
-        plans = [("acoustic", Tokenizers.acoustic, 24000, 24000, args.files_acoustic, 128), ("acoustic", Tokenizers.acoustic, 48000, 24000, args.files_acoustic // 2, 128),
+        # (256 x 30 s per acoustic batch, eight batches: the pipeline's overlap — stage batch i + 1 and write batch i - 1 while batch i encodes — is what is
+        # measured, with its fill (the first batch's decode + upload) and drain amortised as a real directory would; measured on one box, fraction of the
+        # device-resident rate of the same batch shape: 512 files x batch 128 0.69-0.75, 1 024 x 256 0.79, 2 048 x 256 0.86; at batch 64-128 the encoder's
+        # own device-resident rate is lower — its two 2 250-step LSTM layers are latency-bound and want 256 clips side by side)
+        plans = [("acoustic", Tokenizers.acoustic, 24000, 24000, args.files_acoustic, args.files_acoustic_batch), ("acoustic", Tokenizers.acoustic, 48000, 24000, args.files_acoustic // 2, args.files_acoustic_batch),
                  ("semantic_m", Tokenizers.semantic_m, 16000, 16000, args.files_semantic, 64), ("semantic_m", Tokenizers.semantic_m, 44100, 16000, args.files_semantic // 2, 64)]
         toks = {}
         for name, which, src, dst, n_files, bs in plans:
@@ -905,7 +910,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="all", choices=["all", "both", "acoustic", "semantic_m", "semantic_s", "selftest", "files"])
-    ap.add_argument("--files-acoustic", type=int, default=512, help="files leg: 30 s files per GPU for the acoustic tokenizer (half as many for the resampled leg; 0 = skip)")
+    ap.add_argument("--files-acoustic", type=int, default=2048, help="files leg: 30 s files per GPU for the acoustic tokenizer (half as many for the resampled leg; 0 = skip)")
+    ap.add_argument("--files-acoustic-batch", type=int, default=256, help="files leg: encode_batch_files batch_size of the acoustic legs")
     ap.add_argument("--files-semantic", type=int, default=192, help="files leg: 30 s files per GPU for semantic_m")
     ap.add_argument("--files-workers", type=int, default=8, help="files leg: decode-ahead workers (encode_batch_files num_workers)")
     ap.add_argument("--hub-batch", type=int, default=128, help="semantic_s clips per GPU per step (BASELINE configs[2]: 128)")
