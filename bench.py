@@ -909,7 +909,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="all", choices=["all", "both", "acoustic", "semantic_m", "semantic_s", "selftest", "files"])
+    ap.add_argument("--workload", default="all", choices=["all", "both", "acoustic", "semantic_m", "semantic_s", "selftest", "files", "decode"])
     ap.add_argument("--files-acoustic", type=int, default=2048, help="files leg: 30 s files per GPU for the acoustic tokenizer (half as many for the resampled leg; 0 = skip)")
     ap.add_argument("--files-acoustic-batch", type=int, default=256, help="files leg: encode_batch_files batch_size of the acoustic legs")
     ap.add_argument("--files-semantic", type=int, default=192, help="files leg: 30 s files per GPU for semantic_m")
@@ -1010,13 +1010,20 @@ def main(argv=None):
     torch.cuda.empty_cache()
 
     dec = None
-    if args.workload == "all":
+    if args.workload in ("all", "decode"):
         try:
             dec = run_decode(args, rank, world, dev, dist)
         except Exception as e:
-            if dist is not None:
+            if args.workload == "decode" or dist is not None:
                 raise
             dec = {"error": f"{type(e).__name__}: {e}"}
+    if args.workload == "decode":   # (the PMC passes of tools/gpu_pmc_semantic.sh decode)
+        if rank == 0:
+            print(json.dumps(dict({"metric": "audio-sec decoded / wall-sec (acoustic tokens -> waveform)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                   "higher_is_better": True, "scaling": "weak", "data": "synthetic"}, **dec)), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
     hub = hub_err = None
     if args.workload in ("all", "semantic_s"):
         try:

@@ -14,6 +14,7 @@ cd $R
 bash tools/gpu_pmc_semantic.sh acoustic $TAG/pmc_acoustic > $O/pmc_acoustic.log 2>&1
 bash tools/gpu_pmc_semantic.sh semantic_m $TAG/pmc_semantic_m > $O/pmc_semantic_m.log 2>&1
 bash tools/gpu_pmc_semantic.sh semantic_s $TAG/pmc_semantic_s > $O/pmc_semantic_s.log 2>&1
+bash tools/gpu_pmc_semantic.sh decode $TAG/pmc_decode > $O/pmc_decode.log 2>&1
 python3 tools/gemm_groups_from_trace.py $(find $O/stats -name "*kernel_trace.csv" | head -1) > $O/gemm_roles_from_trace.txt 2>&1
 find $O -name "*.csv" -size +1M -delete; find $O -name "*.db" -delete
 cut -c1-400 $O/bench.json

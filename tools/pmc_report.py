@@ -20,6 +20,8 @@ GROUPS = {   # workload -> bench.py group -> kernel-name prefix (first match, mo
                    "attention": "at::relpos_attention", "layernorm": "at::layernorm_split_kernel"},
     "semantic_s": {"ffn": "at::gemm_f16x2_tg_kernel<false", "attn_proj": "at::gemm_f16x2_tg_kernel<false", "attention": "at::relpos_attention",
                    "feature_convs": "at::gemm_f16x2_tg_kernel<true", "positional_conv": "at::gemm_f32_kernel", "conv0": "at::hub_conv0"},
+    "acoustic_decode": {"dec_tail": "at::seanet_dectail", "lstm_rec": "at::lstm_pipe", "dec_res1": "at::seanet_res128", "dec_res2": "at::seanet_res64",
+                        "dec_up0": "at::gemm_f16x2_tg_kernel<true", "dec_res0": "at::gemm_f32_kernel"},
 }
 
 
@@ -62,7 +64,8 @@ def main():
                 fh.write(",".join(f'"{o[c]}"' if c == "kernel" else str(o[c]) for c in cols) + "\n")
         kernels = {}
         for group, pref in GROUPS.get(workload, {}).items():
-            cands = [o for o in out_rows if o["kernel"].startswith(pref) and o["hbm_bytes_per_launch"] is not None]
+            bare = pref.split("::")[-1].split("<")[0]   # rocprofv3 leaves some template instantiations mangled (_ZN2at26relpos_attention_w8_kernelILb1EEE...)
+            cands = [o for o in out_rows if (o["kernel"].startswith(pref) or (o["kernel"].startswith("_Z") and bare in o["kernel"])) and o["hbm_bytes_per_launch"] is not None]
             if not cands:
                 continue
             o = max(cands, key=lambda c: c["launches"])
