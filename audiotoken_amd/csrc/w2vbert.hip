@@ -67,7 +67,8 @@ struct at_w2vbert {
     DeviceArena arena;          // every device allocation of finalize(), in order (packed_model.h: export / import of the finalized model)
     PackedHeader imp{};         // import_packed: the exporter's record (layer count, flags) while finalize is replayed
     std::vector<int> split_seq; // the schemes whose weight pieces exist, in the order they were split (= their order in the arena)
-    int* range_tab = nullptr;   // device, {flag, census} per WSite, zeroed at the start of every encode (at_w2vbert_range_report reads it)
+    int* range_tab = nullptr;   // device, {flag, census} per (layer, WSite), zeroed at the start of every encode (at_w2vbert_range_report / _layer_status read it)
+    std::vector<int> layer_arith;   // per conformer layer: -1 = the handle's arithmetic, else ARITH_BF16X3 / ARITH_F16X2 for that layer only (option "layer_arith:<i>")
     const float *window = nullptr, *melw = nullptr;
     double* dft64 = nullptr;  // [520][400] DFT matrix in double (see dft_f64_kernel)
     const float *fp_ln_g = nullptr, *fp_ln_b = nullptr, *fp_w = nullptr, *fp_b = nullptr;
@@ -232,6 +233,8 @@ int split_weights(at_w2vbert* h, int scheme) {
 // Sites of the handle's range table (gemm_bf16x3.h, launch_range_combine): where activations become fp16 pieces. The same site in every layer.
 enum WSite { WS_LN_FFN1 = 0, WS_FFN1_HIDDEN, WS_LN_ATTN, WS_QKV_KV, WS_ATTENTION, WS_LN_CONV, WS_DWCONV, WS_LN_FFN2, WS_FFN2_HIDDEN, WS_OTHER, W_NSITES };
 static const char* const kWSiteNames[W_NSITES] = {"ln_ffn1", "ffn1_hidden", "ln_attn", "qkv_kv", "attention", "ln_conv", "dwconv_out", "ln_ffn2", "ffn2_hidden", "other"};
+constexpr int kRangeLayers = 64;                              // rows of the range table: one per conformer layer
+constexpr int kRangeInts = kRangeLayers * 2 * (int)W_NSITES;
 struct SplitCtx {
     int scheme; int* tab;
     int* site(int k) const { return tab ? tab + 2 * k : nullptr; }
@@ -440,8 +443,8 @@ static int finalize_impl(at_w2vbert* h) {
         if (int rc = split_weights(h, h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
     }
     if (!host_only_test() && !h->range_tab) {   // run-time state, not part of the packed model
-        AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, 64 * sizeof(int)));
-        AT_CHECK_HIP(hipMemset(h->range_tab, 0, 64 * sizeof(int)));
+        AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, kRangeInts * sizeof(int)));
+        AT_CHECK_HIP(hipMemset(h->range_tab, 0, kRangeInts * sizeof(int)));
     }
     h->finalized = true;
     return 0;
@@ -551,6 +554,19 @@ int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value) {
         h->arith = value;
         return 0;
     }
+    if (n.rfind("layer_arith:", 0) == 0) {   // "layer_arith:<i>": -1 = follow "arith", 1 = bf16x3, 2 = f16x2 for conformer layer i only
+        const int li = std::atoi(n.c_str() + 12);
+        AT_REQUIRE(li >= 0 && li < (int)h->layers.size(), "layer_arith: no such layer");
+        AT_REQUIRE(value == -1 || value == ARITH_BF16X3 || value == ARITH_F16X2, "layer_arith:<i>: -1 = the handle's arithmetic, 1 = bf16x3, 2 = f16x2");
+        if (value > 0) {
+            DeviceGuard guard(h->device);
+            AT_REQUIRE(guard.ok, "cannot select the handle's device");
+            if (int rc = split_weights(h, value == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
+        }
+        if (h->layer_arith.size() < h->layers.size()) h->layer_arith.resize(h->layers.size(), -1);
+        h->layer_arith[li] = value;
+        return 0;
+    }
     if (n == "dwconv_stream") { h->dwconv_stream = value != 0; return 0; }
     if (n == "vq_split") { h->vq_split = value != 0; return 0; }
     if (n == "attn_w8") { h->attn_w8 = value < 0 ? -1 : (value != 0); return 0; }
@@ -561,6 +577,10 @@ int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value) {
 int at_w2vbert_get_option(const at_w2vbert_t* h, const char* name) {
     if (!h || !name) return -1;
     if (std::string(name) == "arith") return h->arith;
+    if (std::string(name).rfind("layer_arith:", 0) == 0) {
+        const int li = std::atoi(name + 12);
+        return (li >= 0 && li < (int)h->layer_arith.size()) ? h->layer_arith[li] : -1;
+    }
     if (std::string(name) == "dwconv_stream") return h->dwconv_stream ? 1 : 0;
     if (std::string(name) == "vq_split") return h->vq_split ? 1 : 0;
     if (std::string(name) == "attn_w8") return h->attn_w8;
@@ -595,9 +615,13 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     Profiler& prof = h->prof;
     if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
     const bool split = h->arith != ARITH_F32;
-    AT_CHECK_HIP(hipMemsetAsync(h->range_tab, 0, 64 * sizeof(int), stream));
-    const SplitCtx sc{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, h->range_tab};
-    const int attn_arith = h->arith;   // attention follows the linear layers' arithmetic (0: the fp32-MFMA kernel)
+    AT_REQUIRE(n_layers <= kRangeLayers, "more conformer layers than range-table rows");
+    AT_CHECK_HIP(hipMemsetAsync(h->range_tab, 0, kRangeInts * sizeof(int), stream));
+    // arithmetic per layer: the handle's, unless that layer is pinned to another split scheme (option "layer_arith:<i>": what the product's range
+    // fallback sets for a layer whose activations do not fit fp16 — the other layers stay on f16x2). Each layer has its own row of the range table.
+    auto arith_of = [&](int li) { return (split && li < (int)h->layer_arith.size() && h->layer_arith[li] > 0) ? h->layer_arith[li] : h->arith; };
+    auto ctx_of = [&](int li) { return SplitCtx{arith_of(li) == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, h->range_tab + li * 2 * (int)W_NSITES}; };
+    const SplitCtx sc_model{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, nullptr};   // the VQ score GEMM (no range site)
 
     // ---- log-mel front-end (reference processors.py) -------------------------------------------
     double* frames = reinterpret_cast<double*>(ws + p.off_frames);
@@ -634,6 +658,8 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     const long long Mpad = (long long)p.Mpad;
     for (int li = 0; li < n_layers; ++li) {
         const LayerW& L = h->layers[li];
+        const SplitCtx sc = ctx_of(li);
+        const int attn_arith = arith_of(li);   // attention follows the layer's arithmetic (0: the fp32-MFMA kernel)
         if (split) {
             // Split arithmetic: every GEMM operand is produced directly as K-blocked pieces — LayerNorm (launch_layernorm_split), the first
             // FFN GEMM's swish epilogue, the attention kernel's context and the depthwise-conv kernel's output — so no fp32 activation is
@@ -699,7 +725,8 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
                 // final_layer_norm of this layer and ffn1_layer_norm of the next in ONE pass over the residual stream: x = LN(x) as fp32 rows and
                 // t1s = split(LN'(x)) (bit-identical to the two launches; saves one read of x per layer)
                 const LayerW& Ln = h->layers[li + 1];
-                if (int rc = launch_layernorm2_split(x, L.ln_fin_g, L.ln_fin_b, x, Ln.ln_ffn1_g, Ln.ln_ffn1_b, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_FFN1), stream)) return rc;
+                const SplitCtx scn = ctx_of(li + 1);   // the pieces are the NEXT layer's operand: its scheme, its range row
+                if (int rc = launch_layernorm2_split(x, L.ln_fin_g, L.ln_fin_b, x, Ln.ln_ffn1_g, Ln.ln_ffn1_b, t1s, M, Mpad, kHid, scn.scheme, scn.act_scale(), scn.site(WS_LN_FFN1), stream)) return rc;
             } else if (int rc = launch_layernorm(x, L.ln_fin_g, L.ln_fin_b, nullptr, x, M, kHid, stream)) {
                 return rc;
             }
@@ -717,7 +744,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
         if (int rc = linear(t1, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, 1.f, nullptr, nullptr, 3 * kHid, stream)) return rc;
         prof.end(stream);
         prof.begin("attention", 1, stream);
-        if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, attn_arith, sc.site(WS_ATTENTION))) return rc;
+        if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, h->arith, nullptr)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
         if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, 1.f, x, nullptr, kHid, stream)) return rc;
@@ -736,21 +763,21 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
         prof.end(stream);
     }
     if (status_dev)   // every site's range verdict of this call -> the caller's status word
-        if (int rc = launch_range_combine(h->range_tab, (int)W_NSITES, reinterpret_cast<int*>(status_dev), stream)) return rc;
+        if (int rc = launch_range_combine(h->range_tab, n_layers * (int)W_NSITES, reinterpret_cast<int*>(status_dev), stream)) return rc;
     if (hidden_out) AT_CHECK_HIP(hipMemcpyAsync(hidden_out, x, (size_t)M * kHid * sizeof(float), hipMemcpyDeviceToDevice, stream));
 
     if (tokens) {
         // non-affine LayerNorm (reference encoder.py:138-143,176) then nearest code (encoder.py:180-181)
         prof.begin("vq", 3, stream);
-        if (split && h->vq_split && h->cb_s[sc.scheme]) {
+        if (split && h->vq_split && h->cb_s[sc_model.scheme]) {
             // the score GEMM on the split kernel: the LayerNorm writes its fp32 rows (|x|^2 of the distance) and the operand pieces in one pass. Non-affine
             // LayerNorm output is bounded by sqrt(1024) = 32: x 16 cannot leave the fp16 range, so this site has no range word.
-            if (int rc = launch_layernorm_split(x, nullptr, nullptr, nullptr, t1, t1s, M, Mpad, kHid, sc.scheme, sc.act_scale(), nullptr, stream)) return rc;
+            if (int rc = launch_layernorm_split(x, nullptr, nullptr, nullptr, t1, t1s, M, Mpad, kHid, sc_model.scheme, sc_model.act_scale(), nullptr, stream)) return rc;
             Bf16x3Args va;
-            va.A = t1s; va.W = h->cb_s[sc.scheme]; va.bias = nullptr; va.M = (int)M; va.N = kCodes; va.K = kHid; va.Mpad = (int)Mpad;
+            va.A = t1s; va.W = h->cb_s[sc_model.scheme]; va.bias = nullptr; va.M = (int)M; va.N = kCodes; va.K = kHid; va.Mpad = (int)Mpad;
             va.epi = XB_EPI_LINEAR; va.C = big; va.ldc = kCodes; va.R = nullptr; va.ldr = kCodes; va.alpha = 1.f;
-            va.scheme = sc.scheme; va.status = nullptr;
-            if (sc.scheme == XB_SCHEME_F16X2) { va.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->cb_scale); va.split_scale = XB_F16_ACT_SCALE; }
+            va.scheme = sc_model.scheme; va.status = nullptr;
+            if (sc_model.scheme == XB_SCHEME_F16X2) { va.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->cb_scale); va.split_scale = XB_F16_ACT_SCALE; }
             if (int rc = launch_gemm_bf16x3(va, stream)) return rc;
         } else {
             if (int rc = launch_layernorm(x, nullptr, nullptr, nullptr, t1, M, kHid, stream)) return rc;
@@ -768,11 +795,32 @@ int at_w2vbert_range_report(at_w2vbert_t* h, float* max_scaled, int cap) {
     AT_REQUIRE(h && h->finalized && h->range_tab && max_scaled && cap >= (int)W_NSITES, "at_w2vbert_range_report: bad arguments");
     DeviceGuard guard(h->device);
     AT_REQUIRE(guard.ok, "cannot select the handle's device");
-    int host[2 * W_NSITES];
+    std::vector<int> host(kRangeInts);
     AT_CHECK_HIP(hipDeviceSynchronize());
-    AT_CHECK_HIP(hipMemcpy(host, h->range_tab, sizeof(host), hipMemcpyDeviceToHost));
-    for (int k = 0; k < (int)W_NSITES; ++k) { float f; std::memcpy(&f, &host[2 * k + 1], sizeof(f)); max_scaled[k] = f; }
+    AT_CHECK_HIP(hipMemcpy(host.data(), h->range_tab, kRangeInts * sizeof(int), hipMemcpyDeviceToHost));
+    for (int k = 0; k < (int)W_NSITES; ++k) {
+        float m = 0.f;
+        for (int l = 0; l < kRangeLayers; ++l) { float f; std::memcpy(&f, &host[(l * (int)W_NSITES + k) * 2 + 1], sizeof(f)); m = f > m ? f : m; }   // (NaN census: kept out by >)
+        max_scaled[k] = m;
+    }
     return (int)W_NSITES;
+}
+// Per conformer layer, the OR of its sites' status flags in the LAST encode (bit 1 = an activation of that layer left the fp16 range; an overflow turns
+// into infinities that later layers flag too: the FIRST flagged layer is the cause). Returns the number of layers written. Synchronises the device.
+int at_w2vbert_layer_status(at_w2vbert_t* h, int32_t* flags, int cap) {
+    AT_REQUIRE(h && h->finalized && h->range_tab && flags && cap >= 1, "at_w2vbert_layer_status: bad arguments");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    std::vector<int> host(kRangeInts);
+    AT_CHECK_HIP(hipDeviceSynchronize());
+    AT_CHECK_HIP(hipMemcpy(host.data(), h->range_tab, kRangeInts * sizeof(int), hipMemcpyDeviceToHost));
+    const int n = std::min<int>({cap, (int)h->layers.size(), kRangeLayers});
+    for (int l = 0; l < n; ++l) {
+        int v = 0;
+        for (int k = 0; k < (int)W_NSITES; ++k) v |= host[(l * (int)W_NSITES + k) * 2];
+        flags[l] = v;
+    }
+    return n;
 }
 int at_w2vbert_range_sites(char* names, size_t cap) {
     std::string s;

@@ -338,7 +338,8 @@ class Wav2VecBertEncoder(torch.nn.Module):
             raise ValueError(f"checkpoint has {self.n_layers} conformer layers, output_layer={self.output_layer} needs that many")
         self._ws: Optional[torch.Tensor] = None
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.fallback_batches = 0    # batches `verified` repeated with arith=bf16x3 (fp16 range overflow)
+        self.fallback_batches = 0    # batches `verified` repeated (fp16 range overflow)
+        self.pinned_layers = []      # conformer layers `verified` moved to bf16x3 for good (their activations do not fit the fp16 range)
         self.nonfinite_batches = 0
 
     def __del__(self):
@@ -367,8 +368,8 @@ class Wav2VecBertEncoder(torch.nn.Module):
 
     def verified(self, tokens: torch.Tensor, input_batch: torch.Tensor, mask: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
         """Product-path guard, called where the caller synchronises anyway: if the call that produced `tokens` reported an fp16 range
-        overflow, log it, repeat THIS batch with the bf16x3 arithmetic (full fp32 exponent range), count it in ``fallback_batches`` and
-        switch back — the next batch runs on f16x2 again."""
+        overflow, log it, find the conformer layer that caused it, move THAT layer to the bf16x3 arithmetic (full fp32 exponent range) for
+        good (``pinned_layers``) and repeat this batch (``fallback_batches``); every other layer stays on f16x2."""
         status = self.last_status()
         if status == 0:
             return tokens
@@ -381,8 +382,29 @@ class Wav2VecBertEncoder(torch.nn.Module):
             if status & ~4 == 0:
                 return tokens
         self.fallback_batches += 1
-        logger.error(f"semantic_m encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
-                     f"the tokens of this batch were discarded; re-encoding THIS batch with arith=bf16x3 (fallback batch #{self.fallback_batches})")
+        # Which layer? Every layer has its own row of range flags; an overflow turns into infinities that all later layers flag too, so the FIRST flagged
+        # layer is the cause. That layer alone is moved to bf16x3 (full fp32 exponent range) — and STAYS there: activation outliers are a property of the
+        # checkpoint, the next batch would overflow at the same place. The other layers keep f16x2, so a model with one such layer pays ~1 / n_layers of the
+        # bf16x3 price from now on instead of a repeat of every batch. Up to three layers are found this way per batch; beyond that the whole batch is
+        # repeated on bf16x3 as in round 3.
+        for _ in range(3):
+            bad = [l for l, f in enumerate(self.layer_status()) if f & 2]
+            if not bad:
+                break
+            layer = bad[0]
+            self.pinned_layers.append(layer)
+            logger.error(f"semantic_m encode reported status {status}: an activation of conformer layer {layer} exceeded the fp16 range of the f16x2 "
+                         f"arithmetic. The tokens of this batch were discarded; layer {layer} runs on bf16x3 from now on (option layer_arith:{layer} = 1), "
+                         f"this batch is re-encoded (fallback batch #{self.fallback_batches})")
+            self.set_option(f"layer_arith:{layer}", 1)
+            tokens = self.forward(input_batch, mask, **kw)
+            status = self.last_status()
+            if not status & 2:
+                if status & 4:
+                    self.nonfinite_batches += 1
+                    logger.error(f"a NaN or an infinity reached the quantiser with layer {layer} on bf16x3 too (non-finite batch #{self.nonfinite_batches}): check the input waveform")
+                return tokens
+        logger.error(f"semantic_m encode still reports status {status}: re-encoding THIS batch with arith=bf16x3 for every layer")
         saved = self.get_option("arith")
         self.set_option("arith", "bf16x3")
         try:
@@ -395,6 +417,20 @@ class Wav2VecBertEncoder(torch.nn.Module):
         finally:
             self.set_option("arith", saved)
         return tokens
+
+    def layer_status(self):
+        """Per conformer layer, the OR of its split sites' status flags in the LAST call (bit 1 = fp16 range overflow in that layer). Synchronises."""
+        buf = (C.c_int32 * 64)()
+        n = self.lib.at_w2vbert_layer_status(self.handle, buf, 64)
+        if n < 0:
+            raise _cabi.HipLibraryError(f"at_w2vbert_layer_status failed: {_cabi.last_error()}")
+        return [int(buf[i]) for i in range(n)]
+
+    def unpin_layers(self) -> None:
+        """Return every layer the range fallback moved to bf16x3 to the handle's arithmetic."""
+        for layer in set(self.pinned_layers):
+            self.set_option(f"layer_arith:{layer}", -1)
+        self.pinned_layers = []
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes:

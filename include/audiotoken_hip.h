@@ -272,6 +272,12 @@ int at_w2vbert_range_sites(char* names, size_t cap);
 int at_w2vbert_range_report(at_w2vbert_t* h, float* max_scaled, int cap);
 int at_hubert_range_sites(char* names, size_t cap);
 int at_hubert_range_report(at_hubert_t* h, float* max_scaled, int cap);
+/* Per conformer layer, the OR of its split sites' status flags in the LAST encode (bit 1 = an activation of that layer left the fp16 range). An overflow
+ * becomes infinities that every later layer flags as well: the FIRST flagged layer is the cause. Returns the number of layers written (<= cap).
+ * Synchronises the device. With option "layer_arith:<i>" (at_w2vbert_set_option; -1 = the handle's "arith", 1 = bf16x3, 2 = f16x2) ONE layer can be moved
+ * to the wide-range arithmetic while the others stay on f16x2 — what the product's range fallback does (round 4; the reference has no such notion:
+ * its fp32 arithmetic cannot overflow, audiotoken/encoder.py:163-186). */
+int at_w2vbert_layer_status(at_w2vbert_t* h, int32_t* flags, int cap);
 
 /* Windowed fp32 GEMM: out[b][m][n] = act(alpha*(sum_kk A(b,m,kk)*W[n][kk] + bias[n])) (+ R[b][m][n]) with
  * A(b,m,kk) = pro(X[b][m*stride + kk/Cin - pad_left][kk%Cin]); rows outside [0,Tin) reflect (pad_mode=1) or are

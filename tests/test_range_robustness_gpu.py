@@ -212,3 +212,49 @@ def test_acoustic_per_channel_outliers(cuda_device):
     ref, margins = R.acoustic_encode(w, wav, 8, return_margins=True)
     P.assert_rvq_equal_or_explained(codes, ref, margins, P.RVQ_TIE, "[range] acoustic per-channel outliers x256")
     assert status == 0 and enc.fallback_batches == 0, "four x256 channels must not leave the fp16 range"
+
+
+def test_semantic_m_bad_layer_is_pinned_not_the_batch(cuda_device):
+    """Per-layer range fallback (round 4). ONE conformer layer whose activations leave the fp16 range (layer 1: the bias of one FFN hidden unit at 6 000,
+    swish(.) x 16 > 65504) — what a real checkpoint with an activation outlier does on every batch. The status word reports it, the per-layer flags name
+    layer 1 first (layer 2 only inherits its infinities), verified() moves layer 1 alone to bf16x3 for good and repeats the batch: tokens equal the
+    oracle's, the NEXT batch runs clean without a repeat (round 3 repeated every batch on bf16x3 for all layers). Mixed arithmetic per layer is also checked
+    on healthy weights (the fused final-LayerNorm / next-layer-LayerNorm pass writes the NEXT layer's scheme)."""
+    from audiotoken_amd.configs import Wav2VecBertConfig
+    from audiotoken_amd.encoder import Wav2VecBertEncoder
+    from oracle import w2vbert_ref as R
+    wav = torch.from_numpy(W.synth_waveform(2, 48000, 16000, seed=43))
+    mask = torch.ones_like(wav)
+    x, m = wav.cuda(), mask.cuda()
+    valid = R.processor(wav, mask, 2)[1].bool().unsqueeze(1)
+
+    healthy = W.synth_w2vbert_weights(n_layers=3, seed=9, with_vq=True)
+    enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=3), device="cuda:0", quantize=True, weights=healthy)
+    ref, margins = R.semantic_m_encode({k: torch.from_numpy(v) for k, v in healthy.items()}, wav, mask, 2, 3, return_margins=True)
+    for pinned in ((0,), (1,), (2,), (0, 2)):
+        for l in pinned:
+            enc.set_option(f"layer_arith:{l}", 1)
+        toks = enc(x, m)
+        assert enc.last_status() == 0 and [enc.get_option(f"layer_arith:{l}") for l in range(3)] == [1 if l in pinned else -1 for l in range(3)]
+        P.assert_tokens_equal_or_explained(toks, ref, margins, P.VQ_TIE, f"[range] semantic_m layers {pinned} on bf16x3", valid)
+        for l in pinned:
+            enc.set_option(f"layer_arith:{l}", -1)
+
+    w = dict(healthy)
+    b = w["encoder.layers.1.ffn1.intermediate_dense.bias"].copy()
+    b[0] = 6000.0
+    w["encoder.layers.1.ffn1.intermediate_dense.bias"] = b
+    enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=3), device="cuda:0", quantize=True, weights=w)
+    ref, margins = R.semantic_m_encode({k: torch.from_numpy(v) for k, v in w.items()}, wav, mask, 2, 3, return_margins=True)
+    toks = enc(x, m)
+    assert enc.last_status() & 2, "the poisoned layer must overflow the fp16 range"
+    flags = enc.layer_status()
+    assert len(flags) == 3 and flags[0] == 0 and flags[1] & 2, flags
+    toks = enc.verified(toks, x, m)
+    assert enc.pinned_layers == [1] and enc.fallback_batches == 1 and enc.get_option("arith") == 2 and enc.get_option("layer_arith:1") == 1
+    P.assert_tokens_equal_or_explained(toks, ref, margins, P.VQ_TIE, "[range] semantic_m layer 1 pinned (repeat)", valid)
+    toks2 = enc(x, m)                           # the next batch: no overflow, no repeat
+    assert enc.last_status() == 0 and torch.equal(enc.verified(toks2, x, m), toks) and enc.fallback_batches == 1
+    enc.unpin_layers()
+    enc(x, m)
+    assert enc.last_status() & 2 and enc.pinned_layers == []
