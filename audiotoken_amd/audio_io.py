@@ -41,6 +41,7 @@ class RawAudio:
     sample_rate: int
     scale: float
     offset: float = 0.0
+    pinned: object = None     # (device feeder) the page-locked tensor `pcm` is a view of, when the file was read straight into one
 
     def to_float(self):
         import torch
@@ -50,6 +51,51 @@ class RawAudio:
         if self.pcm.dtype != np.float32:
             x = x * np.float32(self.scale)
         return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def wav_probe(path):
+    """Header of a plain RIFF / WAVE file whose ``data`` chunk can go to the device exactly as it lies in the file (the device feeder reads it straight into
+    pinned memory: feeder.py): ``(numpy dtype, sample_rate, data_offset, data_bytes, scale, offset)`` — or None for everything else (more than one channel,
+    24-bit samples, WAVE_FORMAT_EXTENSIBLE with another sub-format, RF64 / RIFX, a data chunk that runs past the end of the file ...), which the general
+    reader (`decode_raw`, scipy) handles or rejects with its own messages."""
+    try:
+        size = os.path.getsize(path)
+        with open(path, "rb") as f:
+            head = f.read(12)
+            if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+                return None
+            fmt = None
+            pos = 12
+            while pos + 8 <= size:
+                f.seek(pos)
+                hdr = f.read(8)
+                if len(hdr) < 8:
+                    return None
+                cid, csize = hdr[:4], struct.unpack("<I", hdr[4:])[0]
+                if cid == b"fmt ":
+                    body = f.read(min(csize, 40))
+                    if len(body) < 16:
+                        return None
+                    tag, ch, sr, _, align, bits = struct.unpack("<HHIIHH", body[:16])
+                    if tag == 0xFFFE and len(body) >= 26:          # WAVE_FORMAT_EXTENSIBLE: the real tag opens the sub-format GUID
+                        tag = struct.unpack("<H", body[24:26])[0]
+                    fmt = (tag, ch, sr, align, bits)
+                elif cid == b"data":
+                    if fmt is None:
+                        return None
+                    tag, ch, sr, align, bits = fmt
+                    kinds = {(1, 16): (np.dtype("<i2"), 1.0 / 32768.0, 0.0), (1, 32): (np.dtype("<i4"), 1.0 / 2147483648.0, 0.0),
+                             (1, 8): (np.dtype(np.uint8), 1.0 / 128.0, 128.0), (3, 32): (np.dtype("<f4"), 1.0, 0.0)}
+                    if ch != 1 or (tag, bits) not in kinds or align != bits // 8 or sr <= 0:
+                        return None
+                    dtype, scale, offset = kinds[(tag, bits)]
+                    if csize == 0 or pos + 8 + csize > size or csize % dtype.itemsize:
+                        return None
+                    return dtype, int(sr), pos + 8, int(csize), scale, offset
+                pos += 8 + csize + (csize & 1)
+    except (OSError, struct.error):
+        return None
+    return None
 
 
 def _wav_raw(path_or_file) -> RawAudio:

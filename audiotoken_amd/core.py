@@ -222,7 +222,15 @@ class AudioToken:
         if audio_files is not None:
             files = [str(f) for f in audio_files]
         else:
-            files = sorted(str(p) for ext in AUDIO_EXTS + TAR_EXTS + ZIP_EXTS for p in Path(audio_dir).rglob(f"*{ext}"))
+            # every file under audio_dir with one of the extensions — the set the reference's `glob.iglob(f"{audio_dir}/**/*{ext}", recursive=True)` per
+            # extension finds (datasets.py:47-50; glob does not descend into or match dot-names) — in ONE walk instead of fourteen, sorted (the sharding
+            # below needs every rank to see the same order)
+            exts = AUDIO_EXTS + TAR_EXTS + ZIP_EXTS
+            files = []
+            for d, dirs, names in os.walk(str(audio_dir)):
+                dirs[:] = [x for x in dirs if not x.startswith(".")]
+                files.extend(os.path.join(d, n) for n in names if n.endswith(exts) and not n.startswith("."))
+            files.sort()
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             # duration-aware: whole files by greedy LPT on their sizes (distributed.shard_by_size); every rank stats the same list and gets the same answer

@@ -21,7 +21,9 @@ from __future__ import annotations
 
 import ctypes as C
 import io
+import threading
 import time
+from collections import deque
 from copy import deepcopy
 from typing import Callable, Iterator, List, Optional
 
@@ -29,7 +31,7 @@ import numpy as np
 import torch
 
 from . import _cabi
-from .audio_io import AudioDecodeError, RawAudio, archive_members, decode_raw, resample_table, resampled_length
+from .audio_io import AudioDecodeError, RawAudio, archive_members, decode_raw, resample_table, resampled_length, wav_probe
 from .configs import AUDIO_EXTS, TAR_EXTS, ZIP_EXTS, AudioConfig
 from .harness import MIN_SEGMENT_SAMPLES
 from .logger import get_logger
@@ -39,6 +41,41 @@ logger = get_logger(__name__)
 
 _FMT = {np.dtype(np.int16): _cabi.PCM_S16, np.dtype(np.int32): _cabi.PCM_S32, np.dtype(np.float32): _cabi.PCM_F32, np.dtype(np.uint8): _cabi.PCM_U8}
 _STAGE_BYTES = 32 << 20
+_POOL_GRAIN = 1 << 20            # pinned read buffers come in multiples of 1 MiB
+_POOL_KEEP_BYTES = 512 << 20     # idle pinned buffers kept for reuse; beyond that they are released
+_POOL_MAX_FILE = 512 << 20       # larger files take the staged path (two 32 MiB pinned buffers) instead of one pinned buffer of their size
+
+
+class _PinnedPool:
+    """Page-locked read buffers for the decode workers: a plain PCM WAV file is read from the page cache STRAIGHT into one of these (one copy, in the
+    worker thread, GIL released) and goes to the device from there by DMA — the main thread no longer copies every sample into a staging buffer
+    (that copy, ~9 GB/s on one core, was the largest host cost per batch: 369 MB for 256 files of 30 s). Buffers return when their copy has finished."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._free = {}          # capacity -> [tensors]
+        self._kept = 0
+        self.allocations = 0     # buffers page-locked so far (a miss of the free lists)
+
+    def take(self, nbytes: int) -> torch.Tensor:
+        cap = max(_POOL_GRAIN, (nbytes + _POOL_GRAIN - 1) // _POOL_GRAIN * _POOL_GRAIN)
+        with self._lock:
+            lst = self._free.get(cap)
+            if lst:
+                self._kept -= cap
+                return lst.pop()
+            self.allocations += 1
+        return torch.empty(cap, dtype=torch.uint8).pin_memory()
+
+    def give(self, t: torch.Tensor) -> None:
+        cap = t.numel()
+        with self._lock:
+            if self._kept + cap <= _POOL_KEEP_BYTES:
+                self._free.setdefault(cap, []).append(t)
+                self._kept += cap
+
+
+_POOL = _PinnedPool()            # one per process: page-locking is slow, the buffers are reused across encode_batch_files calls
 
 
 class DeviceFeeder:
@@ -63,14 +100,18 @@ class DeviceFeeder:
         self._stage = [torch.empty(_STAGE_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
         self._stage_free = [None, None]
         self._slot = 0
-        self.timings = {"decode_wait_s": 0.0, "upload_s": 0.0, "launch_s": 0.0, "bytes_uploaded": 0, "files": 0, "segments": 0}
+        self._pool = _POOL
+        self._inflight = deque()  # (event, pinned buffer) of direct uploads still in flight, oldest first
+        self.timings = {"decode_wait_s": 0.0, "upload_s": 0.0, "launch_s": 0.0, "bytes_uploaded": 0, "files": 0, "segments": 0, "pinned_allocs": 0}
+        self._allocs0 = _POOL.allocations
 
     # ---- host: decoding (worker threads; scipy's WAV reader and the C++ FLAC decoder release the GIL) ------------------------------------------
     def _decode(self, file_path: str):
         """One unit of host work -> an iterable of (name, RawAudio). Undecodable inputs are reported through ``on_skip`` and yield nothing."""
         if file_path.endswith(AUDIO_EXTS):
             try:
-                return [(file_path, decode_raw(file_path))]
+                direct = self._read_pinned(file_path)
+                return [(file_path, direct if direct is not None else decode_raw(file_path))]
             except AudioDecodeError as e:
                 self.on_skip(file_path, str(e))
                 return []
@@ -85,7 +126,55 @@ class DeviceFeeder:
         self.on_skip(file_path, "unsupported extension")
         return []
 
-    # ---- device: uploads through two pinned staging buffers on the feeder's stream ----------------------------------------------------------------
+    def _read_pinned(self, file_path: str) -> Optional[RawAudio]:
+        """A mono PCM / float32 WAV file read from the file straight into a pinned buffer (worker thread); None = take the general reader."""
+        if not file_path.lower().endswith(".wav"):
+            return None
+        hdr = wav_probe(file_path)
+        if hdr is None or hdr[3] > _POOL_MAX_FILE:
+            return None
+        dtype, sr, off, nbytes, scale, offset = hdr
+        buf = self._pool.take(nbytes)
+        try:
+            view = memoryview(buf.numpy())[:nbytes]
+            with open(file_path, "rb", buffering=0) as f:
+                f.seek(off)
+                got = 0
+                while got < nbytes:
+                    n = f.readinto(view[got:])
+                    if not n:
+                        raise AudioDecodeError(f"{file_path}: file shrank while it was read")
+                    got += n
+        except BaseException:
+            self._pool.give(buf)
+            raise
+        pcm = buf.numpy()[:nbytes].view(dtype.newbyteorder("=")).reshape(1, -1)
+        return RawAudio(pcm, sr, scale, offset, pinned=buf)
+
+    # ---- device: uploads on the feeder's stream — straight from a worker's pinned read buffer, or through two pinned staging buffers -------------------
+    def _reap(self, wait: bool = False) -> None:
+        """Return the pinned buffers whose copy has finished (the copies complete in issue order on the feeder's one stream: only the oldest is asked)."""
+        q = self._inflight
+        while q and (wait or q[0][0].query()):
+            ev, buf = q.popleft()
+            if wait:
+                ev.synchronize()
+            self._pool.give(buf)
+
+    def _upload_raw(self, raw: RawAudio) -> torch.Tensor:
+        if raw.pinned is None:
+            return self._upload(raw.pcm[0])
+        nbytes = raw.pcm.nbytes
+        with torch.cuda.stream(self.stream):
+            dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            dev.copy_(raw.pinned[:nbytes], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._inflight.append((ev, raw.pinned))
+        self.timings["bytes_uploaded"] += int(nbytes)
+        self._reap()
+        return dev
+
     def _upload(self, arr: np.ndarray) -> torch.Tensor:
         with torch.cuda.stream(self.stream):          # (never held across a yield: the consumer's encode must stay on ITS stream)
             return self._upload_on_stream(arr)
@@ -175,7 +264,7 @@ class DeviceFeeder:
                         self.on_skip(str(name), f"Audio needs to be mono, provided {raw.pcm.shape[0]} channels for {name}")
                         continue
                     t0 = time.perf_counter()
-                    pcm_dev = self._upload(raw.pcm[0])
+                    pcm_dev = self._upload_raw(raw)
                     self.timings["upload_s"] += time.perf_counter() - t0
                     self.timings["files"] += 1
                     for row, cfg, ref in self._segments_of(name, raw, pcm_dev):
@@ -191,3 +280,5 @@ class DeviceFeeder:
                     close()
         if rows:
             yield self._launch(rows, pointers, keep)
+        self._reap(wait=True)
+        self.timings["pinned_allocs"] = _POOL.allocations - self._allocs0

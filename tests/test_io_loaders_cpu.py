@@ -167,3 +167,55 @@ def test_undecodable_files_are_skipped_visibly_and_bugs_propagate(tmp_path, monk
     monkeypatch.setattr(A, "resample", lambda *a, **k: (_ for _ in ()).throw(ZeroDivisionError("bug in resample")))
     with pytest.raises(ZeroDivisionError):
         tok.encode_batch_files(batch_size=2, outdir=tmp_path / "o3", chunk_size=1, audio_files=[tmp_path / "sr16.wav"], num_workers=0)
+
+
+def test_wav_probe_matches_the_general_reader(tmp_path):
+    """`audio_io.wav_probe` (the header walk behind the device feeder's read-into-pinned-memory path) against scipy's reader: same dtype, rate and
+    samples for the formats it accepts; None — i.e. the general reader decides — for everything else (stereo, 24-bit, truncated, odd chunks first)."""
+    rng = np.random.default_rng(3)
+    cases = {"s16": (rng.integers(-32768, 32767, 5001).astype(np.int16), 22050), "s32": (rng.integers(-2**31, 2**31 - 1, 777).astype(np.int32), 48000),
+             "u8": (rng.integers(0, 255, 1234).astype(np.uint8), 8000), "f32": (rng.standard_normal(999).astype(np.float32), 16000)}
+    for name, (data, sr) in cases.items():
+        p = str(tmp_path / f"{name}.wav")
+        wavfile.write(p, sr, data)
+        hdr = A.wav_probe(p)
+        assert hdr is not None, name
+        dtype, rate, off, nbytes, scale, offset = hdr
+        raw = A.decode_raw(p)
+        assert rate == sr == raw.sample_rate and nbytes == data.nbytes and scale == raw.scale and offset == raw.offset
+        with open(p, "rb") as f:
+            f.seek(off)
+            got = np.frombuffer(f.read(nbytes), dtype=dtype)
+        assert got.dtype == raw.pcm.dtype and np.array_equal(got, raw.pcm[0]) and np.array_equal(got, data)
+    # an extra chunk (LIST, odd length -> pad byte) in front of `data` is walked over
+    p = str(tmp_path / "list.wav")
+    wavfile.write(p, 16000, cases["s16"][0])
+    b = open(p, "rb").read()
+    i = b.index(b"data")
+    extra = b"LIST" + (5).to_bytes(4, "little") + b"abcde" + b"\0"
+    b2 = b[:i] + extra + b[i:]
+    b2 = b2[:4] + (len(b2) - 8).to_bytes(4, "little") + b2[8:]
+    open(p, "wb").write(b2)
+    hdr = A.wav_probe(p)
+    assert hdr is not None and hdr[2] == i + len(extra) + 8 and np.array_equal(A.decode_raw(p).pcm[0], cases["s16"][0])
+    # not for the fast path
+    stereo = str(tmp_path / "stereo.wav")
+    wavfile.write(stereo, 16000, np.stack([cases["s16"][0], cases["s16"][0]], 1))
+    assert A.wav_probe(stereo) is None
+    trunc = str(tmp_path / "trunc.wav")
+    open(trunc, "wb").write(b[:-100])
+    assert A.wav_probe(trunc) is None
+    s24 = str(tmp_path / "s24.wav")     # 24-bit PCM: 3-byte samples need unpacking
+    hdr24 = b[:i]
+    fi = hdr24.index(b"fmt ") + 8
+    fmt = bytearray(hdr24[fi:fi + 16])
+    fmt[12:14] = (3).to_bytes(2, "little"); fmt[14:16] = (24).to_bytes(2, "little"); fmt[8:12] = (16000 * 3).to_bytes(4, "little")
+    body = bytes(range(240))
+    raw24 = hdr24[:fi] + bytes(fmt) + hdr24[fi + 16:] + b"data" + len(body).to_bytes(4, "little") + body
+    raw24 = raw24[:4] + (len(raw24) - 8).to_bytes(4, "little") + raw24[8:]
+    open(s24, "wb").write(raw24)
+    assert A.wav_probe(s24) is None and A.decode_raw(s24).pcm.shape == (1, 80)
+    assert A.wav_probe(str(tmp_path / "missing.wav")) is None
+    junk = str(tmp_path / "junk.wav")
+    open(junk, "wb").write(b"not a wave file at all")
+    assert A.wav_probe(junk) is None
