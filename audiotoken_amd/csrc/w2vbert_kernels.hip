@@ -327,7 +327,10 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
     typedef typename SC::T PT;
     typedef typename SC::V4 V4;
     constexpr int NP = SC::NP;
-    __shared__ __attribute__((aligned(16))) PT tile[NP][LNS_D / 16][LNS_ROWS][16];   // 64 KB (two pieces) / 96 KB (three)
+    // [piece][k-block][8 rows x 16 + 16 pad]: with the natural 256-byte k-block stride all 16 k-blocks a wave writes at once fell on the same banks
+    // (PMC, round 4: 47 % of this kernel's LDS cycles were conflict replays); + 32 bytes per k-block spreads them over all 64 banks
+    constexpr int KB_LD = LNS_ROWS * 16 + 16;
+    __shared__ __attribute__((aligned(16))) PT tile[NP][LNS_D / 16][KB_LD];   // 36 KB (two pieces) / 54 KB (three)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long r0 = (long long)blockIdx.x * LNS_ROWS;
     RangeMax over;
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
             V4 p[NP];
             over |= split4<SC>(v[j], scale, p);
 #pragma unroll
-            for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(&tile[i][c >> 2][lr][(c & 3) * 4]) = p[i];
+            for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(&tile[i][c >> 2][lr * 16 + (c & 3) * 4]) = p[i];
         }
     }
     __syncthreads();
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
         const int lr = ch >> 1;
         if (r0 + lr < rows_pad)
             *reinterpret_cast<u4_*>(out + pi * ps + ((long long)kb * rows_pad + r0 + lr) * 16 + (ch & 1) * 8) =
-                *reinterpret_cast<const u4_*>(&tile[pi][kb][lr][(ch & 1) * 8]);
+                *reinterpret_cast<const u4_*>(&tile[pi][kb][lr * 16 + (ch & 1) * 8]);
     }
     if constexpr (SC::RANGE_CHECK)
         range_publish(status, status ? status + 1 : nullptr, over);
