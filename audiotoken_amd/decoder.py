@@ -41,9 +41,14 @@ class AcousticDecoder(torch.nn.Module):
         if status == 0:
             return wav
         if status & 1:
-            logger.error(f"persistent LSTM hand-off timed out in the decoder (status {status}): waveform discarded; "
-                         "decoding again with per-step LSTM launches (option persistent_lstm=0) from now on")
-            self.set_option("persistent_lstm", 0)
+            if self.get_option("lstm_pipe") == 1 and tokens.shape[0] <= 80:
+                logger.error(f"persistent LSTM hand-off timed out in the decoder (status {status}): waveform discarded; "
+                             "decoding again with the layer-by-layer persistent LSTM (option lstm_pipe=0) from now on")
+                self.set_option("lstm_pipe", 0)
+            else:
+                logger.error(f"persistent LSTM hand-off timed out in the decoder (status {status}): waveform discarded; "
+                             "decoding again with per-step LSTM launches (option persistent_lstm=0) from now on")
+                self.set_option("persistent_lstm", 0)
         saved = {}
         if status & 2:
             self.fallback_batches += 1
@@ -54,6 +59,10 @@ class AcousticDecoder(torch.nn.Module):
                 self.set_option(opt, 0)
         try:
             wav = self.forward(tokens)
+            if self.last_status() & 1 and self.get_option("persistent_lstm") == 1:   # the layer-by-layer persistent launch timed out as well
+                logger.error("persistent LSTM hand-off timed out again in the decoder: decoding with per-step LSTM launches (option persistent_lstm=0) from now on")
+                self.set_option("persistent_lstm", 0)
+                wav = self.forward(tokens)
             if self.last_status() != 0:
                 raise _cabi.HipLibraryError("acoustic decode failed twice (status non-zero on the fallback kernels)")
         finally:

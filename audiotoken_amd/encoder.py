@@ -185,9 +185,15 @@ class AcousticEncoder(torch.nn.Module):
             if status & ~4 == 0:
                 return codes
         if status & 1:
-            logger.error(f"persistent LSTM hand-off timed out (status {status}): the tokens of this batch were discarded; "
-                         "re-encoding with per-step LSTM launches (option persistent_lstm=0) from now on")
-            self.set_option("persistent_lstm", 0)
+            if self.get_option("lstm_pipe") == 1 and input_batch.shape[0] <= 80:
+                # the pipelined two-layer launch (lstm_pipe.hip) needs 48 co-resident workgroups per 16 clips, the layer-by-layer one 16: try that first
+                logger.error(f"persistent LSTM hand-off timed out (status {status}): the tokens of this batch were discarded; "
+                             "re-encoding with the layer-by-layer persistent LSTM (option lstm_pipe=0) from now on")
+                self.set_option("lstm_pipe", 0)
+            else:
+                logger.error(f"persistent LSTM hand-off timed out (status {status}): the tokens of this batch were discarded; "
+                             "re-encoding with per-step LSTM launches (option persistent_lstm=0) from now on")
+                self.set_option("persistent_lstm", 0)
         saved = {}
         if status & 2:
             self.fallback_batches += 1
@@ -198,6 +204,10 @@ class AcousticEncoder(torch.nn.Module):
                 self.set_option(opt, 0)
         try:
             codes = self.forward(input_batch, attention_mask)
+            if self.last_status() & 1 and self.get_option("persistent_lstm") == 1:   # the layer-by-layer persistent launch timed out as well
+                logger.error("persistent LSTM hand-off timed out again: re-encoding with per-step LSTM launches (option persistent_lstm=0) from now on")
+                self.set_option("persistent_lstm", 0)
+                codes = self.forward(input_batch, attention_mask)
             if self.last_status() & 4:          # still non-finite on the safe kernels: it came with the input, not from the fp16 range
                 self.nonfinite_batches += 1
                 logger.error(f"a NaN or an infinity reached the quantiser on the fallback kernels too (non-finite batch #{self.nonfinite_batches}): check the input waveform")
