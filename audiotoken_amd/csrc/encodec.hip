@@ -149,6 +149,8 @@ struct at_encodec {
     bool res64_x3 = true;           // 64-channel residual block on the bf16 matrix cores (seanet_res64x3.hip); follows bf16x3
     bool res128_x3 = true;          // 128-channel residual block on the bf16 matrix cores (seanet_res128x3.hip); follows bf16x3
     bool fused_dectail = true;      // decoder: last transposed conv + block + final conv in one kernel (seanet_dectail.hip)
+    bool tail_f16x2 = true;         // ... with its contractions on the two-piece fp16 scheme (seanet_dectail_x2.hip)
+    float dtail_up_fs = 0.f;        // power-of-two scale of the last transposed conv's weights for it
     bool bf16x3 = false;            // plain linear layers (LSTM input projections) on the split-bf16 GEMM ($AUDIOTOKEN_BF16X3_ACOUSTIC)
     const __bf16* wih_s[2] = {nullptr, nullptr};
     const __bf16* dwih_s[2] = {nullptr, nullptr};
@@ -796,6 +798,7 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
                 for (int s2 = 0; s2 < 4; ++s2) {
                     h->dres_fs[s2][0] = xb_weight_scale(wmax(d_res[s2][0].w, (size_t)(Cd2 / 2) * 3 * Cd2));
                     h->dres_fs[s2][1] = xb_weight_scale(wmax(d_res[s2][1].w, (size_t)Cd2 * (Cd2 / 2 + Cd2)));
+                    if (s2 == 3) h->dtail_up_fs = xb_weight_scale(wmax(d_up[3].w, (size_t)64 * 128));   // the fused tail kernel's transposed conv [2 * 32][2 * 64]
                     if (s2 < 3) {   // transposed conv of this stage as a two-tap windowed split GEMM: [r * Cout][2 * Cin], Cin = 2 * Cd2
                         const int Cin_u = 2 * Cd2, Nu = kRatiosDec[s2] * Cd2, Ku = 2 * Cin_u;
                         if (Nu % 64 == 0 && Ku % 64 == 0) {
@@ -1103,6 +1106,7 @@ const BoolOption kBoolOptions[] = {
     {"res64_x3", &at_encodec::res64_x3},
     {"res128_x3", &at_encodec::res128_x3},
     {"fused_dectail", &at_encodec::fused_dectail},
+    {"tail_f16x2", &at_encodec::tail_f16x2},
     {"ih_f16x2", &at_encodec::ih_f16x2},
     {"res_f16x2", &at_encodec::res_f16x2},
     {"rvq_f16x2", &at_encodec::rvq_f16x2},
@@ -1237,7 +1241,13 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
                 da.wt = h->dres[3][1].w; da.bt = h->dres[3][1].b; da.wl = h->dlast.w; da.bl = h->dlast.b;
                 da.B = g; da.L = Li;
                 prof.begin("dec_tail", 1, stream);
-                if (int rc = launch_seanet_dectail(da, stream)) return rc;
+                if (h->tail_f16x2 && h->bf16x3 && h->dtail_up_fs > 0.f && h->dres_fs[3][0] > 0.f) {
+                    da.act_scale = XB_F16_ACT_SCALE; da.wu_scale = h->dtail_up_fs; da.w3_scale = h->dres_fs[3][0]; da.wt_scale = h->dres_fs[3][1];
+                    da.status = h->range_tab + 2 * AS_DEC_RES;
+                    if (int rc = launch_seanet_dectail_x2(da, stream)) return rc;
+                } else if (int rc = launch_seanet_dectail(da, stream)) {
+                    return rc;
+                }
                 prof.end(stream);
                 tail_done = true;
                 break;

@@ -156,8 +156,13 @@ struct DecTailArgs {
     const float *wt, *bt;   // block tail packed [32][16 + 32], summed bias [32]
     const float *wl, *bl;   // last conv packed [7*32], [1]
     int B, L;
+    // seanet_dectail_x2 only: the two-piece fp16 scheme's activation scale, the three weight matrices' power-of-two scales, the range status word
+    float act_scale = 0.f, wu_scale = 0.f, w3_scale = 0.f, wt_scale = 0.f;
+    int* status = nullptr;
 };
 int launch_seanet_dectail(const DecTailArgs& a, hipStream_t stream);
+// the same kernel with its three contractions as two-piece fp16 operand splits (seanet_dectail_x2.hip); the last conv stays fp32 on the VALU
+int launch_seanet_dectail_x2(const DecTailArgs& a, hipStream_t stream);
 // Same block at 128 channels (seanet_res128.hip): x [B][L][128] -> out [B][L][128]; w3 [64][3*128], wt [128][64 + 128]
 int launch_seanet_res128(const Res64Args& a, hipStream_t stream);
 

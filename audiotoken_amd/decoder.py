@@ -53,8 +53,8 @@ class AcousticDecoder(torch.nn.Module):
         if status & 2:
             self.fallback_batches += 1
             logger.error(f"fp16 range overflow in the decoder's f16x2 kernels (LSTM input projection, residual blocks, transposed convs; status {status}): "
-                         "waveform discarded; decoding THIS batch again without them (options ih_f16x2=0, res_f16x2=0, up_f16x2=0)")
-            for opt in ("ih_f16x2", "res_f16x2", "up_f16x2"):
+                         "waveform discarded; decoding THIS batch again without them (options ih_f16x2=0, res_f16x2=0, up_f16x2=0, tail_f16x2=0)")
+            for opt in ("ih_f16x2", "res_f16x2", "up_f16x2", "tail_f16x2"):
                 saved[opt] = self.get_option(opt)
                 self.set_option(opt, 0)
         try:

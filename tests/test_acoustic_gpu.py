@@ -285,6 +285,7 @@ def test_fused_decoder_kernels_equal_unfused(enc_weights):
         x3 = dec(codes).clone()
         dec.set_option("res128_x3", 0)   # the split-bf16 blocks round differently: compared by tolerance
         dec.set_option("res64_x3", 0)
+        dec.set_option("tail_f16x2", 0)  # so does the tail kernel on the fp16 scheme (seanet_dectail_x2.hip)
         ref = dec(codes).clone()
         assert (ref - x3).abs().max().item() <= 2e-5 * ref.abs().max().item(), (B, T, (ref - x3).abs().max().item())
         for opt in ("fused_dectail", "fused_res64", "fused_res128"):
@@ -294,6 +295,13 @@ def test_fused_decoder_kernels_equal_unfused(enc_weights):
             assert torch.equal(ref, got), (opt, B, T, (ref - got).abs().max().item())
         dec.set_option("res128_x3", 1)
         dec.set_option("res64_x3", 1)
+        dec.set_option("tail_f16x2", 1)
+        only_tail = dec(codes)           # the fp16-scheme tail alone against its fp32 twin
+        dec.set_option("tail_f16x2", 0)
+        fp32_tail = dec(codes)
+        dec.set_option("tail_f16x2", 1)
+        assert dec.last_status() == 0
+        assert (only_tail - fp32_tail).abs().max().item() <= 2e-5 * fp32_tail.abs().max().item(), (B, T, (only_tail - fp32_tail).abs().max().item())
 
 
 F16X2_OPTIONS = ["chain_f16x2", "ih_f16x2", "res_f16x2", "rvq_f16x2", "fin_f16x2", "lstm_f16x2"]
