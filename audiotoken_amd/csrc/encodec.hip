@@ -150,6 +150,8 @@ struct at_encodec {
     bool res128_x3 = true;          // 128-channel residual block on the bf16 matrix cores (seanet_res128x3.hip); follows bf16x3
     bool fused_dectail = true;      // decoder: last transposed conv + block + final conv in one kernel (seanet_dectail.hip)
     bool tail_f16x2 = true;         // ... with its contractions on the two-piece fp16 scheme (seanet_dectail_x2.hip)
+    bool dec_chain = true;          // decoder stage 0 (256 channels): the block as two split GEMMs whose output is the next transposed conv's operand (seanet_dec256.hip)
+    const piece_t* dchain_f[2] = {nullptr, nullptr};   // its k3 conv [128][3 * 256] (window order) and tail [256][128 + 256] as two fp16 pieces (scales: dres_fs[0])
     float dtail_up_fs = 0.f;        // power-of-two scale of the last transposed conv's weights for it
     bool bf16x3 = false;            // plain linear layers (LSTM input projections) on the split-bf16 GEMM ($AUDIOTOKEN_BF16X3_ACOUSTIC)
     const __bf16* wih_s[2] = {nullptr, nullptr};
@@ -495,6 +497,7 @@ struct DecPlan {
     size_t off_z, off_x0, off_xg, off_xg2, off_h0, off_h1, off_c, off_y, off_sync, off_xs;
     size_t off_u[4], off_h[4], off_r[4];
     size_t off_ap;     // operand pieces of a transposed conv run as a windowed split GEMM: [2][G][Cin/16][Lpu][16] fp16 (one float per element)
+    int dMpc = 0, dLpc = 0; size_t off_dac3 = 0, off_dat3 = 0;   // stage-0 block as split GEMMs: padded rows, k3 operand [2][G][16][dLpc][16], tail operand [2][G][24][dMpc][16]
     int Mpu[3], Lpu[3];   // per stage: padded output rows / operand rows per clip
     size_t total_floats;
 };
@@ -535,6 +538,10 @@ DecPlan make_dec_plan(int B, int T, int sub) {
         }
         p.off_ap = take(ap + 64);
     }
+    p.dMpc = (p.L[1] + 255) / 256 * 256;
+    p.dLpc = (p.dMpc + 2 + 63) / 64 * 64;
+    p.off_dac3 = take((size_t)p.G * p.dLpc * 256 + 64);
+    p.off_dat3 = take((size_t)p.G * p.dMpc * 384 + 64);
     p.total_floats = cur;
     return p;
 }
@@ -798,6 +805,17 @@ int at_encodec_finalize(at_encodec_t* h, int with_decoder) {
                 for (int s2 = 0; s2 < 4; ++s2) {
                     h->dres_fs[s2][0] = xb_weight_scale(wmax(d_res[s2][0].w, (size_t)(Cd2 / 2) * 3 * Cd2));
                     h->dres_fs[s2][1] = xb_weight_scale(wmax(d_res[s2][1].w, (size_t)Cd2 * (Cd2 / 2 + Cd2)));
+                    if (s2 == 0) {   // the 256-channel block's two weight matrices as fp16 pieces for the split GEMMs (as the encoder's chain_f[1], chain_f[2])
+                        const float* src[2] = {h->dres[0][0].w, h->dres[0][1].w};
+                        const int ns[2] = {128, 256}, ks[2] = {768, 384}, wcb[2] = {16, 0};
+                        for (int j = 0; j < 2; ++j) {
+                            piece_t* f = nullptr;
+                            AT_CHECK_HIP(hipMalloc((void**)&f, (size_t)2 * ns[j] * ks[j] * sizeof(piece_t)));
+                            h->extra_allocs.push_back(f);
+                            if (int rc = launch_split_blocked(src[j], ks[j], ns[j], ns[j], ks[j], f, nullptr, XB_SCHEME_F16X2, h->dres_fs[0][j], nullptr, wcb[j], 1)) return rc;
+                            h->dchain_f[j] = f;
+                        }
+                    }
                     if (s2 == 3) h->dtail_up_fs = xb_weight_scale(wmax(d_up[3].w, (size_t)64 * 128));   // the fused tail kernel's transposed conv [2 * 32][2 * 64]
                     if (s2 < 3) {   // transposed conv of this stage as a two-tap windowed split GEMM: [r * Cout][2 * Cin], Cin = 2 * Cd2
                         const int Cin_u = 2 * Cd2, Nu = kRatiosDec[s2] * Cd2, Ku = 2 * Cin_u;
@@ -1107,6 +1125,7 @@ const BoolOption kBoolOptions[] = {
     {"res128_x3", &at_encodec::res128_x3},
     {"fused_dectail", &at_encodec::fused_dectail},
     {"tail_f16x2", &at_encodec::tail_f16x2},
+    {"dec_chain", &at_encodec::dec_chain},
     {"ih_f16x2", &at_encodec::ih_f16x2},
     {"res_f16x2", &at_encodec::res_f16x2},
     {"rvq_f16x2", &at_encodec::rvq_f16x2},
@@ -1232,6 +1251,7 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
         const float* in = y + (long long)b0 * T * kH;
         int Cin = kH;
         bool tail_done = false;
+        bool ap_ready = false;   // the next stage's transposed-conv operand already lies in `ap` as pieces
         for (int s = 0; s < 4; ++s) {
             const int Li = p.L[s], Lo = p.L[s + 1], Co = Cin / 2;
             if (s == 3 && h->fused_dectail && Li >= 8) {
@@ -1260,7 +1280,9 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
                 // as a two-tap windowed split GEMM on the fp16 scheme: the (already ELU'd) input -> pieces with ONE ZERO front row (x[-1] = 0)
                 __bf16* ap = reinterpret_cast<__bf16*>(ws + p.off_ap);
                 int* range_status = h->range_tab + 2 * AS_DEC_UP;
-                if (int rc = launch_split_windowed(in, g, Li, Cin, 1, 1, p.Lpu[s], ap, stream, XB_SCHEME_F16X2, XB_F16_ACT_SCALE, range_status, 0)) return rc;
+                if (!ap_ready)   // (after the stage-0 chain the block's tail GEMM has already written these pieces)
+                    if (int rc = launch_split_windowed(in, g, Li, Cin, 1, 1, p.Lpu[s], ap, stream, XB_SCHEME_F16X2, XB_F16_ACT_SCALE, range_status, 0)) return rc;
+                ap_ready = false;
                 Bf16x3Args ua;
                 ua.A = ap; ua.W = h->dup_f[s]; ua.bias = h->dup[s].b;
                 ua.M = Li; ua.Mpad = p.Mpu[s]; ua.N = kRatiosDec[s] * Co; ua.K = 2 * Cin;
@@ -1274,7 +1296,33 @@ int at_encodec_decode_checked(at_encodec_t* h, const int64_t* codes, int B, int 
             prof.end(stream);
             float* r = ws + p.off_r[s];
             prof.begin(kDRes[s], 1, stream);
-            if ((Co == 64 && h->fused_res64) || (Co == 128 && h->fused_res128)) {
+            // stage 0 (256 channels) as the encoder's stage-3 block: one pass u -> ELU(u) pieces (+ reflect rows) and raw u pieces, the k3 conv and the tail as
+            // split GEMMs; the tail's ELU -> pieces epilogue writes the NEXT transposed conv's operand (one zero front row): no fp32 block output, no split pass
+            const bool chain0 = s == 0 && Co == 256 && h->dec_chain && h->bf16x3 && h->res_f16x2 && h->up_f16x2 && h->dchain_f[0] && h->dchain_f[1] && h->dup_f[1] && Lo >= 3;
+            if (chain0) {
+                __bf16* ac3 = reinterpret_cast<__bf16*>(ws + p.off_dac3);
+                __bf16* at3 = reinterpret_cast<__bf16*>(ws + p.off_dat3);
+                __bf16* apn = reinterpret_cast<__bf16*>(ws + p.off_ap);
+                int* rs = h->range_tab + 2 * AS_DEC_RES;
+                if (int rc = launch_zero_piece_rows(at3, (long long)2 * g * 24, p.dMpc, Lo, p.dMpc, stream)) return rc;
+                if (int rc = launch_dec_res256_split(u, g, Lo, ac3, p.dLpc, at3, p.dMpc, XB_F16_ACT_SCALE, rs, stream)) return rc;
+                Bf16x3Args ca;
+                ca.A = ac3; ca.W = h->dchain_f[0]; ca.bias = h->dres[0][0].b; ca.M = Lo; ca.Mpad = p.dMpc; ca.N = 128; ca.K = 768;
+                ca.batch = g; ca.stride = 1; ca.cblocks = 16; ca.Lp = p.dLpc;
+                ca.scheme = XB_SCHEME_F16X2; ca.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->dres_fs[0][0]); ca.split_scale = XB_F16_ACT_SCALE; ca.status = rs;
+                ca.epi = XB_EPI_ELU_SPLIT; ca.S = at3; ca.Spad = p.dMpc; ca.Sphases = 1; ca.Sfront = 0; ca.Sblocks = 24; ca.Sblock0 = 0;
+                if (int rc = launch_gemm_bf16x3(ca, stream)) return rc;
+                // the next stage's operand: [2][g][16][Lpu][16], row t at index t + 1; row 0 and the rows past the data zero
+                if (int rc = launch_zero_piece_rows(apn, (long long)2 * g * 16, p.Lpu[1], 0, 1, stream)) return rc;
+                if (int rc = launch_zero_piece_rows(apn, (long long)2 * g * 16, p.Lpu[1], Lo + 1, p.Lpu[1], stream)) return rc;
+                Bf16x3Args ta;
+                ta.A = at3; ta.W = h->dchain_f[1]; ta.bias = h->dres[0][1].b; ta.M = Lo; ta.Mpad = p.dMpc; ta.N = 256; ta.K = 384;
+                ta.batch = g; ta.stride = 1; ta.cblocks = 24; ta.Lp = p.dMpc;
+                ta.scheme = XB_SCHEME_F16X2; ta.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->dres_fs[0][1]); ta.split_scale = XB_F16_ACT_SCALE; ta.status = rs;
+                ta.epi = XB_EPI_ELU_SPLIT; ta.S = apn; ta.Spad = p.Lpu[1]; ta.Sphases = 1; ta.Sfront = 1;
+                if (int rc = launch_gemm_bf16x3(ta, stream)) return rc;
+                ap_ready = true;
+            } else if ((Co == 64 && h->fused_res64) || (Co == 128 && h->fused_res128)) {
                 Res64Args ra;
                 ra.x = u; ra.out = r; ra.w3 = h->dres[s][0].w; ra.b3 = h->dres[s][0].b; ra.wt = h->dres[s][1].w; ra.bt = h->dres[s][1].b;
                 ra.B = g; ra.L = Lo;

@@ -160,6 +160,10 @@ struct DecTailArgs {
     float act_scale = 0.f, wu_scale = 0.f, w3_scale = 0.f, wt_scale = 0.f;
     int* status = nullptr;
 };
+// decoder stage 0 on the split GEMMs (seanet_dec256.hip): u fp32 [g][L][256] -> ELU(u) pieces with two reflected front rows (the k3 conv's operand) and
+// raw u pieces in K-blocks 8..23 of the tail's operand; rows past the data zero-filled
+int launch_dec_res256_split(const float* u, int g, int L, __bf16* ac3, int Lpc, __bf16* at3, int Mpc, float scale, int* status, hipStream_t stream);
+int launch_zero_piece_rows(__bf16* S, long long planes, int Lp, int row0, int row1, hipStream_t stream);
 int launch_seanet_dectail(const DecTailArgs& a, hipStream_t stream);
 // the same kernel with its three contractions as two-piece fp16 operand splits (seanet_dectail_x2.hip); the last conv stays fp32 on the VALU
 int launch_seanet_dectail_x2(const DecTailArgs& a, hipStream_t stream);

@@ -302,6 +302,10 @@ def test_fused_decoder_kernels_equal_unfused(enc_weights):
         dec.set_option("tail_f16x2", 1)
         assert dec.last_status() == 0
         assert (only_tail - fp32_tail).abs().max().item() <= 2e-5 * fp32_tail.abs().max().item(), (B, T, (only_tail - fp32_tail).abs().max().item())
+        dec.set_option("dec_chain", 0)   # stage 0's 256-channel block as fp32 GEMMs instead of the split-GEMM chain (seanet_dec256.hip)
+        unchained = dec(codes)
+        dec.set_option("dec_chain", 1)
+        assert (only_tail - unchained).abs().max().item() <= 2e-5 * unchained.abs().max().item(), (B, T, (only_tail - unchained).abs().max().item())
 
 
 F16X2_OPTIONS = ["chain_f16x2", "ih_f16x2", "res_f16x2", "rvq_f16x2", "fin_f16x2", "lstm_f16x2"]
