@@ -23,7 +23,7 @@
 using namespace at;
 
 namespace {
-constexpr int kCd = 512, kHid = 768, kFfn = 3072, kHeads = 12, kPosK = 128, kGroups = 16, kGc = 48, kCenters = 1000;
+constexpr int kCd = 512, kHid = 768, kFfn = 3072, kHeads = 12, kPosK = 128, kGroups = 16, kGc = 48, kCenters = 1000, kCentersPad = 1024;
 constexpr int kKs[7] = {10, 3, 3, 3, 3, 2, 2}, kSt[7] = {5, 2, 2, 2, 2, 2, 2};
 
 struct HostTensor {
@@ -56,6 +56,9 @@ struct at_hubert {
     const piece_t* conv_ws[2][7] = {};   // conv weights of layers 1..6 as operand pieces, per scheme
     const piece_t* pos_ws = nullptr;     // positional-conv weights as fp16 pieces in the per-K-step layout of hubert_posconv.hip (f16x2 scheme only)
     float pos_wscale = 1.f;
+    const piece_t* cen_s[2] = {};        // the k-means centres as operand pieces per scheme, rows padded 1000 -> 1024 (zero rows): the score GEMM on the split kernel
+    float cen_scale = 1.f;
+    bool kmeans_split = true;            // option "kmeans_split": that GEMM on the split kernel instead of the fp32 MFMA (as at_w2vbert's "vq_split")
     bool posconv_split = true;           // option "posconv_split": the LDS-resident grouped conv kernel (hubert_posconv.hip) instead of 16 fp32 windowed GEMMs
     float conv_wscale[7] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     int arith = ARITH_F16X2;   // linear layers + conv chain: ARITH_* ($AUDIOTOKEN_SEMANTIC_ARITH = f32 | bf16x3 | f16x2; option "arith")
@@ -195,6 +198,20 @@ int split_weights(at_hubert* h, int scheme) {
         const int ns[4] = {3 * kHid, kHid, kFfn, kHid}, ks[4] = {kHid, kHid, kHid, kFfn};
         for (int j = 0; j < 4; ++j)
             if (int rc = one(src[j], ns[j], ks[j], &L.ws[scheme][j], &L.wscale[j])) return rc;
+    }
+    if (h->centers) {   // k-means centres [1000][768] -> pieces of 1024 rows (the last 24 zero: their scores are never read)
+        piece_t* d = static_cast<piece_t*>(h->arena.alloc((size_t)np * kCentersPad * kHid * sizeof(piece_t)));
+        if (!d) return -1;
+        float sc = 1.0f;
+        if (scheme == XB_SCHEME_F16X2) {
+            auto it = h->wmax.find(h->centers);
+            AT_REQUIRE(it != h->wmax.end(), "weight maximum not recorded");
+            sc = xb_weight_scale(it->second);
+            h->cen_scale = sc;
+        }
+        if (!h->arena.importing)
+            if (int rc = launch_split_blocked(h->centers, kHid, kCenters, kCentersPad, kHid, d, nullptr, scheme, sc, nullptr)) return rc;
+        h->cen_s[scheme] = d;
     }
     AT_CHECK_HIP(hipDeviceSynchronize());
     h->split_done[scheme] = true;
@@ -475,6 +492,7 @@ int at_hubert_set_option(at_hubert_t* h, const char* name, int value) {
     }
     if (n == "attn_w8") { h->attn_w8 = value < 0 ? -1 : (value != 0); return 0; }
     if (n == "posconv_split") { h->posconv_split = value != 0; return 0; }
+    if (n == "kmeans_split") { h->kmeans_split = value != 0; return 0; }
     set_error("at_hubert_set_option: unknown option " + n);
     return -1;
 }
@@ -484,6 +502,7 @@ int at_hubert_get_option(const at_hubert_t* h, const char* name) {
     if (std::string(name) == "arith") return h->arith;
     if (std::string(name) == "attn_w8") return h->attn_w8;
     if (std::string(name) == "posconv_split") return h->posconv_split ? 1 : 0;
+    if (std::string(name) == "kmeans_split") return h->kmeans_split ? 1 : 0;
     return -1;
 }
 
@@ -633,8 +652,21 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
     if (tokens) {
         prof.begin("kmeans", 3, stream);
         if (int rc = launch_layernorm(x, nullptr, nullptr, nullptr, t1, M, kHid, stream)) return rc;
-        if (int rc = linear(t1, kHid, h->centers, nullptr, big, kCenters, M, EPI_NONE, nullptr, nullptr, kCenters, stream)) return rc;
-        if (int rc = launch_vq_argmax(t1, big, h->c2, tokens, M, kHid, kCenters, stream, reinterpret_cast<int*>(status_dev))) return rc;
+        if (split && h->kmeans_split && h->cen_s[sc.scheme]) {
+            // the score GEMM on the split kernel against the centres padded to 1024 rows; the non-affine LayerNorm output is bounded by sqrt(768) = 27.7, so
+            // x 16 cannot leave the fp16 range: no range site
+            if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, xs, stream, sc.scheme, sc.act_scale(), nullptr)) return rc;
+            Bf16x3Args va;
+            va.A = xs; va.W = h->cen_s[sc.scheme]; va.bias = nullptr; va.M = (int)M; va.N = kCentersPad; va.K = kHid; va.Mpad = (int)Mpad;
+            va.epi = XB_EPI_LINEAR; va.C = big; va.ldc = kCentersPad; va.R = nullptr; va.ldr = kCentersPad; va.alpha = 1.f;
+            va.scheme = sc.scheme; va.status = nullptr;
+            if (sc.scheme == XB_SCHEME_F16X2) { va.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->cen_scale); va.split_scale = XB_F16_ACT_SCALE; }
+            if (int rc = launch_gemm_bf16x3(va, stream)) return rc;
+            if (int rc = launch_vq_argmax(t1, big, h->c2, tokens, M, kHid, kCenters, stream, reinterpret_cast<int*>(status_dev), kCentersPad)) return rc;
+        } else {
+            if (int rc = linear(t1, kHid, h->centers, nullptr, big, kCenters, M, EPI_NONE, nullptr, nullptr, kCenters, stream)) return rc;
+            if (int rc = launch_vq_argmax(t1, big, h->c2, tokens, M, kHid, kCenters, stream, reinterpret_cast<int*>(status_dev))) return rc;
+        }
         prof.end(stream);
     }
     return 0;

@@ -45,7 +45,8 @@ int launch_layernorm2_split(const float* x, const float* gamma, const float* bet
 int launch_layernorm_split(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, __bf16* out, long long rows, long long rows_pad,
                            int D, int scheme, float scale, int* status, hipStream_t stream);
 // status (nullable): OR-ed with XB_STATUS_NONFINITE when a row of x holds a NaN / infinity
+// ld: row stride of `dots` (0 = C; > C when the score GEMM ran against a zero-padded code book)
 int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,
-                     hipStream_t stream, int* status = nullptr);
+                     hipStream_t stream, int* status = nullptr, int ld = 0);
 
 }  // namespace at

@@ -827,7 +827,7 @@ int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, c
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict__ x, const float* __restrict__ dots,
                                                         const float* __restrict__ e2, int16_t* __restrict__ out, long long rows,
-                                                        int D, int C, int* __restrict__ status) {
+                                                        int D, int C, int* __restrict__ status, int ld) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
     float best = -INFINITY;
     int bidx = 0;
     for (int c = lane; c < (C >> 2); c += 64) {   // increasing n per lane: strict > keeps the first index
-        const f4 d = reinterpret_cast<const f4*>(dots + row * C)[c];
+        const f4 d = reinterpret_cast<const f4*>(dots + row * ld)[c];
         const f4 y2 = reinterpret_cast<const f4*>(e2)[c];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -861,9 +861,9 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
 }
 
 int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,
-                     hipStream_t stream, int* status) {
+                     hipStream_t stream, int* status, int ld) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(vq_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, dots, e2, out, rows, D, C, status);
+    hipLaunchKernelGGL(vq_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, dots, e2, out, rows, D, C, status, ld > 0 ? ld : C);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }

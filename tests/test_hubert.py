@@ -116,3 +116,29 @@ def test_gpu_positional_conv_kernels_agree(cuda_device, B, N):
     ref, margins = R.semantic_s_encode(w, wav, mask, 2, return_margins=True)
     from tests import parity as P
     P.assert_tokens_equal_or_explained(t1f, ref, margins, P.VQ_TIE, f"positional conv (split kernel) B={B} N={N}")
+
+
+@pytest.mark.gpu
+def test_gpu_kmeans_score_gemm_kernels_agree(cuda_device):
+    """The k-means score GEMM (hidden state . centres^T, 1000 centres) on the split kernel against centres zero-padded to 1024 rows (option kmeans_split = 1,
+    default) and on the fp32 MFMA (= 0): identical ids on ragged clips, and the oracle's ids (equal or explained); the 24 padding rows can never win (their
+    scores are not read)."""
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    from tests import parity as P
+    w = W.synth_hubert_weights(2, 23, True)
+    enc = HubertEncoder(HubertEncoderConfig(output_layer=2), device="cuda:0", quantize=True, weights=w)
+    wav = hubert_processor(torch.from_numpy(W.synth_waveform(3, 40000, 16000, seed=77)))
+    mask = torch.ones_like(wav)
+    mask[1, 30000:] = 0
+    x, m = wav.cuda(), mask.cuda()
+    assert enc.get_option("kmeans_split") == 1
+    t1 = enc(x, m)
+    assert enc.last_status() == 0
+    enc.set_option("kmeans_split", 0)
+    t0 = enc(x, m)
+    enc.set_option("kmeans_split", 1)
+    ref, margins = R.semantic_s_encode(w, wav, mask, 2, return_margins=True)
+    P.assert_tokens_equal_or_explained(t1, ref, margins, P.VQ_TIE, "k-means on the split kernel")
+    P.assert_tokens_equal_or_explained(t0, ref, margins, P.VQ_TIE, "k-means on the fp32 MFMA")
+    assert int(t1.max()) < 1000
