@@ -353,7 +353,8 @@ def run_hubert(args, rank, world, dev, dist):
         "fallback_batches": fallback * args.steps, "fallback_status": fb_status,
     }
     if "kmeans" in breakdown and breakdown["kmeans"]["ms_per_step"] > 0:
-        res["argmin"] = argmin_entry("kmeans", breakdown["kmeans"]["ms_per_step"], flops["kmeans"] * B, (4.0 * T * 768 + 2.0 * T) * B, 1)
+        km_products = {0: 1, 1: 6, 2: 3}[arith] if enc.get_option("kmeans_split") == 1 else 1   # the score GEMM on the split kernel (option kmeans_split) or the fp32 MFMA
+        res["argmin"] = argmin_entry("kmeans", breakdown["kmeans"]["ms_per_step"], flops["kmeans"] * B, (4.0 * T * 768 + 2.0 * T) * B, km_products)
     del enc
     torch.cuda.empty_cache()
     return res
