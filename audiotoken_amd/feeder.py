@@ -145,6 +145,9 @@ class DeviceFeeder:
                     if not n:
                         raise AudioDecodeError(f"{file_path}: file shrank while it was read")
                     got += n
+        except OSError as e:             # unreadable / vanished: the same report the general reader gives
+            self._pool.give(buf)
+            raise AudioDecodeError(f"{file_path}: {type(e).__name__}: {e}") from e
         except BaseException:
             self._pool.give(buf)
             raise
