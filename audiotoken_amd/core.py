@@ -213,7 +213,8 @@ class AudioToken:
         (``device_feeder=False`` keeps the reference's host data flow). Host path: a thread pool by default — the heavy work (file read, FLAC decode, the
         resampling conv1d) releases the GIL — or spawned worker PROCESSES with ``worker_processes=True`` (the reference's arrangement; archives are always
         streamed by a thread). Under ``torch.distributed`` every rank takes whole files, balanced by size (distributed.shard_by_size): all chunks of a file stay
-        on one rank, preserving the append order."""
+        on one rank, preserving the append order (``shard_across_ranks=False``: this rank takes every file it was given — for callers that have already
+        split the work, e.g. one directory per rank)."""
         self.load_encoder()
         self.skipped_files = []
         assert audio_files or audio_dir, "Either audio_files or audio_dir must be provided"
@@ -232,7 +233,7 @@ class AudioToken:
                 files.extend(os.path.join(d, n) for n in names if n.endswith(exts) and not n.startswith("."))
             files.sort()
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dataloader_kwargs.get("shard_across_ranks", True):
             # duration-aware: whole files by greedy LPT on their sizes (distributed.shard_by_size); every rank stats the same list and gets the same answer
             from .distributed import shard_by_size
             sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in files]

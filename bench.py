@@ -572,15 +572,17 @@ def run_files(args, rank, world, dev, dist, device_rates):
                 del xb, mb
             out = os.path.join(root, f"out_{name}_{src}")
             warm = sorted(os.path.join(d, f) for f in os.listdir(d))[:bs]
-            tok.encode_batch_files(batch_size=bs, outdir=out + "_warm", chunk_size=30, audio_files=warm, num_workers=args.files_workers)   # allocations, tables, worker threads
+            tok.encode_batch_files(batch_size=bs, outdir=out + "_warm", chunk_size=30, audio_files=warm, num_workers=args.files_workers, shard_across_ranks=False)   # allocations, tables, worker threads
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
             t0 = time.perf_counter()
-            tok.encode_batch_files(batch_size=bs, outdir=out, chunk_size=30, audio_dir=d, num_workers=args.files_workers)
+            # (every rank generated its OWN directory: it takes all of it — the LPT sharding of a common directory is covered by tests/test_distributed_cpu.py)
+            tok.encode_batch_files(batch_size=bs, outdir=out, chunk_size=30, audio_dir=d, num_workers=args.files_workers, shard_across_ranks=False)
             torch.cuda.synchronize()
             el = max_over_ranks(time.perf_counter() - t0, dev, dist)
             n_out = len(os.listdir(out))
+            assert n_out == n_files, f"files leg: {n_out} token files for {n_files} inputs"
             rate = world * n_files * 30.0 / el
             rt, ft = dict(tok.run_timings), dict(tok.feeder_timings or {})
             legs.append({"tokenizer": name, "files_per_gpu": n_files, "file": f"30 s, 16-bit PCM WAV @ {src} Hz" + ("" if src == dst else f" (resampled to {dst} Hz on the device)"),

@@ -19,3 +19,14 @@ for n in ("both", "hub"):
     except Exception as e:
         print(n, "parse failed", e); print(open("$out/%s.err" % n).read()[-3000:])
 PY
+# the files leg on two ranks (every rank its own generated files; LPT sharding is exercised by tests/test_distributed_cpu.py)
+timeout 1200 python bench.py --gpus 2 --backend gloo --shared-device --workload files --files-acoustic 256 --files-acoustic-batch 64 --files-semantic 0 --no-cpu-baseline --no-verify > $out/files.json 2> $out/files.err; echo "files rc $?"
+python - <<PY
+import json
+try:
+    d = json.load(open("$out/files.json"))
+    for leg in d["files"]["legs"]:
+        print("files", leg["tokenizer"], leg["file"][-28:], "value", leg["value"], "token files", leg["token_files_written"])
+except Exception as e:
+    print("files parse failed", e); print(open("$out/files.err").read()[-3000:])
+PY
