@@ -30,3 +30,14 @@ try:
 except Exception as e:
     print("files parse failed", e); print(open("$out/files.err").read()[-3000:])
 PY
+# the default workload ("all": both tokenizers + decode + semantic_s + files) at reduced sizes
+timeout 1200 python bench.py --gpus 2 --backend gloo --shared-device --steps 2 --warmup 1 --no-cpu-baseline --no-verify --batch 32 --sem-batch 8 --sem-layers 3 --hub-batch 8 --files-acoustic 64 --files-acoustic-batch 32 --files-semantic 0 > $out/all.json 2> $out/all.err; echo "all rc $?"
+python - <<PY
+import json
+try:
+    d = json.load(open("$out/all.json"))
+    print("all: n_gpus", d["n_gpus"], "value", d["value"], "keys", [k for k in ("acoustic", "semantic_m", "semantic_s", "acoustic_decode", "files") if k in d],
+          "decode ms", d.get("acoustic_decode", {}).get("ms_per_step"), "decode err", d.get("acoustic_decode", {}).get("error"))
+except Exception as e:
+    print("all parse failed", e); print(open("$out/all.err").read()[-3000:])
+PY
