@@ -47,7 +47,8 @@ struct at_hubert {
     DeviceArena arena;          // every device allocation of finalize(), in order (packed_model.h: export / import of the finalized model)
     PackedHeader imp{};         // import_packed: the exporter's record (layer count, flags) while finalize is replayed
     std::vector<int> split_seq; // the schemes whose weight pieces exist, in the order they were split (= their order in the arena)
-    int* range_tab = nullptr;   // device, {flag, census} per HSite, zeroed at the start of every encode (at_hubert_range_report reads it)
+    int* range_tab = nullptr;   // device, {flag, census} per (row, HSite): row 0 = conv feature encoder + positional conv, row 1 + l = transformer layer l; zeroed per encode
+    std::vector<int> layer_arith;   // per transformer layer: -1 = the handle's arithmetic, else ARITH_BF16X3 / ARITH_F16X2 for that layer only (option "layer_arith:<i>")
     const float* conv_w[7] = {};
     const float *gn_g = nullptr, *gn_b = nullptr, *fp_ln_g = nullptr, *fp_ln_b = nullptr, *fp_w = nullptr, *fp_b = nullptr;
     const float *pos_w = nullptr, *pos_b = nullptr, *enc_ln_g = nullptr, *enc_ln_b = nullptr;
@@ -156,6 +157,8 @@ Plan make_plan(int B, int N) {
 // Sites of the handle's range table (gemm_bf16x3.h, launch_range_combine): where activations become fp16 pieces
 enum HSite { HS_CONV0 = 0, HS_FE_CONV, HS_X_IN, HS_QKV_KV, HS_ATTENTION, HS_FFN_HIDDEN, HS_OTHER, H_NSITES };
 static const char* const kHSiteNames[H_NSITES] = {"conv0_out", "feature_convs", "layer_input", "qkv_kv", "attention", "ffn_hidden", "other"};
+constexpr int kRangeRows = 33;                               // rows of the range table: the front end + up to 32 transformer layers
+constexpr int kRangeInts = kRangeRows * 2 * (int)H_NSITES;
 struct SplitCtx {
     int scheme; int* tab;
     int* site(int k) const { return tab ? tab + 2 * k : nullptr; }
@@ -397,8 +400,8 @@ static int finalize_impl(at_hubert* h) {
         if (int rc = split_weights(h, h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
     }
     if (!host_only_test() && !h->range_tab) {   // run-time state, not part of the packed model
-        AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, 64 * sizeof(int)));
-        AT_CHECK_HIP(hipMemset(h->range_tab, 0, 64 * sizeof(int)));
+        AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, kRangeInts * sizeof(int)));
+        AT_CHECK_HIP(hipMemset(h->range_tab, 0, kRangeInts * sizeof(int)));
     }
     h->finalized = true;
     return 0;
@@ -490,6 +493,19 @@ int at_hubert_set_option(at_hubert_t* h, const char* name, int value) {
         h->arith = value;
         return 0;
     }
+    if (n.rfind("layer_arith:", 0) == 0) {   // "layer_arith:<l>": -1 = follow "arith", 1 = bf16x3, 2 = f16x2 for transformer layer l only
+        const int li = std::atoi(n.c_str() + 12);
+        AT_REQUIRE(li >= 0 && li < (int)h->layers.size(), "layer_arith: no such layer");
+        AT_REQUIRE(value == -1 || value == ARITH_BF16X3 || value == ARITH_F16X2, "layer_arith:<l>: -1 = the handle's arithmetic, 1 = bf16x3, 2 = f16x2");
+        if (value > 0) {
+            DeviceGuard guard(h->device);
+            AT_REQUIRE(guard.ok, "cannot select the handle's device");
+            if (int rc = split_weights(h, value == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
+        }
+        if (h->layer_arith.size() < h->layers.size()) h->layer_arith.resize(h->layers.size(), -1);
+        h->layer_arith[li] = value;
+        return 0;
+    }
     if (n == "attn_w8") { h->attn_w8 = value < 0 ? -1 : (value != 0); return 0; }
     if (n == "posconv_split") { h->posconv_split = value != 0; return 0; }
     if (n == "kmeans_split") { h->kmeans_split = value != 0; return 0; }
@@ -500,6 +516,10 @@ int at_hubert_set_option(at_hubert_t* h, const char* name, int value) {
 int at_hubert_get_option(const at_hubert_t* h, const char* name) {
     if (!h || !name) return -1;
     if (std::string(name) == "arith") return h->arith;
+    if (std::string(name).rfind("layer_arith:", 0) == 0) {
+        const int li = std::atoi(name + 12);
+        return (li >= 0 && li < (int)h->layer_arith.size()) ? h->layer_arith[li] : -1;
+    }
     if (std::string(name) == "attn_w8") return h->attn_w8;
     if (std::string(name) == "posconv_split") return h->posconv_split ? 1 : 0;
     if (std::string(name) == "kmeans_split") return h->kmeans_split ? 1 : 0;
@@ -530,8 +550,12 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
     Profiler& prof = h->prof;
     if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), (hipStream_t)stream_));
     const bool split = h->arith != ARITH_F32;
-    AT_CHECK_HIP(hipMemsetAsync(h->range_tab, 0, 64 * sizeof(int), (hipStream_t)stream_));
-    const SplitCtx sc{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, h->range_tab};
+    AT_REQUIRE(n_layers + 1 <= kRangeRows, "more transformer layers than range-table rows");
+    AT_CHECK_HIP(hipMemsetAsync(h->range_tab, 0, kRangeInts * sizeof(int), (hipStream_t)stream_));
+    const SplitCtx sc{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, h->range_tab};   // the front end (row 0) and the k-means GEMM
+    // transformer layer l: its own row of the range table and, when the range fallback has pinned it (option "layer_arith:<l>"), its own arithmetic
+    auto arith_of = [&](int li) { return (split && li < (int)h->layer_arith.size() && h->layer_arith[li] > 0) ? h->layer_arith[li] : h->arith; };
+    auto ctx_of = [&](int li) { return SplitCtx{arith_of(li) == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, h->range_tab + (1 + li) * 2 * (int)H_NSITES}; };
 
     // ---- conv feature encoder (7 valid strided convs, GroupNorm after the first, GELU) ----------------------
     float* bufs[2] = {ws + p.off_a, ws + p.off_b};
@@ -605,31 +629,33 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
 
     for (int li = 0; li < n_layers; ++li) {
         const LayerW& L = h->layers[li];
+        const SplitCtx scl = ctx_of(li);              // this layer's scheme and range row
+        const int attn_arith_l = split ? arith_of(li) : attn_arith;
         prof.begin("attn_proj", 3, stream);
         // f16x2: the projection's epilogue writes k / v as fp16 pieces, the attention kernel stages them unsplit and writes its context as the
         // output projection's operand pieces (as in w2vbert.hip)
-        const bool kvp = split && attn_arith == ARITH_F16X2 && sc.scheme == XB_SCHEME_F16X2 && attn_kvp;
+        const bool kvp = split && attn_arith_l == ARITH_F16X2 && scl.scheme == XB_SCHEME_F16X2 && attn_kvp;
         if (kvp) {
-            if (int rc = launch_split_blocked(x, kHid, M, Mpad, kHid, xs, stream, sc.scheme, sc.act_scale(), sc.site(HS_X_IN))) return rc;
+            if (int rc = launch_split_blocked(x, kHid, M, Mpad, kHid, xs, stream, scl.scheme, scl.act_scale(), scl.site(HS_X_IN))) return rc;
             Bf16x3Args qa;
-            qa.A = xs; qa.W = L.ws[sc.scheme][HW_QKV]; qa.bias = L.bqkv; qa.M = (int)M; qa.N = 3 * kHid; qa.K = kHid; qa.Mpad = (int)Mpad;
+            qa.A = xs; qa.W = L.ws[scl.scheme][HW_QKV]; qa.bias = L.bqkv; qa.M = (int)M; qa.N = 3 * kHid; qa.K = kHid; qa.Mpad = (int)Mpad;
             qa.epi = XB_EPI_QKV; qa.C = big; qa.ldc = 3 * kHid; qa.S = kvs; qa.Spad = (int)Mpad; qa.qkv_hid = kHid;
-            qa.scheme = sc.scheme; qa.status = sc.site(HS_QKV_KV); qa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[HW_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
+            qa.scheme = scl.scheme; qa.status = scl.site(HS_QKV_KV); qa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[HW_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
             if (int rc = launch_gemm_bf16x3(qa, stream)) return rc;
         } else if (split) {
-            if (int rc = linear_split(sc, x, kHid, nullptr, xs, L, HW_QKV, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream)) return rc;
+            if (int rc = linear_split(scl, x, kHid, nullptr, xs, L, HW_QKV, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream)) return rc;
         } else if (int rc = linear(x, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, nullptr, nullptr, 3 * kHid, stream)) {
             return rc;
         }
         prof.end(stream);
         prof.begin("attention", 1, stream);
-        const bool ctx_as_pieces = split && attn_arith > 0;
-        if (int rc = launch_relpos_attention(big, fmask, nullptr, ctx_as_pieces ? nullptr : t1, B, T, stream, kHeads, attn_arith, sc.site(HS_ATTENTION),
+        const bool ctx_as_pieces = split && attn_arith_l > 0;
+        if (int rc = launch_relpos_attention(big, fmask, nullptr, ctx_as_pieces ? nullptr : t1, B, T, stream, kHeads, attn_arith_l, scl.site(HS_ATTENTION),
                                              ctx_as_pieces ? xs : nullptr, Mpad, kvp ? kvs : nullptr, h->attn_w8)) return rc;
         prof.end(stream);
         prof.begin("attn_proj", 0, stream);
         if (split) {
-            if (int rc = linear_split(sc, ctx_as_pieces ? nullptr : t1, kHid, xs, xs, L, HW_O, L.bo, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
+            if (int rc = linear_split(scl, ctx_as_pieces ? nullptr : t1, kHid, xs, xs, L, HW_O, L.bo, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
         } else if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) {
             return rc;
         }
@@ -637,8 +663,8 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         prof.end(stream);
         prof.begin("ffn", 3, stream);
         if (split) {   // hidden activation written split by the first GEMM's epilogue
-            if (int rc = linear_split(sc, x, kHid, nullptr, xs, L, HW_1, L.b1, nullptr, kFfn, M, Mpad, XB_EPI_GELU_SPLIT, nullptr, kFfn, bigs, stream)) return rc;
-            if (int rc = linear_split(sc, nullptr, kFfn, bigs, nullptr, L, HW_2, L.b2, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
+            if (int rc = linear_split(scl, x, kHid, nullptr, xs, L, HW_1, L.b1, nullptr, kFfn, M, Mpad, XB_EPI_GELU_SPLIT, nullptr, kFfn, bigs, stream)) return rc;
+            if (int rc = linear_split(scl, nullptr, kFfn, bigs, nullptr, L, HW_2, L.b2, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
         } else {
             if (int rc = linear(x, kHid, L.w1, L.b1, big, kFfn, M, EPI_GELU, nullptr, nullptr, kFfn, stream)) return rc;
             if (int rc = linear(big, kFfn, L.w2, L.b2, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) return rc;
@@ -647,7 +673,7 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         prof.end(stream);
     }
     if (status_dev)   // every site's range verdict of this call -> the caller's status word
-        if (int rc = launch_range_combine(h->range_tab, (int)H_NSITES, reinterpret_cast<int*>(status_dev), stream)) return rc;
+        if (int rc = launch_range_combine(h->range_tab, (1 + n_layers) * (int)H_NSITES, reinterpret_cast<int*>(status_dev), stream)) return rc;
     if (hidden_out) AT_CHECK_HIP(hipMemcpyAsync(hidden_out, x, (size_t)M * kHid * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (tokens) {
         prof.begin("kmeans", 3, stream);
@@ -677,11 +703,33 @@ int at_hubert_range_report(at_hubert_t* h, float* max_scaled, int cap) {
     AT_REQUIRE(h && h->finalized && h->range_tab && max_scaled && cap >= (int)H_NSITES, "at_hubert_range_report: bad arguments");
     DeviceGuard guard(h->device);
     AT_REQUIRE(guard.ok, "cannot select the handle's device");
-    int host[2 * H_NSITES];
+    std::vector<int> host(kRangeInts);
     AT_CHECK_HIP(hipDeviceSynchronize());
-    AT_CHECK_HIP(hipMemcpy(host, h->range_tab, sizeof(host), hipMemcpyDeviceToHost));
-    for (int k = 0; k < (int)H_NSITES; ++k) { float f; std::memcpy(&f, &host[2 * k + 1], sizeof(f)); max_scaled[k] = f; }
+    AT_CHECK_HIP(hipMemcpy(host.data(), h->range_tab, kRangeInts * sizeof(int), hipMemcpyDeviceToHost));
+    for (int k = 0; k < (int)H_NSITES; ++k) {
+        float m = 0.f;
+        for (int r = 0; r < kRangeRows; ++r) { float f; std::memcpy(&f, &host[(r * (int)H_NSITES + k) * 2 + 1], sizeof(f)); m = f > m ? f : m; }
+        max_scaled[k] = m;
+    }
     return (int)H_NSITES;
+}
+// Status flags of the LAST encode per part of the model: flags[0] = conv feature encoder + positional conv, flags[1 + l] = transformer layer l (the OR of its
+// split sites; bit 1 = an activation left the fp16 range; the FIRST flagged entry is the cause, later ones inherit its infinities). Returns the number of
+// entries written (1 + layers, <= cap). Synchronises the device. (As at_w2vbert_layer_status.)
+int at_hubert_layer_status(at_hubert_t* h, int32_t* flags, int cap) {
+    AT_REQUIRE(h && h->finalized && h->range_tab && flags && cap >= 1, "at_hubert_layer_status: bad arguments");
+    DeviceGuard guard(h->device);
+    AT_REQUIRE(guard.ok, "cannot select the handle's device");
+    std::vector<int> host(kRangeInts);
+    AT_CHECK_HIP(hipDeviceSynchronize());
+    AT_CHECK_HIP(hipMemcpy(host.data(), h->range_tab, kRangeInts * sizeof(int), hipMemcpyDeviceToHost));
+    const int n = std::min<int>({cap, 1 + (int)h->layers.size(), kRangeRows});
+    for (int r = 0; r < n; ++r) {
+        int v = 0;
+        for (int k = 0; k < (int)H_NSITES; ++k) v |= host[(r * (int)H_NSITES + k) * 2];
+        flags[r] = v;
+    }
+    return n;
 }
 int at_hubert_range_sites(char* names, size_t cap) {
     std::string s;

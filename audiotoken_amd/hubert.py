@@ -111,6 +111,7 @@ class HubertEncoder(torch.nn.Module):
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.fallback_batches = 0
         self.nonfinite_batches = 0
+        self.pinned_layers = []      # transformer layers `verified` moved to bf16x3 for good (their activations do not fit the fp16 range)
 
     def __del__(self):
         h = self.__dict__.pop("handle", None)
@@ -136,8 +137,24 @@ class HubertEncoder(torch.nn.Module):
         """{site: largest |x * scale| its split writers saw in the LAST call}; the f16x2 arithmetic overflows at 65504."""
         return _cabi.range_report(self.lib, "hubert", self.handle)
 
+    def layer_status(self):
+        """Status flags of the LAST call per part: [0] = conv feature encoder + positional conv, [1 + l] = transformer layer l (bit 1 = fp16 overflow)."""
+        import ctypes as C
+        buf = (C.c_int32 * 64)()
+        n = self.lib.at_hubert_layer_status(self.handle, buf, 64)
+        if n < 0:
+            raise _cabi.HipLibraryError(f"at_hubert_layer_status failed: {_cabi.last_error()}")
+        return [int(buf[i]) for i in range(n)]
+
+    def unpin_layers(self) -> None:
+        for layer in set(self.pinned_layers):
+            self.set_option(f"layer_arith:{layer}", -1)
+        self.pinned_layers = []
+
     def verified(self, tokens: torch.Tensor, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Product-path guard (see Wav2VecBertEncoder.verified): on an fp16 range overflow repeat THIS batch with arith=bf16x3, then switch back."""
+        """Product-path guard (see Wav2VecBertEncoder.verified): on an fp16 range overflow in a TRANSFORMER layer that layer moves to bf16x3 for good and
+        the batch is repeated; an overflow in the conv feature encoder / positional conv (a property of the input's level) repeats THIS batch with
+        arith=bf16x3 for the whole model, then switches back."""
         status = self.last_status()
         if status == 0:
             return tokens
@@ -150,6 +167,24 @@ class HubertEncoder(torch.nn.Module):
             if status & ~4 == 0:
                 return tokens
         self.fallback_batches += 1
+        for _ in range(3):
+            flags = self.layer_status()
+            bad = [i for i, f in enumerate(flags) if f & 2]
+            if not bad or bad[0] == 0:      # nothing per layer to act on, or the front end itself: the whole-batch repeat below
+                break
+            layer = bad[0] - 1
+            self.pinned_layers.append(layer)
+            logger.error(f"semantic_s encode reported status {status}: an activation of transformer layer {layer} exceeded the fp16 range of the f16x2 arithmetic. "
+                         f"The tokens of this batch were discarded; layer {layer} runs on bf16x3 from now on (option layer_arith:{layer} = 1), this batch is "
+                         f"re-encoded (fallback batch #{self.fallback_batches})")
+            self.set_option(f"layer_arith:{layer}", 1)
+            tokens = self.forward(input_batch, attention_mask)
+            status = self.last_status()
+            if not status & 2:
+                if status & 4:
+                    self.nonfinite_batches += 1
+                    logger.error(f"a NaN or an infinity reached the quantiser with layer {layer} on bf16x3 too (non-finite batch #{self.nonfinite_batches}): check the input waveform")
+                return tokens
         logger.error(f"semantic_s encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
                      f"the tokens of this batch were discarded; re-encoding THIS batch with arith=bf16x3 (fallback batch #{self.fallback_batches})")
         saved = self.get_option("arith")

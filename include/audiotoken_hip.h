@@ -278,6 +278,9 @@ int at_hubert_range_report(at_hubert_t* h, float* max_scaled, int cap);
  * to the wide-range arithmetic while the others stay on f16x2 — what the product's range fallback does (round 4; the reference has no such notion:
  * its fp32 arithmetic cannot overflow, audiotoken/encoder.py:163-186). */
 int at_w2vbert_layer_status(at_w2vbert_t* h, int32_t* flags, int cap);
+/* The same for at_hubert_t: flags[0] = conv feature encoder + positional conv, flags[1 + l] = transformer layer l; option "layer_arith:<l>" of
+ * at_hubert_set_option moves one transformer layer to bf16x3 / f16x2. */
+int at_hubert_layer_status(at_hubert_t* h, int32_t* flags, int cap);
 
 /* Windowed fp32 GEMM: out[b][m][n] = act(alpha*(sum_kk A(b,m,kk)*W[n][kk] + bias[n])) (+ R[b][m][n]) with
  * A(b,m,kk) = pro(X[b][m*stride + kk/Cin - pad_left][kk%Cin]); rows outside [0,Tin) reflect (pad_mode=1) or are

@@ -258,3 +258,47 @@ def test_semantic_m_bad_layer_is_pinned_not_the_batch(cuda_device):
     enc.unpin_layers()
     enc(x, m)
     assert enc.last_status() & 2 and enc.pinned_layers == []
+
+
+def test_semantic_s_bad_layer_is_pinned_not_the_batch(cuda_device):
+    """The per-layer range fallback for the HuBERT tokenizer (as test_semantic_m_bad_layer_is_pinned_not_the_batch): transformer layer 1's FFN hidden
+    overflows the fp16 range on every batch (one bias at 6 000: GELU(.) x 16 > 65504). layer_status()[0] (the conv front end) stays clean, entry 2
+    (= layer 1) is the first flagged one; verified() pins that layer to bf16x3 and repeats the batch; the next batch runs clean; mixed arithmetic per layer
+    equals the oracle on healthy weights."""
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    from oracle import hubert_ref as R
+    wav = hubert_processor(torch.from_numpy(W.synth_waveform(2, 48000, 16000, seed=47)))
+    mask = torch.ones_like(wav)
+    x, m = wav.cuda(), mask.cuda()
+    healthy = W.synth_hubert_weights(3, 19, True)
+    enc = HubertEncoder(HubertEncoderConfig(output_layer=3), device="cuda:0", quantize=True, weights=healthy)
+    ref, margins = R.semantic_s_encode(healthy, wav, mask, 3, return_margins=True)
+    for pinned in ((0,), (2,), (0, 1)):
+        for l in pinned:
+            enc.set_option(f"layer_arith:{l}", 1)
+        toks = enc(x, m)
+        assert enc.last_status() == 0
+        P.assert_tokens_equal_or_explained(toks, ref, margins, P.VQ_TIE, f"[range] semantic_s layers {pinned} on bf16x3")
+        for l in pinned:
+            enc.set_option(f"layer_arith:{l}", -1)
+
+    w = dict(healthy)
+    key = "encoder.layers.1.feed_forward.intermediate_dense.bias"
+    b = np.array(w[key], dtype=np.float32).copy()
+    b[0] = 6000.0
+    w[key] = b
+    enc = HubertEncoder(HubertEncoderConfig(output_layer=3), device="cuda:0", quantize=True, weights=w)
+    ref, margins = R.semantic_s_encode(w, wav, mask, 3, return_margins=True)
+    toks = enc(x, m)
+    assert enc.last_status() & 2, "the poisoned layer must overflow the fp16 range"
+    flags = enc.layer_status()
+    assert len(flags) == 4 and flags[0] == 0 and flags[1] == 0 and flags[2] & 2, flags
+    toks = enc.verified(toks, x, m)
+    assert enc.pinned_layers == [1] and enc.fallback_batches == 1 and enc.get_option("arith") == 2 and enc.get_option("layer_arith:1") == 1
+    P.assert_tokens_equal_or_explained(toks, ref, margins, P.VQ_TIE, "[range] semantic_s layer 1 pinned (repeat)")
+    toks2 = enc(x, m)
+    assert enc.last_status() == 0 and torch.equal(enc.verified(toks2, x, m), toks) and enc.fallback_batches == 1
+    enc.unpin_layers()
+    enc(x, m)
+    assert enc.last_status() & 2 and enc.pinned_layers == []
