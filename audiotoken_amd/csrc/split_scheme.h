@@ -60,7 +60,16 @@ __device__ __forceinline__ void range_publish(int* status, int* census, const Ra
         if (status && !(m <= 65504.0f)) atomicOr(status, XB_STATUS_F16_OVERFLOW);
         if (census) {
             const int bits = __float_as_int(m);   // m >= 0 (or +inf); a NaN cannot come out of fmaxf unless every operand was one
-            if (bits > __atomic_load_n(census, __ATOMIC_RELAXED)) atomicMax(census, bits);
+            // Agent-scope loads (L2-served: this CU's L1 is not coherent). A NEGATIVE word is a LINK: the model handles keep one flag word per (layer, site) — so
+            // that the range fallback knows which layer overflowed — but ONE census word per site, shared by all layers; the per-layer rows hold
+            // {flag, -(distance in ints to the shared census word)}. (Round 4: with a freshly zeroed census word per layer the first thousands of
+            // waves of every launch all saw 0 and all issued the atomic: + 35 us per LayerNorm launch, 2-4 ms per semantic_m step.)
+            int cur = __hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur < 0) {
+                census += cur;
+                cur = __hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (bits > cur) atomicMax(census, bits);
         }
     }
 }

@@ -443,8 +443,14 @@ static int finalize_impl(at_w2vbert* h) {
         if (int rc = split_weights(h, h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3)) return rc;
     }
     if (!host_only_test() && !h->range_tab) {   // run-time state, not part of the packed model
-        AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, kRangeInts * sizeof(int)));
-        AT_CHECK_HIP(hipMemset(h->range_tab, 0, kRangeInts * sizeof(int)));
+        // the table and, behind it, its per-encode initial image: row 0 = {flag 0, census 0} per site; every further row {flag 0, LINK to row 0's census word of
+        // that site} (split_scheme.h, range_publish): one flag word per (row, site), one census word per site
+        AT_CHECK_HIP(hipMalloc((void**)&h->range_tab, 2 * kRangeInts * sizeof(int)));
+        std::vector<int> init(kRangeInts, 0);
+        for (int r = 1; r < kRangeLayers; ++r)
+            for (int k = 0; k < (int)W_NSITES; ++k) init[(r * (int)W_NSITES + k) * 2 + 1] = -(r * (int)W_NSITES * 2);
+        AT_CHECK_HIP(hipMemcpy(h->range_tab + kRangeInts, init.data(), kRangeInts * sizeof(int), hipMemcpyHostToDevice));
+        AT_CHECK_HIP(hipMemcpy(h->range_tab, init.data(), kRangeInts * sizeof(int), hipMemcpyHostToDevice));
     }
     h->finalized = true;
     return 0;
@@ -616,7 +622,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     if (status_dev) AT_CHECK_HIP(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
     const bool split = h->arith != ARITH_F32;
     AT_REQUIRE(n_layers <= kRangeLayers, "more conformer layers than range-table rows");
-    AT_CHECK_HIP(hipMemsetAsync(h->range_tab, 0, kRangeInts * sizeof(int), stream));
+    AT_CHECK_HIP(hipMemcpyAsync(h->range_tab, h->range_tab + kRangeInts, kRangeInts * sizeof(int), hipMemcpyDeviceToDevice, stream));   // flags 0, census 0 / links
     // arithmetic per layer: the handle's, unless that layer is pinned to another split scheme (option "layer_arith:<i>": what the product's range
     // fallback sets for a layer whose activations do not fit fp16 — the other layers stay on f16x2). Each layer has its own row of the range table.
     auto arith_of = [&](int li) { return (split && li < (int)h->layer_arith.size() && h->layer_arith[li] > 0) ? h->layer_arith[li] : h->arith; };
@@ -799,9 +805,9 @@ int at_w2vbert_range_report(at_w2vbert_t* h, float* max_scaled, int cap) {
     AT_CHECK_HIP(hipDeviceSynchronize());
     AT_CHECK_HIP(hipMemcpy(host.data(), h->range_tab, kRangeInts * sizeof(int), hipMemcpyDeviceToHost));
     for (int k = 0; k < (int)W_NSITES; ++k) {
-        float m = 0.f;
-        for (int l = 0; l < kRangeLayers; ++l) { float f; std::memcpy(&f, &host[(l * (int)W_NSITES + k) * 2 + 1], sizeof(f)); m = f > m ? f : m; }   // (NaN census: kept out by >)
-        max_scaled[k] = m;
+        float f;   // row 0 holds the one census word of the site; the other rows' second words are links to it (split_scheme.h)
+        std::memcpy(&f, &host[k * 2 + 1], sizeof(f));
+        max_scaled[k] = f;
     }
     return (int)W_NSITES;
 }
