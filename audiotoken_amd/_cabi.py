@@ -107,6 +107,8 @@ SIGNATURES = {
     "at_encodec_range_report": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "at_w2vbert_range_sites": (C.c_int, [C.c_char_p, C.c_size_t]),
     "at_w2vbert_range_report": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "at_w2vbert_site_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "at_hubert_site_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "at_w2vbert_layer_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "at_hubert_layer_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "at_hubert_range_sites": (C.c_int, [C.c_char_p, C.c_size_t]),

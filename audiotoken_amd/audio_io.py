@@ -123,7 +123,14 @@ def _flac_raw(data: bytes, name) -> RawAudio:
         raise AudioDecodeError(f"{name}: {_cabi.last_error()}")
     if total.value <= 0:
         raise AudioDecodeError(f"{name}: FLAC stream without a sample count in STREAMINFO (streamed encodes are not supported)")
-    out = np.empty((ch.value, total.value), dtype=np.int32)
+    # STREAMINFO is untrusted input (36-bit sample count, 8 channels). A CONSTANT sub-frame codes a whole block of up to 65 535 samples in ~10 bytes, so the sample count a file of len(data) bytes can hold is bounded by 65 535 samples per 10 bytes, not by the
+    # header's word; anything beyond that, and an allocation the host refuses, is a damaged file to skip — not a MemoryError that aborts the whole run
+    if total.value > (len(data) // 10 + 1) * 65535 or not (1 <= ch.value <= 8):
+        raise AudioDecodeError(f"{name}: STREAMINFO claims {total.value} samples x {ch.value} channels in a {len(data)}-byte file")
+    try:
+        out = np.empty((ch.value, total.value), dtype=np.int32)
+    except (MemoryError, OverflowError, ValueError) as e:
+        raise AudioDecodeError(f"{name}: cannot hold {total.value} samples x {ch.value} channels ({type(e).__name__})") from e
     n = lib.at_flac_decode(buf.ctypes.data, len(data), out.ctypes.data, total.value)
     if n != total.value:
         raise AudioDecodeError(f"{name}: {_cabi.last_error()}")

@@ -228,16 +228,31 @@ class AudioToken:
             # below needs every rank to see the same order)
             exts = AUDIO_EXTS + TAR_EXTS + ZIP_EXTS
             files = []
-            for d, dirs, names in os.walk(str(audio_dir)):
-                dirs[:] = [x for x in dirs if not x.startswith(".")]
+            seen = set()    # glob follows symlinked sub-directories (datasets laid out as symlink farms); so does this walk, once per real directory
+            for d, dirs, names in os.walk(str(audio_dir), followlinks=True):
+                keep = []
+                for x in dirs:
+                    if x.startswith("."):
+                        continue
+                    try:
+                        st = os.stat(os.path.join(d, x))
+                    except OSError:
+                        continue
+                    if (st.st_dev, st.st_ino) not in seen:
+                        seen.add((st.st_dev, st.st_ino))
+                        keep.append(x)
+                dirs[:] = keep
                 files.extend(os.path.join(d, n) for n in names if n.endswith(exts) and not n.startswith("."))
             files.sort()
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dataloader_kwargs.get("shard_across_ranks", True):
-            # duration-aware: whole files by greedy LPT on their sizes (distributed.shard_by_size); every rank stats the same list and gets the same answer
+            # duration-aware: whole files by greedy LPT on their sizes (distributed.shard_by_size). Rank 0 stats the list ONCE and broadcasts the sizes (N_files
+            # stats instead of N_files x world on a shared filesystem; and every rank provably shards the same numbers)
             from .distributed import shard_by_size
-            sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in files]
-            files = [files[i] for i in shard_by_size(sizes, dist.get_rank(), dist.get_world_size())]
+            sizes = [[os.path.getsize(f) if os.path.exists(f) else 0 for f in files]] if dist.get_rank() == 0 else [None]
+            dist.broadcast_object_list(sizes, src=0)
+            assert len(sizes[0]) == len(files), "ranks see different file lists: encode_batch_files needs the same audio_files / audio_dir on every rank"
+            files = [files[i] for i in shard_by_size(sizes[0], dist.get_rank(), dist.get_world_size())]
         start_time = time.time()
         on_gpu = torch.device(self.device).type == "cuda"
         copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
@@ -291,36 +306,52 @@ class AudioToken:
         staged = stage_next()
         rt["stage_s"] += time.perf_counter() - t0
         pending = None    # (tokens on the host, file pointers) of the batch before: written while the device encodes the next one, in batch order
-        while staged is not None:
-            input_ids, attention_masks, file_pointers, ev = staged
-            t0 = time.perf_counter()
-            if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
-                input_ids.record_stream(torch.cuda.current_stream(self.device))
-                attention_masks.record_stream(torch.cuda.current_stream(self.device))
-            encoded_audio = self.encoder(input_ids, attention_masks)      # asynchronous on the device
-            t1 = time.perf_counter()
+        try:
+            while staged is not None:
+                input_ids, attention_masks, file_pointers, ev = staged
+                t0 = time.perf_counter()
+                if ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                    input_ids.record_stream(torch.cuda.current_stream(self.device))
+                    attention_masks.record_stream(torch.cuda.current_stream(self.device))
+                encoded_audio = self.encoder(input_ids, attention_masks)      # asynchronous on the device
+                t1 = time.perf_counter()
+                if pending is not None:
+                    save(*pending)
+                    pending = None
+                t2 = time.perf_counter()
+                staged = stage_next()                                         # the next batch is decoded / uploaded / cut while this one encodes
+                t3 = time.perf_counter()
+                if hasattr(self.encoder, "verified"):   # the copy below synchronises anyway: check the call's device status first
+                    encoded_audio = self.encoder.verified(encoded_audio, input_ids, attention_masks)
+                pending = (encoded_audio.cpu(), file_pointers)   # ONE device-to-host copy per batch (a per-row .cpu() inside the save would synchronise B times)
+                t4 = time.perf_counter()
+                rt["encode_call_s"] += t1 - t0; rt["save_s"] += t2 - t1; rt["stage_s"] += t3 - t2; rt["device_wait_s"] += t4 - t3
+                rt["batches"] += 1; rt["rows"] += len(file_pointers)
+        finally:
+            # also when the encode / staging of batch k raised: the verified tokens of batch k - 1 are on the host and belong in their files (earlier
+            # batches are already there) — the save is deferred by one batch, it must not be lost by it
             if pending is not None:
+                t0 = time.perf_counter()
                 save(*pending)
-                pending = None
-            t2 = time.perf_counter()
-            staged = stage_next()                                         # the next batch is decoded / uploaded / cut while this one encodes
-            t3 = time.perf_counter()
-            if hasattr(self.encoder, "verified"):   # the copy below synchronises anyway: check the call's device status first
-                encoded_audio = self.encoder.verified(encoded_audio, input_ids, attention_masks)
-            pending = (encoded_audio.cpu(), file_pointers)   # ONE device-to-host copy per batch (a per-row .cpu() inside the save would synchronise B times)
-            t4 = time.perf_counter()
-            rt["encode_call_s"] += t1 - t0; rt["save_s"] += t2 - t1; rt["stage_s"] += t3 - t2; rt["device_wait_s"] += t4 - t3
-            rt["batches"] += 1; rt["rows"] += len(file_pointers)
-        if pending is not None:
-            t0 = time.perf_counter()
-            save(*pending)
-            rt["save_s"] += time.perf_counter() - t0
+                rt["save_s"] += time.perf_counter() - t0
+            self._end_of_run()
         rt["total_s"] = time.time() - start_time
         logger.debug(f"Encoding batch files took: {time.time() - start_time:.2f}s")
         if self.skipped_files:
             logger.error(f"encode_batch_files: {len(self.skipped_files)} input(s) were skipped and have NO token file (AudioToken.skipped_files): "
                          + "; ".join(f"{p} ({why})" for p, why in self.skipped_files[:8]) + (" ..." if len(self.skipped_files) > 8 else ""))
+
+    def _end_of_run(self):
+        """End of an encode_batch_files run: layers the range fallback moved to bf16x3 because of THIS run's inputs go back to f16x2 (a loud or clipped file
+        must not slow down, or change the rounding of, every later run of the process); what happened is kept in ``run_summary``."""
+        enc = self.encoder
+        self.run_summary = {"fallback_batches": getattr(enc, "fallback_batches", 0), "pinned_layers": sorted(set(getattr(enc, "pinned_layers", []) or [])),
+                            "nonfinite_batches": getattr(enc, "nonfinite_batches", 0), "skipped_files": len(self.skipped_files)}
+        if self.run_summary["pinned_layers"]:
+            logger.error(f"encode_batch_files: layers {self.run_summary['pinned_layers']} ran on bf16x3 for part of this run (fp16 range overflow); restored to f16x2")
+        if hasattr(enc, "unpin_layers"):
+            enc.unpin_layers()
 
     def load_decoder(self, **kwargs):
         """core.py:291-315 — only the acoustic decoder exists here (the semantic decoders are out of scope)."""

@@ -24,6 +24,12 @@ typedef __bf16 piece_t;
 inline int xb_pieces(int scheme) { return scheme == XB_SCHEME_F16X2 ? 2 : 3; }
 // power-of-two scale that puts max |w| into [2^14, 2^15) (1 for an all-zero tensor)
 float xb_weight_scale(float max_abs);
+// The provable activation scale of a LayerNorm-fed split site (round 5). A normalised row has Euclidean norm <= sqrt(D), so |LN(x)_k| <= sqrt(D) |gamma_k| +
+// |beta_k| for ANY input: with gmax = max |gamma|, bmax = max |beta| (recorded at upload; carried by the packed model) the largest power of two s with
+// s (sqrt(D) gmax + bmax) <= 65 000 cannot overflow fp16 (65 504) whatever the data. A site keeps XB_F16_ACT_SCALE (16) unless that bound forbids it: the
+// scale of a power-of-two split only matters at the two ends of the fp16 range, so ordinary checkpoints compute exactly what they did before. swish(LN(.))
+// and gelu(LN(.)) obey the same bound (|act(y)| <= |y|).
+float xb_ln_site_scale(float gmax, float bmax, int D);
 
 enum { XB_EPI_LINEAR = 0, XB_EPI_SWISH_SPLIT = 1, XB_EPI_GLU = 2, XB_EPI_GELU_SPLIT = 3, XB_EPI_GELU = 4, XB_EPI_ELU_SPLIT = 5, XB_EPI_RAW_ELU_SPLIT2 = 6,
        XB_EPI_QKV = 7 };

@@ -39,6 +39,12 @@ float xb_weight_scale(float max_abs) {
     const float e = std::floor(std::log2(32767.0f / max_abs));
     return std::exp2(std::fmin(std::fmax(e, -60.0f), 60.0f));
 }
+float xb_ln_site_scale(float gmax, float bmax, int D) {
+    const float bound = std::sqrt((float)D) * gmax + bmax;
+    float s = XB_F16_ACT_SCALE;
+    while (s > 1.0f / 1048576.0f && !(s * bound <= 65000.0f)) s *= 0.5f;
+    return s;
+}
 
 constexpr int XB_K = 16;
 // Two tile shapes with IDENTICAL per-element arithmetic (the k order and the order of the six products do not depend on the

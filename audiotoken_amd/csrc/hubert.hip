@@ -35,6 +35,10 @@ struct LayerW {
     // the four linear layers as 16-bit operand pieces per scheme [XB_SCHEME_*][HW_*] (gemm_bf16x3.h); wscale: the fp16 scheme's weight scales
     const piece_t* ws[2][4] = {};
     float wscale[4] = {1.f, 1.f, 1.f, 1.f};
+    // f16x2: the activation scales of the two LayerNorm-fed split sites of this layer — the input of the q/k/v projection (written by the previous
+    // layer's final_layer_norm, or encoder.layer_norm for layer 0) and the input of the first FFN GEMM (this layer's layer_norm): 16 unless the
+    // LayerNorm's gains force the provable scale below that (xb_ln_site_scale, gemm_bf16x3.h)
+    float xs_qkv = XB_F16_ACT_SCALE, xs_ffn = XB_F16_ACT_SCALE;
 };
 enum { HW_QKV = 0, HW_O, HW_1, HW_2 };
 enum { ARITH_F32 = 0, ARITH_BF16X3 = 1, ARITH_F16X2 = 2 };
@@ -223,17 +227,19 @@ int split_weights(at_hubert* h, int scheme) {
 }
 
 // C = epi(X . W^T) through the split GEMM: X fp32 row-major [M][K] is split into xs first (unless it already is: X == nullptr)
+// x_scale: the f16x2 scale of the A operand (the pieces in xs, or what X is split with here); 16 except at the LayerNorm-fed sites
 int linear_split(const SplitCtx& c, const float* X, int K, const piece_t* xs, piece_t* xs_w, const LayerW& L, int w, const float* bias, float* C, int N,
-                 long long M, long long Mpad, int epi, const float* R, int ldc, piece_t* S, hipStream_t stream) {
+                 long long M, long long Mpad, int epi, const float* R, int ldc, piece_t* S, hipStream_t stream, float x_scale = XB_F16_ACT_SCALE) {
+    if (c.scheme != XB_SCHEME_F16X2) x_scale = 1.0f;
     if (X) {
-        if (int rc = launch_split_blocked(X, K, M, Mpad, K, xs_w, stream, c.scheme, c.act_scale(), c.site(HS_X_IN))) return rc;
+        if (int rc = launch_split_blocked(X, K, M, Mpad, K, xs_w, stream, c.scheme, x_scale, c.site(HS_X_IN))) return rc;
         xs = xs_w;
     }
     Bf16x3Args a;
     a.A = xs; a.W = L.ws[c.scheme][w]; a.bias = bias; a.M = (int)M; a.N = N; a.K = K; a.Mpad = (int)Mpad;
     a.epi = epi; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc; a.alpha = 1.0f; a.S = S; a.Spad = (int)Mpad;
     a.scheme = c.scheme; a.status = c.site(w == HW_1 ? HS_FFN_HIDDEN : HS_OTHER);
-    if (c.scheme == XB_SCHEME_F16X2) { a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[w]); a.split_scale = XB_F16_ACT_SCALE; }
+    if (c.scheme == XB_SCHEME_F16X2) { a.acc_scale = 1.0f / (x_scale * L.wscale[w]); a.split_scale = XB_F16_ACT_SCALE; }
     return launch_gemm_bf16x3(a, stream);
 }
 
@@ -352,6 +358,13 @@ static int finalize_impl(at_hubert* h) {
         L.ln2_g = take(h, p + ".final_layer_norm.weight", {kHid}, ok);
         L.ln2_b = take(h, p + ".final_layer_norm.bias", {kHid}, ok);
         if (!ok) return -1;
+        {
+            auto mx = [&](const float* d) { auto it = h->wmax.find(d); return it == h->wmax.end() ? 0.f : it->second; };
+            const float* pg = h->layers.empty() ? h->enc_ln_g : h->layers.back().ln2_g;
+            const float* pb = h->layers.empty() ? h->enc_ln_b : h->layers.back().ln2_b;
+            L.xs_qkv = xb_ln_site_scale(mx(pg), mx(pb), kHid);
+            L.xs_ffn = xb_ln_site_scale(mx(L.ln1_g), mx(L.ln1_b), kHid);
+        }
         h->layers.push_back(L);
     }
     if (imp) {
@@ -642,14 +655,14 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         // output projection's operand pieces (as in w2vbert.hip)
         const bool kvp = split && attn_arith_l == ARITH_F16X2 && scl.scheme == XB_SCHEME_F16X2 && attn_kvp;
         if (kvp) {
-            if (int rc = launch_split_blocked(x, kHid, M, Mpad, kHid, xs, stream, scl.scheme, scl.act_scale(), scl.site(HS_X_IN))) return rc;
+            if (int rc = launch_split_blocked(x, kHid, M, Mpad, kHid, xs, stream, scl.scheme, L.xs_qkv, scl.site(HS_X_IN))) return rc;   // (kvp: the scheme is f16x2)
             Bf16x3Args qa;
             qa.A = xs; qa.W = L.ws[scl.scheme][HW_QKV]; qa.bias = L.bqkv; qa.M = (int)M; qa.N = 3 * kHid; qa.K = kHid; qa.Mpad = (int)Mpad;
             qa.epi = XB_EPI_QKV; qa.C = big; qa.ldc = 3 * kHid; qa.S = kvs; qa.Spad = (int)Mpad; qa.qkv_hid = kHid;
-            qa.scheme = scl.scheme; qa.status = scl.site(HS_QKV_KV); qa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[HW_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
+            qa.scheme = scl.scheme; qa.status = scl.site(HS_QKV_KV); qa.acc_scale = 1.0f / (L.xs_qkv * L.wscale[HW_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
             if (int rc = launch_gemm_bf16x3(qa, stream)) return rc;
         } else if (split) {
-            if (int rc = linear_split(scl, x, kHid, nullptr, xs, L, HW_QKV, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream)) return rc;
+            if (int rc = linear_split(scl, x, kHid, nullptr, xs, L, HW_QKV, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream, L.xs_qkv)) return rc;
         } else if (int rc = linear(x, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, nullptr, nullptr, 3 * kHid, stream)) {
             return rc;
         }
@@ -669,7 +682,7 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         prof.end(stream);
         prof.begin("ffn", 3, stream);
         if (split) {   // hidden activation written split by the first GEMM's epilogue
-            if (int rc = linear_split(scl, x, kHid, nullptr, xs, L, HW_1, L.b1, nullptr, kFfn, M, Mpad, XB_EPI_GELU_SPLIT, nullptr, kFfn, bigs, stream)) return rc;
+            if (int rc = linear_split(scl, x, kHid, nullptr, xs, L, HW_1, L.b1, nullptr, kFfn, M, Mpad, XB_EPI_GELU_SPLIT, nullptr, kFfn, bigs, stream, L.xs_ffn)) return rc;
             if (int rc = linear_split(scl, nullptr, kFfn, bigs, nullptr, L, HW_2, L.b2, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
         } else {
             if (int rc = linear(x, kHid, L.w1, L.b1, big, kFfn, M, EPI_GELU, nullptr, nullptr, kFfn, stream)) return rc;
@@ -735,6 +748,15 @@ int at_hubert_layer_status(at_hubert_t* h, int32_t* flags, int cap) {
         for (int k = 0; k < (int)H_NSITES; ++k) v |= host[(r * (int)H_NSITES + k) * 2];
         flags[r] = v;
     }
+    return n;
+}
+// The activation scales of the two LayerNorm-fed split sites of every transformer layer: scales[2 l] = the q/k/v projection's input, scales[2 l + 1] = the
+// first FFN GEMM's input (16 unless a LayerNorm's gains force the provable scale below that). Returns the number of floats written. Host-only.
+int at_hubert_site_scales(const at_hubert_t* h, float* scales, int cap) {
+    AT_REQUIRE(h && h->finalized && scales, "at_hubert_site_scales: bad arguments");
+    const int n = 2 * (int)h->layers.size();
+    AT_REQUIRE(cap >= n, "at_hubert_site_scales: buffer too small");
+    for (size_t l = 0; l < h->layers.size(); ++l) { scales[2 * l] = h->layers[l].xs_qkv; scales[2 * l + 1] = h->layers[l].xs_ffn; }
     return n;
 }
 int at_hubert_range_sites(char* names, size_t cap) {

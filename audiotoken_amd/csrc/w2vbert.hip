@@ -54,6 +54,10 @@ struct LayerW {
     float wscale[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     const piece_t* dist_s = nullptr;   // the distance embeddings as fp16 pieces [2][96][64] (attention_f16x2_w8.hip's rel-pos table MFMAs; f16x2 scheme only)
     float dist_scale = 1.f;
+    // f16x2: the power of two every activation is multiplied by before it is split, per split site (WSite). XB_F16_ACT_SCALE (16) everywhere, except that
+    // the LayerNorm-fed sites get the PROVABLE scale of xb_ln_site_scale() (gemm_bf16x3.h) when the LayerNorm's gains are large enough for 16 to overflow (finalize)
+    float site_scale[10] = {XB_F16_ACT_SCALE, XB_F16_ACT_SCALE, XB_F16_ACT_SCALE, XB_F16_ACT_SCALE, XB_F16_ACT_SCALE,
+                            XB_F16_ACT_SCALE, XB_F16_ACT_SCALE, XB_F16_ACT_SCALE, XB_F16_ACT_SCALE, XB_F16_ACT_SCALE};
 };
 enum { W_1A = 0, W_1B, W_2A, W_2B, W_QKV, W_O, W_PW1, W_PW2 };
 // arithmetic of the linear layers: the fp32 MFMA, or operand splits on the 16-bit matrix cores (gemm_bf16x3.h)
@@ -233,20 +237,30 @@ int split_weights(at_w2vbert* h, int scheme) {
 // Sites of the handle's range table (gemm_bf16x3.h, launch_range_combine): where activations become fp16 pieces. The same site in every layer.
 enum WSite { WS_LN_FFN1 = 0, WS_FFN1_HIDDEN, WS_LN_ATTN, WS_QKV_KV, WS_ATTENTION, WS_LN_CONV, WS_DWCONV, WS_LN_FFN2, WS_FFN2_HIDDEN, WS_OTHER, W_NSITES };
 static const char* const kWSiteNames[W_NSITES] = {"ln_ffn1", "ffn1_hidden", "ln_attn", "qkv_kv", "attention", "ln_conv", "dwconv_out", "ln_ffn2", "ffn2_hidden", "other"};
+static_assert((int)W_NSITES == 10, "LayerW::site_scale has one entry per WSite");
 constexpr int kRangeLayers = 64;                              // rows of the range table: one per conformer layer
 constexpr int kRangeInts = kRangeLayers * 2 * (int)W_NSITES;
 struct SplitCtx {
-    int scheme; int* tab;
+    int scheme; int* tab; const LayerW* L;
     int* site(int k) const { return tab ? tab + 2 * k : nullptr; }
-    float act_scale() const { return scheme == XB_SCHEME_F16X2 ? XB_F16_ACT_SCALE : 1.0f; }
+    // the activation scale of split site k of this layer (1 on the bf16x3 scheme: full fp32 exponent range)
+    float act_scale(int k = WS_OTHER) const { return scheme == XB_SCHEME_F16X2 ? (L ? L->site_scale[k] : XB_F16_ACT_SCALE) : 1.0f; }
 };
+// which split site produced the A operand of linear layer w
+int a_site_of(int w) {
+    switch (w) {
+        case W_1A: return WS_LN_FFN1;  case W_1B: return WS_FFN1_HIDDEN;  case W_2A: return WS_LN_FFN2;  case W_2B: return WS_FFN2_HIDDEN;
+        case W_QKV: return WS_LN_ATTN; case W_O: return WS_ATTENTION;     case W_PW1: return WS_LN_CONV; default: return WS_DWCONV;
+    }
+}
 int gemm_split(const SplitCtx& c, const piece_t* A, const LayerW& L, int w, const float* bias, int N, int K, long long M, long long Mpad, int epi,
                float alpha, float* C, const float* R, int ldc, piece_t* S, hipStream_t stream) {
     Bf16x3Args a;
     a.A = A; a.W = L.ws[c.scheme][w]; a.bias = bias; a.M = (int)M; a.N = N; a.K = K; a.Mpad = (int)Mpad;
     a.epi = epi; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldc; a.alpha = alpha; a.S = S; a.Spad = (int)Mpad;
-    a.scheme = c.scheme; a.status = c.site(w == W_1A ? WS_FFN1_HIDDEN : w == W_2A ? WS_FFN2_HIDDEN : WS_OTHER);
-    if (c.scheme == XB_SCHEME_F16X2) { a.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[w]); a.split_scale = XB_F16_ACT_SCALE; }
+    const int out_site = w == W_1A ? WS_FFN1_HIDDEN : w == W_2A ? WS_FFN2_HIDDEN : WS_OTHER;
+    a.scheme = c.scheme; a.status = c.site(out_site);
+    if (c.scheme == XB_SCHEME_F16X2) { a.acc_scale = 1.0f / (c.act_scale(a_site_of(w)) * L.wscale[w]); a.split_scale = c.act_scale(out_site); }
     return launch_gemm_bf16x3(a, stream);
 }
 
@@ -392,6 +406,14 @@ static int finalize_impl(at_w2vbert* h) {
         L.ln_fin_g = take(h, p + ".final_layer_norm.weight", {kHid}, ok);
         L.ln_fin_b = take(h, p + ".final_layer_norm.bias", {kHid}, ok);
         if (!ok) return -1;
+        {
+            auto mx = [&](const float* d) { auto it = h->wmax.find(d); return it == h->wmax.end() ? 0.f : it->second; };
+            L.site_scale[WS_LN_FFN1] = xb_ln_site_scale(mx(L.ln_ffn1_g), mx(L.ln_ffn1_b), kHid);
+            L.site_scale[WS_LN_ATTN] = xb_ln_site_scale(mx(L.ln_att_g), mx(L.ln_att_b), kHid);
+            L.site_scale[WS_LN_CONV] = xb_ln_site_scale(mx(L.ln_conv_g), mx(L.ln_conv_b), kHid);
+            L.site_scale[WS_DWCONV] = xb_ln_site_scale(mx(L.ln_dw_g), mx(L.ln_dw_b), kHid);
+            L.site_scale[WS_LN_FFN2] = xb_ln_site_scale(mx(L.ln_ffn2_g), mx(L.ln_ffn2_b), kHid);
+        }
         h->layers.push_back(L);
         // free the staged host copies of this layer early
         for (auto it = h->staged.begin(); it != h->staged.end();)
@@ -626,8 +648,8 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
     // arithmetic per layer: the handle's, unless that layer is pinned to another split scheme (option "layer_arith:<i>": what the product's range
     // fallback sets for a layer whose activations do not fit fp16 — the other layers stay on f16x2). Each layer has its own row of the range table.
     auto arith_of = [&](int li) { return (split && li < (int)h->layer_arith.size() && h->layer_arith[li] > 0) ? h->layer_arith[li] : h->arith; };
-    auto ctx_of = [&](int li) { return SplitCtx{arith_of(li) == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, h->range_tab + li * 2 * (int)W_NSITES}; };
-    const SplitCtx sc_model{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, nullptr};   // the VQ score GEMM (no range site)
+    auto ctx_of = [&](int li) { return SplitCtx{arith_of(li) == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, h->range_tab + li * 2 * (int)W_NSITES, &h->layers[li]}; };
+    const SplitCtx sc_model{h->arith == ARITH_F16X2 ? XB_SCHEME_F16X2 : XB_SCHEME_BF16X3, nullptr, nullptr};   // the VQ score GEMM (no range site, non-affine LayerNorm: scale 16)
 
     // ---- log-mel front-end (reference processors.py) -------------------------------------------
     double* frames = reinterpret_cast<double*>(ws + p.off_frames);
@@ -670,10 +692,9 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             // Split arithmetic: every GEMM operand is produced directly as K-blocked pieces — LayerNorm (launch_layernorm_split), the first
             // FFN GEMM's swish epilogue, the attention kernel's context and the depthwise-conv kernel's output — so no fp32 activation is
             // written only to be re-read by a split pass.
-            const float as = sc.act_scale();
             if (li == 0) {   // layers > 0: the previous layer's final LayerNorm wrote these pieces in the same pass (launch_layernorm2_split below)
                 prof.begin("layernorm", 1, stream);
-                if (int rc = launch_layernorm_split(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_FFN1), stream)) return rc;
+                if (int rc = launch_layernorm_split(x, L.ln_ffn1_g, L.ln_ffn1_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, sc.act_scale(WS_LN_FFN1), sc.site(WS_LN_FFN1), stream)) return rc;
                 prof.end(stream);
             }
             prof.begin("ffn", 2, stream);
@@ -682,7 +703,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             prof.end(stream);
 
             prof.begin("layernorm", 1, stream);
-            if (int rc = launch_layernorm_split(x, L.ln_att_g, L.ln_att_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_ATTN), stream)) return rc;
+            if (int rc = launch_layernorm_split(x, L.ln_att_g, L.ln_att_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, sc.act_scale(WS_LN_ATTN), sc.site(WS_LN_ATTN), stream)) return rc;
             prof.end(stream);
             prof.begin("attn_proj", 1, stream);
             // f16x2: the projection's epilogue writes k and v directly as fp16 pieces (q stays fp32 for the rel-pos table); the attention kernel
@@ -692,7 +713,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
                 Bf16x3Args qa;
                 qa.A = t1s; qa.W = L.ws[sc.scheme][W_QKV]; qa.bias = L.bqkv; qa.M = (int)M; qa.N = 3 * kHid; qa.K = kHid; qa.Mpad = (int)Mpad;
                 qa.epi = XB_EPI_QKV; qa.C = big; qa.ldc = 3 * kHid; qa.S = kvs; qa.Spad = (int)Mpad; qa.qkv_hid = kHid;
-                qa.scheme = sc.scheme; qa.status = sc.site(WS_QKV_KV); qa.acc_scale = 1.0f / (XB_F16_ACT_SCALE * L.wscale[W_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
+                qa.scheme = sc.scheme; qa.status = sc.site(WS_QKV_KV); qa.acc_scale = 1.0f / (sc.act_scale(WS_LN_ATTN) * L.wscale[W_QKV]); qa.split_scale = XB_F16_ACT_SCALE;   // k / v pieces: the attention kernel's fixed 16
                 if (int rc = launch_gemm_bf16x3(qa, stream)) return rc;
             } else if (int rc = gemm_split(sc, t1s, L, W_QKV, L.bqkv, 3 * kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, big, nullptr, 3 * kHid, nullptr, stream)) {
                 return rc;
@@ -703,7 +724,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
                 if (int rc = launch_relpos_attention(big, amask, L.dist, nullptr, B, T, stream, 16, attn_arith, sc.site(WS_ATTENTION), t1s, Mpad, kvp ? kvs : nullptr, h->attn_w8, L.dist_s, L.dist_scale)) return rc;
             } else {
                 if (int rc = launch_relpos_attention(big, amask, L.dist, t1, B, T, stream, 16, 0, nullptr)) return rc;
-                if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream, sc.scheme, as, sc.site(WS_ATTENTION))) return rc;
+                if (int rc = launch_split_blocked(t1, kHid, M, Mpad, kHid, t1s, stream, sc.scheme, sc.act_scale(WS_ATTENTION), sc.site(WS_ATTENTION))) return rc;
             }
             prof.end(stream);
             prof.begin("attn_proj", 1, stream);
@@ -711,16 +732,16 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             prof.end(stream);
 
             prof.begin("layernorm", 1, stream);
-            if (int rc = launch_layernorm_split(x, L.ln_conv_g, L.ln_conv_b, amask, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_CONV), stream)) return rc;
+            if (int rc = launch_layernorm_split(x, L.ln_conv_g, L.ln_conv_b, amask, nullptr, t1s, M, Mpad, kHid, sc.scheme, sc.act_scale(WS_LN_CONV), sc.site(WS_LN_CONV), stream)) return rc;
             prof.end(stream);
             prof.begin("conv_module", 3, stream);
             if (int rc = gemm_split(sc, t1s, L, W_PW1, nullptr, 2 * kHid, kHid, M, Mpad, XB_EPI_GLU, 1.f, big, nullptr, kHid, nullptr, stream)) return rc;
-            if (int rc = (h->dwconv_stream ? launch_dwconv_stream : launch_dwconv_ln_swish)(big, L.dw, L.ln_dw_g, L.ln_dw_b, nullptr, B, T, stream, t1s, Mpad, sc.scheme, as, sc.site(WS_DWCONV))) return rc;
+            if (int rc = (h->dwconv_stream ? launch_dwconv_stream : launch_dwconv_ln_swish)(big, L.dw, L.ln_dw_g, L.ln_dw_b, nullptr, B, T, stream, t1s, Mpad, sc.scheme, sc.act_scale(WS_DWCONV), sc.site(WS_DWCONV))) return rc;
             if (int rc = gemm_split(sc, t1s, L, W_PW2, nullptr, kHid, kHid, M, Mpad, XB_EPI_LINEAR, 1.f, x, x, kHid, nullptr, stream)) return rc;
             prof.end(stream);
 
             prof.begin("layernorm", 1, stream);
-            if (int rc = launch_layernorm_split(x, L.ln_ffn2_g, L.ln_ffn2_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, as, sc.site(WS_LN_FFN2), stream)) return rc;
+            if (int rc = launch_layernorm_split(x, L.ln_ffn2_g, L.ln_ffn2_b, nullptr, nullptr, t1s, M, Mpad, kHid, sc.scheme, sc.act_scale(WS_LN_FFN2), sc.site(WS_LN_FFN2), stream)) return rc;
             prof.end(stream);
             prof.begin("ffn", 2, stream);
             if (int rc = gemm_split(sc, t1s, L, W_2A, L.b2a, kFfn, kHid, M, Mpad, XB_EPI_SWISH_SPLIT, 1.f, nullptr, nullptr, kFfn, bigs, stream)) return rc;
@@ -732,7 +753,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
                 // t1s = split(LN'(x)) (bit-identical to the two launches; saves one read of x per layer)
                 const LayerW& Ln = h->layers[li + 1];
                 const SplitCtx scn = ctx_of(li + 1);   // the pieces are the NEXT layer's operand: its scheme, its range row
-                if (int rc = launch_layernorm2_split(x, L.ln_fin_g, L.ln_fin_b, x, Ln.ln_ffn1_g, Ln.ln_ffn1_b, t1s, M, Mpad, kHid, scn.scheme, scn.act_scale(), scn.site(WS_LN_FFN1), stream)) return rc;
+                if (int rc = launch_layernorm2_split(x, L.ln_fin_g, L.ln_fin_b, x, Ln.ln_ffn1_g, Ln.ln_ffn1_b, t1s, M, Mpad, kHid, scn.scheme, scn.act_scale(WS_LN_FFN1), scn.site(WS_LN_FFN1), stream)) return rc;
             } else if (int rc = launch_layernorm(x, L.ln_fin_g, L.ln_fin_b, nullptr, x, M, kHid, stream)) {
                 return rc;
             }
@@ -826,6 +847,16 @@ int at_w2vbert_layer_status(at_w2vbert_t* h, int32_t* flags, int cap) {
         for (int k = 0; k < (int)W_NSITES; ++k) v |= host[(l * (int)W_NSITES + k) * 2];
         flags[l] = v;
     }
+    return n;
+}
+// The activation scale of every (layer, site): scales[l * n_sites + k], n_sites = at_w2vbert_range_sites. 16 everywhere unless a LayerNorm's gains force
+// the provable scale of a LayerNorm-fed site below that (xb_ln_site_scale). Returns the number of floats written. Host-only.
+int at_w2vbert_site_scales(const at_w2vbert_t* h, float* scales, int cap) {
+    AT_REQUIRE(h && h->finalized && scales, "at_w2vbert_site_scales: bad arguments");
+    const int n = (int)h->layers.size() * (int)W_NSITES;
+    AT_REQUIRE(cap >= n, "at_w2vbert_site_scales: buffer too small");
+    for (size_t l = 0; l < h->layers.size(); ++l)
+        for (int k = 0; k < (int)W_NSITES; ++k) scales[l * W_NSITES + k] = h->layers[l].site_scale[k];
     return n;
 }
 int at_w2vbert_range_sites(char* names, size_t cap) {

@@ -350,6 +350,7 @@ class Wav2VecBertEncoder(torch.nn.Module):
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.fallback_batches = 0    # batches `verified` repeated (fp16 range overflow)
         self.pinned_layers = []      # conformer layers `verified` moved to bf16x3 for good (their activations do not fit the fp16 range)
+        self.layer_overflows = {}    # {layer: batches on which it overflowed}: a layer is pinned from the PIN_AFTER-th such batch on
         self.nonfinite_batches = 0
 
     def __del__(self):
@@ -358,6 +359,11 @@ class Wav2VecBertEncoder(torch.nn.Module):
             self.lib.at_w2vbert_destroy(h)
 
     ARITH = {"f32": 0, "bf16x3": 1, "f16x2": 2}
+    # Range fallback policy: a layer's FIRST overflowing batch is repeated with that layer on bf16x3 and the layer goes back to f16x2 (the outlier may have
+    # come with the input: one loud or clipped file must not slow down — or change the rounding of — the rest of a run); from its PIN_AFTER-th overflowing batch
+    # on the layer stays on bf16x3 (an activation outlier that is a property of the checkpoint would repeat every batch otherwise). AudioToken unpins at the
+    # end of encode_batch_files and records what happened in `run_summary`.
+    PIN_AFTER = 2
 
     def set_option(self, name: str, value) -> None:
         """"arith": "f32" | "bf16x3" | "f16x2" (or 0/1/2) — arithmetic of the linear layers (include/audiotoken_hip.h)."""
@@ -378,8 +384,9 @@ class Wav2VecBertEncoder(torch.nn.Module):
 
     def verified(self, tokens: torch.Tensor, input_batch: torch.Tensor, mask: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
         """Product-path guard, called where the caller synchronises anyway: if the call that produced `tokens` reported an fp16 range
-        overflow, log it, find the conformer layer that caused it, move THAT layer to the bf16x3 arithmetic (full fp32 exponent range) for
-        good (``pinned_layers``) and repeat this batch (``fallback_batches``); every other layer stays on f16x2."""
+        overflow, log it, find the conformer layer that caused it, move THAT layer to the bf16x3 arithmetic (full fp32 exponent range) and repeat this
+        batch (``fallback_batches``); every other layer stays on f16x2. The layer returns to f16x2 after the batch unless it is its PIN_AFTER-th overflowing
+        batch (then it stays: ``pinned_layers``)."""
         status = self.last_status()
         if status == 0:
             return tokens
@@ -393,27 +400,35 @@ class Wav2VecBertEncoder(torch.nn.Module):
                 return tokens
         self.fallback_batches += 1
         # Which layer? Every layer has its own row of range flags; an overflow turns into infinities that all later layers flag too, so the FIRST flagged
-        # layer is the cause. That layer alone is moved to bf16x3 (full fp32 exponent range) — and STAYS there: activation outliers are a property of the
-        # checkpoint, the next batch would overflow at the same place. The other layers keep f16x2, so a model with one such layer pays ~1 / n_layers of the
-        # bf16x3 price from now on instead of a repeat of every batch. Up to three layers are found this way per batch; beyond that the whole batch is
-        # repeated on bf16x3 as in round 3.
-        for _ in range(3):
-            bad = [l for l, f in enumerate(self.layer_status()) if f & 2]
-            if not bad:
-                break
-            layer = bad[0]
-            self.pinned_layers.append(layer)
-            logger.error(f"semantic_m encode reported status {status}: an activation of conformer layer {layer} exceeded the fp16 range of the f16x2 "
-                         f"arithmetic. The tokens of this batch were discarded; layer {layer} runs on bf16x3 from now on (option layer_arith:{layer} = 1), "
-                         f"this batch is re-encoded (fallback batch #{self.fallback_batches})")
-            self.set_option(f"layer_arith:{layer}", 1)
-            tokens = self.forward(input_batch, mask, **kw)
-            status = self.last_status()
-            if not status & 2:
-                if status & 4:
-                    self.nonfinite_batches += 1
-                    logger.error(f"a NaN or an infinity reached the quantiser with layer {layer} on bf16x3 too (non-finite batch #{self.nonfinite_batches}): check the input waveform")
-                return tokens
+        # layer is the cause. That layer alone is moved to bf16x3 (full fp32 exponent range); it stays there once it has overflowed on PIN_AFTER batches
+        # (an activation outlier of the checkpoint: the next batch would overflow at the same place). The other layers keep f16x2, so a model with one such
+        # layer pays ~1 / n_layers of the bf16x3 price instead of a repeat of every batch. Up to three layers are found this way per batch; beyond that the
+        # whole batch is repeated on bf16x3 as in round 3.
+        transient = []    # layers moved for THIS batch only (their first overflow): restored below
+        try:
+            for _ in range(3):
+                bad = [l for l, f in enumerate(self.layer_status()) if f & 2]
+                if not bad:
+                    break
+                layer = bad[0]
+                self.layer_overflows[layer] = self.layer_overflows.get(layer, 0) + 1
+                pin = self.layer_overflows[layer] >= self.PIN_AFTER
+                (self.pinned_layers if pin else transient).append(layer)
+                logger.error(f"semantic_m encode reported status {status}: an activation of conformer layer {layer} exceeded the fp16 range of the f16x2 "
+                             f"arithmetic (batch #{self.layer_overflows[layer]} on which it did). The tokens of this batch were discarded; layer {layer} runs on "
+                             f"bf16x3 (option layer_arith:{layer} = 1) " + ("from now on" if pin else "for this batch") +
+                             f", this batch is re-encoded (fallback batch #{self.fallback_batches})")
+                self.set_option(f"layer_arith:{layer}", 1)
+                tokens = self.forward(input_batch, mask, **kw)
+                status = self.last_status()
+                if not status & 2:
+                    if status & 4:
+                        self.nonfinite_batches += 1
+                        logger.error(f"a NaN or an infinity reached the quantiser with layer {layer} on bf16x3 too (non-finite batch #{self.nonfinite_batches}): check the input waveform")
+                    return tokens
+        finally:
+            for layer in transient:
+                self.set_option(f"layer_arith:{layer}", -1)
         logger.error(f"semantic_m encode still reports status {status}: re-encoding THIS batch with arith=bf16x3 for every layer")
         saved = self.get_option("arith")
         self.set_option("arith", "bf16x3")
@@ -428,6 +443,18 @@ class Wav2VecBertEncoder(torch.nn.Module):
             self.set_option("arith", saved)
         return tokens
 
+    def site_scales(self) -> Dict[str, list]:
+        """{site: [scale per conformer layer]} — the power of two each split site multiplies its activations by (16, or the provable scale of a
+        LayerNorm-fed site whose gains are too large for 16: include/audiotoken_hip.h, at_w2vbert_site_scales)."""
+        names = C.create_string_buffer(2048)
+        ns = self.lib.at_w2vbert_range_sites(names, 2048)
+        buf = (C.c_float * (64 * 16))()
+        n = self.lib.at_w2vbert_site_scales(self.handle, buf, 64 * 16)
+        if ns <= 0 or n < 0:
+            raise _cabi.HipLibraryError(f"at_w2vbert_site_scales failed: {_cabi.last_error()}")
+        keys = names.value.decode().split("\n")[:ns]
+        return {k: [float(buf[l * ns + i]) for l in range(n // ns)] for i, k in enumerate(keys)}
+
     def layer_status(self):
         """Per conformer layer, the OR of its split sites' status flags in the LAST call (bit 1 = fp16 range overflow in that layer). Synchronises."""
         buf = (C.c_int32 * 64)()
@@ -441,6 +468,7 @@ class Wav2VecBertEncoder(torch.nn.Module):
         for layer in set(self.pinned_layers):
             self.set_option(f"layer_arith:{layer}", -1)
         self.pinned_layers = []
+        self.layer_overflows = {}
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes:

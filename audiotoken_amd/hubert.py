@@ -112,6 +112,7 @@ class HubertEncoder(torch.nn.Module):
         self.fallback_batches = 0
         self.nonfinite_batches = 0
         self.pinned_layers = []      # transformer layers `verified` moved to bf16x3 for good (their activations do not fit the fp16 range)
+        self.layer_overflows = {}    # {layer: batches on which it overflowed}: a layer is pinned from the PIN_AFTER-th such batch on (Wav2VecBertEncoder.PIN_AFTER)
 
     def __del__(self):
         h = self.__dict__.pop("handle", None)
@@ -137,6 +138,15 @@ class HubertEncoder(torch.nn.Module):
         """{site: largest |x * scale| its split writers saw in the LAST call}; the f16x2 arithmetic overflows at 65504."""
         return _cabi.range_report(self.lib, "hubert", self.handle)
 
+    def site_scales(self):
+        """[(scale of the q/k/v projection's input, scale of the first FFN GEMM's input) per transformer layer]: 16, or the provable scale of a LayerNorm
+        whose gains are too large for 16 (include/audiotoken_hip.h, at_hubert_site_scales)."""
+        buf = (C.c_float * 128)()
+        n = self.lib.at_hubert_site_scales(self.handle, buf, 128)
+        if n < 0:
+            raise _cabi.HipLibraryError(f"at_hubert_site_scales failed: {_cabi.last_error()}")
+        return [(float(buf[2 * l]), float(buf[2 * l + 1])) for l in range(n // 2)]
+
     def layer_status(self):
         """Status flags of the LAST call per part: [0] = conv feature encoder + positional conv, [1 + l] = transformer layer l (bit 1 = fp16 overflow)."""
         import ctypes as C
@@ -146,14 +156,17 @@ class HubertEncoder(torch.nn.Module):
             raise _cabi.HipLibraryError(f"at_hubert_layer_status failed: {_cabi.last_error()}")
         return [int(buf[i]) for i in range(n)]
 
+    PIN_AFTER = 2   # as Wav2VecBertEncoder.PIN_AFTER
+
     def unpin_layers(self) -> None:
         for layer in set(self.pinned_layers):
             self.set_option(f"layer_arith:{layer}", -1)
         self.pinned_layers = []
+        self.layer_overflows = {}
 
     def verified(self, tokens: torch.Tensor, input_batch: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Product-path guard (see Wav2VecBertEncoder.verified): on an fp16 range overflow in a TRANSFORMER layer that layer moves to bf16x3 for good and
-        the batch is repeated; an overflow in the conv feature encoder / positional conv (a property of the input's level) repeats THIS batch with
+        """Product-path guard (see Wav2VecBertEncoder.verified): on an fp16 range overflow in a TRANSFORMER layer that layer moves to bf16x3 and the batch is
+        repeated (the layer returns to f16x2 afterwards unless it was its PIN_AFTER-th overflowing batch); an overflow in the conv feature encoder / positional conv (a property of the input's level) repeats THIS batch with
         arith=bf16x3 for the whole model, then switches back."""
         status = self.last_status()
         if status == 0:
@@ -167,24 +180,31 @@ class HubertEncoder(torch.nn.Module):
             if status & ~4 == 0:
                 return tokens
         self.fallback_batches += 1
-        for _ in range(3):
-            flags = self.layer_status()
-            bad = [i for i, f in enumerate(flags) if f & 2]
-            if not bad or bad[0] == 0:      # nothing per layer to act on, or the front end itself: the whole-batch repeat below
-                break
-            layer = bad[0] - 1
-            self.pinned_layers.append(layer)
-            logger.error(f"semantic_s encode reported status {status}: an activation of transformer layer {layer} exceeded the fp16 range of the f16x2 arithmetic. "
-                         f"The tokens of this batch were discarded; layer {layer} runs on bf16x3 from now on (option layer_arith:{layer} = 1), this batch is "
-                         f"re-encoded (fallback batch #{self.fallback_batches})")
-            self.set_option(f"layer_arith:{layer}", 1)
-            tokens = self.forward(input_batch, attention_mask)
-            status = self.last_status()
-            if not status & 2:
-                if status & 4:
-                    self.nonfinite_batches += 1
-                    logger.error(f"a NaN or an infinity reached the quantiser with layer {layer} on bf16x3 too (non-finite batch #{self.nonfinite_batches}): check the input waveform")
-                return tokens
+        transient = []    # layers moved for THIS batch only (their first overflow): restored below
+        try:
+            for _ in range(3):
+                flags = self.layer_status()
+                bad = [i for i, f in enumerate(flags) if f & 2]
+                if not bad or bad[0] == 0:      # nothing per layer to act on, or the front end itself: the whole-batch repeat below
+                    break
+                layer = bad[0] - 1
+                self.layer_overflows[layer] = self.layer_overflows.get(layer, 0) + 1
+                pin = self.layer_overflows[layer] >= self.PIN_AFTER
+                (self.pinned_layers if pin else transient).append(layer)
+                logger.error(f"semantic_s encode reported status {status}: an activation of transformer layer {layer} exceeded the fp16 range of the f16x2 arithmetic "
+                             f"(batch #{self.layer_overflows[layer]} on which it did). The tokens of this batch were discarded; layer {layer} runs on bf16x3 (option "
+                             f"layer_arith:{layer} = 1) " + ("from now on" if pin else "for this batch") + f", this batch is re-encoded (fallback batch #{self.fallback_batches})")
+                self.set_option(f"layer_arith:{layer}", 1)
+                tokens = self.forward(input_batch, attention_mask)
+                status = self.last_status()
+                if not status & 2:
+                    if status & 4:
+                        self.nonfinite_batches += 1
+                        logger.error(f"a NaN or an infinity reached the quantiser with layer {layer} on bf16x3 too (non-finite batch #{self.nonfinite_batches}): check the input waveform")
+                    return tokens
+        finally:
+            for layer in transient:
+                self.set_option(f"layer_arith:{layer}", -1)
         logger.error(f"semantic_s encode reported status {status} (an activation exceeded the fp16 range of the f16x2 arithmetic): "
                      f"the tokens of this batch were discarded; re-encoding THIS batch with arith=bf16x3 (fallback batch #{self.fallback_batches})")
         saved = self.get_option("arith")

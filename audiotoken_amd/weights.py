@@ -71,18 +71,81 @@ def encodec_decoder_specs() -> List[Tuple[str, str, int, int, int, int]]:
     return specs
 
 
-def _wn_pair(w: Dict[str, np.ndarray], prefix: str, shape, norm_dim0: int, seed: int):
+
+# ----------------------------------------------------------------------------------------------
+# weight families. "uniform" (rounds 1-4): every matrix U(-a, a) with variance 1 / fan_in, LayerNorm gains U(0.8, 1.2). "trained_like" (round 5) keeps
+# every variance and emulates what published checkpoints look like where it matters for the two-piece fp16 arithmetic and for near-tie statistics:
+# heavy-tailed matrices (tail index 4, largest entries 30-50 standard deviations out), log-normal LayerNorm / GroupNorm gains (sigma 0.5), a few
+# "massive activation" channels (the same MASSIVE_CHANNELS indices in every layer: gain x 30-100 in the LayerNorm that writes the residual stream, and
+# in every third layer also in the LayerNorm that feeds the first FFN GEMM), non-zero betas with a few large entries.
+# ----------------------------------------------------------------------------------------------
+FAMILIES = ("uniform", "trained_like")
+N_MASSIVE = 3
+
+
+def _family_check(family: str) -> bool:
+    if family not in FAMILIES:
+        raise ValueError(f"weight family {family!r}: one of {FAMILIES}")
+    return family == "trained_like"
+
+
+def massive_channels(model: str, dim: int, seed: int = 0) -> np.ndarray:
+    """The N_MASSIVE channel indices of `model` that carry massive activations in the trained_like family."""
+    u = prng.uniform01(f"{model}.massive_channels", 4 * N_MASSIVE, seed)
+    idx = []
+    for v in (u * dim).astype(np.int64):
+        if int(v) not in idx:
+            idx.append(int(v))
+        if len(idx) == N_MASSIVE:
+            break
+    return np.asarray(idx, dtype=np.int64)
+
+
+def _trained_ln(w, name: str, dim: int, seed: int, massive=None):
+    g = prng.log_normal(name + ".weight", (dim,), 0.5, seed)
+    b = prng.irwin_hall(name + ".bias", (dim,), 0.3, seed)
+    big = (prng.uniform01(name + ".bias#big", dim, seed) < 4.0 / dim)          # ~4 betas of magnitude ~3
+    b = np.where(big, np.sign(b) * np.float32(3.0) + b, b).astype(np.float32)
+    if massive is not None:
+        g = g.copy()
+        g[massive] *= prng.uniform(name + ".weight#massive", (len(massive),), 30.0, 100.0, seed)
+    w[name + ".weight"], w[name + ".bias"] = g.astype(np.float32), b
+
+
+def _run_jobs(jobs):
+    """Generate tensors on a thread pool (numpy releases the GIL inside its loops): jobs = [(key, fn)]; returns {key: array}."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n = os.cpu_count() or 1
+    with ThreadPoolExecutor(max_workers=max(1, min(16, n))) as ex:
+        return dict(zip([k for k, _ in jobs], ex.map(lambda kf: kf[1](), jobs)))
+
+def _wn_pair(w: Dict[str, np.ndarray], prefix: str, shape, norm_dim0: int, seed: int, trained: bool = False):
     """weight_g / weight_v / bias for one weight-normalised conv. ``shape`` is the torch weight shape."""
+    if trained:   # heavy-tailed direction, log-normal norm with the same median as the uniform family's mean
+        w[f"{prefix}.weight_v"] = prng.heavy_tailed(f"{prefix}.weight_v", shape, 0.5773502691896258, seed)
+        w[f"{prefix}.weight_g"] = prng.log_normal(f"{prefix}.weight_g", (norm_dim0, 1, 1), 0.35, seed, median=1.2)
+        return
     w[f"{prefix}.weight_v"] = prng.uniform(f"{prefix}.weight_v", shape, -1.0, 1.0, seed)
     w[f"{prefix}.weight_g"] = prng.uniform(f"{prefix}.weight_g", (norm_dim0, 1, 1), 0.9, 1.5, seed)
 
 
-def synth_encodec_weights(seed: int = 0, with_decoder: bool = True, n_codebooks: int = ENCODEC_MAX_NQ) -> Dict[str, np.ndarray]:
-    """Synthetic EnCodec-24kHz weights (encoder, RVQ codebooks, optionally decoder)."""
+def synth_encodec_weights(seed: int = 0, with_decoder: bool = True, n_codebooks: int = ENCODEC_MAX_NQ, family: str = "uniform") -> Dict[str, np.ndarray]:
+    """Synthetic EnCodec-24kHz weights (encoder, RVQ codebooks, optionally decoder). family "trained_like": heavy-tailed weight_v / LSTM matrices /
+    biases and log-normal weight_g (the variances of the uniform family are kept, so signal levels through the stack stay comparable)."""
+    trained = _family_check(family)
     w: Dict[str, np.ndarray] = {}
+
+    def bias(prefix, cout):
+        w[f"{prefix}.bias"] = (prng.heavy_tailed(f"{prefix}.bias", (cout,), 0.0577, seed) if trained
+                               else prng.uniform(f"{prefix}.bias", (cout,), -0.1, 0.1, seed))
+
     for prefix, cin, cout, k, _s in encodec_conv_specs():
-        _wn_pair(w, prefix, (cout, cin, k), cout, seed)
-        w[f"{prefix}.bias"] = prng.uniform(f"{prefix}.bias", (cout,), -0.1, 0.1, seed)
+        _wn_pair(w, prefix, (cout, cin, k), cout, seed, trained)
+        bias(prefix, cout)
     a = 1.0 / np.sqrt(ENCODEC_LSTM)
     for which in ("encoder.model.13", "decoder.model.1"):
         if which.startswith("decoder") and not with_decoder:
@@ -91,14 +154,14 @@ def synth_encodec_weights(seed: int = 0, with_decoder: bool = True, n_codebooks:
             for nm, shape in (("weight_ih", (4 * ENCODEC_LSTM, ENCODEC_LSTM)), ("weight_hh", (4 * ENCODEC_LSTM, ENCODEC_LSTM)),
                               ("bias_ih", (4 * ENCODEC_LSTM,)), ("bias_hh", (4 * ENCODEC_LSTM,))):
                 key = f"{which}.lstm.{nm}_l{layer}"
-                w[key] = prng.uniform(key, shape, -a, a, seed)
+                w[key] = prng.heavy_tailed(key, shape, a / np.sqrt(3.0), seed) if trained else prng.uniform(key, shape, -a, a, seed)
     if with_decoder:
         for kind, prefix, cin, cout, k, _s in encodec_decoder_specs():
             if kind == "conv":
-                _wn_pair(w, prefix, (cout, cin, k), cout, seed)
+                _wn_pair(w, prefix, (cout, cin, k), cout, seed, trained)
             else:  # ConvTranspose1d weight is [in, out, k]; weight-norm dim 0 = input channel
-                _wn_pair(w, prefix, (cin, cout, k), cin, seed)
-            w[f"{prefix}.bias"] = prng.uniform(f"{prefix}.bias", (cout,), -0.1, 0.1, seed)
+                _wn_pair(w, prefix, (cin, cout, k), cin, seed, trained)
+            bias(prefix, cout)
     for q in range(n_codebooks):
         key = f"quantizer.vq.layers.{q}._codebook.embed"
         scale = 1.2 * (0.75 ** q)
@@ -156,18 +219,30 @@ W2V_LAYERS_USED = 19          # hidden_states[19] = output of layer index 18 (re
 W2V_CODEBOOK = 2048
 
 
-def synth_w2vbert_weights(n_layers: int = W2V_LAYERS_USED, seed: int = 0, with_vq: bool = True) -> Dict[str, np.ndarray]:
-    """Synthetic Wav2Vec2-BERT weights (first ``n_layers`` conformer layers) + the 2048 x 1024 VQ codebook."""
+def synth_w2vbert_weights(n_layers: int = W2V_LAYERS_USED, seed: int = 0, with_vq: bool = True, family: str = "uniform") -> Dict[str, np.ndarray]:
+    """Synthetic Wav2Vec2-BERT weights (first ``n_layers`` conformer layers) + the 2048 x 1024 VQ codebook. ``family``: see FAMILIES above."""
+    trained = _family_check(family)
     w: Dict[str, np.ndarray] = {}
+    jobs = []                      # trained_like: the big matrices are generated on a thread pool
     H, Fd = W2V_HIDDEN, W2V_FFN
+    massive = massive_channels("w2vbert", H, seed) if trained else None
+
+    def mat(name, shape, a):       # variance a^2 / 3 in both families
+        if trained:
+            jobs.append((name, lambda: prng.heavy_tailed(name, shape, a / np.sqrt(3.0), seed)))
+        else:
+            w[name] = prng.uniform(name, shape, -a, a, seed)
 
     def lin(name, out_f, in_f, bias=True, gain=1.0):
-        a = gain * np.sqrt(3.0 / in_f)
-        w[name + ".weight"] = prng.uniform(name + ".weight", (out_f, in_f), -a, a, seed)
+        mat(name + ".weight", (out_f, in_f), gain * np.sqrt(3.0 / in_f))
         if bias:
-            w[name + ".bias"] = prng.uniform(name + ".bias", (out_f,), -0.05, 0.05, seed)
+            w[name + ".bias"] = (prng.heavy_tailed(name + ".bias", (out_f,), 0.05, seed) if trained
+                                 else prng.uniform(name + ".bias", (out_f,), -0.05, 0.05, seed))
 
-    def ln(name, dim):
+    def ln(name, dim, massive_here=False):
+        if trained:
+            _trained_ln(w, name, dim, seed, massive if massive_here else None)
+            return
         w[name + ".weight"] = prng.uniform(name + ".weight", (dim,), 0.8, 1.2, seed)
         w[name + ".bias"] = prng.uniform(name + ".bias", (dim,), -0.1, 0.1, seed)
 
@@ -175,28 +250,29 @@ def synth_w2vbert_weights(n_layers: int = W2V_LAYERS_USED, seed: int = 0, with_v
     lin("feature_projection.projection", H, W2V_FEAT)
     for i in range(n_layers):
         p = f"encoder.layers.{i}"
-        ln(p + ".ffn1_layer_norm", H)
+        ln(p + ".ffn1_layer_norm", H, massive_here=(i % 3 == 1))
         lin(p + ".ffn1.intermediate_dense", Fd, H, gain=1.4)
         lin(p + ".ffn1.output_dense", H, Fd)
         ln(p + ".self_attn_layer_norm", H)
         for nm in ("linear_q", "linear_k", "linear_v", "linear_out"):
             lin(p + ".self_attn." + nm, H, H, gain=1.6 if nm in ("linear_q", "linear_k") else 1.0)
-        w[p + ".self_attn.distance_embedding.weight"] = prng.uniform(
-            p + ".self_attn.distance_embedding.weight", (W2V_REL_BUCKETS, W2V_HEAD_DIM), -0.5, 0.5, seed)
+        mat(p + ".self_attn.distance_embedding.weight", (W2V_REL_BUCKETS, W2V_HEAD_DIM), 0.5)
         ln(p + ".conv_module.layer_norm", H)
         a = np.sqrt(3.0 / H)
-        w[p + ".conv_module.pointwise_conv1.weight"] = prng.uniform(p + ".conv_module.pointwise_conv1.weight", (2 * H, H, 1), -1.4 * a, 1.4 * a, seed)
-        ad = np.sqrt(3.0 / W2V_DW_KERNEL)
-        w[p + ".conv_module.depthwise_conv.weight"] = prng.uniform(p + ".conv_module.depthwise_conv.weight", (H, 1, W2V_DW_KERNEL), -ad, ad, seed)
+        mat(p + ".conv_module.pointwise_conv1.weight", (2 * H, H, 1), 1.4 * a)
+        mat(p + ".conv_module.depthwise_conv.weight", (H, 1, W2V_DW_KERNEL), np.sqrt(3.0 / W2V_DW_KERNEL))
         ln(p + ".conv_module.depthwise_layer_norm", H)
-        w[p + ".conv_module.pointwise_conv2.weight"] = prng.uniform(p + ".conv_module.pointwise_conv2.weight", (H, H, 1), -a, a, seed)
+        mat(p + ".conv_module.pointwise_conv2.weight", (H, H, 1), a)
         ln(p + ".ffn2_layer_norm", H)
         lin(p + ".ffn2.intermediate_dense", Fd, H, gain=1.4)
         lin(p + ".ffn2.output_dense", H, Fd)
-        ln(p + ".final_layer_norm", H)
+        ln(p + ".final_layer_norm", H, massive_here=True)      # this LayerNorm writes the residual stream the next layer reads
     if with_vq:
         # state-dict key of vector_quantize_pytorch.VectorQuantize (reference audiotoken/utils.py:331-339)
         w["vq._codebook.embed"] = prng.irwin_hall("vq._codebook.embed", (1, W2V_CODEBOOK, H), 1.0, seed)
+    if jobs:
+        made = _run_jobs(jobs)
+        w = {**w, **made}
     return w
 
 
@@ -224,18 +300,29 @@ def hubert_num_frames(n_samples: int) -> int:
     return L
 
 
-def synth_hubert_weights(n_layers: int = HUB_LAYERS_USED, seed: int = 0, with_kmeans: bool = True) -> Dict[str, np.ndarray]:
+def synth_hubert_weights(n_layers: int = HUB_LAYERS_USED, seed: int = 0, with_kmeans: bool = True, family: str = "uniform") -> Dict[str, np.ndarray]:
+    trained = _family_check(family)
     w: Dict[str, np.ndarray] = {}
+    jobs = []
     H, Fd, Cd = HUB_HIDDEN, HUB_FFN, HUB_CONV_DIM
+    massive = massive_channels("hubert", H, seed) if trained else None
 
     def u(name, shape, a):
-        w[name] = prng.uniform(name, shape, -a, a, seed)
+        if trained and len(shape) > 1:
+            jobs.append((name, lambda: prng.heavy_tailed(name, shape, a / np.sqrt(3.0), seed)))
+        elif trained:
+            w[name] = prng.heavy_tailed(name, shape, a / np.sqrt(3.0), seed)
+        else:
+            w[name] = prng.uniform(name, shape, -a, a, seed)
 
     def lin(name, out_f, in_f, gain=1.0):
         u(name + ".weight", (out_f, in_f), gain * np.sqrt(3.0 / in_f))
         u(name + ".bias", (out_f,), 0.05)
 
-    def ln(name, dim):
+    def ln(name, dim, massive_here=False):
+        if trained:
+            _trained_ln(w, name, dim, seed, massive if (massive_here and dim == H) else None)
+            return
         w[name + ".weight"] = prng.uniform(name + ".weight", (dim,), 0.8, 1.2, seed)
         w[name + ".bias"] = prng.uniform(name + ".bias", (dim,), -0.1, 0.1, seed)
 
@@ -257,10 +344,12 @@ def synth_hubert_weights(n_layers: int = HUB_LAYERS_USED, seed: int = 0, with_km
         ln(p + ".layer_norm", H)
         lin(p + ".feed_forward.intermediate_dense", Fd, H, gain=1.4)
         lin(p + ".feed_forward.output_dense", H, Fd)
-        ln(p + ".final_layer_norm", H)
+        ln(p + ".final_layer_norm", H, massive_here=True)      # post-LN: this LayerNorm writes the residual stream
     if with_kmeans:
         # sklearn KMeans.cluster_centers_ [1000, 768] (reference audiotoken/encoder.py:84-85)
         w["kmeans.cluster_centers_"] = prng.irwin_hall("kmeans.cluster_centers_", (HUB_CENTROIDS, H), 1.0, seed)
+    if jobs:
+        w = {**w, **_run_jobs(jobs)}
     return w
 
 

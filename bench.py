@@ -313,7 +313,7 @@ def run_hubert(args, rank, world, dev, dist):
 
     nl, B, secs = 11, args.hub_batch, args.sem_seconds
     N = int(round(secs * 16000))
-    weights = W.synth_hubert_weights(n_layers=nl, seed=0, with_kmeans=True) if rank == 0 else None
+    weights = W.synth_hubert_weights(n_layers=nl, seed=0, with_kmeans=True, family=args.weights) if rank == 0 else None
     enc = HubertEncoder(HubertEncoderConfig(output_layer=nl), device=str(dev), quantize=True, weights=weights) if rank == 0 else None
     if world > 1:   # the finalized model travels as one device blob (as semantic_m)
         from audiotoken_amd.distributed import broadcast_packed
@@ -345,10 +345,10 @@ def run_hubert(args, rank, world, dev, dist):
         "dtype": {0: "f32", 1: "f32 (linear layers and convs: three bf16 pieces per operand, six MFMA products, fp32 accumulate)",
                   2: "f32 (linear layers and convs: two fp16 pieces per operand, three MFMA products, fp32 accumulate)"}[arith],
         "config": {"workload": f"Tokenizers.semantic_s encode, {B} clips x {secs:g} s @16 kHz per GPU, mHuBERT-base 11 layers, k-means 1000",
-                   "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0"},
+                   "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": f"synthetic seed 0, family {args.weights}", "clips": "speech-like, all distinct (audiotoken_amd/synthetic.py)"},
         "roofline": roofline_of(breakdown, flops, None, B, BF16X3_GROUPS if arith else (), "semantic_s", products), "breakdown": breakdown,
         "token_checksum": S.token_checksum(toks),
-        "checksum_pinned": (S.token_checksum(toks) == S.PINNED_CHECKSUMS["semantic_s"]) if (rank == 0 and B == 128 and N == 480000) else None,
+        "checksum_pinned": (S.token_checksum(toks) == S.PINNED_CHECKSUMS[(args.weights, "semantic_s")]) if (rank == 0 and B == 128 and N == 480000) else None,
         "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
         "fallback_batches": fallback * args.steps, "fallback_status": fb_status,
     }
@@ -612,13 +612,15 @@ def settle_status(enc, call, name):
         return 0, 0, call
     inputs = enc._bench_inputs
     timed = lambda: enc.verified(call(), *inputs)
-    timed()
-    assert enc.last_status() == 0, f"{name}: status word non-zero on the fallback path too"
-    if getattr(enc, "pinned_layers", None):
-        # semantic_m (round 4): verified() found the overflowing conformer layer(s) and moved THEM to bf16x3 for good; the plain call is clean from now on
-        call()
-        if enc.last_status() == 0:
-            return 0, status, call
+    for _ in range(1 + 3 * getattr(enc, "PIN_AFTER", 0)):
+        timed()
+        assert enc.last_status() == 0, f"{name}: status word non-zero on the fallback path too"
+        if getattr(enc, "pinned_layers", None):
+            # semantic_m / semantic_s: verified() found the overflowing layer(s) and, from their PIN_AFTER-th overflowing batch on, keeps THEM on bf16x3; once every
+            # such layer is pinned the plain call is clean
+            call()
+            if enc.last_status() == 0:
+                return 0, status, call
     return 1, status, timed
 
 
@@ -632,7 +634,7 @@ def setup_acoustic(args, rank, world, dev, dist):
     n_q = args.num_codebooks
     B, N = args.batch, int(round(args.seconds * 24000))
     # weights: rank 0 generates, RCCL broadcast over xGMI to the other ranks
-    weights = W.synth_encodec_weights(seed=0, with_decoder=False) if rank == 0 else None
+    weights = W.synth_encodec_weights(seed=0, with_decoder=False, family=args.weights) if rank == 0 else None
     t0 = time.perf_counter()
     weights = broadcast_weights(weights, dev, dist)
     bcast_ms = (time.perf_counter() - t0) * 1e3
@@ -678,12 +680,12 @@ def report_acoustic(wl, args, rank, world, dev, dist):
         "dtype": ("f32 (contractions as operand splits on the 16-bit matrix cores with fp32 accumulate; per kernel group two fp16 pieces / three "
                   "products or three bf16 pieces / six products: see mfma_products_per_mac; conv0 on the fp32 MFMA)") if ACOUSTIC_X3_GROUPS else "f32",
         "config": {"workload": f"Tokenizers.acoustic encode, {B} clips x {args.seconds:g} s @24 kHz per GPU, num_codebooks={n_q} (BASELINE configs[1])",
-                   "clips_per_gpu": B, "samples_per_clip": N, "frames_per_clip": T, "weights": "synthetic seed 0",
+                   "clips_per_gpu": B, "samples_per_clip": N, "frames_per_clip": T, "weights": f"synthetic seed 0, family {args.weights}", "clips": "speech-like, all distinct (audiotoken_amd/synthetic.py)",
                    "parallelism": f"clip-sharded x{world}, no data-path collective", **({"options": list(args.acoustic_option)} if args.acoustic_option else {})},
         "roofline": roofline_of(breakdown, flops, nbytes, B, ACOUSTIC_X3_GROUPS, "acoustic", 3 if dom in f16_groups else 6), "breakdown": breakdown,
         "mfma_products_per_mac": {**{g: (3 if g in f16_groups else 6) for g in ACOUSTIC_X3_GROUPS}, "final_conv": 3 if "final_conv" in f16_groups else 1},
         "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)", "token_checksum": checksum,
-        "checksum_pinned": (checksum == S.PINNED_CHECKSUMS["acoustic"]) if (rank == 0 and B == 256 and N == 240000 and n_q == 8) else None,
+        "checksum_pinned": (checksum == S.PINNED_CHECKSUMS[(args.weights, "acoustic")]) if (rank == 0 and B == 256 and N == 240000 and n_q == 8) else None,
         "lstm_handoff_status": status, "fallback_batches": wl["fallback_batches_per_step"] * args.steps, "fallback_status": wl["fallback_status"],
     }
     if "rvq" in breakdown and breakdown["rvq"]["ms_per_step"] > 0:
@@ -763,7 +765,7 @@ def run_decode(args, rank, world, dev, dist):
     from audiotoken_amd.decoder import AcousticDecoder
     from audiotoken_amd.distributed import broadcast_weights
 
-    weights = W.synth_encodec_weights(seed=0) if rank == 0 else None
+    weights = W.synth_encodec_weights(seed=0, family=args.weights) if rank == 0 else None
     weights = broadcast_weights(weights, dev, dist)
     dec = AcousticDecoder(config=AcousticDecoderConfig(bandwidth=num_codebooks_to_bandwidth(args.num_codebooks)), device=str(dev), weights=weights)
     B, T = 64, int(round(args.seconds * 75))
@@ -806,7 +808,7 @@ def setup_semantic(args, rank, world, dev, dist):
     N = int(round(secs * 16000))
     # weights: rank 0 generates, finalizes (fold, upload, split on its device) and exports the finalized model as ONE device blob; the other ranks
     # receive it by one RCCL broadcast and rebuild the handle over it (at_w2vbert_import_packed): no D2H copy, no second host pass
-    weights = W.synth_w2vbert_weights(n_layers=nl, seed=0, with_vq=True) if rank == 0 else None
+    weights = W.synth_w2vbert_weights(n_layers=nl, seed=0, with_vq=True, family=args.weights) if rank == 0 else None
     if args.stress_range and weights is not None:
         # --stress-range: ONE split site leaves the fp16 range on every batch (layer min(7, nl - 1)'s first FFN: the bias of hidden unit 0 raised to 6 000, so
         # swish(.) * 16 > 65504 there). The product's verified() finds that layer on the first batch, moves IT to bf16x3 for good and repeats the batch;
@@ -880,13 +882,13 @@ def report_semantic(wl, args, rank, world, dev, dist):
         "dtype": {0: "f32", 1: "f32 (linear layers: three bf16 pieces per operand, six MFMA products, fp32 accumulate)",
                   2: "f32 (linear layers: two fp16 pieces per operand, three MFMA products, fp32 accumulate)"}[arith],
         "config": {"workload": f"Tokenizers.semantic_m encode, {B} clips x {secs:g} s @16 kHz per GPU, {nl} conformer layers, VQ 2048x1024 (BASELINE configs[3] per-GPU share)",
-                   "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": "synthetic seed 0",
+                   "clips_per_gpu": B, "samples_per_clip": N, "tokens_per_clip": T, "weights": f"synthetic seed 0, family {args.weights}", "clips": "speech-like, all distinct (audiotoken_amd/synthetic.py)",
                    "parallelism": f"clip-sharded x{world}, no data-path collective",
                    "note": "BASELINE configs[3] is 512 clips over 8 GPUs = 64 per GPU; at N=1 one step is one such 64-clip micro-batch"},
         "roofline": roofline_of(breakdown, flops_all, None, B, ("ffn", "attn_proj", "conv_module") if arith else (), "semantic_m", products), "breakdown": breakdown,
         "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)",
         "token_checksum": checksum,
-        "checksum_pinned": (checksum == S.PINNED_CHECKSUMS["semantic_m"]) if (rank == 0 and B == 64 and N == 480000 and nl == 19 and not args.stress_range) else None,
+        "checksum_pinned": (checksum == S.PINNED_CHECKSUMS[(args.weights, "semantic_m")]) if (rank == 0 and B == 64 and N == 480000 and nl == 19 and not args.stress_range) else None,
         "total_tflops": round(sum(flops.values()) * B / (ms * 1e-3) / 1e12, 2),
         "fallback_batches": wl["fallback_batches_per_step"] * args.steps, "fallback_status": wl["fallback_status"],
         "pinned_layers": sorted(set(getattr(enc, "pinned_layers", []))),   # conformer layers the range fallback moved to bf16x3 before the timed region (normally none)
@@ -933,6 +935,9 @@ def parse_args(argv=None):
     ap.add_argument("--sem-layers", type=int, default=19)
     ap.add_argument("--acoustic-option", action="append", default=[], metavar="NAME=0|1",
                     help="A/B tooling: set a kernel-selection option of the acoustic handle (at_encodec_set_option) before the run; echoed in config")
+    ap.add_argument("--weights", default="uniform", choices=["uniform", "trained_like"],
+                    help="synthetic weight family (audiotoken_amd/weights.py FAMILIES): 'uniform' = rounds 1-4 (the BASELINE measurement); 'trained_like' = heavy-tailed "
+                         "matrices, log-normal LayerNorm gains, massive-activation channels — reports fallback_batches / pinned_layers on such a checkpoint")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stress-range", action="store_true",
                     help="semantic_m with one split site overflowing the fp16 range on every batch: times the product's per-batch fallback (bf16x3 repeat)")
@@ -1075,7 +1080,7 @@ def main(argv=None):
                        "step": "one pass of the hot path over one batch of each tokenizer named in `metric`, both inside one timed region; value = audio-seconds of "
                                "all of them / that time (BASELINE.json's combined metric); per-tokenizer rates in the named sub-objects",
                        "audio_s_per_step_per_gpu": sum(r["config"]["clips_per_gpu"] * r["config"]["samples_per_clip"] / (24000 if "frames_per_clip" in r["config"] else 16000) for r in parts),
-                       "weights": "synthetic seed 0", "parallelism": f"clip-sharded x{world}, no data-path collective"},
+                       "weights": f"synthetic seed 0, family {args.weights}", "clips": "speech-like, all distinct (audiotoken_amd/synthetic.py)", "parallelism": f"clip-sharded x{world}, no data-path collective"},
             "roofline": dict(dominant["roofline"], workload=names[parts.index(dominant)] if dominant in parts else "semantic_s"),
             "rccl_ranks": ranks["rccl_ranks"], "per_rank_ms": ranks["per_rank_ms"],
             "backend": args.backend if world > 1 else None,

@@ -272,6 +272,13 @@ int at_w2vbert_range_sites(char* names, size_t cap);
 int at_w2vbert_range_report(at_w2vbert_t* h, float* max_scaled, int cap);
 int at_hubert_range_sites(char* names, size_t cap);
 int at_hubert_range_report(at_hubert_t* h, float* max_scaled, int cap);
+/* The power of two each split site multiplies its activations by before the fp16 split (round 5). 16 everywhere, except that a site fed by an affine
+ * LayerNorm gets, at finalize, the largest power of two s <= 16 with s (sqrt(D) max|gamma| + max|beta|) <= 65 000: |LN(x)_k| <= sqrt(D) |gamma_k| + |beta_k|
+ * for any input, so those sites provably cannot overflow whatever the data. at_w2vbert_site_scales: scales[l * n_sites + k] (n_sites and the order of
+ * at_w2vbert_range_sites); at_hubert_site_scales: scales[2 l] = input of layer l's q/k/v projection, scales[2 l + 1] = input of its first FFN GEMM. Return
+ * the number of floats written. (The reference has no such notion: fp32 throughout, audiotoken/encoder.py:87-108,163-186.) */
+int at_w2vbert_site_scales(const at_w2vbert_t* h, float* scales, int cap);
+int at_hubert_site_scales(const at_hubert_t* h, float* scales, int cap);
 /* Per conformer layer, the OR of its split sites' status flags in the LAST encode (bit 1 = an activation of that layer left the fp16 range). An overflow
  * becomes infinities that every later layer flags as well: the FIRST flagged layer is the cause. Returns the number of layers written (<= cap).
  * Synchronises the device. With option "layer_arith:<i>" (at_w2vbert_set_option; -1 = the handle's "arith", 1 = bf16x3, 2 = f16x2) ONE layer can be moved

@@ -107,6 +107,19 @@ def test_resampled_rows_match_the_host_resampler(cuda_device, tmp_path, src, dst
     e_host = (hs[0, :Lr].double() - y64[:dst]).abs().max().item()
     print(f"    vs float64: device {e_dev:.2e}, host conv1d {e_host:.2e}")
     assert e_dev <= 5e-7
+    # and against the INDEPENDENT oracle (oracle/resample_ref.py: torchaudio's published sinc_interp_hann evaluated per output sample in float64, no
+    # polyphase table, no code shared with audio_io.resample_table) on the whole first chunk, chunk ends included, and on the (shorter) last chunk
+    from oracle import resample_ref as RR
+    full = raw.to_float()[0].numpy()
+    first = RR.sinc_interp_hann(full[:src], src, dst)
+    assert len(first) == dst
+    e_first = float(np.abs(ds[0, :dst].double().numpy() - first).max())
+    tail = RR.sinc_interp_hann(full[2 * src:], src, dst)                     # third streamed chunk: 0.37 s + 11 samples
+    assert len(tail) == A.resampled_length(n - 2 * src, src, dst)
+    e_tail = float(np.abs(ds[2, :len(tail)].double().numpy() - tail).max())
+    print(f"    vs the independent oracle: first chunk {e_first:.2e}, last (short) chunk {e_tail:.2e}")
+    assert e_first <= 5e-7 and e_tail <= 5e-7
+    assert float(ds[2, len(tail):].abs().max()) == 0.0 and float(dm[2, :len(tail)].min()) == 1.0 and float(dm[2, len(tail):].max()) == 0.0
 
 
 def test_flac_tar_and_skips_through_the_feeder(cuda_device, tmp_path):

@@ -109,3 +109,34 @@ def test_encoder_of_the_fixtures_is_deterministic():
     assert np.array_equal(raw.pcm, PCM["a"][:, :8192 + 777])
     ref = open(os.path.join(G, "flac_a.flac"), "rb").read()
     assert blob[42:42 + 2000] == ref[42:42 + 2000]          # same first frames as the committed file (the header differs: length, MD5)
+
+
+# ---- externally produced files (round 5) -------------------------------------------------------------------------------------------------------------
+# The three example files of RFC 9639 Appendix D, byte for byte (tests/golden/rfc9639_d{1,2,3}.flac; 57 / 227 / 73 bytes). D.2 carries the vendor string
+# "reference libFLAC 1.3.3 20190804": these are libFLAC's output, not this repository's encoder — the only FLAC bytes available offline that the author of
+# csrc/flac_decode.hip did not write. The decoder checks every frame's CRC-8 and CRC-16 and the STREAMINFO MD5 of the decoded PCM, so a wrong byte in a
+# fixture or a wrong sample out of the decoder cannot pass. Between them: verbatim subframes with wasted bits (D.1), PADDING / SEEKTABLE / VORBIS_COMMENT
+# blocks, side-channel stereo, fixed predictors, Rice partitions, a short last block (D.2), an 8-bit 32 kHz LPC subframe of order 3 (D.3).
+RFC_EXAMPLES = {
+    "rfc9639_d1.flac": (44100, 16, [[25588], [10416]]),
+    "rfc9639_d2.flac": (44100, 16, [[10372, 18041, 14942, 17876, 15627, 17899, 16242, 18077, 16824, 18263, 17295, -14418, -15201, -14508, -15195, -14818, -15486, -15349, -16054],
+                                    [6070, 10545, 8743, 10449, 9143, 10463, 9502, 10569, 9840, 10680, 10113, -8428, -8895, -8476, -8896, -8653, -9072, -8958, -9410]]),
+    "rfc9639_d3.flac": (32000, 8, [[0, 79, 111, 78, 8, -61, -90, -68, -13, 42, 67, 53, 13, -27, -46, -38, -12, 14, 24, 19, 6, -4, -5, 0]]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RFC_EXAMPLES))
+def test_rfc9639_appendix_examples_decode(name):
+    sr, bits, pcm = RFC_EXAMPLES[name]
+    path = os.path.join(G, name)
+    raw = A.decode_raw(path)
+    assert raw.sample_rate == sr
+    got = (raw.to_float().double() * float(1 << (bits - 1))).round().long()
+    assert got.tolist() == pcm
+    if name == "rfc9639_d2.flac":
+        assert b"reference libFLAC 1.3.3 20190804" in open(path, "rb").read()
+    # a flipped payload bit must be caught by the frame CRC (i.e. the fixtures above really were verified, not just parsed)
+    data = bytearray(open(path, "rb").read())
+    data[-4] ^= 0x10
+    with pytest.raises(A.AudioDecodeError):
+        A.decode_raw(name, io.BytesIO(bytes(data)))

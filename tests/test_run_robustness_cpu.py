@@ -1,0 +1,105 @@
+"""CPU: the failure-handling edges of ``AudioToken.encode_batch_files`` the round-4 advisor named (reference core.py:198-289 has none of them: its loop saves each
+batch before touching the next and its directory scan is ``glob.iglob(..., recursive=True)``, which follows symlinked sub-directories):
+the one-batch-deferred save is flushed when a later batch raises; a directory given as a farm of symlinks is scanned (once per real directory);
+a FLAC whose STREAMINFO claims an absurd sample count is skipped, not a MemoryError that aborts the run; the range fallback's pins end with the run."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_distributed_cpu import _HashEncoder, _write_inputs
+
+
+def _tok(encoder):
+    from audiotoken_amd import AudioToken, Tokenizers
+    tok = AudioToken(Tokenizers.acoustic, device="cpu", num_codebooks=2)
+    tok.encoder = encoder
+    tok.load_encoder = lambda: None
+    return tok
+
+
+def test_pending_batch_is_saved_when_a_later_batch_raises(tmp_path):
+    os.makedirs(tmp_path / "in")
+    names = sorted(_write_inputs(str(tmp_path / "in")))[:4]
+    ref = _tok(_HashEncoder())
+    ref.encode_batch_files(batch_size=3, outdir=str(tmp_path / "ok"), chunk_size=1, num_workers=0, audio_files=names)
+    assert ref.run_timings["batches"] >= 3
+
+    def frames_on_disk(fail_at, out):
+        class Failing(_HashEncoder):
+            calls = 0
+
+            def forward(self, x, m):
+                Failing.calls += 1
+                if Failing.calls == fail_at:
+                    raise RuntimeError("device lost")
+                return super().forward(x, m)
+
+        tok = _tok(Failing())
+        with pytest.raises(RuntimeError, match="device lost"):
+            tok.encode_batch_files(batch_size=3, outdir=str(tmp_path / out), chunk_size=1, num_workers=0, audio_files=names)
+        assert tok.run_summary["fallback_batches"] == 0
+        files = sorted(os.listdir(tmp_path / out)) if os.path.isdir(tmp_path / out) else []
+        for n in files:       # what is there is a prefix of the complete run's file
+            got, want = np.load(tmp_path / out / n), np.load(tmp_path / "ok" / n)
+            assert np.array_equal(got, want[:, :got.shape[1]])
+        return sum(np.load(tmp_path / out / n).shape[1] for n in files)
+
+    # the encode of batch k raises while batch k - 1 is still `pending` (its save is deferred by one batch): everything encoded before the failure is on disk
+    total = sum(np.load(tmp_path / "ok" / n).shape[1] for n in os.listdir(tmp_path / "ok"))
+    f2, f3 = frames_on_disk(2, "fail2"), frames_on_disk(3, "fail3")
+    assert 0 < f2 < f3 < total, (f2, f3, total)      # before the fix a failure in batch 2 left nothing on disk and one in batch 3 only batch 1
+
+
+def test_symlinked_directories_are_scanned_once(tmp_path):
+    real = tmp_path / "real" / "speaker1"
+    os.makedirs(real)
+    names = _write_inputs(str(real))[:2]
+    farm = tmp_path / "farm"
+    os.makedirs(farm / ".hidden")
+    os.symlink(tmp_path / "real" / "speaker1", farm / "spk_a")
+    os.symlink(tmp_path / "real" / "speaker1", farm / "spk_a_again")          # the same real directory a second time: visited once
+    os.symlink(farm, tmp_path / "real" / "speaker1" / "loop")                  # a cycle
+    tok = _tok(_HashEncoder())
+    tok.encode_batch_files(batch_size=4, outdir=str(tmp_path / "out"), chunk_size=1, num_workers=0, audio_dir=str(farm))
+    out = sorted(os.path.relpath(os.path.join(d, f), tmp_path / "out") for d, _, fs in os.walk(tmp_path / "out") for f in fs)
+    wavs = [o for o in out if o.split("/")[-1].startswith("clip")]
+    assert len(wavs) == 7 and all(o.startswith(("spk_a/", "spk_a_again/")) for o in wavs) and len({o.split("/")[0] for o in wavs}) == 1, out
+
+
+def test_flac_with_an_absurd_streaminfo_is_skipped(tmp_path):
+    from audiotoken_amd import audio_io as A
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    data = bytearray(open(os.path.join(G, "flac_a.flac"), "rb").read())
+    # STREAMINFO: bytes 8.. = min/max block (2+2), min/max frame (3+3), then 20 bits rate | 3 bits channels-1 | 5 bits bps-1 | 36 bits total samples
+    off = 8 + 10
+    v = int.from_bytes(data[off:off + 8], "big")
+    v = (v & ~((1 << 36) - 1)) | ((1 << 36) - 1)                    # 2^36 - 1 samples
+    data[off:off + 8] = v.to_bytes(8, "big")
+    p = tmp_path / "huge.flac"
+    p.write_bytes(bytes(data))
+    with pytest.raises(A.AudioDecodeError, match="STREAMINFO claims"):
+        A.decode_raw(p)
+    tok = _tok(_HashEncoder())
+    good = _write_inputs(str(tmp_path))[:1]
+    tok.encode_batch_files(batch_size=2, outdir=str(tmp_path / "out"), chunk_size=1, num_workers=0, audio_files=[str(p)] + good)
+    assert [os.path.basename(n) for n, _ in tok.skipped_files] == ["huge.flac"] and len(os.listdir(tmp_path / "out")) == 1
+    assert tok.run_summary["skipped_files"] == 1
+
+
+def test_pins_end_with_the_run(tmp_path):
+    class Pinning(_HashEncoder):
+        def __init__(self):
+            super().__init__()
+            self.pinned_layers, self.fallback_batches, self.unpinned = [7], 2, 0
+
+        def unpin_layers(self):
+            self.unpinned += 1
+            self.pinned_layers = []
+
+    enc = Pinning()
+    tok = _tok(enc)
+    tok.encode_batch_files(batch_size=2, outdir=str(tmp_path / "out"), chunk_size=1, num_workers=0, audio_files=_write_inputs(str(tmp_path))[:1])
+    assert enc.unpinned == 1 and enc.pinned_layers == [] and tok.run_summary["pinned_layers"] == [7] and tok.run_summary["fallback_batches"] == 2

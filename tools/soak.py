@@ -44,17 +44,17 @@ bad = 0
 enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=W.synth_encodec_weights(seed=0, with_decoder=False))
 wav = S.acoustic_batch(256, 240000, dev, 0)
 mask = torch.ones_like(wav)
-bad += soak("acoustic 256 x 10 s", enc, lambda: enc(wav, mask), n_ac, S.PINNED_CHECKSUMS["acoustic"])
+bad += soak("acoustic 256 x 10 s", enc, lambda: enc(wav, mask), n_ac, S.PINNED_CHECKSUMS[("uniform", "acoustic")])
 del enc, wav, mask
 enc = Wav2VecBertEncoder(Wav2VecBertConfig(output_layer=19), device="cuda:0", quantize=True, weights=W.synth_w2vbert_weights(n_layers=19, seed=0, with_vq=True))
 wav = S.semantic_m_batch(64, 480000, dev, 0)
 mask = torch.ones_like(wav)
-bad += soak("semantic_m 64 x 30 s", enc, lambda: enc(wav, mask), n_sm, S.PINNED_CHECKSUMS["semantic_m"])
+bad += soak("semantic_m 64 x 30 s", enc, lambda: enc(wav, mask), n_sm, S.PINNED_CHECKSUMS[("uniform", "semantic_m")])
 del enc, wav, mask
 enc = HubertEncoder(HubertEncoderConfig(output_layer=11), device="cuda:0", quantize=True, weights=W.synth_hubert_weights(n_layers=11, seed=0, with_kmeans=True))
 wav = S.semantic_s_batch(128, 480000, dev, 0)
 mask = torch.ones_like(wav)
-bad += soak("semantic_s 128 x 30 s", enc, lambda: enc(wav, mask), n_ss, S.PINNED_CHECKSUMS["semantic_s"])
+bad += soak("semantic_s 128 x 30 s", enc, lambda: enc(wav, mask), n_ss, S.PINNED_CHECKSUMS[("uniform", "semantic_s")])
 del enc, wav, mask
 torch.cuda.empty_cache()
 # round 4: the pipelined two-layer LSTM launch (three chained hand-off roles; <= 80 clips) in the encoder and the decoder's 64-clip configuration
