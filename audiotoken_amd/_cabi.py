@@ -22,7 +22,8 @@ class HipLibraryError(RuntimeError):
 class SegmentDesc(C.Structure):
     """Mirror of ``at_segment_desc`` (include/audiotoken_hip.h): one output row of at_segments_from_pcm."""
     _fields_ = [("pcm", C.c_void_p), ("table", C.c_void_p), ("chunk_off", C.c_int64), ("chunk_len", C.c_int32), ("out_start", C.c_int32),
-                ("valid_len", C.c_int32), ("fmt", C.c_int32), ("scale", C.c_float), ("o", C.c_int32), ("n", C.c_int32), ("width", C.c_int32)]
+                ("valid_len", C.c_int32), ("fmt", C.c_int32), ("scale", C.c_float), ("o", C.c_int32), ("n", C.c_int32), ("width", C.c_int32),
+                ("chunk_out_len", C.c_int32)]
 
 
 PCM_S16, PCM_S32, PCM_F32, PCM_U8 = 0, 1, 2, 3
@@ -114,6 +115,9 @@ SIGNATURES = {
     "at_hubert_range_sites": (C.c_int, [C.c_char_p, C.c_size_t]),
     "at_hubert_range_report": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "at_segments_from_pcm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "at_clock_stamp": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "at_segments_zmuv_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "at_segments_from_pcm_zmuv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "at_flac_info": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.c_void_p]),
     "at_flac_decode": (C.c_int64, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64]),
     "at_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),

@@ -271,8 +271,11 @@ class AudioToken:
             return ids, masks, file_pointers, ev
 
         # Device feeder (feeder.py): decoding stays on the host, sample conversion / per-chunk resampling / segmentation / padding run in one HIP kernel per
-        # batch. For tokenizers without a host-side transform (acoustic, semantic_m); `device_feeder=False` keeps the host data flow of the reference.
-        use_feeder = on_gpu and self.transform_func is None and dataloader_kwargs.get("device_feeder", True)
+        # batch — for semantic_s including its per-chunk zero-mean / unit-variance transform (feeder.py, transform="zmuv"); a custom transform_func and
+        # `device_feeder=False` keep the host data flow of the reference.
+        from .hubert import hubert_processor as _zmuv
+        dev_transform = "zmuv" if self.transform_func is _zmuv else None     # semantic_s: the per-chunk normalisation runs in the feeder's kernels
+        use_feeder = on_gpu and (self.transform_func is None or dev_transform) and dataloader_kwargs.get("device_feeder", True)
         self.feeder_timings = None
         if use_feeder:
             from .feeder import DeviceFeeder
@@ -281,7 +284,7 @@ class AudioToken:
                 logger.error(f"Skipping {name}: {why}")
                 self.skipped_files.append((name, why))
             feeder = DeviceFeeder(self.device, self.model_config.model_sample_rate, chunk_size, self.model_config.model_token_rate,
-                                  self.model_config.pad_token, num_workers, skipped)
+                                  self.model_config.pad_token, num_workers, skipped, transform=dev_transform)
             self.feeder_timings = feeder.timings
             staged_iter = feeder.batches(files, batch_size)
             stage_next = lambda: next(staged_iter, None)

@@ -14,8 +14,10 @@ throughput. So the split here is:
           per-chunk windowed-sinc resampling (same kernel table as the host twin ``audio_io.resample``), segmentation, zero padding, mask.
 
 The batches are the ones the host path (``AudioToken._chunk_stream`` + ``collate_fn``) produces, row for row: identical at the model's sample rate
-(integer * power of two is exact), within fp32 summation order (<= 1e-6) when resampled — tests/test_feeder_gpu.py. Used for the tokenizers whose
-``transform_func`` is None (acoustic, semantic_m); semantic_s normalises each chunk on the host (hubert_processor) and keeps the host path.
+(integer * power of two is exact), within fp32 summation order (<= 1e-6) when resampled — tests/test_feeder_gpu.py. Since round 5 also for
+Tokenizers.semantic_s: its per-chunk transform (``hubert_processor``: zero mean / unit variance over every streamed chunk, reference encoder.py:20-26 applied at
+datasets.py:78-79) is ``transform="zmuv"`` here — two more small launches take the chunk's float64 moments in a fixed order, the segment kernel normalises
+(``at_segments_from_pcm_zmuv``); rows equal the host transform's within float32 summation error.
 """
 from __future__ import annotations
 
@@ -84,7 +86,9 @@ class DeviceFeeder:
     (decode wait, upload, descriptors + launch) for bench.py's files leg."""
 
     def __init__(self, device, model_sample_rate: int, chunk_size: int, model_token_rate: int, pad_token: Optional[int] = 0, num_workers: int = 0,
-                 on_skip: Optional[Callable[[str, str], None]] = None):
+                 on_skip: Optional[Callable[[str, str], None]] = None, transform: Optional[str] = None):
+        assert transform in (None, "zmuv"), "the device feeder knows one per-chunk transform: 'zmuv' (hubert_processor)"
+        self.transform = transform
         self.device = torch.device(device)
         assert self.device.type == "cuda", "the device feeder needs a HIP device"
         self.lib = _cabi.load()
@@ -232,7 +236,7 @@ class DeviceFeeder:
                 if valid < MIN_SEGMENT_SAMPLES:
                     logger.warning(f'File segment {i // self.sr} of {name} is too short. Skipping')
                     continue
-                yield (pcm_dev.data_ptr(), table_ptr, c0, clen, i, valid, fmt, float(raw.scale), o, n, width), deepcopy(cfg), pcm_dev
+                yield (pcm_dev.data_ptr(), table_ptr, c0, clen, i, valid, fmt, float(raw.scale), o, n, width, Lr), deepcopy(cfg), pcm_dev
 
     def _launch(self, rows, pointers, keep):
         t0 = time.perf_counter()
@@ -243,8 +247,16 @@ class DeviceFeeder:
             d_dev = self._upload_on_stream(blob)
             segs = torch.empty((B, self.seg_len), dtype=torch.float32, device=self.device)
             masks = torch.empty((B, self.seg_len), dtype=torch.float32, device=self.device)
-            _cabi.check(self.lib.at_segments_from_pcm(d_dev.data_ptr(), B, self.seg_len, self.pad_value, segs.data_ptr(), masks.data_ptr(),
-                                                      C.c_void_p(self.stream.cuda_stream)), "at_segments_from_pcm")
+            if self.transform == "zmuv":
+                max_len = max(r[11] for r in rows)
+                nbytes = self.lib.at_segments_zmuv_workspace_bytes(B, max_len)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                _cabi.check(self.lib.at_segments_from_pcm_zmuv(d_dev.data_ptr(), B, self.seg_len, max_len, self.pad_value, 1e-7, segs.data_ptr(), masks.data_ptr(),
+                                                               ws.data_ptr(), nbytes, C.c_void_p(self.stream.cuda_stream)), "at_segments_from_pcm_zmuv")
+                del ws
+            else:
+                _cabi.check(self.lib.at_segments_from_pcm(d_dev.data_ptr(), B, self.seg_len, self.pad_value, segs.data_ptr(), masks.data_ptr(),
+                                                          C.c_void_p(self.stream.cuda_stream)), "at_segments_from_pcm")
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.timings["launch_s"] += time.perf_counter() - t0

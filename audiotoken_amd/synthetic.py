@@ -15,8 +15,8 @@ from . import weights as W
 # Keyed by (weight family, tokenizer); the batches are the kind="speech" ones at the BASELINE sizes (256 x 10 s, 64 x 30 s, 128 x 30 s), rank 0.
 # (Rounds 2-4 pinned 775618559 / 49212128 / 51528128 for the repeated 4-sine batches; re-pinned ONCE in round 5 when the clips became distinct.)
 PINNED_CHECKSUMS = {
-    ("uniform", "acoustic"): None, ("uniform", "semantic_m"): None, ("uniform", "semantic_s"): None,
-    ("trained_like", "acoustic"): None, ("trained_like", "semantic_m"): None, ("trained_like", "semantic_s"): None,
+    ("uniform", "acoustic"): 779361555, ("uniform", "semantic_m"): 85477913, ("uniform", "semantic_s"): 130741104,
+    ("trained_like", "acoustic"): 742693889, ("trained_like", "semantic_m"): 82653249, ("trained_like", "semantic_s"): None,
 }
 
 

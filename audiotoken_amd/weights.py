@@ -350,6 +350,19 @@ def synth_hubert_weights(n_layers: int = HUB_LAYERS_USED, seed: int = 0, with_km
         w["kmeans.cluster_centers_"] = prng.irwin_hall("kmeans.cluster_centers_", (HUB_CENTROIDS, H), 1.0, seed)
     if jobs:
         w = {**w, **_run_jobs(jobs)}
+    if trained:
+        # A post-LN stack hands its LayerNorm output — massive channels included — straight to the next layer's q / k projections. With RANDOM q / k weights
+        # those three channels alone produce logits of several hundred: the softmax degenerates into an arg-max whose winner flips under the smallest
+        # perturbation, and the network amplifies fp32 rounding noise 10 x per layer (measured, tools/family_probe.py + profiles/r05_family_probe_*.txt: the
+        # float32 ORACLE then sits 0.5 from its own float64 evaluation in LayerNorm-normalised units at depth 11, and no two fp32 implementations agree on
+        # the ids). Trained checkpoints are not chaotic: their q / k weights have learned the scale of those channels. Emulated here by dividing the q / k
+        # columns of the massive channels by the gain the preceding LayerNorm gives them; v, out_proj and the FFN keep seeing the massive values (the range /
+        # precision stress the family exists for). Conditioning after this: oracle32 vs oracle64 <= 5e-4 (uniform family: 5e-6).
+        for i in range(1, n_layers):
+            g = w[f"encoder.layers.{i - 1}.final_layer_norm.weight"][massive]
+            for nm in ("q_proj", "k_proj"):
+                key = f"encoder.layers.{i}.attention.{nm}.weight"
+                w[key][:, massive] = (w[key][:, massive] / g[None, :]).astype(np.float32)
     return w
 
 

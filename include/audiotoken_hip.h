@@ -256,8 +256,23 @@ typedef struct at_segment_desc {
     int32_t chunk_len, out_start, valid_len, fmt;
     float scale;
     int32_t o, n, width;
+    int32_t chunk_out_len;   /* samples of the whole resampled chunk (ceil(n * chunk_len / o); chunk_len at the model's rate): the span of the per-chunk moments below */
 } at_segment_desc;
 int at_segments_from_pcm(const at_segment_desc* descs_dev, int nseg, int seg_len, float pad_value, float* segments, float* masks, at_stream_t stream);
+/* The same with the reference's per-chunk transform of Tokenizers.semantic_s folded in (round 5): `hubert_processor` = HF Wav2Vec2FeatureExtractor with
+ * do_normalize (reference audiotoken/encoder.py:20-26), applied by the reference to every streamed chunk BEFORE it is cut and padded
+ * (audiotoken/datasets.py:78-79): valid samples become (x - mean) / sqrt(var + eps) with mean / population variance over the row's whole resampled chunk
+ * (float64 sums in a fixed order: deterministic), eps = 1e-7; padding stays pad_value. workspace: at_segments_zmuv_workspace_bytes(nseg, max over rows of
+ * chunk_out_len) bytes of device memory. Three launches, stream-ordered, no allocation. */
+size_t at_segments_zmuv_workspace_bytes(int nseg, int max_chunk_out_len);
+int at_segments_from_pcm_zmuv(const at_segment_desc* descs_dev, int nseg, int seg_len, int max_chunk_out_len, float pad_value, float eps, float* segments,
+                              float* masks, void* workspace, size_t workspace_bytes, at_stream_t stream);
+
+/* ---- measurement aid (bench.py): the clock the chip held over a stretch of the stream ----------------------------------------------------------------
+ * slots_dev: device uint64 [16][2], zeroed by the caller. One tiny launch writes {s_memtime (shader cycles), s_memrealtime (100 MHz)} into slot [xcc] for every
+ * XCD a wave of it ran on. Between two stamps A, B on one stream: held clock = (B.memtime - A.memtime) / (B.memrealtime - A.memrealtime) x 100 MHz per XCD
+ * (XCDs' counters are not mutually synchronised). No product kernel carries a stamp; the reference has no counterpart. */
+int at_clock_stamp(uint64_t* slots_dev, at_stream_t stream);
 
 /* ---- operator-level entry points (the kernels behind the models; used by the parity tests) ------------- */
 

@@ -22,11 +22,11 @@ def _host_rows(tok, files, chunk):
     return segs, masks, cfgs
 
 
-def _feeder_rows(tok, files, chunk, batch_size, workers=0):
+def _feeder_rows(tok, files, chunk, batch_size, workers=0, transform=None):
     from audiotoken_amd.feeder import DeviceFeeder
     skipped = []
     f = DeviceFeeder("cuda:0", tok.model_config.model_sample_rate, chunk, tok.model_config.model_token_rate, tok.model_config.pad_token, workers,
-                     lambda n, why: skipped.append((n, why)))
+                     lambda n, why: skipped.append((n, why)), transform=transform)
     segs, masks, cfgs = [], [], []
     for s, m, ptrs, ev in f.batches([str(x) for x in files], batch_size):
         torch.cuda.current_stream().wait_event(ev)
@@ -174,3 +174,59 @@ def test_token_files_are_the_same_with_and_without_the_feeder(cuda_device, tmp_p
         t = tok.encoder(seg.cuda(), torch.ones_like(seg).cuda()).cpu().numpy()[0]
         direct.append(t[:, :int(np.ceil(c.shape[1] / 24000 * 75))])
     assert np.array_equal(np.hstack(direct), np.load(tmp_path / "dev" / "r.npy"))
+
+
+# ---- round 5: Tokenizers.semantic_s through the device feeder (its per-chunk transform on the device) ---------------------------------------------------
+@pytest.mark.parametrize("src", [16000, 44100, 8000])
+def test_semantic_s_rows_match_the_host_transform(cuda_device, tmp_path, src):
+    """The reference normalises every streamed chunk with hubert_processor BEFORE cutting and padding it (audiotoken/encoder.py:20-26 applied at
+    datasets.py:78-79). The feeder's transform="zmuv" does it in its kernels (float64 chunk moments in a fixed order, then (x - mean) / sqrt(var + 1e-7)): rows
+    equal the host flow's (numpy float32 mean / var on the host-resampled chunk) to <= 1e-6 relative to unit-variance samples, masks and AudioConfigs are
+    identical, padding stays 0, and two runs are bit-identical. Files: 2.37 chunks (a padded last row whose moments span only its own samples), speech-like
+    and 4-sine content, a quiet file (level -46 dB: the normalisation multiplies by ~200)."""
+    from audiotoken_amd import synthetic as S
+    from audiotoken_amd.hubert import hubert_processor
+    tok = _tok("semantic_s")
+    tok.transform_func = hubert_processor
+    dst = tok.model_config.model_sample_rate
+    assert dst == 16000
+    n = int(src * 2.37) + 11
+    files = []
+    for i, x in enumerate((S.speech_like_waveform(1, n, src, seed=900 + src)[0], W.synth_waveform(1, n, src, seed=78)[0] * 0.005, W.synth_waveform(1, src, src, seed=79)[0])):
+        p = tmp_path / f"x{i}.wav"
+        _write(p, x / max(1e-9, np.abs(x).max()) * (0.9 if i != 1 else 0.005), src, "s16")
+        files.append(p)
+    hs, hm, hc = _host_rows(tok, files, 1)
+    ds, dm, dc, skipped, _ = _feeder_rows(tok, files, 1, batch_size=4, transform="zmuv")
+    assert skipped == [] and hs.shape == ds.shape == (7, dst)
+    assert torch.equal(hm, dm)
+    _same_configs(hc, dc)
+    err = (hs - ds).abs().max().item()
+    print(f"semantic_s rows from {src} Hz: max |device - host hubert_processor| {err:.2e} (max |row| {hs.abs().max().item():.2f}); "
+          f"row means {ds.sum(1).div(dm.sum(1)).abs().max().item():.1e}")
+    assert err <= 1e-6 * max(1.0, hs.abs().max().item())
+    assert float(ds[dm == 0].abs().max()) == 0.0                                # padding is pad_token, not (0 - mean) / std
+    valid = dm[2] == 1                                                            # the short last chunk of file 0: its OWN moments
+    assert abs(float(ds[2][valid].mean())) < 1e-5 and abs(float(ds[2][valid].var(unbiased=False)) - 1.0) < 1e-4
+    ds2 = _feeder_rows(tok, files, 1, batch_size=4, transform="zmuv")[0]
+    assert torch.equal(ds, ds2)
+
+
+def test_semantic_s_token_files_through_the_feeder(cuda_device, tmp_path):
+    """encode_batch_files of Tokenizers.semantic_s end to end: the device feeder is now used (round 5) and writes the token files the host data flow writes."""
+    from audiotoken_amd import AudioToken, Tokenizers
+    from audiotoken_amd import synthetic as S
+    w = W.synth_hubert_weights(11, 0, True)
+    _write(tmp_path / "n.wav", S.speech_like_waveform(1, 16000 * 3 + 500, 16000, seed=15)[0] * 4, 16000, "s16")
+    _write(tmp_path / "r.wav", W.synth_waveform(1, int(44100 * 2.2), 44100, seed=16)[0], 44100, "s16")
+    files = [tmp_path / "n.wav", tmp_path / "r.wav", os.path.join(G, "flac_a.flac")]
+    tok = AudioToken(Tokenizers.semantic_s, device="cuda:0", weights=w)
+    tok.encode_batch_files(batch_size=3, outdir=tmp_path / "dev", chunk_size=1, audio_files=files, num_workers=2)
+    assert tok.feeder_timings is not None and tok.feeder_timings["segments"] == 3 + 3 + 2
+    tok.encode_batch_files(batch_size=3, outdir=tmp_path / "host", chunk_size=1, audio_files=files, num_workers=0, device_feeder=False)
+    assert tok.feeder_timings is None
+    for name in ("n.npy", "r.npy", "flac_a.npy"):
+        a, b = np.load(tmp_path / "dev" / name), np.load(tmp_path / "host" / name)
+        assert a.shape == b.shape and a.dtype == np.int16 and a.shape[0] == 1
+        print(f"{name}: {a.shape} tokens, device feeder == host path at {float((a == b).mean()):.4f}")
+        assert np.array_equal(a, b)
