@@ -178,7 +178,8 @@ __device__ __forceinline__ float lstm_tanh(float x) {
 // Exact-form GELU 0.5 y (1 + erf(y / sqrt 2)) with erfc from Abramowitz-Stegun 7.1.26 on v_rcp_f32 / v_exp_f32:
 // |error| <= 4.3e-7 over [-10, 10] (about one ulp of the result where it is largest), ~20 VALU issue slots instead of
 // ~45 for ocml erff — HuBERT evaluates 19 G of these per step and VALU time is not hidden behind the fp32 MFMA.
-__device__ __forceinline__ float gelu_erf(float y) {
+// half = 0.5 s: returns s * GELU(y) for a power of two s, bit for bit s times gelu_erf(y) (only the leading multiply's constant changes)
+__device__ __forceinline__ float gelu_erf_scaled(float y, float half) {
     const float x = fabsf(y) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
     float p = fmaf(t, 1.061405429f, -1.453152027f);
@@ -186,8 +187,9 @@ __device__ __forceinline__ float gelu_erf(float y) {
     p = fmaf(t, p, -0.284496736f);
     p = fmaf(t, p, 0.254829592f);
     const float e = (p * t) * __expf(-x * x);        // erfc(|y| / sqrt 2)
-    return 0.5f * y * (y < 0.0f ? e : 2.0f - e);
+    return half * y * (y < 0.0f ? e : 2.0f - e);
 }
+__device__ __forceinline__ float gelu_erf(float y) { return gelu_erf_scaled(y, 0.5f); }
 // swish of the conformer conv module's depthwise-conv kernels: x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (~1 ulp each) like the GEMM's swish and GLU
 // epilogues (until late in round 3: ocml expf + a correctly rounded division, ~30 more vector instructions per value in a vector-bound kernel)
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }

@@ -64,6 +64,7 @@ struct at_hubert {
     const piece_t* cen_s[2] = {};        // the k-means centres as operand pieces per scheme, rows padded 1000 -> 1024 (zero rows): the score GEMM on the split kernel
     float cen_scale = 1.f;
     bool kmeans_split = true;            // option "kmeans_split": that GEMM on the split kernel instead of the fp32 MFMA (as at_w2vbert's "vq_split")
+    bool ln_split = true;                // option "ln_split" (round 5): the post-LN LayerNorms write the fp32 residual stream AND the next GEMM's operand pieces in one pass (launch_layernorm_split, D = 768) instead of LayerNorm + a separate split pass; bit-identical
     bool posconv_split = true;           // option "posconv_split": the LDS-resident grouped conv kernel (hubert_posconv.hip) instead of 16 fp32 windowed GEMMs
     float conv_wscale[7] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     int arith = ARITH_F16X2;   // linear layers + conv chain: ARITH_* ($AUDIOTOKEN_SEMANTIC_ARITH = f32 | bf16x3 | f16x2; option "arith")
@@ -527,6 +528,7 @@ int at_hubert_set_option(at_hubert_t* h, const char* name, int value) {
     }
     if (n == "attn_w8") { h->attn_w8 = value < 0 ? -1 : (value != 0); return 0; }
     if (n == "posconv_split") { h->posconv_split = value != 0; return 0; }
+    if (n == "ln_split") { h->ln_split = value != 0; return 0; }
     if (n == "kmeans_split") { h->kmeans_split = value != 0; return 0; }
     set_error("at_hubert_set_option: unknown option " + n);
     return -1;
@@ -541,6 +543,7 @@ int at_hubert_get_option(const at_hubert_t* h, const char* name) {
     }
     if (std::string(name) == "attn_w8") return h->attn_w8;
     if (std::string(name) == "posconv_split") return h->posconv_split ? 1 : 0;
+    if (std::string(name) == "ln_split") return h->ln_split ? 1 : 0;
     if (std::string(name) == "kmeans_split") return h->kmeans_split ? 1 : 0;
     return -1;
 }
@@ -643,7 +646,21 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         a.M = T; a.N = kGc; a.K = kPosK * kGc; a.batch = B; a.epi = EPI_GELU;
         if (int rc = launch_gemm(a, stream)) return rc;
     }
-    if (int rc = launch_layernorm(pos, h->enc_ln_g, h->enc_ln_b, nullptr, x, M, kHid, stream)) return rc;
+    // xs_ready: the LayerNorm that wrote x also wrote the pieces of x the next split GEMM reads (option "ln_split"; the scheme / scale / range row are the
+    // CONSUMING layer's)
+    bool xs_ready = false;
+    auto ln_to = [&](const float* src, const float* g, const float* b, int consumer_layer, bool for_qkv) -> int {
+        if (split && h->ln_split && consumer_layer < n_layers) {
+            const SplitCtx c = ctx_of(consumer_layer);
+            const LayerW& Lc = h->layers[consumer_layer];
+            const float sc_x = c.scheme == XB_SCHEME_F16X2 ? (for_qkv ? Lc.xs_qkv : Lc.xs_ffn) : 1.0f;
+            xs_ready = true;
+            return launch_layernorm_split(src, g, b, nullptr, x, xs, M, Mpad, kHid, c.scheme, sc_x, c.site(HS_X_IN), stream);
+        }
+        xs_ready = false;
+        return launch_layernorm(src, g, b, nullptr, x, M, kHid, stream);
+    };
+    if (int rc = ln_to(pos, h->enc_ln_g, h->enc_ln_b, 0, true)) return rc;
     prof.end(stream);
 
     for (int li = 0; li < n_layers; ++li) {
@@ -655,14 +672,15 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         // output projection's operand pieces (as in w2vbert.hip)
         const bool kvp = split && attn_arith_l == ARITH_F16X2 && scl.scheme == XB_SCHEME_F16X2 && attn_kvp;
         if (kvp) {
-            if (int rc = launch_split_blocked(x, kHid, M, Mpad, kHid, xs, stream, scl.scheme, L.xs_qkv, scl.site(HS_X_IN))) return rc;   // (kvp: the scheme is f16x2)
+            if (!xs_ready)
+                if (int rc = launch_split_blocked(x, kHid, M, Mpad, kHid, xs, stream, scl.scheme, L.xs_qkv, scl.site(HS_X_IN))) return rc;   // (kvp: the scheme is f16x2)
             Bf16x3Args qa;
             qa.A = xs; qa.W = L.ws[scl.scheme][HW_QKV]; qa.bias = L.bqkv; qa.M = (int)M; qa.N = 3 * kHid; qa.K = kHid; qa.Mpad = (int)Mpad;
             qa.epi = XB_EPI_QKV; qa.C = big; qa.ldc = 3 * kHid; qa.S = kvs; qa.Spad = (int)Mpad; qa.qkv_hid = kHid;
             qa.scheme = scl.scheme; qa.status = scl.site(HS_QKV_KV); qa.acc_scale = 1.0f / (L.xs_qkv * L.wscale[HW_QKV]); qa.split_scale = XB_F16_ACT_SCALE;
             if (int rc = launch_gemm_bf16x3(qa, stream)) return rc;
         } else if (split) {
-            if (int rc = linear_split(scl, x, kHid, nullptr, xs, L, HW_QKV, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream, L.xs_qkv)) return rc;
+            if (int rc = linear_split(scl, xs_ready ? nullptr : x, kHid, xs, xs, L, HW_QKV, L.bqkv, big, 3 * kHid, M, Mpad, XB_EPI_LINEAR, nullptr, 3 * kHid, nullptr, stream, L.xs_qkv)) return rc;
         } else if (int rc = linear(x, kHid, L.wqkv, L.bqkv, big, 3 * kHid, M, EPI_NONE, nullptr, nullptr, 3 * kHid, stream)) {
             return rc;
         }
@@ -678,17 +696,17 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
         } else if (int rc = linear(t1, kHid, L.wo, L.bo, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) {
             return rc;
         }
-        if (int rc = launch_layernorm(x, L.ln1_g, L.ln1_b, nullptr, x, M, kHid, stream)) return rc;
+        if (int rc = ln_to(x, L.ln1_g, L.ln1_b, li, false)) return rc;
         prof.end(stream);
         prof.begin("ffn", 3, stream);
         if (split) {   // hidden activation written split by the first GEMM's epilogue
-            if (int rc = linear_split(scl, x, kHid, nullptr, xs, L, HW_1, L.b1, nullptr, kFfn, M, Mpad, XB_EPI_GELU_SPLIT, nullptr, kFfn, bigs, stream, L.xs_ffn)) return rc;
+            if (int rc = linear_split(scl, xs_ready ? nullptr : x, kHid, xs, xs, L, HW_1, L.b1, nullptr, kFfn, M, Mpad, XB_EPI_GELU_SPLIT, nullptr, kFfn, bigs, stream, L.xs_ffn)) return rc;
             if (int rc = linear_split(scl, nullptr, kFfn, bigs, nullptr, L, HW_2, L.b2, x, kHid, M, Mpad, XB_EPI_LINEAR, x, kHid, nullptr, stream)) return rc;
         } else {
             if (int rc = linear(x, kHid, L.w1, L.b1, big, kFfn, M, EPI_GELU, nullptr, nullptr, kFfn, stream)) return rc;
             if (int rc = linear(big, kFfn, L.w2, L.b2, x, kHid, M, EPI_NONE, x, nullptr, kHid, stream)) return rc;
         }
-        if (int rc = launch_layernorm(x, L.ln2_g, L.ln2_b, nullptr, x, M, kHid, stream)) return rc;
+        if (int rc = ln_to(x, L.ln2_g, L.ln2_b, li + 1, true)) return rc;     // (the last layer: plain LayerNorm, nothing consumes pieces)
         prof.end(stream);
     }
     if (status_dev)   // every site's range verdict of this call -> the caller's status word

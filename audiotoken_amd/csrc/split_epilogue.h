@@ -21,14 +21,16 @@ struct XbEpilogue {
     }
 
     // split outputs: [pieces][batch][blocks][phases][pad][16]; output row m lives in plane m % phases at index m / phases + front
-    template <bool FD = false>
+    // PRE: `v` already carries a.split_scale (the swish / GELU epilogues fold the power of two into their last multiply: bit-identical, one instruction less)
+    template <bool FD = false, bool PRE = false>
     __device__ __forceinline__ void write_split(__bf16* S_, int pad, int phases, int front, int blocks, int block0, int m, int n, const f4& v, const FastDivU* fd = nullptr) {
         PT* S = reinterpret_cast<PT*>(S_);
         const int nb = blocks > 0 ? blocks : a.N / 16;
         const long long s_clip = (long long)pad * phases * nb * 16;   // elements of one clip of one piece
         const long long psS = s_clip * a.batch;
         typename SC::V4 p[SC::NP];
-        over |= split4<SC>(v, a.split_scale, p);
+        if constexpr (PRE) over |= split4_prescaled<SC>(v, p);
+        else over |= split4<SC>(v, a.split_scale, p);
         const int sq = FD ? (int)fd->div((unsigned)m) : m / phases, sp = m - sq * phases;
         PT* d = S + clip * s_clip + (((long long)(block0 + (n >> 4)) * phases + sp) * pad + sq + front) * 16 + (n & 15);
 #pragma unroll
@@ -64,13 +66,15 @@ struct XbEpilogue {
         return v;
     }
     // phases == 1: [pieces][batch][blocks][pad][16]
+    template <bool PRE = false>
     __device__ __forceinline__ void write_split_ph1(__bf16* S_, int pad, int front, int blocks, int block0, int m, int n, const f4& v) {
         PT* S = reinterpret_cast<PT*>(S_);
         const int nb = blocks > 0 ? blocks : a.N / 16;
         const long long s_clip = (long long)pad * nb * 16;
         const long long psS = s_clip * a.batch;
         typename SC::V4 p[SC::NP];
-        over |= split4<SC>(v, a.split_scale, p);
+        if constexpr (PRE) over |= split4_prescaled<SC>(v, p);
+        else over |= split4<SC>(v, a.split_scale, p);
         PT* d = S + clip * s_clip + (long long)(block0 + (n >> 4)) * pad * 16 + (m + front) * 16 + (n & 15);
 #pragma unroll
         for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(d + i * psS) = p[i];
@@ -90,14 +94,20 @@ struct XbEpilogue {
             const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
             write_split<FASTDIV>(a.S2, a.S2pad, a.S2phases, a.S2front, a.S2blocks, a.S2block0, m, n, e, &a.fdS2);
         } else if constexpr (E == XB_EPI_SWISH_SPLIT || E == XB_EPI_GELU_SPLIT || E == XB_EPI_ELU_SPLIT) {
+            // fp16 scheme, swish / GELU: the site's power-of-two scale s rides on the activation's last multiply — swish: x * rcp((1 + e) / s) with (1 + e) / s
+            // formed by ONE fma(e, 1 / s, 1 / s) in place of the add (v_rcp_f32 of a power-of-two multiple is that multiple of the reciprocal: only the
+            // exponent moves); GELU: (0.5 s) y (...) — so the values handed to the split are bit for bit s times the unscaled activation and the split's
+            // own v_pk_mul_f32 goes (round 5)
+            constexpr bool PRE = SC::NP == 2 && (E == XB_EPI_SWISH_SPLIT || E == XB_EPI_GELU_SPLIT);
+            const float s_ = PRE ? a.split_scale : 1.0f, inv_s = PRE ? 1.0f / a.split_scale : 1.0f;
             f4 w;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                w[k] = E == XB_EPI_GELU_SPLIT ? gelu_erf(v[k])
+                w[k] = E == XB_EPI_GELU_SPLIT ? gelu_erf_scaled(v[k], 0.5f * s_)
                      : E == XB_EPI_ELU_SPLIT ? elu1(v[k])
-                                             : v[k] * sigmoidf_(v[k]);   // v_exp_f32 + v_rcp_f32 (~1 ulp each), as the fp32 GEMM's epilogue (the correctly rounded reciprocal cost 5 more instructions per value)
-            if constexpr (PH1) write_split_ph1(a.S, a.Spad, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
-            else write_split<FASTDIV>(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w, &a.fdS);
+                                             : v[k] * __builtin_amdgcn_rcpf(fmaf(__expf(-v[k]), inv_s, inv_s));   // = s x sigmoid(x): v_exp_f32 + v_rcp_f32 (~1 ulp each), as the fp32 GEMM's epilogue
+            if constexpr (PH1) write_split_ph1<PRE>(a.S, a.Spad, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
+            else write_split<FASTDIV, PRE>(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w, &a.fdS);
         } else if constexpr (E == XB_EPI_QKV) {
             if (n < a.qkv_hid) {
                 *reinterpret_cast<f4*>(Cb + (long long)m * a.ldc + n) = v;

@@ -83,23 +83,35 @@ __device__ __forceinline__ void split_n(float a, typename SC::T (&p)[SC::NP]) {
         a -= (float)p[i];
     }
 }
+// four already scaled values -> fp16 hi quad and lo quad (see split4)
+template <class V4>
+__device__ __forceinline__ void split_pair_f16(float a0, float a1, float b0, float b1, V4& hi4, V4& lo4) {
+    unsigned ha, hb, la, lb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ha) : "v"(a0), "v"(a1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hb) : "v"(b0), "v"(b1));
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(la) : "v"(ha), "v"(a0));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(la) : "v"(ha), "v"(a1));
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(b0));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(b1));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    static_assert(sizeof(V4) == sizeof(u2), "a quad of 16-bit pieces is two dwords");
+    hi4 = __builtin_bit_cast(V4, u2{ha, hb});
+    lo4 = __builtin_bit_cast(V4, u2{la, lb});
+}
+
 // four values * scale -> NP pieces of four; returns max |v * scale| of the four for the caller's RangeMax (0 for a scheme without a range check)
 template <class SC>
 __device__ __forceinline__ float split4(const f4& v, float scale, typename SC::V4 (&p)[SC::NP]) {
     if constexpr (SC::NP == 2) {
-        // the fp16 scheme written on value PAIRS so that it compiles to the packed forms (v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32: three
-        // instructions per value instead of five; the element-wise form below left half of the pairs to scalar code). Same arithmetic: the scale
-        // is a power of two (x * s exact), hi = rne(x s), x s - hi exact, lo = rne(x s - hi).
+        // the fp16 scheme on value PAIRS, 2 instructions per value (round 5; 3 before): hi = rne(x s) by v_cvt_pk_f16_f32 on the scaled pair
+        // (v_pk_mul_f32: the scale is a power of two, x s exact), lo = rne(x s - hi) by v_fma_mixlo / mixhi_f16 — (-hi as fp16) * 1.0 + x s with the
+        // exact difference formed inside the fma and rounded once: the very values of convert, convert back, subtract, convert (x s - hi is exact in
+        // fp32), without the two v_cvt_f32_f16 and the packed subtract. (attention_f16x2_w8.hip has split its probabilities this way since round 4.)
         typedef float f2 __attribute__((ext_vector_type(2)));
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const f2 a = f2{v[0], v[1]} * scale, b = f2{v[2], v[3]} * scale;
         float over = 0.f;
         if constexpr (SC::RANGE_CHECK) over = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(b[0]), fabsf(b[1])));
-        const h2 ah = __builtin_convertvector(a, h2), bh = __builtin_convertvector(b, h2);
-        const f2 ar = a - __builtin_convertvector(ah, f2), br = b - __builtin_convertvector(bh, f2);
-        const h2 al = __builtin_convertvector(ar, h2), bl = __builtin_convertvector(br, h2);
-        p[0] = typename SC::V4{ah[0], ah[1], bh[0], bh[1]};
-        p[1] = typename SC::V4{al[0], al[1], bl[0], bl[1]};
+        split_pair_f16(a[0], a[1], b[0], b[1], p[0], p[1]);
         return over;
     } else {
         float over = 0.f;
@@ -114,6 +126,16 @@ __device__ __forceinline__ float split4(const f4& v, float scale, typename SC::V
         }
         return over;
     }
+}
+
+// split4 for values the caller has ALREADY multiplied by the site's scale (an epilogue that folds the power of two into its last multiply: exact)
+template <class SC>
+__device__ __forceinline__ float split4_prescaled(const f4& vs, typename SC::V4 (&p)[SC::NP]) {
+    static_assert(SC::NP == 2, "prescaled split: the fp16 scheme");
+    float over = 0.f;
+    if constexpr (SC::RANGE_CHECK) over = fmaxf(fmaxf(fabsf(vs[0]), fabsf(vs[1])), fmaxf(fabsf(vs[2]), fabsf(vs[3])));
+    split_pair_f16(vs[0], vs[1], vs[2], vs[3], p[0], p[1]);
+    return over;
 }
 
 // pieces of the 4 consecutive columns col .. col + 3 (col % 4 == 0) of row `row`, into K-blocked pieces [NP][K/16][rows_pad][16]

@@ -319,7 +319,8 @@ constexpr int LNS_RW = LNS_ROWS / 4;          // rows per wave
 // DOUBLE: two LayerNorms back to back — y = LN(x; gamma, beta) is written as fp32 rows (WRITE_Y) and the pieces are split(LN(y; gamma2, beta2)). That is the
 // conformer's final_layer_norm followed by the next layer's ffn1_layer_norm (w2vbert.hip): one pass over the residual stream instead of two (y is not read
 // back). Each LayerNorm reduces exactly as layernorm_kernel / the single form do (same lane mapping, same sums): bit-identical to the two launches.
-template <class SC, bool WRITE_Y, bool DOUBLE = false>
+// D: 1024 (conformer) or 768 (HuBERT, round 5: its post-LN layers write the fp32 residual stream AND the next GEMM's pieces in one pass); D / 256 float4 per lane
+template <class SC, bool WRITE_Y, bool DOUBLE = false, int D = LNS_D>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ row_mask, float* __restrict__ y, typename SC::T* __restrict__ out,
                                                               long long rows, long long rows_pad, float scale, int* __restrict__ status,
@@ -330,53 +331,55 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
     // [piece][k-block][8 rows x 16 + 16 pad]: with the natural 256-byte k-block stride all 16 k-blocks a wave writes at once fell on the same banks
     // (PMC, round 4: 47 % of this kernel's LDS cycles were conflict replays); + 32 bytes per k-block spreads them over all 64 banks
     constexpr int KB_LD = LNS_ROWS * 16 + 16;
-    __shared__ __attribute__((aligned(16))) PT tile[NP][LNS_D / 16][KB_LD];   // 36 KB (two pieces) / 54 KB (three)
+    constexpr int NJ = D / 256;
+    static_assert(D % 256 == 0 && NJ >= 1 && NJ <= 4, "layernorm_split: D = 256 .. 1024 in steps of 256");
+    __shared__ __attribute__((aligned(16))) PT tile[NP][D / 16][KB_LD];   // 36 KB (two pieces) / 54 KB (three)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long r0 = (long long)blockIdx.x * LNS_ROWS;
     RangeMax over;
     // all rows of the wave are loaded before the first is reduced (one row at a time left 4 KB per wave in flight: 3.5 TB/s, 70 % of the wave
     // cycles waiting); 8 rows per workgroup instead of 16 puts four workgroups on a CU: 16.0 -> 13.7 ms per semantic_m step (4 rows: no further gain)
-    f4 vall[LNS_RW][4];
+    f4 vall[LNS_RW][NJ];
 #pragma unroll
     for (int rr = 0; rr < LNS_RW; ++rr) {
         const long long row = r0 + wave * LNS_RW + rr;
         if (row < rows) {
-            const f4* xr = reinterpret_cast<const f4*>(x + row * LNS_D);
+            const f4* xr = reinterpret_cast<const f4*>(x + row * D);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vall[rr][j] = xr[lane + 64 * j];
+            for (int j = 0; j < NJ; ++j) vall[rr][j] = xr[lane + 64 * j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vall[rr][j] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) vall[rr][j] = f4{0.f, 0.f, 0.f, 0.f};
         }
     }
 #pragma unroll
     for (int rr = 0; rr < LNS_RW; ++rr) {
         const int lr = wave * LNS_RW + rr;
         const long long row = r0 + lr;
-        f4 v[4];
+        f4 v[NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = vall[rr][j];
+        for (int j = 0; j < NJ; ++j) v[j] = vall[rr][j];
         const bool zero = row >= rows || (row_mask && row_mask[row] == 0.f);
         // v -> LayerNorm(v; g, bb) in place (torch's CPU operation order, as layernorm_kernel)
         auto normalize = [&](const float* g_, const float* b_) {
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            for (int j = 0; j < NJ; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-            const float mean = s / (float)LNS_D;
+            const float mean = s / (float)D;
             float q = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const f4 d = v[j] - mean;
                 q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
-            const float rstd = 1.0f / sqrtf(q / (float)LNS_D + 1e-5f);
+            const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
             const float shift = -rstd * mean;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int c = lane + 64 * j;           // float4 index: columns 4c .. 4c + 3 = k-block c / 4, quarter c % 4
                 f4 o;
 #pragma unroll
@@ -395,11 +398,11 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
         if constexpr (WRITE_Y)
             if (row < rows) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) reinterpret_cast<f4*>(y + row * LNS_D)[lane + 64 * j] = v[j];
+                for (int j = 0; j < NJ; ++j) reinterpret_cast<f4*>(y + row * D)[lane + 64 * j] = v[j];
             }
         if constexpr (DOUBLE) normalize(gamma2, beta2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int c = lane + 64 * j;
             V4 p[NP];
             over |= split4<SC>(v[j], scale, p);
@@ -410,10 +413,11 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
     __syncthreads();
     // (piece, k-block) = LNS_ROWS rows x 32 B contiguous = 2 LNS_ROWS chunks of 16 B: thread -> chunk
     typedef unsigned int u4_ __attribute__((ext_vector_type(4)));
-    const long long ps = rows_pad * (long long)LNS_D;
+    const long long ps = rows_pad * (long long)D;
     constexpr int CH = 2 * LNS_ROWS;
-    for (int e = threadIdx.x; e < NP * (LNS_D / 16) * CH; e += 256) {
-        const int ch = e % CH, kb = (e / CH) & 63, pi = e / (CH * 64);
+    constexpr int KB = D / 16;
+    for (int e = threadIdx.x; e < NP * KB * CH; e += 256) {
+        const int ch = e % CH, kb = (e / CH) % KB, pi = e / (CH * KB);
         const int lr = ch >> 1;
         if (r0 + lr < rows_pad)
             *reinterpret_cast<u4_*>(out + pi * ps + ((long long)kb * rows_pad + r0 + lr) * 16 + (ch & 1) * 8) =
@@ -440,8 +444,19 @@ int launch_layernorm2_split(const float* x, const float* gamma, const float* bet
 
 int launch_layernorm_split(const float* x, const float* gamma, const float* beta, const float* row_mask, float* y, __bf16* out, long long rows, long long rows_pad,
                            int D, int scheme, float scale, int* status, hipStream_t stream) {
-    AT_REQUIRE(D == LNS_D && rows_pad >= rows && rows_pad % LNS_ROWS == 0 && out, "layernorm_split: D must be 1024, rows_pad a multiple of 8");
+    AT_REQUIRE((D == LNS_D || D == 768) && rows_pad >= rows && rows_pad % LNS_ROWS == 0 && out, "layernorm_split: D must be 1024 or 768, rows_pad a multiple of 8");
     const unsigned blocks = (unsigned)(rows_pad / LNS_ROWS);
+    if (D == 768) {   // HuBERT: always with the fp32 rows (the post-LN residual stream)
+        AT_REQUIRE(y != nullptr, "layernorm_split: the 768-wide form writes fp32 rows as well");
+        if (scheme == XB_SCHEME_F16X2)
+            hipLaunchKernelGGL((layernorm_split_kernel<SchemeF16x2, true, false, 768>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y,
+                               reinterpret_cast<_Float16*>(out), rows, rows_pad, scale, status, (const float*)nullptr, (const float*)nullptr);
+        else
+            hipLaunchKernelGGL((layernorm_split_kernel<SchemeBf16x3, true, false, 768>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, out, rows,
+                               rows_pad, scale, status, (const float*)nullptr, (const float*)nullptr);
+        AT_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (scheme == XB_SCHEME_F16X2) {
         _Float16* o = reinterpret_cast<_Float16*>(out);
         if (y) hipLaunchKernelGGL((layernorm_split_kernel<SchemeF16x2, true>), dim3(blocks), dim3(256), 0, stream, x, gamma, beta, row_mask, y, o, rows, rows_pad, scale, status, (const float*)nullptr, (const float*)nullptr);

@@ -101,3 +101,19 @@ def gather_scalars(values: Sequence[float], device: torch.device, dist=None) -> 
     outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, t)
     return [o.tolist() for o in outs]
+
+
+def ranks_agree_on_probe(encode, probe: torch.Tensor, device: torch.device, dist=None, what: str = "encoder") -> dict:
+    """Start-up self-check of a multi-rank run: every rank encodes the SAME small probe batch with the model it ended up with (rank 0 built it from the
+    checkpoint, the others received it by broadcast_weights / broadcast_packed + import_packed) and the token checksums — sum of ids and a position-weighted
+    sum, so a permutation cannot cancel — are all-gathered. Any rank that differs from rank 0 raises on EVERY rank before a single timed step or token file:
+    a wrong import on one rank must not produce a fast, wrong scaling curve (the reference is single-device, audiotoken/core.py:66: nothing to mirror)."""
+    toks = encode(probe).to(torch.int64).reshape(-1)
+    w = torch.arange(1, toks.numel() + 1, device=toks.device, dtype=torch.int64) % 8191
+    mine = [float(toks.sum().item()), float((toks * w).sum().item() % (1 << 50))]
+    rows = gather_scalars(mine, device, dist)
+    bad = [r for r, row in enumerate(rows) if row != rows[0]]
+    if bad:
+        raise RuntimeError(f"{what}: ranks {bad} encode the start-up probe differently from rank 0 ({[rows[r] for r in bad]} vs {rows[0]}): "
+                           "a rank's model differs (packed-model import / weight broadcast) — refusing to run")
+    return {"ranks": len(rows), "token_checksum": int(rows[0][0]), "weighted_checksum": int(rows[0][1])}

@@ -16,7 +16,7 @@ from . import weights as W
 # (Rounds 2-4 pinned 775618559 / 49212128 / 51528128 for the repeated 4-sine batches; re-pinned ONCE in round 5 when the clips became distinct.)
 PINNED_CHECKSUMS = {
     ("uniform", "acoustic"): 779361555, ("uniform", "semantic_m"): 85477913, ("uniform", "semantic_s"): 130741104,
-    ("trained_like", "acoustic"): 742693889, ("trained_like", "semantic_m"): 82653249, ("trained_like", "semantic_s"): None,
+    ("trained_like", "acoustic"): 742693889, ("trained_like", "semantic_m"): 82653249, ("trained_like", "semantic_s"): 134409645,
 }
 
 

@@ -219,16 +219,26 @@ def all_host_threads() -> int:
         return os.cpu_count() or 1
 
 
-def at_all_threads(run, sample_audio_s: float, base: dict) -> dict:
+def at_all_threads(run, sample_audio_s: float, base: dict, probe=None, probe_audio_s: float = 1.0, probe_base_s: float = None) -> dict:
     """BASELINE.md section 3 prescribes torch.set_num_threads(os.cpu_count()) for the CPU baseline; the headline figure uses <= 16 threads because the
-    oracle's dependent loops (750 LSTM steps) collapse under oversubscription. Both are reported: the SAME sample once more with every core this process may
-    run on (skipped when that is <= the threads already used)."""
+    oracle's dependent loops (750 LSTM steps) collapse under oversubscription. Both are reported. To keep the default run bounded, a 1 s PROBE is timed
+    first with every core this process may run on: only if it is not slower than the same probe at the headline thread count is the whole sample repeated;
+    otherwise the probe's own rate is reported and says so (the collapse is the finding)."""
     n = all_host_threads()
     if n <= base["cores"]:
         return {"value": base["value"], "cores": n, "note": "same thread count as the headline figure"}
     torch.set_num_threads(n)
     try:
         with torch.no_grad():
+            if probe is not None:
+                probe()
+                t0 = time.perf_counter()
+                probe()
+                tp = time.perf_counter() - t0
+                if probe_base_s is not None and tp > 1.25 * probe_base_s:
+                    return {"value": round(probe_audio_s / tp, 3), "unit": "audio-s/s", "cores": n, "seconds": round(tp, 2),
+                            "note": f"probe only ({probe_audio_s:g} s of audio): {tp / probe_base_s:.1f} x SLOWER than the same probe on {base['cores']} threads "
+                                    "(oversubscribed dependent loops) — the full sample was not repeated"}
             t0 = time.perf_counter()
             run()
             dt = time.perf_counter() - t0
@@ -262,7 +272,7 @@ def cpu_baseline_acoustic(n_q: int, budget_s: float = 15.0):
     res = {"value": round(clips * 10.0 / t_total, 3), "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"{clips} clip(s) x 10 s @24 kHz in one batch, n_q={n_q}, oracle/encodec_ref.py (torch-CPU fp32), "
                      f"{t_total:.1f} s of CPU work"}
-    res["at_all_threads"] = at_all_threads(lambda: R.acoustic_encode(wt, wav, n_q), clips * 10.0, res)
+    res["at_all_threads"] = at_all_threads(lambda: R.acoustic_encode(wt, wav, n_q), clips * 10.0, res, lambda: R.acoustic_encode(wt, probe, n_q), 1.0, per_audio_s)
     return res
 
 
@@ -313,7 +323,8 @@ def cpu_baseline_semantic(n_layers: int, budget_s: float = 20.0):
     res = {"value": round(clips * n / 16000.0 / t_total, 3), "unit": "audio-s/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"{clips} clip(s) x {n / 16000.0:.1f} s @16 kHz, {n_layers} conformer layers, oracle/w2vbert_ref.py (torch-CPU fp32), "
                      f"{t_total:.1f} s of CPU work"}
-    res["at_all_threads"] = at_all_threads(lambda: R.semantic_m_encode(wt, wav, torch.ones_like(wav), 2, n_layers), clips * n / 16000.0, res)
+    res["at_all_threads"] = at_all_threads(lambda: R.semantic_m_encode(wt, wav, torch.ones_like(wav), 2, n_layers), clips * n / 16000.0, res,
+                                           lambda: R.semantic_m_encode(wt, probe, torch.ones_like(probe), 2, n_layers), 1.0, per_s)
     return res
 
 
@@ -352,6 +363,7 @@ def run_hubert(args, rank, world, dev, dist):
         del packed
     del weights
     from audiotoken_amd import synthetic as S
+    probe = rank_probe(lambda x: enc(x, torch.ones_like(x)), 16000, dev, dist, "semantic_s")
     wav = S.semantic_s_batch(B, N, dev, rank)
     mask = torch.ones_like(wav)
     enc._bench_inputs = (wav, mask)
@@ -380,7 +392,7 @@ def run_hubert(args, rank, world, dev, dist):
         "token_checksum": S.token_checksum(toks),
         "checksum_pinned": (S.token_checksum(toks) == S.PINNED_CHECKSUMS[(args.weights, "semantic_s")]) if (rank == 0 and B == 128 and N == 480000) else None,
         "total_tflops": round(sum(flops.values()) * B * args.steps / elapsed / 1e12, 2),
-        "fallback_batches": fallback * args.steps, "fallback_status": fb_status,
+        "fallback_batches": fallback * args.steps, "fallback_status": fb_status, "rank_probe": probe,
     }
     if "kmeans" in breakdown and breakdown["kmeans"]["ms_per_step"] > 0:
         km_products = {0: 1, 1: 6, 2: 3}[arith] if enc.get_option("kmeans_split") == 1 else 1   # the score GEMM on the split kernel (option kmeans_split) or the fp32 MFMA
@@ -657,6 +669,8 @@ def run_files(args, rank, world, dev, dist, device_rates):
             for i in range(n_files):
                 wavfile.write(os.path.join(d, f"clip{i:04d}.wav"), src, np.round(base[i % 4] * (12000 + 37 * i)).astype(np.int16))
             if name not in toks:
+                toks.clear()                 # one tokenizer at a time: an acoustic handle sized for 256 x 30 s holds ~200 GB of workspace
+                torch.cuda.empty_cache()
                 if name == "acoustic":
                     toks[name] = AudioToken(which, device=str(dev), num_codebooks=args.num_codebooks, weights=W.synth_encodec_weights(seed=0, with_decoder=False))
                 elif name == "semantic_s":
@@ -709,6 +723,18 @@ def run_files(args, rank, world, dev, dist, device_rates):
                        "this is the host PIPELINE's ceiling (decode, upload, bookkeeping, writes), not a disk measurement", "legs": legs}
 
 
+def rank_probe(encode, sample_rate: int, dev, dist, what: str):
+    """N > 1: every rank encodes the same 2-clip x 2 s probe with ITS copy of the model; the checksums must equal rank 0's before anything is timed
+    (audiotoken_amd/distributed.ranks_agree_on_probe raises on all ranks otherwise). N = 1: the same call, trivially true — the JSON shows the probe ran."""
+    from audiotoken_amd import synthetic as S
+    from audiotoken_amd.distributed import ranks_agree_on_probe
+    x = torch.from_numpy(S.speech_like_waveform(2, 2 * sample_rate, sample_rate, seed=987654)).to(dev)
+    if what == "semantic_s":
+        from audiotoken_amd.hubert import hubert_processor
+        x = torch.stack([hubert_processor(x[i:i + 1].cpu())[0] for i in range(2)]).to(dev)
+    return ranks_agree_on_probe(encode, x, dev, dist, what)
+
+
 def settle_status(enc, call, name):
     """What the product path does at its synchronisation point (AcousticEncoder.verified / Wav2VecBertEncoder.verified): a non-zero device status
     word after the untimed first call means this batch does not fit the fast kernels (fp16 range of the f16x2 arithmetic, LSTM hand-off) — the
@@ -753,6 +779,7 @@ def setup_acoustic(args, rank, world, dev, dist):
     for kv in args.acoustic_option:
         name, _, val = kv.partition("=")
         enc.set_option(name, int(val))
+    probe = rank_probe(lambda x: enc(x, None), 24000, dev, dist, "acoustic")
     wav = S.acoustic_batch(B, N, dev, rank)        # rank r owns clips [r B, (r + 1) B) of the global batch
     mask = torch.ones_like(wav)
     enc._bench_inputs = (wav, mask)
@@ -761,7 +788,7 @@ def setup_acoustic(args, rank, world, dev, dist):
     enc.enable_profile(False)                       # no event taps inside the timed region
     fallback, status, call = settle_status(enc, call, "acoustic")
     return {"name": "acoustic", "enc": enc, "call": call, "wav": wav, "mask": mask, "weights": weights, "audio_s": B * args.seconds, "B": B, "N": N, "n_q": n_q,
-            "broadcast_ms": bcast_ms, "finalize_ms": finalize_ms, "fallback_batches_per_step": fallback, "fallback_status": status}
+            "broadcast_ms": bcast_ms, "finalize_ms": finalize_ms, "fallback_batches_per_step": fallback, "fallback_status": status, "rank_probe": probe}
 
 
 def report_acoustic(wl, args, rank, world, dev, dist):
@@ -795,6 +822,7 @@ def report_acoustic(wl, args, rank, world, dev, dist):
         "breakdown_note": "HIP-event taps of a second short loop (taps are off in the timed region)", "token_checksum": checksum,
         "checksum_pinned": (checksum == S.PINNED_CHECKSUMS[(args.weights, "acoustic")]) if (rank == 0 and B == 256 and N == 240000 and n_q == 8) else None,
         "lstm_handoff_status": status, "fallback_batches": wl["fallback_batches_per_step"] * args.steps, "fallback_status": wl["fallback_status"],
+        "rank_probe": wl.get("rank_probe"),
     }
     if "rvq" in breakdown and breakdown["rvq"]["ms_per_step"] > 0:
         res["argmin"] = argmin_entry("rvq", breakdown["rvq"]["ms_per_step"], flops["rvq"] * B, (4.0 * T * 128 + 2.0 * T * n_q) * B,
@@ -950,6 +978,7 @@ def setup_semantic(args, rank, world, dev, dist):
             torch.cuda.synchronize()
             finalize_ms = (time.perf_counter() - t0) * 1e3    # import: one D2D copy + pointer rebuild
         del packed
+    probe = rank_probe(lambda x: enc(x, torch.ones_like(x)), 16000, dev, dist, "semantic_m")
     wav = S.semantic_m_batch(B, N, dev, rank)
     mask = torch.ones_like(wav)
     enc._bench_inputs = (wav, mask)
@@ -958,7 +987,8 @@ def setup_semantic(args, rank, world, dev, dist):
     enc.enable_profile(False)
     fallback, status, call = settle_status(enc, call, "semantic_m")
     return {"name": "semantic_m", "enc": enc, "call": call, "wav": wav, "mask": mask, "weights": weights if rank == 0 else None, "audio_s": B * secs, "B": B, "N": N, "nl": nl,
-            "secs": secs, "broadcast_ms": bcast_ms, "finalize_ms": finalize_ms, "export_ms": export_ms, "fallback_batches_per_step": fallback, "fallback_status": status}
+            "secs": secs, "broadcast_ms": bcast_ms, "finalize_ms": finalize_ms, "export_ms": export_ms, "fallback_batches_per_step": fallback, "fallback_status": status,
+            "rank_probe": probe}
 
 
 def report_semantic(wl, args, rank, world, dev, dist):
@@ -999,6 +1029,7 @@ def report_semantic(wl, args, rank, world, dev, dist):
         "checksum_pinned": (checksum == S.PINNED_CHECKSUMS[(args.weights, "semantic_m")]) if (rank == 0 and B == 64 and N == 480000 and nl == 19 and not args.stress_range) else None,
         "total_tflops": round(sum(flops.values()) * B / (ms * 1e-3) / 1e12, 2),
         "fallback_batches": wl["fallback_batches_per_step"] * args.steps, "fallback_status": wl["fallback_status"],
+        "rank_probe": wl.get("rank_probe"),
         "pinned_layers": sorted(set(getattr(enc, "pinned_layers", []))),   # conformer layers the range fallback moved to bf16x3 before the timed region (normally none)
     }
     if "vq" in breakdown and breakdown["vq"]["ms_per_step"] > 0:

@@ -182,3 +182,36 @@ def test_skewed_directory_is_balanced_by_duration(tmp_path, world):
             seen[n] = np.load(tmp_path / f"w{world}_rank{r}" / n)
     assert set(seen) == set(ref)
     assert all(np.array_equal(seen[n], ref[n]) for n in ref)
+
+
+# ---- round 5: start-up self-check — every rank must encode a probe like rank 0 ---------------------------------------------------------------------------
+def _probe_worker(rank, world, port, corrupt_rank, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from audiotoken_amd.distributed import ranks_agree_on_probe
+        enc = _HashEncoder()
+        probe = torch.linspace(-1, 1, 2 * 6400).reshape(2, 6400)
+        bias = 0.001 if rank == corrupt_rank else 0.0        # a "model" that differs on one rank (what a wrong import_packed would be)
+        try:
+            res = ranks_agree_on_probe(lambda x: enc(x + bias, torch.ones_like(x)), probe, torch.device("cpu"), dist, "probe")
+            q.put((rank, "ok", res["ranks"]))
+        except RuntimeError as e:
+            q.put((rank, "raised", str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt_rank", [-1, 2])
+def test_ranks_agree_on_probe_world4(corrupt_rank):
+    """bench.py's start-up self-check (audiotoken_amd/distributed.ranks_agree_on_probe): with identical models every rank returns the shared checksums; with ONE
+    rank's model perturbed EVERY rank raises (nobody enters a timed region or writes a token file), naming the rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + (7 if corrupt_rank >= 0 else 0)
+    mp.spawn(_probe_worker, args=(4, port, corrupt_rank, q), nprocs=4, join=True)
+    got = sorted(q.get(timeout=30) for _ in range(4))
+    if corrupt_rank < 0:
+        assert all(s == "ok" and n == 4 for _, s, n in got), got
+    else:
+        assert all(s == "raised" and f"ranks [{corrupt_rank}]" in msg for _, s, msg in got), got

@@ -142,3 +142,32 @@ def test_gpu_kmeans_score_gemm_kernels_agree(cuda_device):
     P.assert_tokens_equal_or_explained(t1, ref, margins, P.VQ_TIE, "k-means on the split kernel")
     P.assert_tokens_equal_or_explained(t0, ref, margins, P.VQ_TIE, "k-means on the fp32 MFMA")
     assert int(t1.max()) < 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", ["f16x2", "bf16x3"])
+def test_gpu_layernorm_split_is_bit_identical(cuda_device, arith):
+    """Round 5: HuBERT's post-LN LayerNorms write the fp32 residual stream and the next GEMM's operand pieces in ONE pass (option ln_split = 1, default;
+    layernorm_split_kernel<.., 768>) instead of LayerNorm + a separate split pass (= 0). Same reductions in the same order, same split: hidden states and
+    ids are BIT-identical, on ragged clips, with a layer pinned to the other scheme (the pieces are written in the CONSUMING layer's scheme), at every depth."""
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    w = W.synth_hubert_weights(3, 29, True)
+    enc = HubertEncoder(HubertEncoderConfig(output_layer=3), device="cuda:0", quantize=True, weights=w)
+    enc.set_option("arith", arith)
+    wav = hubert_processor(torch.from_numpy(W.synth_waveform(3, 52000, 16000, seed=81)))
+    mask = torch.ones_like(wav)
+    mask[2, 31000:] = 0
+    x, m = wav.cuda(), mask.cuda()
+    for pinned in (None, 1):
+        if pinned is not None:
+            enc.set_option(f"layer_arith:{pinned}", 1 if arith == "f16x2" else 2)
+        for depth in (0, 1, 2, 3):
+            assert enc.get_option("ln_split") == 1
+            t1, h1 = enc(x, m, n_layers=depth, return_hidden=True)
+            assert enc.last_status() == 0
+            enc.set_option("ln_split", 0)
+            t0, h0 = enc(x, m, n_layers=depth, return_hidden=True)
+            enc.set_option("ln_split", 1)
+            assert torch.equal(h1, h0), f"{arith}, pinned {pinned}, depth {depth}: hidden states differ by {(h1 - h0).abs().max().item():.2e}"
+            assert torch.equal(t1, t0)
