@@ -190,6 +190,23 @@ __device__ __forceinline__ float gelu_erf_scaled(float y, float half) {
     return half * y * (y < 0.0f ? e : 2.0f - e);
 }
 __device__ __forceinline__ float gelu_erf(float y) { return gelu_erf_scaled(y, 0.5f); }
+// two values at once on the packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two IEEE operations per issue slot; the reciprocal, the
+// exponential and the sign select stay per element). The same operations in the same order as gelu_erf_scaled: bit-identical per element.
+__device__ __forceinline__ auto gelu_erf_scaled2(float __attribute__((ext_vector_type(2))) y, float half) -> float __attribute__((ext_vector_type(2))) {
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    const f2_ x = __builtin_elementwise_abs(y) * 0.70710678118654752440f;
+    const f2_ d = __builtin_elementwise_fma(f2_{0.3275911f, 0.3275911f}, x, f2_{1.0f, 1.0f});
+    const f2_ t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f2_ p = __builtin_elementwise_fma(t, f2_{1.061405429f, 1.061405429f}, f2_{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(t, p, f2_{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(t, p, f2_{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(t, p, f2_{0.254829592f, 0.254829592f});
+    const f2_ a = -x * x;
+    const f2_ e = (p * t) * f2_{__expf(a[0]), __expf(a[1])};
+    const f2_ r = half * y;
+    const f2_ two_minus = 2.0f - e;
+    return r * f2_{y[0] < 0.0f ? e[0] : two_minus[0], y[1] < 0.0f ? e[1] : two_minus[1]};
+}
 // swish of the conformer conv module's depthwise-conv kernels: x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (~1 ulp each) like the GEMM's swish and GLU
 // epilogues (until late in round 3: ocml expf + a correctly rounded division, ~30 more vector instructions per value in a vector-bound kernel)
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(512) void hub_gn_coeff_kernel(const double* __restr
 // conv0: [B][N] -> [B][T0][512], k = 10, stride 5, valid, no bias (20 B in, 2 KB out per frame), then scale/shift and GELU.
 // Workgroup = 64 consecutive frames of one clip; thread = 4 channels, which keeps its 40 taps and 8 affine coefficients in
 // registers for all of its 32 frames (one frame x 4 channels per thread re-fetched 48 words per 16 bytes stored and
-// ran at 1.3 TB/s). The waveform segment (325 samples) goes through LDS; 128 threads write one 2-KB output row.
+// ran at 1.3 TB/s). The waveform segment (325 samples) goes through LDS; 128 threads write one 2-KB output row (fp32 form) or stage
+// 16 frames of pieces in LDS and write them as 256-byte runs (piece form: see below).
 constexpr int C0_FRAMES = 64;
 
 template <class SC>
@@ -108,46 +109,75 @@ __global__ __launch_bounds__(256) void hub_conv0_gn_gelu_kernel(const float* __r
         const long long s = (long long)t0 * 5 + i;
         xs[i] = s < N ? x[s] : 0.f;
     }
-    float wr[4][10], sc[4], sh[4];
+    // Channel PAIRS on the packed fp32 instructions (round 5): this kernel runs no MFMA — it is vector-issue bound (6.3 G outputs x ~33 instructions at 128 x 30 s:
+    // 7.7 of its 8.2 ms) — and v_pk_fma_f32 / v_pk_mul_f32 do two IEEE operations per issue slot. Same operations in the same order per element as the scalar
+    // form (10-tap fma chain, affine fma, gelu_erf_scaled): bit-identical outputs.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 wr[2][10], sc[2], sh[2];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) wr[c][k] = w[(cg * 4 + c) * 10 + k];
-        sc[c] = ss[((long long)b * 512 + cg * 4 + c) * 2];
-        sh[c] = ss[((long long)b * 512 + cg * 4 + c) * 2 + 1];
+        for (int k = 0; k < 10; ++k) wr[c][k] = f2{w[(cg * 4 + 2 * c) * 10 + k], w[(cg * 4 + 2 * c + 1) * 10 + k]};
+        sc[c] = f2{ss[((long long)b * 512 + cg * 4 + 2 * c) * 2], ss[((long long)b * 512 + cg * 4 + 2 * c + 1) * 2]};
+        sh[c] = f2{ss[((long long)b * 512 + cg * 4 + 2 * c) * 2 + 1], ss[((long long)b * 512 + cg * 4 + 2 * c + 1) * 2 + 1]};
     }
     __syncthreads();
     const int nf = T0 - t0 < C0_FRAMES ? T0 - t0 : C0_FRAMES;
     float* orow = out + ((long long)b * T0 + t0) * 512 + cg * 4;
     RangeMax over;
-    for (int f = sub; f < nf; f += 2) {
-        float xv[10];
+    // fp16 scheme: the site's power-of-two scale rides on GELU's leading 0.5 (bit for bit scale x GELU: gelu_erf_scaled), the split takes it prescaled
+    const float half = (SC::NP == 2 && split) ? 0.5f * split_scale : 0.5f;
+    // Piece output through LDS (round 5). The next conv's operand layout is [piece][clip][channel block 32][plane t & 1][t >> 1][16 channels]: a thread's 8-byte
+    // quad of one frame lands 32 bytes from its neighbours' and 1.5 MB from the next channel block's — written straight from registers a wave store was sixteen
+    // separate 32-byte segments (3 TB/s of a kernel that writes 25 GB). Now 16 frames at a time are staged in LDS as [piece][block][plane][8 rows][16]
+    // (+ 32 B per block against bank conflicts) and leave as 256-byte runs (8 rows x 32 B of one (piece, block, plane)), as layernorm_split_kernel does.
+    constexpr int SUBF = 16, BLK_LD = 2 * (SUBF / 2) * 16 + 16;
+    typedef typename SC::T PT;
+    __shared__ __attribute__((aligned(16))) PT tile[SC::NP][32][BLK_LD];
+    typedef unsigned int u4_ __attribute__((ext_vector_type(4)));
+    const long long ps = (long long)gridDim.y * 32 * 2 * Lp * 16;
+    for (int f0 = 0; f0 < (split ? C0_FRAMES : nf); f0 += SUBF) {
+        if (split && f0 >= nf) break;
+#pragma unroll 1
+        for (int f = f0 + sub; f < (split ? f0 + SUBF : nf); f += 2) {
+            if (f >= nf) break;
+            float xv[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) xv[k] = xs[f * 5 + k];
-        f4 o;
+            for (int k = 0; k < 10; ++k) xv[k] = xs[f * 5 + k];
+            f4 o;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float acc = 0.f;
+            for (int c = 0; c < 2; ++c) {
+                f2 acc = f2{0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 10; ++k) acc = fmaf(wr[c][k], xv[k], acc);
-            // fp16 scheme: the site's power-of-two scale rides on GELU's leading 0.5 (bit for bit scale x GELU: gelu_erf_scaled), the split takes it prescaled
-            o[c] = gelu_erf_scaled(fmaf(acc, sc[c], sh[c]), (SC::NP == 2 && split) ? 0.5f * split_scale : 0.5f);
+                for (int k = 0; k < 10; ++k) acc = __builtin_elementwise_fma(wr[c][k], f2{xv[k], xv[k]}, acc);
+                const f2 g = gelu_erf_scaled2(__builtin_elementwise_fma(acc, sc[c], sh[c]), half);
+                o[2 * c] = g[0];
+                o[2 * c + 1] = g[1];
+            }
+            if (split) {
+                // channels 4cg .. 4cg + 3 = channel block cg / 4, quarter cg % 4; frame t -> plane t & 1, row t >> 1 (phase-major time axis for the stride-2 conv)
+                typename SC::V4 p[SC::NP];
+                if constexpr (SC::NP == 2) over |= split4_prescaled<SC>(o, p);
+                else over |= split4<SC>(o, split_scale, p);
+                const int fl = f - f0;
+#pragma unroll
+                for (int i = 0; i < SC::NP; ++i)
+                    *reinterpret_cast<typename SC::V4*>(&tile[i][cg >> 2][((fl & 1) * (SUBF / 2) + (fl >> 1)) * 16 + (cg & 3) * 4]) = p[i];
+            } else {
+                *reinterpret_cast<f4*>(orow + (long long)f * 512) = o;
+            }
         }
-        if (split) {
-            // the next conv runs on the split GEMM: write the K-blocked pieces [NP][B][512/16][2][Lp][16] of this clip
-            // (channels 4cg..4cg+3 = channel block cg/4, quarter cg%4)
-            typename SC::V4 p[SC::NP];
-            if constexpr (SC::NP == 2) over |= split4_prescaled<SC>(o, p);
-            else over |= split4<SC>(o, split_scale, p);
-            // phase-major time axis for the stride-2 conv that follows: frame t -> plane t & 1, index t >> 1 (Lp rows per plane)
-            const int t = t0 + f;
-            const long long off = ((((long long)b * 32 + (cg >> 2)) * 2 + (t & 1)) * Lp + (t >> 1)) * 16 + (cg & 3) * 4;
-            const long long ps = (long long)gridDim.y * 32 * 2 * Lp * 16;
-#pragma unroll
-            for (int i = 0; i < SC::NP; ++i) *reinterpret_cast<typename SC::V4*>(split + i * ps + off) = p[i];
-        } else {
-            *reinterpret_cast<f4*>(orow + (long long)f * 512) = o;
+        if (!split) break;      // (the fp32 output form wrote all its frames in the one pass above)
+        __syncthreads();
+        // 16-byte chunks: [piece][block][plane][row][half]; 16 consecutive lanes = one 256-byte run in global memory
+        const int ts = t0 + f0;                                   // even
+        for (int e = threadIdx.x; e < SC::NP * 32 * 2 * (SUBF / 2) * 2; e += 256) {
+            const int hf = e & 1, row = (e >> 1) & (SUBF / 2 - 1), plane = (e >> 4) & 1, blk = (e >> 5) & 31, pi = e >> 10;
+            if (ts + 2 * row + plane < T0)
+                *reinterpret_cast<u4_*>(split + pi * ps + ((((long long)b * 32 + blk) * 2 + plane) * Lp + (ts >> 1) + row) * 16 + hf * 8) =
+                    *reinterpret_cast<const u4_*>(&tile[pi][blk][(plane * (SUBF / 2) + row) * 16 + hf * 8]);
         }
+        __syncthreads();
     }
     if constexpr (SC::RANGE_CHECK)
         range_publish(status, status ? status + 1 : nullptr, over);

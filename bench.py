@@ -656,9 +656,9 @@ def run_files(args, rank, world, dev, dist, device_rates):
         # device-resident rate of the same batch shape: 512 files x batch 128 0.69-0.75, 1 024 x 256 0.79, 2 048 x 256 0.86; at batch 64-128 the encoder's
         # own device-resident rate is lower — its two 2 250-step LSTM layers are latency-bound and want 256 clips side by side)
         plans = [("acoustic", Tokenizers.acoustic, 24000, 24000, args.files_acoustic, args.files_acoustic_batch), ("acoustic", Tokenizers.acoustic, 48000, 24000, args.files_acoustic // 2, args.files_acoustic_batch),
-                 ("semantic_m", Tokenizers.semantic_m, 16000, 16000, args.files_semantic, 64), ("semantic_m", Tokenizers.semantic_m, 44100, 16000, args.files_semantic // 2, 64),
+                 ("semantic_m", Tokenizers.semantic_m, 16000, 16000, args.files_semantic, args.files_semantic_batch), ("semantic_m", Tokenizers.semantic_m, 44100, 16000, args.files_semantic // 2, args.files_semantic_batch),
                  # round 5: semantic_s goes through the device feeder too (its per-chunk zero-mean / unit-variance transform runs in the feeder's kernels)
-                 ("semantic_s", Tokenizers.semantic_s, 16000, 16000, args.files_semantic_s, 128), ("semantic_s", Tokenizers.semantic_s, 44100, 16000, args.files_semantic_s // 2, 128)]
+                 ("semantic_s", Tokenizers.semantic_s, 16000, 16000, args.files_semantic_s, args.files_semantic_s_batch), ("semantic_s", Tokenizers.semantic_s, 44100, 16000, args.files_semantic_s // 2, args.files_semantic_s_batch)]
         toks = {}
         for name, which, src, dst, n_files, bs in plans:
             if n_files <= 0:
@@ -1064,7 +1064,9 @@ def parse_args(argv=None):
     ap.add_argument("--files-acoustic", type=int, default=2048, help="files leg: 30 s files per GPU for the acoustic tokenizer (half as many for the resampled leg; 0 = skip)")
     ap.add_argument("--files-acoustic-batch", type=int, default=256, help="files leg: encode_batch_files batch_size of the acoustic legs")
     ap.add_argument("--files-semantic", type=int, default=192, help="files leg: 30 s files per GPU for semantic_m")
-    ap.add_argument("--files-semantic-s", type=int, default=384, help="files leg: 30 s files per GPU for semantic_s (batch 128)")
+    ap.add_argument("--files-semantic-s", type=int, default=384, help="files leg: 30 s files per GPU for semantic_s")
+    ap.add_argument("--files-semantic-batch", type=int, default=64, help="files leg: encode_batch_files batch_size of the semantic_m legs")
+    ap.add_argument("--files-semantic-s-batch", type=int, default=128, help="files leg: encode_batch_files batch_size of the semantic_s legs (128 x 30 s needs a 97 GB workspace)")
     ap.add_argument("--files-workers", type=int, default=8, help="files leg: decode-ahead workers (encode_batch_files num_workers)")
     ap.add_argument("--hub-batch", type=int, default=128, help="semantic_s clips per GPU per step (BASELINE configs[2]: 128)")
     ap.add_argument("--batch", type=int, default=256, help="acoustic clips per GPU per step (BASELINE configs[1]: 256)")

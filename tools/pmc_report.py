@@ -25,6 +25,13 @@ GROUPS = {   # workload -> bench.py group -> kernel-name prefix (first match, mo
 }
 
 
+# bench.py kernel GROUPS that span several kernels: group -> (kernel-name prefixes, launches per encode, the kernel that runs once per encode). The
+# figure is the group's HBM bytes per encode / launches per encode = bytes per launch AVERAGED over the group, the unit roofline_of() uses for `avg_launch_ms`.
+GROUP_SUMS = {
+    "semantic_s": {"feature_extractor": (("at::hub_wavstats", "at::hub_gn_coeff", "at::hub_conv0", "at::gemm_f16x2_tg_kernel<true"), 9, "at::hub_gn_coeff")},
+}
+
+
 def f(row, key):
     try:
         return float(row[key + "_per_launch"])
@@ -71,6 +78,16 @@ def main():
             o = max(cands, key=lambda c: c["launches"])
             kernels[group] = {"kernel": o["kernel"], "traffic_bytes_per_launch": o["hbm_bytes_per_launch"], "mfma_pipe_busy_frac": o["mfma_pipe_busy_frac"],
                               "cycles_per_launch": o["cycles_per_launch"], "launches_in_pmc_run": o["launches"]}
+        for group, (prefs, per_encode, once) in GROUP_SUMS.get(workload, {}).items():
+            def match(o, pref):
+                bare = pref.split("::")[-1].split("<")[0]
+                return o["kernel"].replace("void ", "").startswith(pref) or (o["kernel"].startswith("_Z") and bare in o["kernel"])
+            calls = sum(o["launches"] for o in out_rows if match(o, once))
+            members = [o for o in out_rows if any(match(o, p) for p in prefs) and o["hbm_bytes_per_launch"] is not None]
+            if calls and members:
+                total = sum(o["launches"] * o["hbm_bytes_per_launch"] for o in members) / calls
+                kernels[group] = {"kernel": " + ".join(sorted({o["kernel"].split("(")[0][:60] for o in members})), "traffic_bytes_per_encode": int(total),
+                                  "traffic_bytes_per_launch": int(total / per_encode), "launches_per_encode": per_encode, "encodes_in_pmc_run": calls}
         if workload == "semantic_m":   # the one GEMM kernel symbol resolved by ROLE (tools/gemm_roles_pmc.py, per-dispatch counters of the same passes)
             import os
             rp = f"{prefix}_gemm_roles_traffic.json"
