@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024, 1) void dwconv_stream_kernel(const float* __r
                                                                 float scale, int* __restrict__ status) {
     __shared__ float sq[DS_RB][256];
     __shared__ __attribute__((aligned(16))) float stat[DS_RB][4];   // per row: mean, rstd, shift
-    __shared__ __attribute__((aligned(16))) float otile[DS_RB][DS_C];   // pieces only: the 8 output rows, re-read as float4 per channel quad
+    __shared__ __attribute__((aligned(16))) float otile[DS_RB][DS_C + 4];   // pieces only: the 8 output rows, re-read as float4 per channel quad (+ 16 B per row: the re-read walks ROWS fastest)
     const int c = threadIdx.x, lane = c & 63;
     const int b = blockIdx.y;
     const int t_begin = blockIdx.x * seg_len;
@@ -157,10 +157,12 @@ __global__ __launch_bounds__(1024, 1) void dwconv_stream_kernel(const float* __r
         }
         if constexpr (!std::is_void<SC>::value) {
             __syncthreads();
-            // 8 rows x 256 channel quads = 2048 float4: two per thread -> pieces (8-byte store per piece, as the register-stationary kernel)
+            // 8 rows x 256 channel quads = 2048 float4: two per thread -> pieces (8-byte store per piece). Lane order: quad of a k-block fastest, then the
+            // ROW, then the k-block — in the K-blocked layout [k-block][row][16] the 8 rows of a k-block are one 256-byte run, so a wave store is two such
+            // runs (round 5; channel-quad-fastest order made it sixteen separate 32-byte segments: the pattern that held conv0 of semantic_s at 3 TB/s)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int e = c + 1024 * j, i = e >> 8, qd = e & 255;
+                const int e = c + 1024 * j, i = (e >> 2) & (DS_RB - 1), qd = ((e >> 5) << 2) | (e & 3);
                 const int t = tb + i;
                 if (t < t_end) {
                     const f4 o = *reinterpret_cast<const f4*>(&otile[i][qd * 4]);
