@@ -27,6 +27,6 @@ for n in ("both", "hub", "files"):
         print(n, "parse failed", e); print(open("$out/%s.err" % n).read()[-3000:])
 PY
 for tk in acoustic semantic_s; do
-  timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29533 tools/n8_shared_dir.py /dev/shm/n8_$tk $tk 96 8 2> $out/shared_$tk.err | grep "shared-dir" ; echo "shared_dir $tk rc ${PIPESTATUS[0]}"
+  timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29533 tools/n8_shared_dir.py /dev/shm/n8_$tk $tk 384 8 2> $out/shared_$tk.err | grep "shared-dir" ; echo "shared_dir $tk rc ${PIPESTATUS[0]}"
   rm -rf /dev/shm/n8_$tk
 done
