@@ -98,14 +98,15 @@ def test_semantic_s_full_depth_properties(cuda_device):
     P.assert_tokens_equal_or_explained(toks[2:3], ref, margins, P.VQ_TIE, "semantic_s 30 s clip, 11 layers")
 
 
-def test_acoustic_roundtrip_at_size(cuda_device):
-    """configs[4] (C5): 64 clips x 10 s encode -> decode. Token ids of 4 clips against the oracle (equal or explained), and the
+@pytest.mark.parametrize("family", ("uniform", "trained_like"))
+def test_acoustic_roundtrip_at_size(cuda_device, family):
+    """configs[4] (C5): 64 clips x 10 s encode -> decode, on both weight families (round 5). Token ids of 4 clips against the oracle (equal or explained), and the
     decoded waveform of those clips against the oracle's decode of the SAME tokens (reference decoder.py:66-76): relative L2 < 1e-4."""
     from audiotoken_amd.configs import AcousticDecoderConfig, AcousticEncoderConfig
     from audiotoken_amd.decoder import AcousticDecoder
     from audiotoken_amd.encoder import AcousticEncoder
     from oracle import encodec_ref as R
-    w = W.synth_encodec_weights(seed=0)
+    w = W.synth_encodec_weights(seed=0, family=family)
     enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=w)
     dec = AcousticDecoder(config=AcousticDecoderConfig(bandwidth=6), device="cuda:0", weights=w)
     B, N = 64, 240000
