@@ -64,6 +64,7 @@ struct at_hubert {
     const piece_t* cen_s[2] = {};        // the k-means centres as operand pieces per scheme, rows padded 1000 -> 1024 (zero rows): the score GEMM on the split kernel
     float cen_scale = 1.f;
     bool kmeans_split = true;            // option "kmeans_split": that GEMM on the split kernel instead of the fp32 MFMA (as at_w2vbert's "vq_split")
+    bool vq_refine = true;               // option "vq_refine" (round 5): near-tie centres re-evaluated exactly (vq_argmax_kernel)
     bool ln_split = true;                // option "ln_split" (round 5): the post-LN LayerNorms write the fp32 residual stream AND the next GEMM's operand pieces in one pass (launch_layernorm_split, D = 768) instead of LayerNorm + a separate split pass; bit-identical
     bool posconv_split = true;           // option "posconv_split": the LDS-resident grouped conv kernel (hubert_posconv.hip) instead of 16 fp32 windowed GEMMs
     float conv_wscale[7] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
@@ -529,6 +530,7 @@ int at_hubert_set_option(at_hubert_t* h, const char* name, int value) {
     if (n == "attn_w8") { h->attn_w8 = value < 0 ? -1 : (value != 0); return 0; }
     if (n == "posconv_split") { h->posconv_split = value != 0; return 0; }
     if (n == "ln_split") { h->ln_split = value != 0; return 0; }
+    if (n == "vq_refine") { h->vq_refine = value != 0; return 0; }
     if (n == "kmeans_split") { h->kmeans_split = value != 0; return 0; }
     set_error("at_hubert_set_option: unknown option " + n);
     return -1;
@@ -544,6 +546,7 @@ int at_hubert_get_option(const at_hubert_t* h, const char* name) {
     if (std::string(name) == "attn_w8") return h->attn_w8;
     if (std::string(name) == "posconv_split") return h->posconv_split ? 1 : 0;
     if (std::string(name) == "ln_split") return h->ln_split ? 1 : 0;
+    if (std::string(name) == "vq_refine") return h->vq_refine ? 1 : 0;
     if (std::string(name) == "kmeans_split") return h->kmeans_split ? 1 : 0;
     return -1;
 }
@@ -725,10 +728,10 @@ int at_hubert_encode_checked(at_hubert_t* h, const float* wav, const float* mask
             va.scheme = sc.scheme; va.status = nullptr;
             if (sc.scheme == XB_SCHEME_F16X2) { va.acc_scale = 1.0f / (XB_F16_ACT_SCALE * h->cen_scale); va.split_scale = XB_F16_ACT_SCALE; }
             if (int rc = launch_gemm_bf16x3(va, stream)) return rc;
-            if (int rc = launch_vq_argmax(t1, big, h->c2, tokens, M, kHid, kCenters, stream, reinterpret_cast<int*>(status_dev), kCentersPad)) return rc;
+            if (int rc = launch_vq_argmax(t1, big, h->c2, tokens, M, kHid, kCenters, stream, reinterpret_cast<int*>(status_dev), kCentersPad, h->vq_refine ? h->centers : nullptr)) return rc;
         } else {
             if (int rc = linear(t1, kHid, h->centers, nullptr, big, kCenters, M, EPI_NONE, nullptr, nullptr, kCenters, stream)) return rc;
-            if (int rc = launch_vq_argmax(t1, big, h->c2, tokens, M, kHid, kCenters, stream, reinterpret_cast<int*>(status_dev))) return rc;
+            if (int rc = launch_vq_argmax(t1, big, h->c2, tokens, M, kHid, kCenters, stream, reinterpret_cast<int*>(status_dev), 0, h->vq_refine ? h->centers : nullptr)) return rc;
         }
         prof.end(stream);
     }

@@ -81,6 +81,7 @@ struct at_w2vbert {
     const piece_t* cb_s[2] = {};   // the code book as operand pieces, per scheme (the VQ score GEMM on the split kernel; option "vq_split")
     float cb_scale = 1.f;
     bool vq_split = true;
+    bool vq_refine = true;      // option "vq_refine" (round 5): near-tie codes re-evaluated exactly (vq_argmax_kernel); 0 = the expanded fp32 form alone, as rounds 1-4
     int arith = ARITH_F16X2;   // linear layers: ARITH_* ($AUDIOTOKEN_SEMANTIC_ARITH = f32 | bf16x3 | f16x2; option "arith")
     bool split_done[2] = {false, false};
     std::map<const float*, float> wmax;   // max |w| of every uploaded tensor (the fp16 scheme's weight scales)
@@ -597,6 +598,7 @@ int at_w2vbert_set_option(at_w2vbert_t* h, const char* name, int value) {
     }
     if (n == "dwconv_stream") { h->dwconv_stream = value != 0; return 0; }
     if (n == "vq_split") { h->vq_split = value != 0; return 0; }
+    if (n == "vq_refine") { h->vq_refine = value != 0; return 0; }
     if (n == "attn_w8") { h->attn_w8 = value < 0 ? -1 : (value != 0); return 0; }
     set_error("at_w2vbert_set_option: unknown option " + n);
     return -1;
@@ -611,6 +613,7 @@ int at_w2vbert_get_option(const at_w2vbert_t* h, const char* name) {
     }
     if (std::string(name) == "dwconv_stream") return h->dwconv_stream ? 1 : 0;
     if (std::string(name) == "vq_split") return h->vq_split ? 1 : 0;
+    if (std::string(name) == "vq_refine") return h->vq_refine ? 1 : 0;
     if (std::string(name) == "attn_w8") return h->attn_w8;
     return -1;
 }
@@ -810,7 +813,7 @@ int at_w2vbert_encode_checked(at_w2vbert_t* h, const float* wav, const float* ma
             if (int rc = launch_layernorm(x, nullptr, nullptr, nullptr, t1, M, kHid, stream)) return rc;
             if (int rc = linear(t1, kHid, h->codebook, nullptr, big, kCodes, M, EPI_NONE, 1.f, nullptr, nullptr, kCodes, stream)) return rc;
         }
-        if (int rc = launch_vq_argmax(t1, big, h->e2, tokens, M, kHid, kCodes, stream, reinterpret_cast<int*>(status_dev))) return rc;
+        if (int rc = launch_vq_argmax(t1, big, h->e2, tokens, M, kHid, kCodes, stream, reinterpret_cast<int*>(status_dev), 0, h->vq_refine ? h->codebook : nullptr)) return rc;
         prof.end(stream);
     }
     return 0;

@@ -46,7 +46,9 @@ int launch_layernorm_split(const float* x, const float* gamma, const float* beta
                            int D, int scheme, float scale, int* status, hipStream_t stream);
 // status (nullable): OR-ed with XB_STATUS_NONFINITE when a row of x holds a NaN / infinity
 // ld: row stride of `dots` (0 = C; > C when the score GEMM ran against a zero-padded code book)
+// codebook (nullable): the fp32 code rows [C][D]; when given, the codes within a relative window of the best approximate distance are re-evaluated exactly
+// (sum of squared differences in float64) — see vq_argmax_kernel
 int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,
-                     hipStream_t stream, int* status = nullptr, int ld = 0);
+                     hipStream_t stream, int* status = nullptr, int ld = 0, const float* codebook = nullptr);
 
 }  // namespace at

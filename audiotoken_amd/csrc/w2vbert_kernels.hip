@@ -839,17 +839,29 @@ int launch_dwconv_ln_swish(const float* g, const float* w, const float* gamma, c
 // ------------------------------------------------------------------------------------------------------
 // VQ assignment from the score GEMM: dots[m][n] = x_m . e_n. vector_quantize_pytorch eval:
 //   idx = argmax_n -sqrt(max((|x|^2 + |e_n|^2) + (-2 dots), 0)), first maximal index. One wave per row.
+// REFINEMENT (round 5, `codebook` non-null). The expanded form cancels: with centres fitted to the data (what a trained quantiser has) |x|^2 + |e|^2 ~ 2048
+// against distances of ~1, so the GEMM's fp32 accumulation error of x . e (~2e-4 .. 5e-4 at |x . e| ~ 1000: 32 .. 256 sequential accumulator updates) becomes
+// ~1e-3 of the DISTANCE — and on hidden states with massive channels the shipped kernel disagreed with float64 at 29 of 1000 positions at margins >= 1e-3
+// although the hidden states themselves were as close to float64 as the reference's (tools/cond_probe.py; torch's blocked sgemm on the CPU loses 3-5 x less).
+// So the scan only SHORTLISTS: every code whose approximate squared distance is within (|x|^2 + |e_best|^2) 2^-17 of the best (>= 30 x the GEMM's error) is
+// re-evaluated as sum_k (x_k - e_k)^2 — no cancellation, differences and sum in float64, the wave cooperating on one code at a time — and the smallest exact
+// distance wins, ties to the lower index. Where the shortlist has one entry (the rule, away from near-ties) nothing changes; at near-ties the id is the one
+// exact arithmetic gives, which is the reference's wherever the reference's own fp32 quantiser is decisive (its error is ~1e-4 of the squared distance).
 // ------------------------------------------------------------------------------------------------------
+template <int MAXQ>   // float4 of the row per lane: D <= 256 * MAXQ
 __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict__ x, const float* __restrict__ dots,
                                                         const float* __restrict__ e2, int16_t* __restrict__ out, long long rows,
-                                                        int D, int C, int* __restrict__ status, int ld) {
+                                                        int D, int C, int* __restrict__ status, int ld, const float* __restrict__ codebook) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    f4 xr[MAXQ];
     float x2 = 0.f;
-    for (int c = lane; c < (D >> 2); c += 64) {
-        const f4 v = reinterpret_cast<const f4*>(x + row * D)[c];
-        x2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int c = lane + 64 * q;
+        xr[q] = c < (D >> 2) ? reinterpret_cast<const f4*>(x + row * D)[c] : f4{0.f, 0.f, 0.f, 0.f};
+        x2 += (xr[q].x * xr[q].x + xr[q].y * xr[q].y) + (xr[q].z * xr[q].z + xr[q].w * xr[q].w);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) x2 += __shfl_xor(x2, off);
@@ -872,13 +884,66 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
         const int oi = __shfl_xor(bidx, off);
         if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
     }
+    if (codebook && best > -INFINITY) {
+        // shortlist: approximate d^2 <= best d^2 + window (uniform values: every lane holds the reduced best)
+        const float best_d2 = best * best;                                   // (= max(d2, 0) of the winner up to one rounding of the square root)
+        const float window = (x2 + e2[bidx]) * (1.0f / 131072.0f);
+        double ex_best = 1.0e300;
+        int ex_idx = bidx;
+        for (int c0 = 0; c0 < (C >> 2); c0 += 64) {
+            const int c = c0 + lane;
+            unsigned mask4 = 0;
+            if (c < (C >> 2)) {
+                const f4 d = reinterpret_cast<const f4*>(dots + row * ld)[c];
+                const f4 y2 = reinterpret_cast<const f4*>(e2)[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d2 = fmaxf(__fadd_rn(__fadd_rn(x2, y2[k]), -2.0f * d[k]), 0.f);
+                    if (d2 <= best_d2 + window) mask4 |= 1u << k;
+                }
+            }
+            unsigned long long pending = __ballot(mask4 != 0);
+            while (pending) {                                                 // one shortlisted code at a time, the whole wave on its 4 KB row
+                const int src = __ffsll((long long)pending) - 1;
+                const unsigned m = (unsigned)__shfl((int)mask4, src);
+                for (int k = 0; k < 4; ++k) {
+                    if (!((m >> k) & 1u)) continue;
+                    const int n = (c0 + src) * 4 + k;
+                    const float* er = codebook + (long long)n * D;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < MAXQ; ++q) {
+                        const int cc = lane + 64 * q;
+                        if (cc < (D >> 2)) {
+                            const f4 ev = reinterpret_cast<const f4*>(er)[cc];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const double df = (double)xr[q][t] - (double)ev[t];
+                                acc = fma(df, df, acc);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+                    if (acc < ex_best || (acc == ex_best && n < ex_idx)) { ex_best = acc; ex_idx = n; }
+                }
+                pending &= pending - 1;
+            }
+        }
+        bidx = ex_idx;
+    }
     if (lane == 0) out[row] = (int16_t)bidx;
 }
 
 int launch_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, long long rows, int D, int C,
-                     hipStream_t stream, int* status, int ld) {
+                     hipStream_t stream, int* status, int ld, const float* codebook) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(vq_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, dots, e2, out, rows, D, C, status, ld > 0 ? ld : C);
+    AT_REQUIRE(D % 4 == 0 && D <= 1024, "vq_argmax: D must be a multiple of 4, <= 1024");
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (D <= 768)
+        hipLaunchKernelGGL(vq_argmax_kernel<3>, grid, dim3(256), 0, stream, x, dots, e2, out, rows, D, C, status, ld > 0 ? ld : C, codebook);
+    else
+        hipLaunchKernelGGL(vq_argmax_kernel<4>, grid, dim3(256), 0, stream, x, dots, e2, out, rows, D, C, status, ld > 0 ? ld : C, codebook);
     AT_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,105 @@
+"""GPU: a CONDITIONING study, not a parity test of a BASELINE workload (round 5). Question: when a checkpoint is ill-conditioned enough that the reference's fp32
+arithmetic is not reproducible to the contract's 1e-3 — and its quantiser's centres sit in the data, so three quarters of all positions have a top-2 margin below
+1e-2 — how do the HIP path's ids compare with what the reference can say about itself?
+
+Setting: the trained_like weight family (weights.FAMILIES: massive LayerNorm gains, heavy tails; the float32 oracle differs from its own float64 evaluation by
+3.5e-3 in LayerNorm-normalised hidden units at conformer layer 19, 4.6e-4 at HuBERT layer 11, against 4e-6 for the uniform family) with a code book FITTED to the
+hidden states (tests/test_fullsize_gpu.py::fitted_semantic_*). The yardstick is EXACT arithmetic: the network in float64 and the quantiser's distances in float64
+(`exact_assign`); both the reference restatement (network AND quantiser in fp32, as the reference runs them) and the HIP path are compared with it.
+
+What the study found (measured on MI355X, printed by the tests):
+* the HIP path's HIDDEN STATES were as close to float64 as the reference's own fp32 run (median L2 2.6e-6 against 5.7e-6: tools/cond_probe.py), but its QUANTISER was
+  not: the expanded form |x|^2 + |e|^2 - 2 x.e cancels three to four orders of magnitude when the centres sit in the data, and the split GEMM's fp32 accumulation
+  error of x.e became ~1e-3 of the distance — 51 of 2 000 semantic_m ids off at margins >= 1e-3. Since then the near-tie codes are re-evaluated exactly
+  (vq_argmax_kernel, option vq_refine): **0 of 2 000 ids differ from exact arithmetic** (semantic_m), 0 of 1 996 (semantic_s);
+* the REFERENCE's fp32 quantiser suffers from the same cancellation (torch's sgemm loses 3-5 x less than a k-ordered chain, not nothing): on its own fp32 vectors
+  it disagrees with exact distances at 120 of 2 000 positions, 16-22 of them at margins >= 1e-3. On such a checkpoint the reference's ids at those positions are its
+  own rounding noise: no second implementation — another BLAS build of the reference included — reproduces them, and "equal to the reference's fp32 CPU ids" is
+  not attainable there by anything; "equal to what the checkpoint means" is, and is what the HIP path returns.
+The assertions: the HIP path disagrees with exact arithmetic at no more positions (margin >= 1e-3) than the reference's own fp32 run does, and the exact
+re-evaluation never makes things worse. The strict "equal, or oracle margin < 1e-3" bar stays where the reference is reproducible: every other test, incl. the same
+fitted code books on the uniform family."""
+import numpy as np
+import pytest
+import torch
+
+from tests import parity as P
+from tests.test_fullsize_gpu import _oracle_threads, fitted_semantic_m, fitted_semantic_s
+
+pytestmark = pytest.mark.gpu
+
+
+def exact_assign(e, centres):
+    """ids and top-2 distance margins of fp32 vectors `e` [.., D] against fp32 `centres` [C, D] in EXACT arithmetic (float64 expanded form: its cancellation error
+    is 1e-13 here): what the quantiser's formula means, as opposed to what its fp32 evaluation rounds to."""
+    x, c = e.reshape(-1, e.shape[-1]).double(), centres.double()
+    d = ((x * x).sum(-1, keepdim=True) + (c * c).sum(-1)[None] - 2.0 * x @ c.t()).clamp_min(0).sqrt()
+    top2 = (-d).topk(2, dim=-1).values
+    return d.argmin(-1), (top2[:, 0] - top2[:, 1])
+
+
+def _study(what, enc, run_hip, e64, e32, centres, ids32, m32):
+    """e64 / e32: the vectors the quantiser sees (LayerNorm-normalised hidden states, cast to fp32) from the float64 / the fp32 network; ids32 / m32: the fp32
+    oracle's ids and margins (network and quantiser in fp32)."""
+    ids_x, m_x = exact_assign(e64, centres)                       # exact network + exact quantiser
+    n = ids_x.numel()
+    ids32 = ids32.reshape(-1).long()
+
+    def off(ids, m):
+        d = ids.reshape(-1).long().cpu() != ids_x
+        return int(d.sum()), int((d & (m >= P.VQ_TIE)).sum())
+    # the reference's quantiser against exact distances on ITS OWN fp32 vectors (isolates the quantiser's cancellation from the network's rounding)
+    ids_q, _ = exact_assign(e32, centres)
+    dq = ids_q != ids32
+    print(f"[conditioning] {what}: {n} ids; positions with an exact margin < 1e-2: {int((m_x < 1e-2).sum())}, < 1e-3: {int((m_x < 1e-3).sum())}")
+    print(f"[conditioning] {what}: the reference's fp32 quantiser vs EXACT distances on its own fp32 vectors: {int(dq.sum())} ids differ, "
+          f"{int((dq & (m32.reshape(-1) >= P.VQ_TIE)).sum())} at a reference margin >= 1e-3")
+    ref_off = off(ids32, m_x)
+    print(f"[conditioning] {what}: fp32 reference restatement (network + quantiser in fp32) vs exact arithmetic: {ref_off[0]} ids differ, {ref_off[1]} at an exact margin >= 1e-3")
+    enc.set_option("vq_refine", 0)
+    old = off(run_hip(), m_x)
+    enc.set_option("vq_refine", 1)
+    new = off(run_hip(), m_x)
+    print(f"[conditioning] {what}: HIP f16x2 vs exact arithmetic: {new[0]} ids differ, {new[1]} at an exact margin >= 1e-3 "
+          f"(without the exact re-evaluation of near-ties, as rounds 1-4 shipped: {old[0]} / {old[1]})")
+    for arith in ("bf16x3", "f32"):
+        enc.set_option("arith", arith)
+        o = off(run_hip(), m_x)
+        print(f"[conditioning] {what}: HIP {arith} vs exact arithmetic: {o[0]} ids differ, {o[1]} at an exact margin >= 1e-3")
+    enc.set_option("arith", "f16x2")
+    assert new[1] <= ref_off[1] + 2, f"{what}: the HIP path is further from exact arithmetic ({new[1]}) than the reference's own fp32 run ({ref_off[1]})"
+    assert new[1] <= old[1] and new[0] <= max(old[0], ref_off[0])
+
+
+def test_semantic_m_trained_like_fitted_codebook(cuda_device):
+    from oracle import w2vbert_ref as R
+    _oracle_threads()
+    enc, w, wav = fitted_semantic_m("trained_like")
+    mask = torch.ones_like(wav)
+    x, m = wav.cuda(), mask.cuda()
+    toks = enc.verified(enc(x, m), x, m)
+    assert enc.last_status() == 0 and enc.fallback_batches == 0
+    w32 = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
+    w64 = {k: v.double() for k, v in w32.items()}
+    ids32, m32 = R.semantic_m_encode(w32, wav, mask, 2, 19, return_margins=True)
+    f64_, am = R.processor(wav.double(), mask.double(), 2)
+    e64 = torch.nn.functional.layer_norm(R.encoder_hidden_state(w64, f64_, am, 19), (1024,)).float()
+    f32_, am32 = R.processor(wav, mask, 2)
+    e32 = torch.nn.functional.layer_norm(R.encoder_hidden_state(w32, f32_, am32, 19), (1024,))
+    _study("semantic_m, trained_like weights, fitted code book, 4 x 10 s, 19 layers", enc, lambda: enc(x, m), e64, e32, w32["vq._codebook.embed"].reshape(-1, 1024), ids32, m32)
+
+
+def test_semantic_s_trained_like_fitted_centres(cuda_device):
+    from oracle import hubert_ref as R
+    _oracle_threads()
+    enc, w, wav = fitted_semantic_s("trained_like")
+    mask = torch.ones_like(wav)
+    x, m = wav.cuda(), mask.cuda()
+    toks = enc.verified(enc(x, m), x, m)
+    assert enc.last_status() == 0 and enc.fallback_batches == 0
+    w32 = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
+    w64 = {k: v.double() for k, v in w32.items()}
+    ids32, m32 = R.semantic_s_encode(w32, wav, mask, 11, return_margins=True)
+    e64 = torch.nn.functional.layer_norm(R.hidden_states(w64, wav.double(), mask.double(), 11), (768,)).float()
+    e32 = torch.nn.functional.layer_norm(R.hidden_states(w32, wav, mask, 11), (768,))
+    _study("semantic_s, trained_like weights, fitted k-means centres, 4 x 10 s, 11 layers", enc, lambda: enc(x, m), e64, e32, w32["kmeans.cluster_centers_"], ids32, m32)

@@ -52,7 +52,31 @@ if which == "semantic_s":
     def assign(e):
         return R.kmeans_assign(e, centers.to(e.dtype), return_margin=True)
 else:
-    raise SystemExit("only semantic_s so far")
+    from audiotoken_amd.configs import Wav2VecBertConfig
+    from audiotoken_amd.encoder import Wav2VecBertEncoder
+    from oracle import w2vbert_ref as R
+    NL, D = 19, 1024
+    secs = 10
+    w = W.synth_w2vbert_weights(NL, 0, True, family=family)
+    wav = torch.from_numpy(S.speech_like_waveform(n_clips, secs * 16000, 16000, seed=32000)).to(dev)
+    enc = Wav2VecBertEncoder(Wav2VecBertConfig(), device="cuda:0", quantize=True, weights=w)
+    mask = torch.ones_like(wav)
+    w32 = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
+    w64 = {k: v.double() for k, v in w32.items()}
+    f32_, am = R.processor(wav.cpu(), mask.cpu(), 2)
+    f64_, _ = R.processor(wav.cpu().double(), mask.cpu().double(), 2)
+    states32 = R.encoder_hidden_state(w32, f32_, am, NL, return_all=True)
+    states64 = R.encoder_hidden_state(w64, f64_, am.double(), NL, return_all=True)
+    # the fp32 oracle fed the EXACT features: separates the front end's 5e-4 (reference fp32 framing / DFT) from the network's own rounding
+    states32x = R.encoder_hidden_state(w32, f64_.float(), am, NL, return_all=True)
+    centers = w32["vq._codebook.embed"].reshape(-1, D)
+
+    def hip_hidden(k):
+        return enc(wav, mask, n_layers=k, return_taps=True)[1]["hidden"].cpu()
+
+    def assign(e):
+        idx, m = R.vq_assign(e.float(), centers, return_margin=True)
+        return idx, m
 
 
 def ln(x):
@@ -60,12 +84,16 @@ def ln(x):
 
 
 print(f"{which}, {family} weights, {n_clips} clips; per depth: max over positions of max_k |LN(h)_k difference|  (and the 99.9 % quantile)")
-print(f"{'depth':>5} | {'oracle32 vs 64':>22} | " + " | ".join(f"{a + ' vs 64':>22}" for a in ("f16x2", "bf16x3", "f32")))
+extra = which == "semantic_m"
+print(f"{'depth':>5} | {'oracle32 vs 64':>22} | " + (f"{'o32(exact feats) vs 64':>22} | " if extra else "") + " | ".join(f"{a + ' vs 64':>22}" for a in ("f16x2", "bf16x3", "f32")))
 for k in range(NL + 1):
     ref64 = ln(states64[k])
     row = []
     d = (ln(states32[k]).double() - ref64).abs().amax(-1)
     row.append(f"{float(d.max()):10.2e} {float(d.flatten().quantile(0.999)):10.2e}")
+    if extra:
+        d = (ln(states32x[k]).double() - ref64).abs().amax(-1)
+        row.append(f"{float(d.max()):10.2e} {float(d.flatten().quantile(0.999)):10.2e}")
     for a in ("f16x2", "bf16x3", "f32"):
         enc.set_option("arith", a)
         d = (ln(hip_hidden(k)).double() - ref64).abs().amax(-1)
