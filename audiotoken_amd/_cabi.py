@@ -127,6 +127,7 @@ SIGNATURES = {
     "at_op_dwconv_ln_swish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "at_op_dwconv_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "at_op_vq_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "at_op_vq_argmax_refined": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "at_op_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "at_required_tensors": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "at_op_gemm_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,

@@ -919,4 +919,9 @@ int at_op_vq_argmax(const float* x, const float* dots, const float* e2, int16_t*
     return launch_vq_argmax(x, dots, e2, out, rows, D, C, (hipStream_t)stream);
 }
 
+int at_op_vq_argmax_refined(const float* x, const float* dots, const float* e2, const float* codebook, int16_t* out, int64_t rows, int D, int C, at_stream_t stream) {
+    AT_REQUIRE(x && dots && e2 && codebook && out && D % 4 == 0 && C % 4 == 0, "bad arguments");
+    return launch_vq_argmax(x, dots, e2, out, rows, D, C, (hipStream_t)stream, nullptr, 0, codebook);
+}
+
 }  // extern "C"

@@ -377,6 +377,11 @@ int at_op_dwconv_stream(const float* g, const float* w31x1024, const float* gamm
 
 /* VQ assign from precomputed dots [rows][C]: argmax_n -sqrt(max(|x|^2 + e2[n] - 2 dots, 0)), first index. */
 int at_op_vq_argmax(const float* x, const float* dots, const float* e2, int16_t* out, int64_t rows, int D, int C, at_stream_t stream);
+/* The same with the code rows given (codebook [C][D] fp32, round 5): codes whose approximate squared distance lies within (|x|^2 + e2[best]) 2^-17 of the
+ * best are re-evaluated exactly — sum_k (x_k - e_k)^2 in float64 — and the smallest exact distance wins, ties to the lower index. What the two semantic
+ * tokenizers run (option "vq_refine"); replaces the nearest-code step of vector_quantize_pytorch / torch.cdist + argmin (reference audiotoken/encoder.py:
+ * 100-101,180-181), whose expanded fp32 form cancels when the centres sit in the data. */
+int at_op_vq_argmax_refined(const float* x, const float* dots, const float* e2, const float* codebook, int16_t* out, int64_t rows, int D, int C, at_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -275,3 +275,44 @@ def test_split_gemm_small_tile_soak(cuda_device):
             assert err <= 1.5e-5 * max(1.0, np.sqrt((ref ** 2).mean()))
         else:
             assert torch.equal(out, first), f"run {it} differs from run 0"
+
+
+# ---- round 5: nearest code with the near-ties re-evaluated exactly ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,Cn", [(1024, 2048), (768, 1000)])
+def test_vq_argmax_refined_equals_exact_arithmetic(cuda_device, D, Cn):
+    """The quantiser of the two semantic tokenizers (reference: vector_quantize_pytorch / torch.cdist + argmin, audiotoken/encoder.py:100-101,180-181) on the
+    adversarial case a trained quantiser presents: centres that sit IN the data (rows = other centres + 1 % noise, so the nearest centre is ~0.3 away while
+    |x|^2 + |e|^2 ~ 2 D) with three massive channels carrying most of the norm. The expanded fp32 form — even with exact fp64 dot products rounded to fp32, let alone
+    a GEMM's accumulation error — mis-ranks near-ties there; the refined kernel must return exactly the argmin of the float64 distances (first index at exact
+    ties: duplicated centres), and the plain kernel must agree with it wherever the exact margin is comfortably large."""
+    lib = _cabi.load()
+    g = torch.Generator().manual_seed(11)
+    cb = torch.randn(Cn, D, generator=g) * 0.05
+    cb[:, [5, 77, 300]] += torch.randn(Cn, 3, generator=g) * 12.0                      # massive channels: norm^2 ~ 430 + 2.5
+    cb[Cn - 8:] = cb[:8]                                                               # exact duplicates: ties go to the LOWER index
+    rows = 4096
+    x = cb[torch.randint(0, Cn, (rows,), generator=g)] + 0.01 * torch.randn(rows, D, generator=g)
+    x64, c64 = x.double(), cb.double()
+    d2 = (x64 * x64).sum(-1, keepdim=True) + (c64 * c64).sum(-1)[None] - 2.0 * x64 @ c64.t()
+    want = d2.argmin(-1)
+    top2 = (-d2.clamp_min(0).sqrt()).topk(2, dim=-1).values
+    margin = top2[:, 0] - top2[:, 1]
+    dots = (x64 @ c64.t()).float()                                                     # the best a score GEMM could deliver: exact dots rounded to fp32
+    # ... and what it does deliver: an accumulation error of ~3e-4 at |x . e| ~ 400
+    noisy = dots + (torch.rand(dots.shape, generator=g) - 0.5) * 6e-4
+    e2 = (cb * cb).sum(-1)
+    dev = cuda_device
+    xd, cd, e2d = x.to(dev), cb.to(dev), e2.to(dev)
+    for name, dd in (("exact dots", dots), ("dots with a GEMM-sized error", noisy)):
+        out_r = torch.empty(rows, dtype=torch.int16, device=dev)
+        out_p = torch.empty(rows, dtype=torch.int16, device=dev)
+        dd_d = dd.to(dev).contiguous()
+        _cabi.check(lib.at_op_vq_argmax_refined(xd.data_ptr(), dd_d.data_ptr(), e2d.data_ptr(), cd.data_ptr(), out_r.data_ptr(), rows, D, Cn, _cabi.current_stream_handle(dev)), "refined")
+        _cabi.check(lib.at_op_vq_argmax(xd.data_ptr(), dd_d.data_ptr(), e2d.data_ptr(), out_p.data_ptr(), rows, D, Cn, _cabi.current_stream_handle(dev)), "plain")
+        torch.cuda.synchronize()
+        bad_r = int((out_r.cpu().long() != want).sum())
+        plain_off = out_p.cpu().long() != want
+        print(f"vq_argmax D={D} C={Cn}, {name}: refined differs from the float64 argmin at {bad_r} of {rows} rows; the expanded fp32 form alone at {int(plain_off.sum())} "
+              f"({int((plain_off & (margin >= 1e-3)).sum())} of them at an exact margin >= 1e-3); rows with a margin < 1e-2: {int((margin < 1e-2).sum())}")
+        assert bad_r == 0
+        assert not bool((plain_off & (margin > 0.05)).any())
