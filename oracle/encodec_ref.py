@@ -95,8 +95,8 @@ def lstm_skip(w, prefix: str, x: torch.Tensor) -> torch.Tensor:
         b_ih = _t(w, f"{prefix}.lstm.bias_ih_l{layer}")
         b_hh = _t(w, f"{prefix}.lstm.bias_hh_l{layer}")
         H = w_hh.shape[1]
-        h = torch.zeros(B, H)
-        c = torch.zeros(B, H)
+        h = torch.zeros(B, H, dtype=x.dtype)     # (dtype of the input: the conditioning study evaluates this restatement in float64 as well)
+        c = torch.zeros(B, H, dtype=x.dtype)
         outs = []
         xg = F.linear(inp, w_ih, b_ih)  # [T, B, 4H]
         for t in range(T):

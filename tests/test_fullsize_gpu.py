@@ -373,3 +373,40 @@ def test_semantic_s_data_fitted_centres(cuda_device):
     _report("semantic_s, uniform weights, k-means centres fitted to the data, 4 x 10 s, 11 layers", ref.numel(), n, bad, [m], enc)
     assert len(torch.unique(ref)) > 50
     assert bad == 0
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_acoustic_data_fitted_codebooks(cuda_device, family):
+    """The residual VQ with code books FITTED to the data, as a trained EnCodec has them (k-means on the residuals of each stage; reference call site
+    audiotoken/encoder.py:50-52): stage q's 1024 codes are residual vectors of OTHER clips at stage q (+ 1 % noise), so the nearest code is close and near-ties
+    are frequent at every stage. The SEANet encoder is well-conditioned on both weight families (fp32 oracle vs its float64 evaluation: 3e-6 / 8e-6 in the
+    embedding), so the strict bar applies to both: ids equal the oracle's, or the oracle's top-2 margin at the frame's first differing stage is < 1e-3."""
+    from audiotoken_amd import synthetic as S
+    from audiotoken_amd.configs import AcousticEncoderConfig
+    from audiotoken_amd.encoder import AcousticEncoder
+    from oracle import encodec_ref as R
+    _oracle_threads()
+    w = W.synth_encodec_weights(seed=0, with_decoder=False, family=family)
+    enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=w)
+    fit = torch.from_numpy(S.speech_like_waveform(12, 120000, 24000, seed=41000)).cuda()
+    _, emb = enc(fit, None, return_embeddings=True)
+    residual = emb.reshape(-1, 128).double().cpu()
+    g = torch.Generator().manual_seed(3)
+    for q in range(8):
+        idx = torch.randperm(residual.shape[0], generator=g)[:1024]
+        cb = residual[idx] + 0.01 * residual.std() * torch.randn(1024, 128, generator=g, dtype=torch.float64)
+        w[f"quantizer.vq.layers.{q}._codebook.embed"] = cb.float().numpy()
+        d = (residual * residual).sum(-1, keepdim=True) - 2.0 * residual @ cb.t() + (cb * cb).sum(-1)[None]
+        residual = residual - cb[d.argmin(-1)]
+    del enc
+    enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=w)
+    wav = torch.from_numpy(S.speech_like_waveform(6, 120000, 24000, seed=42000))
+    codes = enc.verified(enc(wav.cuda(), None), wav.cuda(), None)
+    assert enc.last_status() == 0 and enc.fallback_batches == 0
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
+    ref, m = R.acoustic_encode(wt, wav, 8, return_margins=True)
+    n_ids, n_frames, bad = P.explain_rvq_mismatches(codes, ref, m, P.RVQ_TIE)
+    _report(f"acoustic, {family} weights, 8 code books fitted to the data, 6 x 5 s", ref.numel(), n_ids, bad, [m], enc)
+    print(f"[parity-at-size] acoustic fitted code books, {family}: {n_frames} frames hold a differing id; distinct ids used at stage 0: {len(torch.unique(ref[:, 0]))}")
+    assert len(torch.unique(ref[:, 0])) > 100
+    assert bad == 0

@@ -294,7 +294,8 @@ def test_vq_argmax_refined_equals_exact_arithmetic(cuda_device, D, Cn):
     x = cb[torch.randint(0, Cn, (rows,), generator=g)] + 0.01 * torch.randn(rows, D, generator=g)
     x64, c64 = x.double(), cb.double()
     d2 = (x64 * x64).sum(-1, keepdim=True) + (c64 * c64).sum(-1)[None] - 2.0 * x64 @ c64.t()
-    want = d2.argmin(-1)
+    # first index among the exact minima (a dgemm gives duplicated columns values 1e-13 apart: "equal" = within 1e-9 of the minimum)
+    want = ((d2 <= d2.min(-1, keepdim=True).values + 1e-9).float().argmax(-1))
     top2 = (-d2.clamp_min(0).sqrt()).topk(2, dim=-1).values
     margin = top2[:, 0] - top2[:, 1]
     dots = (x64 @ c64.t()).float()                                                     # the best a score GEMM could deliver: exact dots rounded to fp32
