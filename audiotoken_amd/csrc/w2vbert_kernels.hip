@@ -888,9 +888,33 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
         // shortlist: approximate d^2 <= best d^2 + window (uniform values: every lane holds the reduced best)
         const float best_d2 = best * best;                                   // (= max(d2, 0) of the winner up to one rounding of the square root)
         const float window = (x2 + e2[bidx]) * (1.0f / 131072.0f);
-        double ex_best = 1.0e300;
+        // exact squared distance of code n, the wave cooperating on its row (uniform n)
+        auto exact = [&](int n) {
+            const float* er = codebook + (long long)n * D;
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                const int cc = lane + 64 * q;
+                if (cc < (D >> 2)) {
+                    const f4 ev = reinterpret_cast<const f4*>(er)[cc];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double df = (double)xr[q][t] - (double)ev[t];
+                        acc = fma(df, df, acc);
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+            return acc;
+        };
+        double ex_best = exact(bidx);                                        // the approximate winner first: it is always a candidate
         int ex_idx = bidx;
-        for (int c0 = 0; c0 < (C >> 2); c0 += 64) {
+        // a degenerate code book (hundreds of near-duplicate rows) or a degenerate vector could shortlist every code: at most VQ_REFINE_MAX exact evaluations
+        // per row, in index order — beyond that the best of what was evaluated stands (deterministic; never worse than the unrefined choice)
+        constexpr int VQ_REFINE_MAX = 96;
+        int evaluated = 1;
+        for (int c0 = 0; c0 < (C >> 2) && evaluated < VQ_REFINE_MAX; c0 += 64) {
             const int c = c0 + lane;
             unsigned mask4 = 0;
             if (c < (C >> 2)) {
@@ -899,32 +923,18 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float d2 = fmaxf(__fadd_rn(__fadd_rn(x2, y2[k]), -2.0f * d[k]), 0.f);
-                    if (d2 <= best_d2 + window) mask4 |= 1u << k;
+                    if (d2 <= best_d2 + window && c * 4 + k != bidx) mask4 |= 1u << k;
                 }
             }
             unsigned long long pending = __ballot(mask4 != 0);
-            while (pending) {                                                 // one shortlisted code at a time, the whole wave on its 4 KB row
+            while (pending && evaluated < VQ_REFINE_MAX) {                    // one shortlisted code at a time, the whole wave on its row
                 const int src = __ffsll((long long)pending) - 1;
                 const unsigned m = (unsigned)__shfl((int)mask4, src);
                 for (int k = 0; k < 4; ++k) {
                     if (!((m >> k) & 1u)) continue;
                     const int n = (c0 + src) * 4 + k;
-                    const float* er = codebook + (long long)n * D;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int q = 0; q < MAXQ; ++q) {
-                        const int cc = lane + 64 * q;
-                        if (cc < (D >> 2)) {
-                            const f4 ev = reinterpret_cast<const f4*>(er)[cc];
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                const double df = (double)xr[q][t] - (double)ev[t];
-                                acc = fma(df, df, acc);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+                    const double acc = exact(n);
+                    ++evaluated;
                     if (acc < ex_best || (acc == ex_best && n < ex_idx)) { ex_best = acc; ex_idx = n; }
                 }
                 pending &= pending - 1;
