@@ -722,11 +722,14 @@ def run_files(args, rank, world, dev, dist, device_rates):
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
-            t0 = time.perf_counter()
+            t0, c0 = time.perf_counter(), time.process_time()
             # (every rank generated its OWN directory: it takes all of it — the LPT sharding of a common directory is covered by tests/test_distributed_cpu.py)
             tok.encode_batch_files(batch_size=bs, outdir=out, chunk_size=30, audio_dir=d, num_workers=args.files_workers, shard_across_ranks=False)
             torch.cuda.synchronize()
-            el = max_over_ranks(time.perf_counter() - t0, dev, dist)
+            mine, cpu_s = time.perf_counter() - t0, time.process_time() - c0   # process_time: CPU seconds of ALL threads of this rank (decode workers included)
+            from audiotoken_amd.distributed import gather_scalars
+            per_rank = gather_scalars([mine, cpu_s], dev, dist)
+            el = max_over_ranks(mine, dev, dist)
             n_out = len(os.listdir(out))
             assert n_out == n_files, f"files leg: {n_out} token files for {n_files} inputs"
             rate = world * n_files * 30.0 / el
@@ -735,6 +738,8 @@ def run_files(args, rank, world, dev, dist, device_rates):
                          "batch_size": bs, "num_workers": args.files_workers, "value": round(rate, 1), "unit": "audio-s/s", "seconds": round(el, 3), "token_files_written": n_out,
                          "device_resident_rate": device_rates.get(name), "fraction_of_device_resident": round(rate / device_rates[name], 3) if device_rates.get(name) else None,
                          "host_seconds": {k: round(v, 3) for k, v in rt.items() if k.endswith("_s")},
+                         "host_cpu_seconds_per_rank": [round(r[1], 2) for r in per_rank], "rank_seconds_max_over_min": round(max(r[0] for r in per_rank) / max(1e-9, min(r[0] for r in per_rank)), 3),
+                         "host_cpu_seconds_per_audio_hour": round(per_rank[0][1] / (n_files * 30.0 / 3600.0), 3),
                          "feeder_seconds": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ft.items()},
                          "upload_GBps": round(ft.get("bytes_uploaded", 0) / el / 1e9, 2) if ft else None})
             shutil.rmtree(d, ignore_errors=True)
