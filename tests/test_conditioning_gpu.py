@@ -24,7 +24,7 @@ import pytest
 import torch
 
 from tests import parity as P
-from tests.test_fullsize_gpu import _oracle_threads, fitted_semantic_m, fitted_semantic_s
+from tests.test_fullsize_gpu import _oracle_threads, fitted_acoustic, fitted_semantic_m, fitted_semantic_s
 
 pytestmark = pytest.mark.gpu
 
@@ -103,3 +103,31 @@ def test_semantic_s_trained_like_fitted_centres(cuda_device):
     e64 = torch.nn.functional.layer_norm(R.hidden_states(w64, wav.double(), mask.double(), 11), (768,)).float()
     e32 = torch.nn.functional.layer_norm(R.hidden_states(w32, wav, mask, 11), (768,))
     _study("semantic_s, trained_like weights, fitted k-means centres, 4 x 10 s, 11 layers", enc, lambda: enc(x, m), e64, e32, w32["kmeans.cluster_centers_"], ids32, m32)
+
+
+def test_acoustic_trained_like_fitted_codebooks_vs_exact(cuda_device):
+    """The acoustic tokenizer against exact arithmetic (SEANet encoder + 8-stage residual VQ in float64) with RVQ code books fitted to the data, trained_like
+    weights. A frame counts from its FIRST differing stage (later stages quantise a different residual); margins are the float64 run's, in the reference's units
+    (squared distances). The HIP path must be at least as close to exact arithmetic as the fp32 restatement of the reference."""
+    from oracle import encodec_ref as R
+    _oracle_threads()
+    enc, w, wav = fitted_acoustic("trained_like")
+    codes = enc.verified(enc(wav.cuda(), None), wav.cuda(), None).cpu().long()
+    assert enc.last_status() == 0 and enc.fallback_batches == 0
+    w32 = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
+    w64 = {k: v.double() for k, v in w32.items()}
+    ids32, _ = R.acoustic_encode(w32, wav, 8, return_margins=True)
+    ids64, m64 = R.acoustic_encode(w64, wav.double(), 8, return_margins=True)
+    ids64 = ids64.long()
+
+    def off(ids):
+        mism = ids.long() != ids64
+        frames = mism.any(dim=1)
+        first = mism.float().argmax(dim=1)
+        m0 = m64.gather(1, first.unsqueeze(1)).squeeze(1)
+        return int(frames.sum()), int((frames & (m0 >= P.RVQ_TIE)).sum())
+    ref_off, hip_off = off(ids32), off(codes)
+    n_frames = ids64.shape[0] * ids64.shape[2]
+    print(f"[conditioning] acoustic, trained_like weights, fitted RVQ code books, 6 x 5 s: of {n_frames} frames (differ from exact arithmetic / at an exact margin >= 1e-3 at the "
+          f"first differing stage) — fp32 reference restatement {ref_off[0]} / {ref_off[1]}; HIP f16x2 {hip_off[0]} / {hip_off[1]}")
+    assert hip_off[1] <= ref_off[1] + 2 and hip_off[0] <= 2 * ref_off[0] + 10

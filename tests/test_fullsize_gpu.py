@@ -375,20 +375,14 @@ def test_semantic_s_data_fitted_centres(cuda_device):
     assert bad == 0
 
 
-@pytest.mark.parametrize("family", FAMILIES)
-def test_acoustic_data_fitted_codebooks(cuda_device, family):
-    """The residual VQ with code books FITTED to the data, as a trained EnCodec has them (k-means on the residuals of each stage; reference call site
-    audiotoken/encoder.py:50-52): stage q's 1024 codes are residual vectors of OTHER clips at stage q (+ 1 % noise), so the nearest code is close and near-ties
-    are frequent at every stage. The SEANet encoder is well-conditioned on both weight families (fp32 oracle vs its float64 evaluation: 3e-6 / 8e-6 in the
-    embedding), so the strict bar applies to both: ids equal the oracle's, or the oracle's top-2 margin at the frame's first differing stage is < 1e-3."""
+def fitted_acoustic(family, n_fit=12, n_test=6):
+    """(encoder with 8 RVQ code books fitted stage by stage to the residuals of other clips, its weights, test clips [n_test, 120000] on the host)."""
     from audiotoken_amd import synthetic as S
     from audiotoken_amd.configs import AcousticEncoderConfig
     from audiotoken_amd.encoder import AcousticEncoder
-    from oracle import encodec_ref as R
-    _oracle_threads()
     w = W.synth_encodec_weights(seed=0, with_decoder=False, family=family)
     enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=w)
-    fit = torch.from_numpy(S.speech_like_waveform(12, 120000, 24000, seed=41000)).cuda()
+    fit = torch.from_numpy(S.speech_like_waveform(n_fit, 120000, 24000, seed=41000)).cuda()
     _, emb = enc(fit, None, return_embeddings=True)
     residual = emb.reshape(-1, 128).double().cpu()
     g = torch.Generator().manual_seed(3)
@@ -400,7 +394,18 @@ def test_acoustic_data_fitted_codebooks(cuda_device, family):
         residual = residual - cb[d.argmin(-1)]
     del enc
     enc = AcousticEncoder(AcousticEncoderConfig(bandwidth=6), device="cuda:0", weights=w)
-    wav = torch.from_numpy(S.speech_like_waveform(6, 120000, 24000, seed=42000))
+    return enc, w, torch.from_numpy(S.speech_like_waveform(n_test, 120000, 24000, seed=42000))
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+def test_acoustic_data_fitted_codebooks(cuda_device, family):
+    """The residual VQ with code books FITTED to the data, as a trained EnCodec has them (k-means on the residuals of each stage; reference call site
+    audiotoken/encoder.py:50-52): stage q's 1024 codes are residual vectors of OTHER clips at stage q (+ 1 % noise), so the nearest code is close and near-ties
+    are frequent at every stage. The SEANet encoder is well-conditioned on both weight families (fp32 oracle vs its float64 evaluation: 3e-6 / 8e-6 in the
+    embedding), so the strict bar applies to both: ids equal the oracle's, or the oracle's top-2 margin at the frame's first differing stage is < 1e-3."""
+    from oracle import encodec_ref as R
+    _oracle_threads()
+    enc, w, wav = fitted_acoustic(family)
     codes = enc.verified(enc(wav.cuda(), None), wav.cuda(), None)
     assert enc.last_status() == 0 and enc.fallback_batches == 0
     wt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
