@@ -98,6 +98,12 @@ def save_rel_audio_tokens(tokens: torch.Tensor, audio_pointer: AudioConfig, root
         arr = tokens.cpu().numpy()
         arr = arr[:, :audio_pointer.length_tokens]
         rel_path = os.path.dirname(os.path.relpath(audio_pointer.file_name, start=rel_dir))
+        if rel_path.startswith("..") or os.path.isabs(rel_path):
+            # DELIBERATE deviation (round 5): a name that is not under rel_dir — a member of a tar / zip found by the directory scan carries the member's own
+            # relative name — makes the reference's os.path.join(root_dir, "../../..") write OUTSIDE outdir, relative to the current directory (utils.py:374-376).
+            # Such token files go to outdir itself here.
+            logger.warning(f'{audio_pointer.file_name} is not under {rel_dir}: its tokens are saved in {root_dir} (the reference would write outside it)')
+            rel_path = ""
         output_path = os.path.join(root_dir, rel_path)
         os.makedirs(output_path, exist_ok=True)
         filename = os.path.splitext(os.path.basename(audio_pointer.file_name))[0]

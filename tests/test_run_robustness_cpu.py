@@ -67,6 +67,10 @@ def test_symlinked_directories_are_scanned_once(tmp_path):
     out = sorted(os.path.relpath(os.path.join(d, f), tmp_path / "out") for d, _, fs in os.walk(tmp_path / "out") for f in fs)
     wavs = [o for o in out if o.split("/")[-1].startswith("clip")]
     assert len(wavs) == 7 and all(o.startswith(("spk_a/", "spk_a_again/")) for o in wavs) and len({o.split("/")[0] for o in wavs}) == 1, out
+    # the tar's members carry their own relative names ("member0.wav"): the reference would write their tokens OUTSIDE outdir, relative to the current directory
+    # (utils.py:374-376); here they land in outdir itself (harness.save_rel_audio_tokens)
+    assert sorted(o for o in out if "/" not in o) == ["member0.npy", "member1.npy"], out
+    assert not os.path.exists("member0.npy") and not os.path.exists("member1.npy")
 
 
 def test_flac_with_an_absurd_streaminfo_is_skipped(tmp_path):
