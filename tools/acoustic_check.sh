@@ -4,7 +4,7 @@
 out=gpurun_out/acoustic_check; mkdir -p $out
 timeout 1200 python -m pytest tests/test_acoustic_gpu.py -m gpu -q > $out/pytest.log 2>&1; tail -4 $out/pytest.log
 for v in 1 2; do
-  timeout 600 python bench.py --workload acoustic --steps 10 --warmup 2 --no-cpu-baseline --no-verify "$@" > $out/b$v.json 2> $out/b$v.err
+  timeout 600 python bench.py --full-line --workload acoustic --steps 10 --warmup 2 --no-cpu-baseline --no-verify "$@" > $out/b$v.json 2> $out/b$v.err
   python - <<PY
 import json
 try:

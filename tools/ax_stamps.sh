@@ -10,5 +10,5 @@ if [ "$1" = "build" ]; then
   hipcc --offload-arch=gfx950 -shared -fPIC -o $R/audiotoken_amd/lib/libaudiotoken_hip_axdbg.so $(ls $C/build/*.o | grep -v -e attention_bf16x3.o -e _dbg.o) $C/build/attention_bf16x3_dbg.o
 else
   export AUDIOTOKEN_HIP_LIB=$R/audiotoken_amd/lib/libaudiotoken_hip_axdbg.so
-  timeout 300 python3 $R/bench.py --workload semantic_m --steps 1 --warmup 0 --no-cpu-baseline --no-verify 2>&1 >/dev/null | grep "ax stamps" | head -8
+  timeout 300 python3 $R/bench.py --full-line --workload semantic_m --steps 1 --warmup 0 --no-cpu-baseline --no-verify 2>&1 >/dev/null | grep "ax stamps" | head -8
 fi

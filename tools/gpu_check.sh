@@ -7,7 +7,7 @@ if [ $# -eq 0 ]; then set -- tests -m gpu; fi
 timeout 1500 python -m pytest "$@" -q -s > $out/pytest.log 2>&1; echo "pytest rc $?" | tee -a $out/pytest.log
 grep -E "passed|failed|error" $out/pytest.log | tail -3
 grep -E "parity-at-size|\[sweep\]|\[edge\]|\[N2\]|split gemm|conv split" $out/pytest.log > $out/parity_counts.txt
-timeout 600 python bench.py --steps 10 --warmup 2 --workload both --no-cpu-baseline > $out/bench.json 2> $out/bench.err; echo "bench rc $?"
+timeout 600 python bench.py --full-line --steps 10 --warmup 2 --workload both --no-cpu-baseline > $out/bench.json 2> $out/bench.err; echo "bench rc $?"
 python - <<PY
 import json
 try:

@@ -5,7 +5,7 @@ W=${1:-semantic_m}; TAG=${2:-stats}; STEPS=${3:-2}
 export TMPDIR=/tmp
 cd /tmp
 rm -rf $R/gpurun_out/$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -- python3 $R/bench.py --workload $W --steps $STEPS --warmup 1 --no-cpu-baseline > $R/gpurun_out/$TAG.json 2> $R/gpurun_out/$TAG.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -- python3 $R/bench.py --full-line --workload $W --steps $STEPS --warmup 1 --no-cpu-baseline > $R/gpurun_out/$TAG.json 2> $R/gpurun_out/$TAG.err
 cd $R
 f=$(find gpurun_out/$TAG -name "*kernel_stats.csv" | head -1)
 cp $f gpurun_out/${TAG}_kernel_stats.csv

@@ -15,7 +15,7 @@ run() { # name, counters...
   for c in "$@"; do if grep -qw "$c" $O/counters_list.txt; then keep="$keep $c"; else echo "counter $c not offered on this box"; fi; done
   set -- $keep
   rm -rf $O/$n
-  timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$n -- python3 $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-verify > $O/$n.json 2> $O/$n.err
+  timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$n -- python3 $R/bench.py --full-line --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-verify > $O/$n.json 2> $O/$n.err
   echo "$n rc=$?"
 }
 run fetch FETCH_SIZE

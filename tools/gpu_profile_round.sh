@@ -7,8 +7,8 @@ export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp
-python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $O/stats_bench.json 2> $O/stats.err
+python3 $R/bench.py --full-line --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --full-line --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $O/stats_bench.json 2> $O/stats.err
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 cd $R
 bash tools/gpu_pmc_semantic.sh acoustic $TAG/pmc_acoustic > $O/pmc_acoustic.log 2>&1

@@ -10,5 +10,5 @@ if [ "$1" = "build" ]; then
   hipcc --offload-arch=gfx950 -shared -fPIC -o $R/audiotoken_amd/lib/libaudiotoken_hip_dbg.so $(ls $C/build/*.o | grep -v -e lstm_seq_x3.o -e lstm_seq_x3_dbg.o) $C/build/lstm_seq_x3_dbg.o
 else
   export AUDIOTOKEN_HIP_LIB=$R/audiotoken_amd/lib/libaudiotoken_hip_dbg.so
-  timeout 300 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 >/dev/null | grep "lstm stamps" | tail -4
+  timeout 300 python3 $R/bench.py --full-line --steps 2 --warmup 1 --no-cpu-baseline 2>&1 >/dev/null | grep "lstm stamps" | tail -4
 fi

@@ -4,8 +4,8 @@
 # max-over-ranks and the rank all-gather. The numbers are NOT a measurement (two processes share one device).
 #   gpurun -- bash tools/n2_rehearsal.sh
 out=gpurun_out/n2; mkdir -p $out
-timeout 1200 python bench.py --gpus 2 --backend gloo --shared-device --steps 2 --warmup 1 --no-cpu-baseline --no-verify --batch 32 --sem-batch 8 --sem-layers 3 --workload both > $out/both.json 2> $out/both.err; echo "both rc $?"
-timeout 1200 python bench.py --gpus 2 --backend gloo --shared-device --steps 2 --warmup 1 --no-cpu-baseline --no-verify --hub-batch 8 --workload semantic_s > $out/hub.json 2> $out/hub.err; echo "semantic_s rc $?"
+timeout 1200 python bench.py --full-line --gpus 2 --backend gloo --shared-device --steps 2 --warmup 1 --no-cpu-baseline --no-verify --batch 32 --sem-batch 8 --sem-layers 3 --workload both > $out/both.json 2> $out/both.err; echo "both rc $?"
+timeout 1200 python bench.py --full-line --gpus 2 --backend gloo --shared-device --steps 2 --warmup 1 --no-cpu-baseline --no-verify --hub-batch 8 --workload semantic_s > $out/hub.json 2> $out/hub.err; echo "semantic_s rc $?"
 python - <<PY
 import json
 for n in ("both", "hub"):
@@ -20,7 +20,7 @@ for n in ("both", "hub"):
         print(n, "parse failed", e); print(open("$out/%s.err" % n).read()[-3000:])
 PY
 # the files leg on two ranks (every rank its own generated files; LPT sharding is exercised by tests/test_distributed_cpu.py)
-timeout 1200 python bench.py --gpus 2 --backend gloo --shared-device --workload files --files-acoustic 256 --files-acoustic-batch 64 --files-semantic 0 --no-cpu-baseline --no-verify > $out/files.json 2> $out/files.err; echo "files rc $?"
+timeout 1200 python bench.py --full-line --gpus 2 --backend gloo --shared-device --workload files --files-acoustic 256 --files-acoustic-batch 64 --files-semantic 0 --no-cpu-baseline --no-verify > $out/files.json 2> $out/files.err; echo "files rc $?"
 python - <<PY
 import json
 try:
@@ -31,7 +31,7 @@ except Exception as e:
     print("files parse failed", e); print(open("$out/files.err").read()[-3000:])
 PY
 # the default workload ("all": both tokenizers + decode + semantic_s + files) at reduced sizes
-timeout 1200 python bench.py --gpus 2 --backend gloo --shared-device --steps 2 --warmup 1 --no-cpu-baseline --no-verify --batch 32 --sem-batch 8 --sem-layers 3 --hub-batch 8 --files-acoustic 64 --files-acoustic-batch 32 --files-semantic 0 > $out/all.json 2> $out/all.err; echo "all rc $?"
+timeout 1200 python bench.py --full-line --gpus 2 --backend gloo --shared-device --steps 2 --warmup 1 --no-cpu-baseline --no-verify --batch 32 --sem-batch 8 --sem-layers 3 --hub-batch 8 --files-acoustic 64 --files-acoustic-batch 32 --files-semantic 0 > $out/all.json 2> $out/all.err; echo "all rc $?"
 python - <<PY
 import json
 try:

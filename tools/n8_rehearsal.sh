@@ -7,7 +7,7 @@
 #   gpurun --timeout 2400 -- bash tools/n8_rehearsal.sh
 out=gpurun_out/n8; mkdir -p $out
 N=${N:-8}
-run() { name=$1; shift; timeout 1500 python bench.py --gpus $N --backend gloo --shared-device --no-cpu-baseline --no-verify "$@" > $out/$name.json 2> $out/$name.err; echo "$name rc $?"; }
+run() { name=$1; shift; timeout 1500 python bench.py --full-line --gpus $N --backend gloo --shared-device --no-cpu-baseline --no-verify "$@" > $out/$name.json 2> $out/$name.err; echo "$name rc $?"; }
 run both --steps 2 --warmup 1 --batch 16 --sem-batch 4 --sem-layers 3 --workload both
 run hub --steps 2 --warmup 1 --hub-batch 4 --workload semantic_s
 run files --workload files --files-acoustic 64 --files-acoustic-batch 16 --files-semantic 8 --files-semantic-batch 4 --files-semantic-s 16 --files-semantic-s-batch 8

@@ -4,7 +4,7 @@
 out=gpurun_out/semantic_check; mkdir -p $out
 timeout 1500 python -m pytest tests/test_semantic_gpu.py tests/test_hubert.py tests/test_packed_gpu.py tests/test_ops_gpu.py -m gpu -q ${1:+-k "$1"} > $out/pytest.log 2>&1; tail -4 $out/pytest.log
 for v in 1 2; do
-  timeout 900 python bench.py --workload semantic_m --steps 5 --warmup 1 --no-cpu-baseline --no-verify > $out/b$v.json 2> $out/b$v.err
+  timeout 900 python bench.py --full-line --workload semantic_m --steps 5 --warmup 1 --no-cpu-baseline --no-verify > $out/b$v.json 2> $out/b$v.err
   python - <<PY
 import json
 try:

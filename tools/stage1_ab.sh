@@ -5,7 +5,7 @@ out=gpurun_out/stage1; mkdir -p $out
 if [ -f tools/stage1_dbg.py ]; then timeout 300 python tools/stage1_dbg.py 2>&1 | tail -4; fi
 timeout 900 python -m pytest tests/test_acoustic_gpu.py -m gpu -q -k "fused_stage1 or repeated or golden or range" > $out/pytest.log 2>&1; tail -5 $out/pytest.log
 for v in 1 0 1; do
-  timeout 600 python bench.py --acoustic-option fused_stage1=$v --workload acoustic --steps 10 --warmup 2 --no-cpu-baseline --no-verify > $out/b$v.json 2> $out/b$v.err
+  timeout 600 python bench.py --full-line --acoustic-option fused_stage1=$v --workload acoustic --steps 10 --warmup 2 --no-cpu-baseline --no-verify > $out/b$v.json 2> $out/b$v.err
   python - <<PY
 import json
 try:

@@ -10,5 +10,5 @@ if [ "$1" = "build" ]; then
   hipcc --offload-arch=gfx950 -shared -fPIC -o $R/audiotoken_amd/lib/libaudiotoken_hip_dbg.so $(ls $C/build/*.o | grep -v -e gemm_f16x2_tg.o -e _dbg.o) $C/build/gemm_f16x2_tg_dbg.o
 else
   export AUDIOTOKEN_HIP_LIB=$R/audiotoken_amd/lib/libaudiotoken_hip_dbg.so
-  timeout 300 python3 $R/bench.py --workload semantic_m --steps 1 --warmup 0 --no-cpu-baseline 2>&1 >/dev/null | grep "tg stamps\|first tile\|all .* tiles" | head -96
+  timeout 300 python3 $R/bench.py --full-line --workload semantic_m --steps 1 --warmup 0 --no-cpu-baseline 2>&1 >/dev/null | grep "tg stamps\|first tile\|all .* tiles" | head -96
 fi
