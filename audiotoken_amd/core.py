@@ -79,22 +79,45 @@ class AudioToken:
         return w if isinstance(w, dict) else None
 
     def load_encoder(self):
-        """core.py:92-118 (lazy construction on first use)."""
-        if self.encoder is None:
-            if self.tokenizer_name == Tokenizers.acoustic:
-                from .encoder import AcousticEncoder
-                self.encoder = AcousticEncoder(device=self.device, config=self.model_config, weights=self._weights_kw())
-            elif self.tokenizer_name == Tokenizers.semantic_s:
-                from .hubert import HubertEncoder, hubert_processor
-                self.encoder = HubertEncoder(config=self.model_config, device=self.device, weights=self._weights_kw())
-                self.transform_func = hubert_processor
-            elif self.tokenizer_name == Tokenizers.semantic_m:
-                from .encoder import Wav2VecBertEncoder
-                self.encoder = Wav2VecBertEncoder(config=self.model_config, device=self.device, quantize=True,
-                                                  weights=self._weights_kw())
-            else:
-                raise ValueError(f"Tokenizer {self.tokenizer_name} not supported")
-            self.encoder.eval()
+        """core.py:92-118 (lazy construction on first use). The reference is single-device; here, when ``torch.distributed`` is initialised with more than one
+        rank, the model is built ONCE: rank 0 reads the checkpoint (the ``weights=`` path / dict, the ``AUDIOTOKEN_*`` variables, or the synthetic default),
+        the other ranks receive it over RCCL — EnCodec as one flat tensor, the semantic tokenizers as rank 0's FINALIZED model (one packed device blob:
+        no N-fold checkpoint read, fold, upload or split; distributed.encoder_on_all_ranks) — and every rank then encodes the same 2-clip probe: a rank whose
+        tokens differ from rank 0's raises on ALL ranks before the first batch (``self.rank_probe`` keeps the checksums). ``broadcast_weights=False`` keeps
+        per-rank loading (every rank must then be given the same checkpoint; the probe still runs unless ``rank_probe=False``). Collective: every rank of the
+        group must construct its ``AudioToken`` and reach its first ``encode*`` call."""
+        if self.encoder is not None:
+            return
+        from . import distributed as D
+        dist = D.active()
+        dev = torch.device(self.device)
+        shared = dist is not None and self.kwargs.get("broadcast_weights", True)
+        wkw = self._weights_kw()
+        if self.tokenizer_name == Tokenizers.acoustic:
+            from .encoder import AcousticEncoder
+            if shared:
+                from .encoder import encodec_weights_from
+                wkw = D.weights_on_all_ranks(lambda: encodec_weights_from(wkw if wkw is not None else self.model_config.weights, with_decoder=False),
+                                             dev, dist, "acoustic encoder")
+            self.encoder = AcousticEncoder(device=self.device, config=self.model_config, weights=wkw)
+        elif self.tokenizer_name == Tokenizers.semantic_s:
+            from .hubert import HubertEncoder, hubert_processor
+            local = lambda: HubertEncoder(config=self.model_config, device=self.device, weights=wkw)
+            self.encoder = (D.encoder_on_all_ranks(local, lambda p: HubertEncoder(config=self.model_config, device=self.device, packed=p), dev, dist, "semantic_s encoder")
+                            if shared else local())
+            self.transform_func = hubert_processor
+        elif self.tokenizer_name == Tokenizers.semantic_m:
+            from .encoder import Wav2VecBertEncoder
+            local = lambda: Wav2VecBertEncoder(config=self.model_config, device=self.device, quantize=True, weights=wkw)
+            self.encoder = (D.encoder_on_all_ranks(local, lambda p: Wav2VecBertEncoder(config=self.model_config, device=self.device, quantize=True, packed=p),
+                                                   dev, dist, "semantic_m encoder") if shared else local())
+        else:
+            raise ValueError(f"Tokenizer {self.tokenizer_name} not supported")
+        self.encoder.eval()
+        self.rank_probe = None
+        if dist is not None and self.kwargs.get("rank_probe", True):
+            x = D.probe_batch(self.model_config.model_sample_rate, self.device, self.transform_func)
+            self.rank_probe = D.ranks_agree_on_probe(lambda w: self.encoder(w, torch.ones_like(w)), x, dev, dist, str(self.tokenizer_name))
 
     def encode(self, audio: Union[torch.Tensor, np.ndarray, os.PathLike, bytes, Path], chunk_size: Optional[int] = None) -> torch.Tensor:
         """core.py:120-185. ``(1, num_samples)`` array/tensor or a path -> tokens ``(1, K, T)`` on the CPU
@@ -229,6 +252,11 @@ class AudioToken:
             exts = AUDIO_EXTS + TAR_EXTS + ZIP_EXTS
             files = []
             seen = set()    # glob follows symlinked sub-directories (datasets laid out as symlink farms); so does this walk, once per real directory
+            try:            # the root counts as seen: a link cycle back to it must not list its own files a second time
+                st = os.stat(str(audio_dir))
+                seen.add((st.st_dev, st.st_ino))
+            except OSError:
+                pass
             for d, dirs, names in os.walk(str(audio_dir), followlinks=True):
                 keep = []
                 for x in dirs:
@@ -248,11 +276,16 @@ class AudioToken:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dataloader_kwargs.get("shard_across_ranks", True):
             # duration-aware: whole files by greedy LPT on their sizes (distributed.shard_by_size). Rank 0 stats the list ONCE and broadcasts the sizes (N_files
             # stats instead of N_files x world on a shared filesystem; and every rank provably shards the same numbers)
-            from .distributed import shard_by_size
-            sizes = [[os.path.getsize(f) if os.path.exists(f) else 0 for f in files]] if dist.get_rank() == 0 else [None]
-            dist.broadcast_object_list(sizes, src=0)
-            assert len(sizes[0]) == len(files), "ranks see different file lists: encode_batch_files needs the same audio_files / audio_dir on every rank"
-            files = [files[i] for i in shard_by_size(sizes[0], dist.get_rank(), dist.get_world_size())]
+            import hashlib
+            from .distributed import collective_device, shard_by_size
+            digest = hashlib.sha256("\0".join(files).encode("utf-8", "surrogateescape")).hexdigest()
+            sizes = [([os.path.getsize(f) if os.path.exists(f) else 0 for f in files], digest)] if dist.get_rank() == 0 else [None]
+            # the pickled list travels on THIS rank's device under RCCL (not torch's current device: a caller that never called set_device would put every rank on cuda:0)
+            dist.broadcast_object_list(sizes, src=0, device=collective_device(torch.device(self.device), dist))
+            sizes, digest0 = sizes[0]
+            assert len(sizes) == len(files) and digest0 == digest, \
+                "ranks see different file lists: encode_batch_files needs the same audio_files / audio_dir on every rank"
+            files = [files[i] for i in shard_by_size(sizes, dist.get_rank(), dist.get_world_size())]
         start_time = time.time()
         on_gpu = torch.device(self.device).type == "cuda"
         copy_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
@@ -320,8 +353,8 @@ class AudioToken:
                 encoded_audio = self.encoder(input_ids, attention_masks)      # asynchronous on the device
                 t1 = time.perf_counter()
                 if pending is not None:
-                    save(*pending)
-                    pending = None
+                    p, pending = pending, None      # ownership first: an interrupt inside the save must not make the `finally` below append the rows again
+                    save(*p)
                 t2 = time.perf_counter()
                 staged = stage_next()                                         # the next batch is decoded / uploaded / cut while this one encodes
                 t3 = time.perf_counter()
@@ -336,9 +369,13 @@ class AudioToken:
             # batches are already there) — the save is deferred by one batch, it must not be lost by it
             if pending is not None:
                 t0 = time.perf_counter()
-                save(*pending)
+                p, pending = pending, None
+                save(*p)
                 rt["save_s"] += time.perf_counter() - t0
-            self._end_of_run()
+            try:
+                self._end_of_run()
+            except Exception as e:   # bookkeeping must not mask the exception that ended the run
+                logger.error(f"encode_batch_files: end-of-run bookkeeping failed: {type(e).__name__}: {e}")
         rt["total_s"] = time.time() - start_time
         logger.debug(f"Encoding batch files took: {time.time() - start_time:.2f}s")
         if self.skipped_files:
@@ -364,7 +401,14 @@ class AudioToken:
                 cfg = AcousticDecoderConfig(bandwidth=num_codebooks_to_bandwidth(self.num_codebooks))
                 if self.kwargs.get("weights") is not None and not isinstance(self.kwargs["weights"], dict):
                     cfg.weights = self.kwargs["weights"]
-                self.decoder = AcousticDecoder(config=cfg, device=self.device, weights=self._weights_kw(), **kwargs)
+                wkw = self._weights_kw()
+                from . import distributed as D
+                dist = D.active()
+                if dist is not None and self.kwargs.get("broadcast_weights", True):   # as load_encoder: rank 0 reads the checkpoint, one RCCL broadcast
+                    from .encoder import encodec_weights_from
+                    wkw = D.weights_on_all_ranks(lambda: encodec_weights_from(wkw if wkw is not None else cfg.weights, with_decoder=True),
+                                                 torch.device(self.device), dist, "acoustic decoder")
+                self.decoder = AcousticDecoder(config=cfg, device=self.device, weights=wkw, **kwargs)
             elif self.tokenizer_name in (Tokenizers.semantic_s, Tokenizers.semantic_m):
                 raise NotImplementedError("semantic decoders (autoregressive GPT + bark fine model) are out of scope of the MI355X hot path")
             else:

@@ -3,7 +3,7 @@ collective. The reference is single-device (audiotoken/core.p
 ``encode_batch_files``-style work shard across the 8 GPUs of a node."""
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -50,10 +50,10 @@ def broadcast_weights(weights: Optional[Dict[str, np.ndarray]], device: torch.de
         return weights
     rank = dist.get_rank()
     meta = [[(k, tuple(v.shape)) for k, v in weights.items()]] if rank == src else [None]
-    dist.broadcast_object_list(meta, src=src)
+    cdev = collective_device(device, dist)
+    dist.broadcast_object_list(meta, src=src, device=cdev)   # the pickled layout travels on THIS rank's device under RCCL, not torch's current one
     layout = meta[0]
     total = int(sum(int(np.prod(s)) for _, s in layout))
-    cdev = collective_device(device, dist)
     if rank == src:
         flat = torch.from_numpy(np.concatenate([np.asarray(weights[k], dtype=np.float32).reshape(-1) for k, _ in layout]))
         flat = flat.to(cdev)
@@ -117,3 +117,59 @@ def ranks_agree_on_probe(encode, probe: torch.Tensor, device: torch.device, dist
         raise RuntimeError(f"{what}: ranks {bad} encode the start-up probe differently from rank 0 ({[rows[r] for r in bad]} vs {rows[0]}): "
                            "a rank's model differs (packed-model import / weight broadcast) — refusing to run")
     return {"ranks": len(rows), "token_checksum": int(rows[0][0]), "weighted_checksum": int(rows[0][1])}
+
+
+# ---- model distribution for the product (AudioToken.load_encoder / load_decoder) ----------------------------------------------------------------------
+def active(dist=None):
+    """``torch.distributed`` when it is initialised with more than one rank, else None."""
+    if dist is None:
+        import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+
+
+def _rank0_first(step, device: torch.device, dist, what: str, src: int = 0):
+    """Run ``step()`` on rank ``src`` only and tell every rank whether it worked BEFORE any tensor collective: a checkpoint that rank 0 cannot read must raise
+    on all ranks, not leave world - 1 of them waiting in a broadcast."""
+    res, err = None, None
+    if dist.get_rank() == src:
+        try:
+            res = step()
+        except Exception as e:   # re-raised below on every rank
+            err = f"{type(e).__name__}: {e}"
+    box = [err]
+    dist.broadcast_object_list(box, src=src, device=collective_device(device, dist))
+    if box[0] is not None:
+        raise RuntimeError(f"{what}: rank {src} could not build the model ({box[0]})")
+    return res
+
+
+def weights_on_all_ranks(load: Callable[[], Dict[str, np.ndarray]], device: torch.device, dist, what: str = "weights", src: int = 0):
+    """EnCodec (34 MB): rank ``src`` reads the checkpoint (``load()``), every rank returns the same name -> array dict (one flat RCCL broadcast)."""
+    w = _rank0_first(load, device, dist, what, src)
+    return broadcast_weights(w, device, dist, src)
+
+
+def encoder_on_all_ranks(build_local: Callable[[], "torch.nn.Module"], build_from_packed: Callable[[tuple], "torch.nn.Module"], device: torch.device, dist,
+                         what: str = "encoder", src: int = 0):
+    """The semantic tokenizers (1.8-4.5 GB of weights): rank ``src`` reads, folds, uploads, splits and finalizes the checkpoint ONCE (``build_local()``), exports
+    the finalized model as one packed device blob, and the other ranks rebuild their handle over the broadcast blob (``build_from_packed((meta, blob))``) —
+    SURVEY.md §8(e); the reference is single-device (audiotoken/core.py:92-118 loads per process)."""
+    def build_and_export():
+        e = build_local()
+        return e, e.export_packed()
+    enc, packed = _rank0_first(build_and_export, device, dist, what, src) or (None, None)
+    packed = broadcast_packed(packed, device, dist, src)
+    if dist.get_rank() != src:
+        enc = build_from_packed(packed)
+    del packed
+    return enc
+
+
+def probe_batch(sample_rate: int, device, transform: Optional[Callable] = None) -> torch.Tensor:
+    """The start-up probe: two distinct speech-like 2 s clips (synthetic.py, fixed seed — the same bytes on every rank), through the tokenizer's per-clip
+    host transform when it has one (semantic_s)."""
+    from . import synthetic as S
+    x = torch.from_numpy(S.speech_like_waveform(2, 2 * sample_rate, sample_rate, seed=987654))
+    if transform is not None:
+        x = torch.stack([transform(x[i:i + 1])[0] for i in range(2)])
+    return x.to(device)

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional, Union
 
 import numpy as np
@@ -60,6 +61,16 @@ def load_encodec_checkpoint(path: str) -> Dict[str, np.ndarray]:
     return {k: v.float().numpy() for k, v in sd.items() if torch.is_tensor(v)}
 
 
+def encodec_weights_from(weights, with_decoder: bool) -> Dict[str, np.ndarray]:
+    """``weights`` as the constructors accept it — None (synthetic, seed 0, logged), a checkpoint path, or a name -> array dict — as the un-folded dict."""
+    if weights is None:
+        logger.warning("No EnCodec checkpoint given (weights=/AUDIOTOKEN_ENCODEC_WEIGHTS): using synthetic weights, seed 0")
+        return W.synth_encodec_weights(seed=0, with_decoder=with_decoder)
+    if isinstance(weights, (str, bytes, os.PathLike)):
+        return load_encodec_checkpoint(weights)
+    return weights
+
+
 class _EncodecHandle:
     """Owns one ``at_encodec_t`` (device weights live inside the library)."""
 
@@ -68,12 +79,7 @@ class _EncodecHandle:
         self.lib = _cabi.load()
         self.device_index = _device_index(device)
         self.device = torch.device("cuda", self.device_index)
-        if weights is None:
-            logger.warning("No EnCodec checkpoint given (weights=/AUDIOTOKEN_ENCODEC_WEIGHTS): using synthetic weights, seed 0")
-            weights = W.synth_encodec_weights(seed=0, with_decoder=with_decoder)
-        elif isinstance(weights, (str, bytes)):
-            weights = load_encodec_checkpoint(weights)
-        folded = fold_encodec_weights(weights)
+        folded = fold_encodec_weights(encodec_weights_from(weights, with_decoder))
         self.handle = self.lib.at_encodec_create(self.device_index)
         if not self.handle:
             raise _cabi.HipLibraryError(f"at_encodec_create failed: {_cabi.last_error()}")

@@ -753,13 +753,17 @@ def run_files(args, rank, world, dev, dist, device_rates):
             if name not in toks:
                 toks.clear()                 # one tokenizer at a time: an acoustic handle sized for 256 x 30 s holds ~200 GB of workspace
                 torch.cuda.empty_cache()
+                # the PRODUCT distributes the model (AudioToken.load_encoder, round 6): only rank 0 holds weights; at N > 1 the others receive EnCodec's flat
+                # tensor / rank 0's finalized packed model over RCCL and every rank passes the start-up probe before its first file
+                r0 = (lambda make: make()) if rank == 0 else (lambda make: None)
                 if name == "acoustic":
-                    toks[name] = AudioToken(which, device=str(dev), num_codebooks=args.num_codebooks, weights=W.synth_encodec_weights(seed=0, with_decoder=False))
+                    toks[name] = AudioToken(which, device=str(dev), num_codebooks=args.num_codebooks, weights=r0(lambda: W.synth_encodec_weights(seed=0, with_decoder=False)))
                 elif name == "semantic_s":
-                    toks[name] = AudioToken(which, device=str(dev), weights=W.synth_hubert_weights(n_layers=11, seed=0, with_kmeans=True))
+                    toks[name] = AudioToken(which, device=str(dev), weights=r0(lambda: W.synth_hubert_weights(n_layers=11, seed=0, with_kmeans=True)))
                 else:
-                    toks[name] = AudioToken(which, device=str(dev), weights=W.synth_w2vbert_weights(n_layers=args.sem_layers, seed=0, with_vq=True))
+                    toks[name] = AudioToken(which, device=str(dev), weights=r0(lambda: W.synth_w2vbert_weights(n_layers=args.sem_layers, seed=0, with_vq=True)))
                 toks[name].load_encoder()
+                assert world == 1 or toks[name].rank_probe["ranks"] == world
             tok = toks[name]
             if not device_rates.get(name):   # (--workload files alone) the device-resident rate of this tokenizer: the same batch shape, inputs in HBM
                 xb = torch.randn(bs, 30 * dst, device=dev) * 0.1
@@ -813,13 +817,11 @@ def run_files(args, rank, world, dev, dist, device_rates):
 def rank_probe(encode, sample_rate: int, dev, dist, what: str):
     """N > 1: every rank encodes the same 2-clip x 2 s probe with ITS copy of the model; the checksums must equal rank 0's before anything is timed
     (audiotoken_amd/distributed.ranks_agree_on_probe raises on all ranks otherwise). N = 1: the same call, trivially true — the JSON shows the probe ran."""
-    from audiotoken_amd import synthetic as S
-    from audiotoken_amd.distributed import ranks_agree_on_probe
-    x = torch.from_numpy(S.speech_like_waveform(2, 2 * sample_rate, sample_rate, seed=987654)).to(dev)
+    from audiotoken_amd.distributed import probe_batch, ranks_agree_on_probe
+    transform = None
     if what == "semantic_s":
-        from audiotoken_amd.hubert import hubert_processor
-        x = torch.stack([hubert_processor(x[i:i + 1].cpu())[0] for i in range(2)]).to(dev)
-    return ranks_agree_on_probe(encode, x, dev, dist, what)
+        from audiotoken_amd.hubert import hubert_processor as transform
+    return ranks_agree_on_probe(encode, probe_batch(sample_rate, dev, transform), dev, dist, what)
 
 
 def settle_status(enc, call, name):

@@ -215,3 +215,125 @@ def test_ranks_agree_on_probe_world4(corrupt_rank):
         assert all(s == "ok" and n == 4 for _, s, n in got), got
     else:
         assert all(s == "raised" and f"ranks [{corrupt_rank}]" in msg for _, s, msg in got), got
+
+
+# ---- round 6: the PRODUCT distributes the model — AudioToken.load_encoder under torch.distributed ----------------------------------------------------
+class _PackedEncoder(torch.nn.Module):
+    """Stand-in for Wav2VecBertEncoder / HubertEncoder (no device, no HIP library): same constructor keywords, `export_packed()` / `packed=`. `weights` is a
+    path to a .npy "checkpoint"; the tokens depend on every weight. `corrupt_import` makes the packed import wrong on the ranks listed in the environment."""
+    loads = 0   # checkpoint reads in this process
+
+    def __init__(self, config=None, device="cpu", quantize=True, weights=None, packed=None):
+        super().__init__()
+        if packed is not None:
+            meta, blob = packed
+            assert meta == b"stand-in v1" and blob.dtype == torch.uint8
+            self.w = blob.clone().view(torch.float32)
+            if str(dist.get_rank()) in os.environ.get("AT_TEST_CORRUPT_IMPORT", "").split(","):
+                self.w[3] += 0.5
+        else:
+            type(self).loads += 1
+            self.w = torch.from_numpy(np.load(weights if weights is not None else config.weights))   # FileNotFoundError on a rank without the file
+
+    def export_packed(self):
+        return b"stand-in v1", self.w.clone().view(torch.uint8)
+
+    def forward(self, x, m):
+        B, N = x.shape
+        T = N // 320
+        f = (x * m)[:, :T * 320].reshape(B, T, 320)
+        k = self.w[:320]
+        return ((f * k).sum(-1).abs() * 4096.0).round().to(torch.int64).remainder(2048).to(torch.int16).unsqueeze(1)
+
+
+def _product_worker(rank, world, port, tmp, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if case == "corrupt":
+        os.environ["AT_TEST_CORRUPT_IMPORT"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import audiotoken_amd.encoder as E
+        from audiotoken_amd import AudioToken, Tokenizers
+        E.Wav2VecBertEncoder = _PackedEncoder
+        ckpt = os.path.join(tmp, "ckpt.npy")
+        # only rank 0 can read the checkpoint: the other ranks are given a path that does not exist (case "missing": rank 0 cannot either)
+        path = ckpt if (rank == 0 and case != "missing") or case == "per_rank" else os.path.join(tmp, "not-here.npy")
+        kw = {"broadcast_weights": False} if case == "per_rank" else {}
+        tok = AudioToken(Tokenizers.semantic_m, device="cpu", weights=path, **kw)
+        try:
+            tok.load_encoder()
+            q.put((rank, "ok", _PackedEncoder.loads, float(tok.encoder.w.double().sum()), tok.rank_probe))
+        except RuntimeError as e:
+            q.put((rank, "raised", _PackedEncoder.loads, str(e), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["shared", "per_rank", "corrupt", "missing"])
+def test_audiotoken_load_encoder_distributes_the_model(tmp_path, case):
+    """AudioToken.load_encoder with world 2 (gloo, stand-in encoder): rank 0 reads the checkpoint ONCE and exports its finalized model, rank 1 rebuilds from the
+    broadcast blob without touching the checkpoint, both run the start-up probe and hold its checksums; `broadcast_weights=False` keeps per-rank loading;
+    a rank whose import went wrong makes EVERY rank raise before the first batch; a checkpoint rank 0 cannot read raises on every rank (nobody waits)."""
+    rng = np.random.default_rng(5)
+    np.save(tmp_path / "ckpt.npy", rng.standard_normal(4096).astype(np.float32))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000) + 11 * ["shared", "per_rank", "corrupt", "missing"].index(case)
+    mp.spawn(_product_worker, args=(2, port, str(tmp_path), case, q), nprocs=2, join=True)
+    got = sorted(q.get(timeout=30) for _ in range(2))
+    want = float(np.load(tmp_path / "ckpt.npy").astype(np.float64).sum())
+    if case == "shared":
+        assert [g[1] for g in got] == ["ok", "ok"], got
+        assert [g[2] for g in got] == [1, 0]                                   # checkpoint reads: rank 0 once, rank 1 never
+        assert all(abs(g[3] - want) < 1e-6 for g in got)
+        assert got[0][4] == got[1][4] and got[0][4]["ranks"] == 2
+    elif case == "per_rank":
+        assert [g[1] for g in got] == ["ok", "ok"] and [g[2] for g in got] == [1, 1] and got[0][4]["ranks"] == 2, got
+    elif case == "corrupt":
+        assert all(g[1] == "raised" and "ranks [1]" in g[3] for g in got), got
+    else:
+        assert all(g[1] == "raised" and "rank 0 could not build the model" in g[3] and "FileNotFoundError" in g[3] for g in got), got
+
+
+class _DictEncoder(torch.nn.Module):
+    """Stand-in for AcousticEncoder: keeps the weight dict it was constructed with."""
+
+    def __init__(self, config=None, device="cpu", weights=None):
+        super().__init__()
+        assert isinstance(weights, dict), type(weights)
+        self.weights = weights
+        self.k = torch.from_numpy(np.concatenate([np.asarray(v, dtype=np.float32).reshape(-1) for v in weights.values()])[:320].copy())
+
+    def forward(self, x, m):
+        B, N = x.shape
+        T = N // 320
+        return ((x[:, :T * 320].reshape(B, T, 320) * self.k).sum(-1).abs() * 4096.0).round().to(torch.int64).remainder(1024).to(torch.int16).unsqueeze(1)
+
+
+def _acoustic_worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import audiotoken_amd.encoder as E
+        from audiotoken_amd import AudioToken, Tokenizers
+        from audiotoken_amd import weights as W
+        E.AcousticEncoder = _DictEncoder
+        ckpt = os.path.join(tmp, "encodec.th")
+        if rank == 0:
+            torch.save({k: torch.from_numpy(v) for k, v in W.synth_encodec_weights(seed=3, with_decoder=False, n_codebooks=2).items()}, ckpt)
+        dist.barrier()
+        tok = AudioToken(Tokenizers.acoustic, device="cpu", num_codebooks=2, weights=ckpt if rank == 0 else os.path.join(tmp, "absent.th"))
+        tok.load_encoder()
+        w = tok.encoder.weights
+        q.put((rank, len(w), float(sum(np.asarray(v, dtype=np.float64).sum() for v in w.values())), tok.rank_probe["token_checksum"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_audiotoken_acoustic_weights_come_from_rank0(tmp_path):
+    """The EnCodec checkpoint is read on rank 0 only (rank 1's path does not exist) and reaches rank 1 as one flat broadcast; both ranks pass the probe."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    mp.spawn(_acoustic_worker, args=(2, 36900 + (os.getpid() % 2000), str(tmp_path), q), nprocs=2, join=True)
+    a, b = sorted(q.get(timeout=30) for _ in range(2))
+    assert a[1:] == b[1:] and a[1] > 50, (a, b)

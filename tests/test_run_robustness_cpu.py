@@ -61,7 +61,9 @@ def test_symlinked_directories_are_scanned_once(tmp_path):
     os.makedirs(farm / ".hidden")
     os.symlink(tmp_path / "real" / "speaker1", farm / "spk_a")
     os.symlink(tmp_path / "real" / "speaker1", farm / "spk_a_again")          # the same real directory a second time: visited once
-    os.symlink(farm, tmp_path / "real" / "speaker1" / "loop")                  # a cycle
+    os.symlink(farm, tmp_path / "real" / "speaker1" / "loop")                  # a cycle back to the ROOT of the scan
+    import shutil
+    shutil.copy(names[0], farm / "rootfile.wav")                               # a file in the root itself: listed once, not again through the cycle
     tok = _tok(_HashEncoder())
     tok.encode_batch_files(batch_size=4, outdir=str(tmp_path / "out"), chunk_size=1, num_workers=0, audio_dir=str(farm))
     out = sorted(os.path.relpath(os.path.join(d, f), tmp_path / "out") for d, _, fs in os.walk(tmp_path / "out") for f in fs)
@@ -69,7 +71,8 @@ def test_symlinked_directories_are_scanned_once(tmp_path):
     assert len(wavs) == 7 and all(o.startswith(("spk_a/", "spk_a_again/")) for o in wavs) and len({o.split("/")[0] for o in wavs}) == 1, out
     # the tar's members carry their own relative names ("member0.wav"): the reference would write their tokens OUTSIDE outdir, relative to the current directory
     # (utils.py:374-376); here they land in outdir itself (harness.save_rel_audio_tokens)
-    assert sorted(o for o in out if "/" not in o) == ["member0.npy", "member1.npy"], out
+    assert sorted(o for o in out if "/" not in o) == ["member0.npy", "member1.npy", "rootfile.npy"], out
+    assert not [o for o in out if o.endswith("rootfile.npy") and "/" in o], out
     assert not os.path.exists("member0.npy") and not os.path.exists("member1.npy")
 
 

@@ -19,7 +19,7 @@ from scipy.io import wavfile
 from audiotoken_amd import AudioToken, Tokenizers
 from audiotoken_amd import synthetic as S
 from audiotoken_amd import weights as W
-from audiotoken_amd.distributed import broadcast_weights, gather_scalars, ranks_agree_on_probe
+from audiotoken_amd.distributed import gather_scalars
 
 work = sys.argv[1]
 which = sys.argv[2] if len(sys.argv) > 2 else "acoustic"
@@ -43,17 +43,19 @@ if rank == 0:
         os.makedirs(sub, exist_ok=True)
         wavfile.write(os.path.join(sub, f"utt{i:03d}.wav"), rate, np.round(x * 30000).astype(np.int16))
 dist.barrier()
-weights = None
-if rank == 0:
-    weights = W.synth_encodec_weights(seed=0, with_decoder=False) if which == "acoustic" else W.synth_hubert_weights(11, 0, True)
-weights = broadcast_weights(weights, dev, dist)
-tok = AudioToken(getattr(Tokenizers, which), device="cuda:0", weights=weights, **({"num_codebooks": 8} if which == "acoustic" else {}))
+# the PRODUCT path (round 6): AudioToken.load_encoder distributes the model — acoustic: a checkpoint FILE that only rank 0 reads (the other ranks get a path that
+# does not exist), one flat broadcast; semantic_s: only rank 0 holds weights, the others rebuild from its finalized packed model — and runs the start-up probe
+if which == "acoustic":
+    ckpt = os.path.join(work, "encodec_24khz.th")
+    if rank == 0:
+        torch.save({k: torch.from_numpy(v) for k, v in W.synth_encodec_weights(seed=0, with_decoder=False).items()}, ckpt)
+    dist.barrier()
+    tok = AudioToken(Tokenizers.acoustic, device="cuda:0", weights=ckpt if rank == 0 else ckpt + ".only-rank-0-reads-it", num_codebooks=8)
+else:
+    tok = AudioToken(getattr(Tokenizers, which), device="cuda:0", weights=W.synth_hubert_weights(11, 0, True) if rank == 0 else None)
 tok.load_encoder()
-probe = torch.from_numpy(S.speech_like_waveform(2, 2 * sr, sr, seed=424242)).to(dev)
-if which == "semantic_s":
-    from audiotoken_amd.hubert import hubert_processor
-    probe = torch.stack([hubert_processor(probe[i:i + 1].cpu())[0] for i in range(2)]).to(dev)
-pr = ranks_agree_on_probe(lambda x: tok.encoder(x, torch.ones_like(x)), probe, dev, dist, which)
+pr = tok.rank_probe
+assert pr is not None and pr["ranks"] == world
 dist.barrier()
 t0, c0 = time.perf_counter(), time.process_time()
 tok.encode_batch_files(batch_size=16, outdir=out_n, chunk_size=10, audio_dir=src_dir, num_workers=workers)
