@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) x2 += __shfl_xor(x2, off);
     if (status && lane == 0 && !(x2 <= 3.0e38f)) atomicOr(status, XB_STATUS_NONFINITE);   // a NaN / infinity anywhere upstream ends up in these rows
-    float best = -INFINITY;
+    float best = -INFINITY, second = -INFINITY;   // `second`: this lane's runner-up (round 6) — decides whether the refinement's second pass can find anything
     int bidx = 0;
     for (int c = lane; c < (C >> 2); c += 64) {   // increasing n per lane: strict > keeps the first index
         const f4 d = reinterpret_cast<const f4*>(dots + row * ld)[c];
@@ -875,9 +875,12 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
         for (int k = 0; k < 4; ++k) {
             const float d2 = __fadd_rn(__fadd_rn(x2, y2[k]), -2.0f * d[k]);
             const float v = -sqrtf(fmaxf(d2, 0.f));
-            if (v > best) { best = v; bidx = c * 4 + k; }
+            if (v > best) { second = best; best = v; bidx = c * 4 + k; }
+            else second = fmaxf(second, v);
         }
     }
+    const float lane_best = best;
+    const int lane_bidx = bidx;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const float ob = __shfl_xor(best, off);
@@ -908,6 +911,15 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
             for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
             return acc;
         };
+        // Is there ANY other code inside the window? A lane's candidates are its own best (unless that is the winner) and its runner-up; v^2 equals the clamped
+        // d^2 up to the rounding of the square root (<= 2^-23 relative), so the test below is the second pass's own test widened by 2^-19: rows without a
+        // near-tie (the rule) skip the second read of their dots row and the float64 work altogether; rows with one run the exact test as before (bit-identical).
+        const float lim = (best_d2 + window) * (1.0f + 1.0f / 524288.0f);
+        const float cand = lane_bidx == bidx ? second : lane_best;
+        if (!__any(cand * cand <= lim)) {
+            if (lane == 0) out[row] = (int16_t)bidx;
+            return;
+        }
         double ex_best = exact(bidx);                                        // the approximate winner first: it is always a candidate
         int ex_idx = bidx;
         // a degenerate code book (hundreds of near-duplicate rows) or a degenerate vector could shortlist every code: at most VQ_REFINE_MAX exact evaluations
@@ -930,7 +942,7 @@ __global__ __launch_bounds__(256) void vq_argmax_kernel(const float* __restrict_
             while (pending && evaluated < VQ_REFINE_MAX) {                    // one shortlisted code at a time, the whole wave on its row
                 const int src = __ffsll((long long)pending) - 1;
                 const unsigned m = (unsigned)__shfl((int)mask4, src);
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < 4 && evaluated < VQ_REFINE_MAX; ++k) {
                     if (!((m >> k) & 1u)) continue;
                     const int n = (c0 + src) * 4 + k;
                     const double acc = exact(n);

@@ -27,6 +27,7 @@ from tests import parity as P
 from tests.test_fullsize_gpu import _oracle_threads, fitted_acoustic, fitted_semantic_m, fitted_semantic_s
 
 pytestmark = pytest.mark.gpu
+N_CLIPS = 16   # per tokenizer (>= 16)
 
 
 def exact_assign(e, centres):
@@ -56,10 +57,19 @@ def _study(what, enc, run_hip, e64, e32, centres, ids32, m32):
           f"{int((dq & (m32.reshape(-1) >= P.VQ_TIE)).sum())} at a reference margin >= 1e-3")
     ref_off = off(ids32, m_x)
     print(f"[conditioning] {what}: fp32 reference restatement (network + quantiser in fp32) vs exact arithmetic: {ref_off[0]} ids differ, {ref_off[1]} at an exact margin >= 1e-3")
-    enc.set_option("vq_refine", 0)
-    old = off(run_hip(), m_x)
-    enc.set_option("vq_refine", 1)
-    new = off(run_hip(), m_x)
+    # the contract's own number (round 6): HIP vs the fp32 reference restatement ("oracle32"), for both settings of the near-tie re-evaluation — `unexplained` =
+    # differing at a position whose ORACLE32 top-2 margin is >= 1e-3 (tests/parity.py's bar). Printed, not asserted: on such a checkpoint oracle32's ids at those
+    # positions are its own sgemm-order noise (see the two lines above); this is the deviation INTEGRATION.md states.
+    m32f = m32.reshape(-1)
+    vs32 = {}
+    for refine in (0, 1):
+        enc.set_option("vq_refine", refine)
+        ids_h = run_hip().reshape(-1).long().cpu()
+        d32 = ids_h != ids32
+        vs32[refine] = (int(d32.sum()), int((d32 & (m32f >= P.VQ_TIE)).sum()), off(ids_h, m_x))
+        print(f"[conditioning] {what}: HIP f16x2, vq_refine={refine} vs ORACLE32 (the fp32 reference restatement): {vs32[refine][0]} of {n} ids differ "
+              f"({100.0 * vs32[refine][0] / n:.2f} %), {vs32[refine][1]} at an oracle32 margin >= 1e-3 ({100.0 * vs32[refine][1] / n:.2f} % 'unexplained' by tests/parity.py's bar)")
+    old, new = vs32[0][2], vs32[1][2]
     print(f"[conditioning] {what}: HIP f16x2 vs exact arithmetic: {new[0]} ids differ, {new[1]} at an exact margin >= 1e-3 "
           f"(without the exact re-evaluation of near-ties, as rounds 1-4 shipped: {old[0]} / {old[1]})")
     for arith in ("bf16x3", "f32"):
@@ -74,7 +84,7 @@ def _study(what, enc, run_hip, e64, e32, centres, ids32, m32):
 def test_semantic_m_trained_like_fitted_codebook(cuda_device):
     from oracle import w2vbert_ref as R
     _oracle_threads()
-    enc, w, wav = fitted_semantic_m("trained_like")
+    enc, w, wav = fitted_semantic_m("trained_like", n_test=N_CLIPS)
     mask = torch.ones_like(wav)
     x, m = wav.cuda(), mask.cuda()
     toks = enc.verified(enc(x, m), x, m)
@@ -86,13 +96,13 @@ def test_semantic_m_trained_like_fitted_codebook(cuda_device):
     e64 = torch.nn.functional.layer_norm(R.encoder_hidden_state(w64, f64_, am, 19), (1024,)).float()
     f32_, am32 = R.processor(wav, mask, 2)
     e32 = torch.nn.functional.layer_norm(R.encoder_hidden_state(w32, f32_, am32, 19), (1024,))
-    _study("semantic_m, trained_like weights, fitted code book, 4 x 10 s, 19 layers", enc, lambda: enc(x, m), e64, e32, w32["vq._codebook.embed"].reshape(-1, 1024), ids32, m32)
+    _study(f"semantic_m, trained_like weights, fitted code book, {N_CLIPS} x 10 s, 19 layers", enc, lambda: enc(x, m), e64, e32, w32["vq._codebook.embed"].reshape(-1, 1024), ids32, m32)
 
 
 def test_semantic_s_trained_like_fitted_centres(cuda_device):
     from oracle import hubert_ref as R
     _oracle_threads()
-    enc, w, wav = fitted_semantic_s("trained_like")
+    enc, w, wav = fitted_semantic_s("trained_like", n_test=N_CLIPS)
     mask = torch.ones_like(wav)
     x, m = wav.cuda(), mask.cuda()
     toks = enc.verified(enc(x, m), x, m)
@@ -102,7 +112,7 @@ def test_semantic_s_trained_like_fitted_centres(cuda_device):
     ids32, m32 = R.semantic_s_encode(w32, wav, mask, 11, return_margins=True)
     e64 = torch.nn.functional.layer_norm(R.hidden_states(w64, wav.double(), mask.double(), 11), (768,)).float()
     e32 = torch.nn.functional.layer_norm(R.hidden_states(w32, wav, mask, 11), (768,))
-    _study("semantic_s, trained_like weights, fitted k-means centres, 4 x 10 s, 11 layers", enc, lambda: enc(x, m), e64, e32, w32["kmeans.cluster_centers_"], ids32, m32)
+    _study(f"semantic_s, trained_like weights, fitted k-means centres, {N_CLIPS} x 10 s, 11 layers", enc, lambda: enc(x, m), e64, e32, w32["kmeans.cluster_centers_"], ids32, m32)
 
 
 def test_acoustic_trained_like_fitted_codebooks_vs_exact(cuda_device):
@@ -131,3 +141,42 @@ def test_acoustic_trained_like_fitted_codebooks_vs_exact(cuda_device):
     print(f"[conditioning] acoustic, trained_like weights, fitted RVQ code books, 6 x 5 s: of {n_frames} frames (differ from exact arithmetic / at an exact margin >= 1e-3 at the "
           f"first differing stage) — fp32 reference restatement {ref_off[0]} / {ref_off[1]}; HIP f16x2 {hip_off[0]} / {hip_off[1]}")
     assert hip_off[1] <= ref_off[1] + 2 and hip_off[0] <= 2 * ref_off[0] + 10
+
+
+def test_semantic_s_untempered_family_is_informational(cuda_device):
+    """The FIRST form of the trained_like HuBERT family — massive post-LN gains feeding RANDOM q / k columns, before the family was tempered (weights.py,
+    DESIGN.md section 5): the fp32 oracle is chaotic there (0.5 from its own float64 evaluation). Printed for the record, with the same three comparisons as the
+    study above and NO parity assertion: it shows what 'ids identical to the reference' means on a network whose fp32 evaluation does not reproduce itself."""
+    from audiotoken_amd import synthetic as S
+    from audiotoken_amd import weights as W
+    from audiotoken_amd.configs import HubertEncoderConfig
+    from audiotoken_amd.hubert import HubertEncoder, hubert_processor
+    from oracle import hubert_ref as R
+    _oracle_threads()
+    w = W.synth_hubert_weights(11, 0, True, family="trained_like")
+    mc = W.massive_channels("hubert", 768, 0)
+    for i in range(1, 11):     # undo the q / k column compensation (tools/family_probe.py `raw`)
+        g = w[f"encoder.layers.{i - 1}.final_layer_norm.weight"][mc]
+        for nm in ("q_proj", "k_proj"):
+            w[f"encoder.layers.{i}.attention.{nm}.weight"][:, mc] *= g[None, :]
+    x = torch.from_numpy(S.speech_like_waveform(4, 160000, 16000, seed=34000))
+    wav = torch.stack([hubert_processor(x[i:i + 1])[0] for i in range(4)])
+    mask = torch.ones_like(wav)
+    enc = HubertEncoder(HubertEncoderConfig(), device="cuda:0", quantize=True, weights=w)
+    w32 = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
+    w64 = {k: v.double() for k, v in w32.items()}
+    ids32, m32 = R.semantic_s_encode(w32, wav, mask, 11, return_margins=True)
+    e64 = torch.nn.functional.layer_norm(R.hidden_states(w64, wav.double(), mask.double(), 11), (768,)).float()
+    e32 = torch.nn.functional.layer_norm(R.hidden_states(w32, wav, mask, 11), (768,))
+    ids_x, m_x = exact_assign(e64, w32["kmeans.cluster_centers_"])
+    ids32 = ids32.reshape(-1).long()
+    n = ids_x.numel()
+    d = ids32 != ids_x
+    print(f"[conditioning] semantic_s, UN-TEMPERED trained_like family (informational), 4 x 10 s: fp32 oracle vs its own float64 evaluation: max |LN(h) difference| "
+          f"{float((e32 - e64).abs().max()):.3f}; oracle32 vs exact arithmetic: {int(d.sum())} of {n} ids differ, {int((d & (m_x >= P.VQ_TIE)).sum())} at an exact margin >= 1e-3")
+    for refine in (0, 1):
+        enc.set_option("vq_refine", refine)
+        ids_h = enc(wav.cuda(), mask.cuda()).reshape(-1).long().cpu()
+        a, b = ids_h != ids32, ids_h != ids_x
+        print(f"[conditioning] semantic_s, UN-TEMPERED family: HIP f16x2, vq_refine={refine}: vs oracle32 {int(a.sum())} differ / {int((a & (m32.reshape(-1) >= P.VQ_TIE)).sum())} at an oracle32 "
+              f"margin >= 1e-3; vs exact arithmetic {int(b.sum())} differ / {int((b & (m_x >= P.VQ_TIE)).sum())} at an exact margin >= 1e-3; status {enc.last_status()}")

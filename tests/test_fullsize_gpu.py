@@ -347,32 +347,39 @@ def fitted_semantic_s(family, n_fit=12, n_test=4):
 
 
 def test_semantic_m_data_fitted_codebook(cuda_device):
+    """Strict bar on the uniform family with a code book fitted to the data — for BOTH settings of `vq_refine` (round 6): 1 = near-ties re-evaluated exactly (default),
+    0 = the reference's expanded fp32 form alone (audiotoken/encoder.py:180, torch.cdist at vector_quantize_pytorch). Either setting is a parity-checked path."""
     from oracle import w2vbert_ref as R
     _oracle_threads()
     enc, w, wav = fitted_semantic_m("uniform")
     mask = torch.ones_like(wav)
-    toks = enc.verified(enc(wav.cuda(), mask.cuda()), wav.cuda(), mask.cuda())
-    assert enc.last_status() == 0 and enc.fallback_batches == 0
     wt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
     ref, m = R.semantic_m_encode(wt, wav, mask, 2, 19, return_margins=True)
-    n, bad, _ = P.explain_token_mismatches(toks, ref, m, P.VQ_TIE)
-    _report("semantic_m, uniform weights, code book fitted to the data, 4 x 10 s, 19 layers", ref.numel(), n, bad, [m], enc)
     assert len(torch.unique(ref)) > 50, "a fitted code book must be USED (many distinct ids)"
-    assert bad == 0
+    for refine in (1, 0):
+        enc.set_option("vq_refine", refine)
+        toks = enc.verified(enc(wav.cuda(), mask.cuda()), wav.cuda(), mask.cuda())
+        assert enc.last_status() == 0 and enc.fallback_batches == 0
+        n, bad, _ = P.explain_token_mismatches(toks, ref, m, P.VQ_TIE)
+        _report(f"semantic_m, uniform weights, code book fitted to the data, 4 x 10 s, 19 layers, vq_refine={refine}", ref.numel(), n, bad, [m], enc)
+        assert bad == 0
 
 
 def test_semantic_s_data_fitted_centres(cuda_device):
+    """As test_semantic_m_data_fitted_codebook: both settings of `vq_refine` meet the strict bar (reference: audiotoken/encoder.py:100-101, torch.cdist + argmin)."""
     from oracle import hubert_ref as R
     _oracle_threads()
     enc, w, wav = fitted_semantic_s("uniform")
     mask = torch.ones_like(wav)
-    toks = enc.verified(enc(wav.cuda(), mask.cuda()), wav.cuda(), mask.cuda())
-    assert enc.last_status() == 0 and enc.fallback_batches == 0
     ref, m = R.semantic_s_encode(w, wav, mask, 11, return_margins=True)
-    n, bad, _ = P.explain_token_mismatches(toks, ref, m, P.VQ_TIE)
-    _report("semantic_s, uniform weights, k-means centres fitted to the data, 4 x 10 s, 11 layers", ref.numel(), n, bad, [m], enc)
     assert len(torch.unique(ref)) > 50
-    assert bad == 0
+    for refine in (1, 0):
+        enc.set_option("vq_refine", refine)
+        toks = enc.verified(enc(wav.cuda(), mask.cuda()), wav.cuda(), mask.cuda())
+        assert enc.last_status() == 0 and enc.fallback_batches == 0
+        n, bad, _ = P.explain_token_mismatches(toks, ref, m, P.VQ_TIE)
+        _report(f"semantic_s, uniform weights, k-means centres fitted to the data, 4 x 10 s, 11 layers, vq_refine={refine}", ref.numel(), n, bad, [m], enc)
+        assert bad == 0
 
 
 def fitted_acoustic(family, n_fit=12, n_test=6):

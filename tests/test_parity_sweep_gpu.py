@@ -52,7 +52,10 @@ def test_sweep_decoder(cuda_device, s, fam):
     ref = R.acoustic_decode(w, codes).reshape(-1)
     err = float((got - ref).abs().max())
     print(f"[sweep] decoder, {fam} weights, seed {100 + s}: max abs err {err:.2e} at waveform scale {float(ref.abs().max()):.2f}")
-    assert err < 1e-3 * max(1.0, float(ref.abs().max()))
+    # the contract's absolute 1e-3 on the uniform family (waveforms of scale ~1; measured ~2e-5); trained_like waveforms reach scales >> 1, where the bar is
+    # relative and close to what is measured (1e-4 of the scale), so that a 10 x regression fails either way
+    bar = 1e-3 if fam == "uniform" else 1e-4 * max(1.0, float(ref.abs().max()))
+    assert err < bar, (err, bar)
 
 
 @pytest.mark.parametrize("s,fam", CASES)
