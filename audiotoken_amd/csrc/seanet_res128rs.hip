@@ -30,6 +30,24 @@ constexpr int RS_HBUF = 2 * RS_HP;
 constexpr int RS_CHUNKS = RS_XROWS * 32;        // float4 chunks of an input tile
 constexpr int RS_PRE = (RS_CHUNKS + 511) / 512; // per thread: 3 (the last one partly)
 constexpr size_t RS_LDS_BYTES = (size_t)(3 * RS_XBUF + 2 * RS_HBUF) * 2;
+
+// tile row of tail fragment column pos = 16 m + r16 when the output goes to the stride-5 consumer's phase planes (see tail_row below)
+__device__ constexpr unsigned char kRsTailRows[32] = {2, 7, 12, 17, 0, 5, 10, 15, 20, 25, 30, 27, 22, 3, 8, 13,
+                                                      4, 9, 14, 19, 1, 6, 11, 16, 21, 26, 31, 28, 24, 29, 18, 23};
+constexpr bool rs_tail_rows_ok() {
+    unsigned seen = 0;
+    for (int m = 0; m < 2; ++m) {
+        unsigned a8 = 0, b8 = 0;   // residues mod 8 of the two 8-row sets of a ds_read_b128 lane group
+        for (int r = 0; r < 16; ++r) {
+            const int row = kRsTailRows[16 * m + r];
+            seen |= 1u << row;
+            if (r >= 4 && r < 12) b8 |= 1u << (row & 7); else a8 |= 1u << (row & 7);
+        }
+        if (a8 != 0xffu || b8 != 0xffu) return false;
+    }
+    return seen == 0xffffffffu;
+}
+static_assert(rs_tail_rows_ok(), "tail row order: a permutation of 0..31 whose ds_read_b128 lane groups are distinct mod 8");
 }  // namespace
 
 __global__ __launch_bounds__(512, 1) void seanet_res128rs_kernel(Res64Args a) {
@@ -113,16 +131,15 @@ __global__ __launch_bounds__(512, 1) void seanet_res128rs_kernel(Res64Args a) {
             }
         }
     };
-    // Which tile row a fragment column of the TAIL stands for. The 1x1 tail may take its rows in any order; with the split output the 32 rows
-    // are sorted by (row % 5, row / 5) — planes of 7, 7, 6, 6, 6 rows — so that the 16 lanes of a row tile hold consecutive indices of (mostly)
-    // one phase plane and their 32-byte piece stores join into longer runs.
+    // Which tile row a fragment column of the TAIL stands for. The 1x1 tail may take its rows in any order; with the split output the 32 rows are grouped by
+    // row % 5 (the consumer's phase planes: rows 5 i + c of one class are consecutive indices of one plane) so that the 32-byte piece stores of neighbouring
+    // lanes join into longer runs. Round 6: the grouping is BANK-AWARE. A ds_read_b128 is served in 16-lane groups {r16 in 0-3 | 12-15 at one q, r16 in 4-11 at
+    // the next q}; with row strides of 18 (x) and 10 (h) 16-byte slots a group is conflict-free exactly when its two sets of 8 rows are distinct mod 8 each.
+    // Round 5's order (classes back to back: 7, 7, 6, 6, 6 rows) put rows 10 / 26 / 2 — all 2 mod 8 — into one set: 3-way conflicts on every tail read, 0.34
+    // of the kernel's LDS cycles (PMC lds_conflict_share; tools/lds_bank_sim.py reproduces it). Now: lanes 4-11 of row tile 0 hold class 0 (+ row 27), of row tile 1
+    // class 1 (+ row 28); lanes 0-3 / 12-15 hold classes 2-4 in runs of 4, 3 and 2 — every set distinct mod 8 (checked at compile time below).
     const bool phase_order = a.S != nullptr;
-    auto tail_row = [&](int pos) {
-        if (!phase_order) return pos;
-        const int pl = pos < 14 ? pos / 7 : 2 + (pos - 14) / 6;
-        const int i = pos < 14 ? pos - 7 * pl : pos - 14 - 6 * (pl - 2);
-        return 5 * i + pl;
-    };
+    auto tail_row = [&](int pos) { return phase_order ? (int)kRsTailRows[pos] : pos; };
 
     const int first = blockIdx.x, step = gridDim.x;
     const int K = first < total_tiles ? (total_tiles - first + step - 1) / step : 0;

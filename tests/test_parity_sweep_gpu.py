@@ -39,7 +39,7 @@ def test_sweep_acoustic(cuda_device, s, fam):
 
 @pytest.mark.parametrize("s,fam", DEC_CASES)
 def test_sweep_decoder(cuda_device, s, fam):
-    """Random codes -> waveform, weight seed 100 + s (reference audiotoken/decoder.py:66-76): max abs error < 1e-3 (measured ~2e-5)."""
+    """Random codes -> waveform, weight seed 100 + s (reference audiotoken/decoder.py:66-76): max abs error < 2e-5 of the waveform scale, and < 1e-3 absolute on the uniform family."""
     from audiotoken_amd.configs import AcousticDecoderConfig
     from audiotoken_amd.decoder import AcousticDecoder
     from oracle import encodec_ref as R
@@ -52,9 +52,10 @@ def test_sweep_decoder(cuda_device, s, fam):
     ref = R.acoustic_decode(w, codes).reshape(-1)
     err = float((got - ref).abs().max())
     print(f"[sweep] decoder, {fam} weights, seed {100 + s}: max abs err {err:.2e} at waveform scale {float(ref.abs().max()):.2f}")
-    # the contract's absolute 1e-3 on the uniform family (waveforms of scale ~1; measured ~2e-5); trained_like waveforms reach scales >> 1, where the bar is
-    # relative and close to what is measured (1e-4 of the scale), so that a 10 x regression fails either way
-    bar = 1e-3 if fam == "uniform" else 1e-4 * max(1.0, float(ref.abs().max()))
+    # measured (round 6): 7e-6 .. 1.3e-5 at waveform scales 5-9 (uniform), 2.4e-5 .. 4.8e-5 at scales 18-31 (trained_like) = 1.2e-6 .. 1.5e-6 of the scale. The bar is
+    # 2e-5 of the scale (a 10 x regression fails on either family), and never above the contract's absolute 1e-3 on the uniform family
+    scale = max(1.0, float(ref.abs().max()))
+    bar = min(1e-3, 2e-5 * scale) if fam == "uniform" else 2e-5 * scale
     assert err < bar, (err, bar)
 
 
