@@ -194,9 +194,10 @@ __device__ __forceinline__ float gelu_erf(float y) { return gelu_erf_scaled(y, 0
 // exponential and the sign select stay per element). The same operations in the same order as gelu_erf_scaled: bit-identical per element.
 __device__ __forceinline__ auto gelu_erf_scaled2(float __attribute__((ext_vector_type(2))) y, float half) -> float __attribute__((ext_vector_type(2))) {
     typedef float f2_ __attribute__((ext_vector_type(2)));
-    const f2_ x = __builtin_elementwise_abs(y) * 0.70710678118654752440f;
-    const f2_ d = __builtin_elementwise_fma(f2_{0.3275911f, 0.3275911f}, x, f2_{1.0f, 1.0f});
-    const f2_ t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    // x = y / sqrt 2 keeps its sign: |x| enters only the denominator below, as the abs MODIFIER of a plain v_fma_f32 (the packed fma has none: |y| first cost a
+    // v_and_b32 per element), and -x * x is sign-blind; |y| c and |y c| are the same float, so every value is bit for bit that of gelu_erf_scaled
+    const f2_ x = y * 0.70710678118654752440f;
+    const f2_ t = {__builtin_amdgcn_rcpf(fmaf(0.3275911f, fabsf(x[0]), 1.0f)), __builtin_amdgcn_rcpf(fmaf(0.3275911f, fabsf(x[1]), 1.0f))};
     f2_ p = __builtin_elementwise_fma(t, f2_{1.061405429f, 1.061405429f}, f2_{-1.453152027f, -1.453152027f});
     p = __builtin_elementwise_fma(t, p, f2_{1.421413741f, 1.421413741f});
     p = __builtin_elementwise_fma(t, p, f2_{-0.284496736f, -0.284496736f});

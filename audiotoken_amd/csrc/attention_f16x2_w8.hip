@@ -75,6 +75,13 @@ constexpr float W8_P_LOG2 = 10.0f;              // probabilities are split as p 
 // magnitude, the row sum is fp32), and the 32-register multiply of O — pure vector work, which does not overlap with MFMAs on this chip — is skipped for all
 // but the first tiles of a query block. Exact algebra: the deferred factor cancels in O / l; only the rounding of exp2's argument moves.
 constexpr float W8_DEFER = 4.0f;
+// EXPERIMENT (round 6, -DW8_P_PIECES=1; the product build keeps 2): the probabilities as ONE fp16 piece in P.V — two products per multiply-add (v lo . p, v hi . p)
+// instead of three, and one conversion per pair of probabilities instead of three instructions. p * 2^10 <= 1024 has no range problem; its precision drops from
+// 22 to 11 bits (relative 2^-12 per probability). Measured and judged in profiles/EXPERIMENTS.md.
+#ifndef W8_P_PIECES
+#define W8_P_PIECES 2
+#endif
+constexpr int W8_PP = W8_P_PIECES;
 
 static size_t w8_lds_bytes(int T, bool relpos) {
     const int nkt = (T + W8_KB - 1) / W8_KB;
@@ -431,9 +438,13 @@ __global__ __launch_bounds__(512 / W8_NQB, W8_NQB == 1 ? 2 : 1) void relpos_atte
         u4_ pp[2][NQB][2];   // [k-step parity][query block][piece]: 8 fp16 = 4 registers
         auto split_pair = [&](int ks, int qb, int j) {
             unsigned hi, lo;
-            w8_split_pair(s[qb][ks >> 1][8 * (ks & 1) + j], s[qb][ks >> 1][8 * (ks & 1) + j + 1], hi, lo);
+            if constexpr (W8_PP == 2) {
+                w8_split_pair(s[qb][ks >> 1][8 * (ks & 1) + j], s[qb][ks >> 1][8 * (ks & 1) + j + 1], hi, lo);
+                pp[ks & 1][qb][1][j >> 1] = lo;
+            } else {
+                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(s[qb][ks >> 1][8 * (ks & 1) + j]), "v"(s[qb][ks >> 1][8 * (ks & 1) + j + 1]));
+            }
             pp[ks & 1][qb][0][j >> 1] = hi;
-            pp[ks & 1][qb][1][j >> 1] = lo;
         };
         V8 vf[2][2];   // [(ks, dt) parity][piece]
         auto load_v = [&](int u) {   // u = 2 ks + dt
@@ -460,12 +471,13 @@ __global__ __launch_bounds__(512 / W8_NQB, W8_NQB == 1 ? 2 : 1) void relpos_atte
         for (int u = 0; u < 8; ++u) {
             const int ks = u >> 1, dt = u & 1;
             if (u + 1 < 8) load_v(u + 1);
+            constexpr int T0 = W8_PP == 2 ? 0 : 1;                          // one probability piece: the products (v lo . p), (v hi . p) only
 #pragma unroll
-            for (int t = 0; t < SC::NPROD; ++t)
+            for (int t = T0; t < SC::NPROD; ++t)
 #pragma unroll
                 for (int qb = 0; qb < NQB; ++qb) {
                     oacc[qb][dt] = SC::mfma(vf[u & 1][SC::prod_a(t)], __builtin_bit_cast(V8, pp[ks & 1][qb][SC::prod_w(t)]), oacc[qb][dt]);
-                    const int sl = (dt * 3 + t) * NQB + qb;                 // 0 .. 6 NQB - 1 within the k-step
+                    const int sl = (dt * (SC::NPROD - T0) + (t - T0)) * NQB + qb;   // 0 .. 6 NQB - 1 (4 NQB - 1) within the k-step
                     if (ks + 1 < 4 && sl < 4 * NQB) split_pair(ks + 1, sl >> 2, 2 * (sl & 3));
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -10,7 +10,7 @@
 //     buffer k & 1) while the T waves run the tail of tile k-1 (h buffer (k-1) & 1 and the raw x of tile k-1 -> out); every wave then stages
 //     its share of tile k+1 (loads issued at the top of the iteration: ELU, two splits, LDS stores). Three x buffers make that hazard-free:
 //     tile k+1 is written to buffer (k+1) % 3 while buffers k % 3 and (k-1) % 3 are read.
-//   * 32-row tiles: 3 x [Xe hi | Xe lo | Xr hi | Xr lo][34 rows][128 + 16] fp16 + 2 x [2][32][64 + 16] = 135 KB of LDS, one workgroup per CU.
+//   * 32-row tiles: 3 x [Xe hi | Xe lo | Xr hi | Xr lo][34 rows][128 + 16] fp16 + 2 x [2][32][64] (swizzled) = 131 KB of LDS, one workgroup per CU.
 // Results are bit-identical to seanet_res128x3_kernel<SchemeF16x2> (same products in the same order per output element); that kernel stays
 // as the bf16-scheme instantiation and as this one's reference (tests/test_acoustic_gpu.py).
 #include "gemm_core.h"
@@ -22,7 +22,9 @@ namespace at {
 namespace {
 constexpr int RS_TT = 32;                       // time rows per tile
 constexpr int RS_XROWS = RS_TT + 2;             // row i <-> time t0 - 2 + i
-constexpr int RS_LDX = 144, RS_LDH = 80;        // row strides (fp16 elements): + 32 B, conflict-free fragment reads (seanet_res128x3.hip)
+constexpr int RS_LDX = 144;                     // x row stride (fp16 elements): + 32 B, conflict-free fragment reads (seanet_res128x3.hip)
+constexpr int RS_LDH = 64;                      // h rows DENSE (128 B), 16-byte chunk index XORed with row & 7 (rs_hoff, round 6): fragment reads conflict-free, the
+                                                // epilogue's 8-byte stores 2-way instead of 4-way (rows 160 B apart put 16 rows of one column on 4 bank pairs)
 constexpr int RS_XP = RS_XROWS * RS_LDX;        // one piece plane of an x tile
 constexpr int RS_XBUF = 4 * RS_XP;              // Xe hi, Xe lo, Xr hi, Xr lo
 constexpr int RS_HP = RS_TT * RS_LDH;           // one piece plane of an h tile
@@ -30,9 +32,10 @@ constexpr int RS_HBUF = 2 * RS_HP;
 constexpr int RS_CHUNKS = RS_XROWS * 32;        // float4 chunks of an input tile
 constexpr int RS_PRE = (RS_CHUNKS + 511) / 512; // per thread: 3 (the last one partly)
 constexpr size_t RS_LDS_BYTES = (size_t)(3 * RS_XBUF + 2 * RS_HBUF) * 2;
+__device__ __forceinline__ int rs_hoff(int row, int chunk) { return row * RS_LDH + ((chunk ^ (row & 7)) << 3); }
 
 // tile row of tail fragment column pos = 16 m + r16 when the output goes to the stride-5 consumer's phase planes (see tail_row below)
-__device__ constexpr unsigned char kRsTailRows[32] = {2, 7, 12, 17, 0, 5, 10, 15, 20, 25, 30, 27, 22, 3, 8, 13,
+__device__ constexpr unsigned char kRsTailRows[32] = {2, 7, 12, 17, 0, 5, 10, 15, 20, 25, 30, 3, 22, 27, 8, 13,
                                                       4, 9, 14, 19, 1, 6, 11, 16, 21, 26, 31, 28, 24, 29, 18, 23};
 constexpr bool rs_tail_rows_ok() {
     unsigned seen = 0;
@@ -136,8 +139,11 @@ __global__ __launch_bounds__(512, 1) void seanet_res128rs_kernel(Res64Args a) {
     // lanes join into longer runs. Round 6: the grouping is BANK-AWARE. A ds_read_b128 is served in 16-lane groups {r16 in 0-3 | 12-15 at one q, r16 in 4-11 at
     // the next q}; with row strides of 18 (x) and 10 (h) 16-byte slots a group is conflict-free exactly when its two sets of 8 rows are distinct mod 8 each.
     // Round 5's order (classes back to back: 7, 7, 6, 6, 6 rows) put rows 10 / 26 / 2 — all 2 mod 8 — into one set: 3-way conflicts on every tail read, 0.34
-    // of the kernel's LDS cycles (PMC lds_conflict_share; tools/lds_bank_sim.py reproduces it). Now: lanes 4-11 of row tile 0 hold class 0 (+ row 27), of row tile 1
-    // class 1 (+ row 28); lanes 0-3 / 12-15 hold classes 2-4 in runs of 4, 3 and 2 — every set distinct mod 8 (checked at compile time below).
+    // of the kernel's LDS cycles (PMC lds_conflict_share; tools/lds_bank_sim.py reproduces it). What a store instruction costs is the number of distinct runs its
+    // 16 rows cover, whatever lanes hold them (the 4 lanes of one row are 16 apart anyway), so each row tile keeps THREE runs like round 5's order: row tile 0 =
+    // class 2 whole (lanes 0-3, 12-13) + class 0 whole (lanes 4-10) + class 3's first three rows (lanes 11, 14, 15); row tile 1 = class 4 whole + class 1 whole +
+    // class 3's last three — every 8-row set distinct mod 8 (checked at compile time). (A first bank-aware order with five runs per row tile was conflict-free
+    // and 4 % SLOWER: profiles/EXPERIMENTS.md.)
     const bool phase_order = a.S != nullptr;
     auto tail_row = [&](int pos) { return phase_order ? (int)kRsTailRows[pos] : pos; };
 
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(512, 1) void seanet_res128rs_kernel(Res64Args a) {
                     const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
                     V4 hp[NP];
                     over |= split4<SC>(e, sa, hp);
-                    const int off = (16 * m + r16) * RS_LDH + ((2 * w + (q >> 1)) << 3) + ((q & 1) << 2);   // channels 16 w + 4 q .. + 3
+                    const int off = rs_hoff(16 * m + r16, 2 * w + (q >> 1)) + ((q & 1) << 2);   // channels 16 w + 4 q .. + 3
 #pragma unroll
                     for (int p = 0; p < NP; ++p) *reinterpret_cast<V4*>(Hs + p * RS_HP + off) = hp[p];
                 }
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(512, 1) void seanet_res128rs_kernel(Res64Args a) {
             auto tread = [&](int ks, V8 (&xf)[NP][2]) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const PT* src = ks < 2 ? Hs + trow[m] * RS_LDH + ((ks * 4 + q) << 3) : Xr + (trow[m] + 2) * RS_LDX + (((ks - 2) * 4 + q) << 3);
+                    const PT* src = ks < 2 ? Hs + rs_hoff(trow[m], ks * 4 + q) : Xr + (trow[m] + 2) * RS_LDX + (((ks - 2) * 4 + q) << 3);
                     const int ps = ks < 2 ? RS_HP : RS_XP;
 #pragma unroll
                     for (int p = 0; p < NP; ++p) xf[p][m] = *reinterpret_cast<const V8*>(src + p * ps);

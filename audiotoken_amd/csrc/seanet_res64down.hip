@@ -28,16 +28,27 @@ namespace {
 
 constexpr int RD_TT = 64;                    // block rows per tile = 16 conv outputs
 constexpr int RD_XROWS = 66;                 // x rows staged: row i <-> time t0 - 2 + i
-constexpr int RD_LDX = 80, RD_LDH = 40;      // as seanet_res64x3.hip
+constexpr int RD_LDX = 80;                   // as seanet_res64x3.hip
+constexpr int RD_LDH = 32;                   // h rows are DENSE (64 B) and XOR-swizzled by row: rd_hoff below (round 6)
 constexpr int RD_XP = RD_XROWS * RD_LDX, RD_HP = RD_TT * RD_LDH;
 constexpr int RD_PL = 17, RD_LDR = 80;       // R: local row i (time t0 - 4 + i, 68 rows) in plane i & 3 at index i >> 2 (seanet_down64x3.hip's layout)
-constexpr int RD_RP = 4 * RD_PL * RD_LDR;    // elements of one piece of one R buffer
+constexpr int RD_PPAD = 8;                   // + 16 B per plane (round 6): see rd_off
+constexpr int RD_PS = RD_PL * RD_LDR + RD_PPAD;
+constexpr int RD_RP = 4 * RD_PS;             // elements of one piece of one R buffer
 constexpr int RD_NBUF = 3;
 constexpr int RD_XBUF = 2 * 2 * RD_XP;         // elements of one X buffer: [Xe | Xr][2 pieces]
-constexpr int RD_LDS_BYTES = (2 * RD_XBUF + 2 * RD_HP + RD_NBUF * 2 * RD_RP) * 2;   // 160 000 of 163 840
+constexpr int RD_LDS_BYTES = (2 * RD_XBUF + 2 * RD_HP + RD_NBUF * 2 * RD_RP) * 2;   // 158 336 of 163 840
 constexpr int RD_THREADS = 768;
 
-__device__ __forceinline__ int rd_off(int row) { return ((row & 3) * RD_PL + (row >> 2)) * RD_LDR; }
+// LDS bank arithmetic (round 6; tools/lds_bank_sim.py reproduces the PMC conflict share of round 5, 0.20, from these address functions):
+// * R stores: the 16 lanes of a ds_write_b64 group hold 16 consecutive block rows of one column = 4 planes x 4 indices. With planes 17 x 160 B apart both the plane
+//   and the index step were = 8 dwords mod 32 banks: 4 addresses per bank, 16 LDS cycles per store instead of 4. 16 B more per plane make the plane step = 12 mod 32:
+//   (2 i + 3 p) mod 8 takes every value twice — 2-way, the floor for 8-byte stores of 16 different 16-byte-aligned rows. The conv role's fragment reads stay inside
+//   one plane (consecutive indices, 10 slots apart): conflict-free as before.
+// * h: [64 rows][32 channels] fp16. Rows 80 B apart (5 slots, odd) made the tail's ds_read_b128 groups — 8 rows at chunk q, 8 rows at chunk q + 1 — collide 2-way.
+//   Now dense 64-byte rows with the 16-byte chunk index XORed by (2 if row & 4) ^ (3 if row & 8): reads conflict-free, the epilogue's stores 2-way (as before).
+__device__ __forceinline__ int rd_off(int row) { return (row & 3) * RD_PS + (row >> 2) * RD_LDR; }
+__device__ __forceinline__ int rd_hoff(int row, int chunk) { return row * RD_LDH + ((chunk ^ ((row >> 1) & 2) ^ (((row >> 3) & 1) * 3)) << 3); }
 
 // Input staging of a tile, half `half` (0 / 1): thread tid of the conv role owns the float4 chunk c = 512 half + tid of the tile's 64 NEW rows
 // (local row 2 + c / 16 <-> time t0 + c / 16, float4 c % 16). Local rows 0, 1 (times t0 - 2, t0 - 1) are the previous tile's rows 64, 65: copied
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(RD_THREADS, 1) void seanet_res64down_kernel(ResDown
                     const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
                     V4 hp[NP];
                     over_h |= split4<SC>(e, sa, hp);
-                    const int off = (32 * mh + 16 * m + r16) * RD_LDH + cn * 16 + q * 4;
+                    const int off = rd_hoff(32 * mh + 16 * m + r16, cn * 2 + (q >> 1)) + (q & 1) * 4;   // channels 16 cn + 4 q .. + 3
 #pragma unroll
                     for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(Hs + i * RD_HP + off) = hp[i];
                 }
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(RD_THREADS, 1) void seanet_res64down_kernel(ResDown
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             const int row = 16 * (mp + m) + r16;
-                            const PT* src = ks == 0 ? Hs + row * RD_LDH + q * 8 : Xr + (row + 2) * RD_LDX + ((ks - 1) * 4 + q) * 8;
+                            const PT* src = ks == 0 ? Hs + rd_hoff(row, q) : Xr + (row + 2) * RD_LDX + ((ks - 1) * 4 + q) * 8;
                             const int ps = ks == 0 ? RD_HP : RD_XP;
 #pragma unroll
                             for (int p = 0; p < NP; ++p) xf[ks][p][m] = *reinterpret_cast<const V8*>(src + p * ps);

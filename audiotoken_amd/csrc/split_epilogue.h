@@ -101,11 +101,18 @@ struct XbEpilogue {
             constexpr bool PRE = SC::NP == 2 && (E == XB_EPI_SWISH_SPLIT || E == XB_EPI_GELU_SPLIT);
             const float s_ = PRE ? a.split_scale : 1.0f, inv_s = PRE ? 1.0f / a.split_scale : 1.0f;
             f4 w;
+            if constexpr (E == XB_EPI_GELU_SPLIT) {
+                // two values per issue slot on the packed fp32 instructions (round 6: 89 -> 62 vector instructions per quad incl. the split; per element the same
+                // operations in the same order as gelu_erf_scaled: bit-identical, the pinned checksums cannot move)
+                typedef float f2_ __attribute__((ext_vector_type(2)));
+                const f2_ g0 = gelu_erf_scaled2(f2_{v[0], v[1]}, 0.5f * s_), g1 = gelu_erf_scaled2(f2_{v[2], v[3]}, 0.5f * s_);
+                w = f4{g0[0], g0[1], g1[0], g1[1]};
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                w[k] = E == XB_EPI_GELU_SPLIT ? gelu_erf_scaled(v[k], 0.5f * s_)
-                     : E == XB_EPI_ELU_SPLIT ? elu1(v[k])
-                                             : v[k] * __builtin_amdgcn_rcpf(fmaf(__expf(-v[k]), inv_s, inv_s));   // = s x sigmoid(x): v_exp_f32 + v_rcp_f32 (~1 ulp each), as the fp32 GEMM's epilogue
+                for (int k = 0; k < 4; ++k)
+                    w[k] = E == XB_EPI_ELU_SPLIT ? elu1(v[k])
+                                                 : v[k] * __builtin_amdgcn_rcpf(fmaf(__expf(-v[k]), inv_s, inv_s));   // = s x sigmoid(x): v_exp_f32 + v_rcp_f32 (~1 ulp each), as the fp32 GEMM's epilogue
+            }
             if constexpr (PH1) write_split_ph1<PRE>(a.S, a.Spad, a.Sfront, a.Sblocks, a.Sblock0, m, n, w);
             else write_split<FASTDIV, PRE>(a.S, a.Spad, a.Sphases, a.Sfront, a.Sblocks, a.Sblock0, m, n, w, &a.fdS);
         } else if constexpr (E == XB_EPI_QKV) {
