@@ -147,6 +147,15 @@ __global__ __launch_bounds__(512, 1) void seanet_res128rs_kernel(Res64Args a) {
     const bool phase_order = a.S != nullptr;
     auto tail_row = [&](int pos) { return phase_order ? (int)kRsTailRows[pos] : pos; };
 
+    // per-lane constants of the loop (hoisted by hand: inside the role branch the table lookup was a dependent global load at the head of EVERY tail)
+    int trow[2], thoff[2][2], hst[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        trow[m] = tail_row(16 * m + r16);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) thoff[m][ks] = rs_hoff(trow[m], ks * 4 + q);          // tail: h fragment of K step ks
+        hst[m] = rs_hoff(16 * m + r16, 2 * w + (q >> 1)) + ((q & 1) << 2);                    // conv3 epilogue: channels 16 w + 4 q .. + 3 of row 16 m + r16
+    }
     const int first = blockIdx.x, step = gridDim.x;
     const int K = first < total_tiles ? (total_tiles - first + step - 1) / step : 0;
     if (K == 0) return;
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(512, 1) void seanet_res128rs_kernel(Res64Args a) {
                     const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
                     V4 hp[NP];
                     over |= split4<SC>(e, sa, hp);
-                    const int off = rs_hoff(16 * m + r16, 2 * w + (q >> 1)) + ((q & 1) << 2);   // channels 16 w + 4 q .. + 3
+                    const int off = hst[m];
 #pragma unroll
                     for (int p = 0; p < NP; ++p) *reinterpret_cast<V4*>(Hs + p * RS_HP + off) = hp[p];
                 }
@@ -214,13 +223,10 @@ __global__ __launch_bounds__(512, 1) void seanet_res128rs_kernel(Res64Args a) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) acc[m][n] = f4{0.f, 0.f, 0.f, 0.f};
-            int trow[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) trow[m] = tail_row(16 * m + r16);
             auto tread = [&](int ks, V8 (&xf)[NP][2]) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const PT* src = ks < 2 ? Hs + rs_hoff(trow[m], ks * 4 + q) : Xr + (trow[m] + 2) * RS_LDX + (((ks - 2) * 4 + q) << 3);
+                    const PT* src = ks < 2 ? Hs + thoff[m][ks] : Xr + (trow[m] + 2) * RS_LDX + (((ks - 2) * 4 + q) << 3);
                     const int ps = ks < 2 ? RS_HP : RS_XP;
 #pragma unroll
                     for (int p = 0; p < NP; ++p) xf[p][m] = *reinterpret_cast<const V8*>(src + p * ps);

@@ -48,7 +48,9 @@ constexpr int RD_THREADS = 768;
 // * h: [64 rows][32 channels] fp16. Rows 80 B apart (5 slots, odd) made the tail's ds_read_b128 groups — 8 rows at chunk q, 8 rows at chunk q + 1 — collide 2-way.
 //   Now dense 64-byte rows with the 16-byte chunk index XORed by (2 if row & 4) ^ (3 if row & 8): reads conflict-free, the epilogue's stores 2-way (as before).
 __device__ __forceinline__ int rd_off(int row) { return (row & 3) * RD_PS + (row >> 2) * RD_LDR; }
-__device__ __forceinline__ int rd_hoff(int row, int chunk) { return row * RD_LDH + ((chunk ^ ((row >> 1) & 2) ^ (((row >> 3) & 1) * 3)) << 3); }
+// (the swizzle term depends on row bits 2, 3 only: for a fragment row 16 k + r16 it is a per-lane constant — rd_hswz(r16) — and the kernel adds it as one)
+__device__ __forceinline__ int rd_hswz(int row) { return ((row >> 1) & 2) ^ (((row >> 3) & 1) * 3); }
+__device__ __forceinline__ int rd_hoff(int row, int chunk) { return row * RD_LDH + ((chunk ^ rd_hswz(row)) << 3); }
 
 // Input staging of a tile, half `half` (0 / 1): thread tid of the conv role owns the float4 chunk c = 512 half + tid of the tile's 64 NEW rows
 // (local row 2 + c / 16 <-> time t0 + c / 16, float4 c % 16). Local rows 0, 1 (times t0 - 2, t0 - 1) are the previous tile's rows 64, 65: copied
@@ -151,6 +153,9 @@ __global__ __launch_bounds__(RD_THREADS, 1) void seanet_res64down_kernel(ResDown
         }
         const f4 b3 = *reinterpret_cast<const f4*>(a.b3 + cn * 16 + q * 4);
         const f4 bt = *reinterpret_cast<const f4*>(a.bt + rw * 16 + q * 4);
+        // h offsets inside a row: rows are 16 k + r16, so the swizzle is this lane's constant
+        const int h_st = r16 * RD_LDH + (((cn * 2 + (q >> 1)) ^ rd_hswz(r16)) << 3) + (q & 1) * 4;   // epilogue store: channels 16 cn + 4 q .. + 3
+        const int h_ld = r16 * RD_LDH + ((q ^ rd_hswz(r16)) << 3);                                   // tail fragment: chunk q
         RangeMax over_x;
         if ((first % tiles_per_clip) != 0 && tid < 512 + 32) {
             // a run that starts inside a clip: local rows 0, 1 of its first tile from memory (32 lanes, prologue only)
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(RD_THREADS, 1) void seanet_res64down_kernel(ResDown
                     const f4 e = {elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
                     V4 hp[NP];
                     over_h |= split4<SC>(e, sa, hp);
-                    const int off = rd_hoff(32 * mh + 16 * m + r16, cn * 2 + (q >> 1)) + (q & 1) * 4;   // channels 16 cn + 4 q .. + 3
+                    const int off = (32 * mh + 16 * m) * RD_LDH + h_st;
 #pragma unroll
                     for (int i = 0; i < NP; ++i) *reinterpret_cast<V4*>(Hs + i * RD_HP + off) = hp[i];
                 }
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(RD_THREADS, 1) void seanet_res64down_kernel(ResDown
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             const int row = 16 * (mp + m) + r16;
-                            const PT* src = ks == 0 ? Hs + rd_hoff(row, q) : Xr + (row + 2) * RD_LDX + ((ks - 1) * 4 + q) * 8;
+                            const PT* src = ks == 0 ? Hs + 16 * (mp + m) * RD_LDH + h_ld : Xr + (row + 2) * RD_LDX + ((ks - 1) * 4 + q) * 8;
                             const int ps = ks == 0 ? RD_HP : RD_XP;
 #pragma unroll
                             for (int p = 0; p < NP; ++p) xf[ks][p][m] = *reinterpret_cast<const V8*>(src + p * ps);

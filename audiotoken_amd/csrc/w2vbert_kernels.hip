@@ -316,6 +316,16 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, cons
 constexpr int LNS_ROWS = 8, LNS_D = 1024;    // rows per workgroup: 2 per wave (32 KB of LDS with two pieces: four workgroups per CU)
 constexpr int LNS_RW = LNS_ROWS / 4;          // rows per wave
 
+// Which 8-row group workgroup b takes (round 6, an order-only change: every group is independent). The GEMM before a LayerNorm leaves the END of each XCD's
+// m-range freshest in that XCD's L2 and in the Infinity Cache (gemm_f16x2_tg.hip: XCD x owns the x-th eighth of the rows and walks it upwards), and the GEMM
+// after it starts at the BEGINNING of each eighth. So workgroup b — dispatched to XCD b & 7 — walks the (b & 7)-th eighth DOWNWARDS: it reads what was written
+// last first (before its own 8 bytes per element of traffic evict it) and writes last what is read first next.
+__device__ __forceinline__ long long lns_group(unsigned b, unsigned nb) {
+    const unsigned per = nb >> 3;
+    if (b >= (per << 3)) return b;                    // the nb % 8 groups at the end keep their place
+    return (long long)((b & 7u) + 1u) * per - 1 - (b >> 3);
+}
+
 // DOUBLE: two LayerNorms back to back — y = LN(x; gamma, beta) is written as fp32 rows (WRITE_Y) and the pieces are split(LN(y; gamma2, beta2)). That is the
 // conformer's final_layer_norm followed by the next layer's ffn1_layer_norm (w2vbert.hip): one pass over the residual stream instead of two (y is not read
 // back). Each LayerNorm reduces exactly as layernorm_kernel / the single form do (same lane mapping, same sums): bit-identical to the two launches.
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
     static_assert(D % 256 == 0 && NJ >= 1 && NJ <= 4, "layernorm_split: D = 256 .. 1024 in steps of 256");
     __shared__ __attribute__((aligned(16))) PT tile[NP][D / 16][KB_LD];   // 36 KB (two pieces) / 54 KB (three)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long r0 = (long long)blockIdx.x * LNS_ROWS;
+    const long long r0 = lns_group(blockIdx.x, gridDim.x) * LNS_ROWS;
     RangeMax over;
     // all rows of the wave are loaded before the first is reduced (one row at a time left 4 KB per wave in flight: 3.5 TB/s, 70 % of the wave
     // cycles waiting); 8 rows per workgroup instead of 16 puts four workgroups on a CU: 16.0 -> 13.7 ms per semantic_m step (4 rows: no further gain)

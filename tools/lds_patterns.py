@@ -2,8 +2,10 @@
 from lds_bank_sim import report
 
 
-def res128rs(tail_row, label):
+def res128rs(tail_row, label, hoff=None):
     LDX, LDH = 144, 80
+    if hoff is None:
+        hoff = lambda row, chunk: row * LDH + chunk * 8     # round 5: rows 160 B apart
     tot = [0, 0]
 
     def add(r):
@@ -12,12 +14,12 @@ def res128rs(tail_row, label):
     # conv3 fragment reads: lane (r16, q) reads 16 B at row (16 m + r16 + tap), chunk (ks & 3) * 4 + q; 12 ks x 2 m x 2 pieces per C wave, 4 C waves
     add(report("conv3 x fragment (rows consecutive)", "ds_read_b128", lambda l: 2 * (((l & 15) + 1) * LDX + ((l >> 4) << 3)), 12 * 2 * 2 * 4))
     for m in range(2):
-        add(report(f"tail h fragment, m={m}", "ds_read_b128", lambda l: 2 * (tail_row(16 * m + (l & 15)) * LDH + ((l >> 4) << 3)), 2 * 2 * 4))
+        add(report(f"tail h fragment, m={m}", "ds_read_b128", lambda l: 2 * hoff(tail_row(16 * m + (l & 15)), l >> 4), 2 * 2 * 4))
         add(report(f"tail x fragment, m={m}", "ds_read_b128", lambda l: 2 * ((tail_row(16 * m + (l & 15)) + 2) * LDX + ((l >> 4) << 3)), 4 * 2 * 4))
     # staging: chunk c = tid + 512 j -> row c >> 5, float4 c & 31 -> 8-byte stores into 4 planes
     add(report("stage x pieces", "ds_write_b64", lambda l: 2 * ((l >> 5) * LDX + ((l & 31) >> 1) * 8 + (l & 1) * 4), 4 * 17))   # 34 x 32 chunks / 64 lanes = 17 wave-stores x 4 planes
     # h epilogue: lane (r16, q) writes 8 B at row 16 m + r16, channels 16 w + 4 q
-    add(report("h epilogue pieces", "ds_write_b64", lambda l: 2 * ((l & 15) * LDH + (((l >> 4) >> 1) << 3) + (((l >> 4) & 1) << 2)), 2 * 2 * 4))
+    add(report("h epilogue pieces", "ds_write_b64", lambda l: 2 * (hoff(l & 15, (l >> 4) >> 1) + (((l >> 4) & 1) << 2)), 2 * 2 * 4))
     print(f"   total {tot[0]} LDS-array cycles per tile, conflict-free {tot[1]}: conflict share {(tot[0] - tot[1]) / tot[0]:.2f}")
 
 
@@ -35,7 +37,12 @@ def main():
     res128rs(lambda p: p, "natural row order: the fp32-output path")
     res128rs(phase_order_r5, "round-5 phase order (rows sorted by row % 5)")
     assert sorted(RS_TAIL_ROWS) == list(range(32))
-    res128rs(lambda p: RS_TAIL_ROWS[p], "round-6 phase order (bank-aware)")
+    res128rs(lambda p: RS_TAIL_ROWS[p], "round-6 phase order (bank-aware), h rows dense + chunk ^ (row & 7)", lambda row, chunk: row * 64 + ((chunk ^ (row & 7)) << 3))
+    stage0x3()
+    res64down()
+    f = lambda row: (((row >> 2) & 1) * 2) ^ (((row >> 3) & 1) * 3)
+    res64down(plane_pad=8, label="round 6: R planes + 16 B, h rows dense + swizzled",
+              h_addr=lambda row, chunk: row * 32 + ((chunk ^ f(row)) << 3), h_waddr=lambda row, col: row * 32 + (((col >> 3) ^ f(row)) << 3) + (col & 7))
 
 
 def stage0x3(LDX=48, LDH=24, LDR=48, RIDX=34, xbit=lambda r: r >> 2, rbit=lambda r: r ^ (r >> 3), swz=lambda col, bit: col ^ ((bit & 1) << 3), label="round 5"):
