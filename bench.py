@@ -578,7 +578,7 @@ def max_over_ranks(x: float, dev, dist) -> float:
 
 def measured_traffic(group: str, workload: str = "acoustic"):
     """HBM bytes per launch of a kernel group from the committed rocprofv3 PMC passes (the newest profiles/r0N_*_traffic.json); None if that group was not profiled. PMC collection needs rocprofv3, so it cannot run inside the timed benchmark."""
-    for name in ("r05_final_traffic.json", "r04_final_traffic.json", "r03_final_traffic.json", "r02_final_traffic.json", "r02_v2_traffic.json", "r01_traffic.json"):
+    for name in ("r06_final_traffic.json", "r05_final_traffic.json", "r04_final_traffic.json", "r03_final_traffic.json", "r02_final_traffic.json", "r02_v2_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 doc = json.load(f)

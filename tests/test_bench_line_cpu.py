@@ -19,7 +19,7 @@ def _strict(line):
 
 def test_compact_line_of_the_round5_object():
     import bench
-    full = json.load(open(os.path.join(ROOT, "profiles", "r05_final_bench.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_final_bench.json")))   # (the round-5 object: a fixed input for the compactor)
     assert len(json.dumps(full)) > 20000                      # the object that could not be recorded
     line = bench.compact_line(full, "gpurun_out/bench_detail.json")
     assert "\n" not in line and len(line.encode()) < 6144, len(line)
@@ -46,7 +46,7 @@ def test_compact_line_of_the_round5_object():
 
 def test_compact_line_sheds_optional_blocks_rather_than_exceed_the_limit():
     import bench
-    full = json.load(open(os.path.join(ROOT, "profiles", "r05_final_bench.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_final_bench.json")))   # (the round-5 object: a fixed input for the compactor)
     full["files"]["legs"] = full["files"]["legs"] * 40       # a bloated optional block
     line = bench.compact_line(full)
     c = _strict(line)

@@ -7,7 +7,9 @@ export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp
-python3 $R/bench.py --full-line --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+# exactly what the driver runs but for the step counts: stdout = BENCH_DETAIL line + the compact line (kept as bench_line.json), full object -> bench.json
+python3 $R/bench.py --steps 20 --warmup 5 --detail-out $O/bench.json > $O/bench_stdout.txt 2> $O/bench.err
+tail -n 1 $O/bench_stdout.txt > $O/bench_line.json; rm -f $O/bench_stdout.txt
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --full-line --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $O/stats_bench.json 2> $O/stats.err
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 cd $R

@@ -3,6 +3,7 @@
 # and the traffic file bench.py reads:   bash tools/refresh_profiles.sh r03_final
 T=${1:-r04_final}; G=gpurun_out/$T
 cp $G/bench.json profiles/${T}_bench.json
+[ -f $G/bench_line.json ] && cp $G/bench_line.json profiles/${T}_bench_line.json
 cp $G/kernel_stats.csv profiles/${T}_kernel_stats.csv
 cp $G/pmc_acoustic/pmc_summary.csv profiles/${T}_acoustic_pmc_summary.csv
 cp $G/pmc_semantic_m/pmc_summary.csv profiles/${T}_semantic_m_pmc_summary.csv
