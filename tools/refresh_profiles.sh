@@ -11,6 +11,7 @@ cp $G/pmc_semantic_m/pmc_summary.csv profiles/${T}_semantic_m_pmc_summary.csv
 [ -f $G/pmc_decode/pmc_summary.csv ] && cp $G/pmc_decode/pmc_summary.csv profiles/${T}_decode_pmc_summary.csv
 [ -f $G/pmc_semantic_m/gemm_roles_traffic.json ] && cp $G/pmc_semantic_m/gemm_roles_traffic.json profiles/${T}_gemm_roles_traffic.json
 [ -f $G/gemm_roles_from_trace.txt ] && cp $G/gemm_roles_from_trace.txt profiles/${T}_gemm_roles_from_trace.txt
+[ -f $G/trace_gaps.txt ] && cp $G/trace_gaps.txt profiles/${T}_trace_gaps.txt
 python3 tools/pmc_report.py profiles/$T acoustic=profiles/${T}_acoustic_pmc_summary.csv semantic_m=profiles/${T}_semantic_m_pmc_summary.csv $( [ -f profiles/${T}_semantic_s_pmc_summary.csv ] && echo semantic_s=profiles/${T}_semantic_s_pmc_summary.csv ) $( [ -f profiles/${T}_decode_pmc_summary.csv ] && echo acoustic_decode=profiles/${T}_decode_pmc_summary.csv ) > /dev/null
 python3 - "$T" <<'PY'
 import csv, json, sys
