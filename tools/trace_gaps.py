@@ -26,6 +26,8 @@ for g in gaps:
         if g < e:
             hist[k] += 1
             break
+small = [g for g in gaps if g < 100e3]     # gaps of 100 us and more are the harness between encodes (host synchronisation, taps, the next loop), not launch gaps
+print(f"gaps below 100 us (launch gaps inside an encode): {len(small) / n_enc:.0f} per encode, {sum(small) / n_enc / 1e6:.3f} ms per encode = {100.0 * sum(small) / max(busy, 1):.2f} % of the kernels' busy time")
 print("gap histogram (ns):", ", ".join(f"<{int(e)}: {h}" for e, h in zip(edges, hist)))
 big = sorted(((g, seg[i]["Kernel_Name"][:50], seg[i + 1]["Kernel_Name"][:50]) for i, g in enumerate(gaps)), reverse=True)[:6]
 for g, a, b in big:
