@@ -54,6 +54,7 @@ class AudioToken:
         self.kwargs = kwargs
         self.device = device
         self.skipped_files: List[tuple] = []   # (path, reason) of the inputs the last encode_batch_files could not decode
+        self.rank_probe: Optional[dict] = None    # checksums of the multi-rank start-up probe (load_encoder under torch.distributed), else None
         self.num_codebooks = kwargs.get("num_codebooks", 16)
         assert self.num_codebooks in [2, 4, 8, 16], "num_codebooks must be one of [2, 4, 8, 16]"
         self.load_config()
@@ -283,8 +284,12 @@ class AudioToken:
             # the pickled list travels on THIS rank's device under RCCL (not torch's current device: a caller that never called set_device would put every rank on cuda:0)
             dist.broadcast_object_list(sizes, src=0, device=collective_device(torch.device(self.device), dist))
             sizes, digest0 = sizes[0]
-            assert len(sizes) == len(files) and digest0 == digest, \
-                "ranks see different file lists: encode_batch_files needs the same audio_files / audio_dir on every rank"
+            # every rank learns whether ALL ranks hold rank 0's list: a rank that differs must stop the others too, not let them encode a shard of a list it does not share
+            from .distributed import gather_scalars
+            same = len(sizes) == len(files) and digest0 == digest
+            votes = gather_scalars([1.0 if same else 0.0], torch.device(self.device), dist)
+            bad = [r for r, v in enumerate(votes) if v[0] != 1.0]
+            assert not bad, f"ranks {bad} see a different file list than rank 0: encode_batch_files needs the same audio_files / audio_dir on every rank"
             files = [files[i] for i in shard_by_size(sizes, dist.get_rank(), dist.get_world_size())]
         start_time = time.time()
         on_gpu = torch.device(self.device).type == "cuda"

@@ -117,7 +117,19 @@ def compact_line(out: dict, detail_path: str = None) -> str:
             break
         c.pop(drop, None)
         line = json.dumps(c, allow_nan=False, separators=(",", ":"))
-    assert len(line) <= COMPACT_LIMIT, len(line)
+    if len(line) > COMPACT_LIMIT:                   # still too long (a very long free-text field): cut the texts, never the numbers — and never raise: a bench run must end with its line
+        def cut(o, n):
+            if isinstance(o, str):
+                return o if len(o) <= n else o[:n - 3] + "..."
+            if isinstance(o, dict):
+                return {k: cut(v, n) for k, v in o.items()}
+            if isinstance(o, list):
+                return [cut(v, n) for v in o]
+            return o
+        for n in (160, 60, 20):
+            line = json.dumps(cut(c, n), allow_nan=False, separators=(",", ":"))
+            if len(line) <= COMPACT_LIMIT:
+                break
     return line
 
 

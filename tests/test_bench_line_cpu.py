@@ -82,3 +82,13 @@ def test_full_line_flag_keeps_the_tools_format():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and "breakdown" in _strict(lines[0])
+
+
+def test_compact_line_never_raises_on_long_texts():
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_final_bench.json")))
+    full["config"]["workload"] = "w" * 9000
+    full["dtype"] = "d" * 3000
+    line = bench.compact_line(full)
+    c = _strict(line)
+    assert len(line) <= bench.COMPACT_LIMIT and c["value"] == full["value"] and c["roofline"]["frac"] == full["roofline"]["frac"] and c["cpu_baseline"]["cores"] == 16

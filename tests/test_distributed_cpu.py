@@ -337,3 +337,32 @@ def test_audiotoken_acoustic_weights_come_from_rank0(tmp_path):
     mp.spawn(_acoustic_worker, args=(2, 36900 + (os.getpid() % 2000), str(tmp_path), q), nprocs=2, join=True)
     a, b = sorted(q.get(timeout=30) for _ in range(2))
     assert a[1:] == b[1:] and a[1] > 50, (a, b)
+
+
+def _mismatch_worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        names = sorted(os.path.join(tmp, "in", n) for n in os.listdir(os.path.join(tmp, "in")))
+        if rank == 1:
+            names = names[:-1] + [names[-1] + ".other"]          # the same COUNT, one different name: the length check alone would not see it
+        try:
+            _encode_files(names, os.path.join(tmp, f"out_rank{rank}"), workers=0)
+            q.put((rank, "ok", ""))
+        except AssertionError as e:
+            q.put((rank, "raised", str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_with_different_file_lists_all_stop(tmp_path):
+    """the size broadcast used to compare list LENGTHS only. Now a digest of the list travels with the sizes and every rank learns the verdict of all
+    ranks: a rank holding a different list (same length) makes EVERY rank raise before a single token file is written."""
+    os.makedirs(tmp_path / "in")
+    _write_inputs(str(tmp_path / "in"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    mp.spawn(_mismatch_worker, args=(2, 37900 + (os.getpid() % 2000), str(tmp_path), q), nprocs=2, join=True)
+    got = sorted(q.get(timeout=30) for _ in range(2))
+    assert all(s == "raised" and "ranks [1] see a different file list" in msg for _, s, msg in got), got
+    assert not os.path.exists(tmp_path / "out_rank0") or not os.listdir(tmp_path / "out_rank0")
