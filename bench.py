@@ -67,9 +67,9 @@ def _pick(d, keys):
 
 
 def compact_line(out: dict, detail_path: str = None) -> str:
-    """The LAST stdout line of a bench run: the contract's keys + roofline + cpu_baseline + one {value, ms_per_step, token_checksum} triple per workload,
+    """The ONE stdout line of a bench run: the contract's keys + roofline + cpu_baseline + one {value, ms_per_step, token_checksum} triple per workload,
     strict JSON (no NaN / Infinity), <= COMPACT_LIMIT bytes. Everything else (breakdowns, notes, files legs, argmin kernels, PCIe-inclusive rates) goes to the
-    detail object printed on an earlier `BENCH_DETAIL ` line and written to `detail_path`."""
+    detail object (`BENCH_DETAIL ` line on stderr, file `detail_path`)."""
     cfg = out.get("config") or {}
     roof = out.get("roofline")
     cpu = out.get("cpu_baseline")
@@ -145,14 +145,14 @@ def _finite(o):
 
 
 def emit(out: dict, detail_out: str = None, full_line: bool = False):
-    """Print the full object on an earlier line (prefixed, so that no line-scanner mistakes it for the result), write it to `detail_out`, and make the
-    LAST stdout line the compact object."""
+    """stdout carries ONE line: the compact object (the driver keeps a bounded amount of stdout — round 5's 22 KB line gave `parsed: null` — so nothing else
+    goes there). The full object goes to stderr on a `BENCH_DETAIL ` line and to the file `detail_out`."""
     out = _finite(out)
     full = json.dumps(out, allow_nan=False)
     if full_line:   # the repo's own tools (tools/*.sh redirect stdout into a .json): the full object alone, as ONE plain line
         print(full, flush=True)
         return
-    print("BENCH_DETAIL " + full, flush=True)
+    print("BENCH_DETAIL " + full, file=sys.stderr, flush=True)
     written = None
     if detail_out:
         try:
@@ -184,13 +184,11 @@ def launch_children(n: int, argv, script: str = None, extra_env=None, timeout: f
     env.setdefault("OMP_NUM_THREADS", "4")
     env.update(extra_env or {})
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
-    line = detail = None
-    for ln in proc.stdout.splitlines():
+    line = None
+    for ln in proc.stdout.splitlines():      # (the children's stderr — rank 0's BENCH_DETAIL line included — is inherited, not captured)
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
-        elif ln.startswith("BENCH_DETAIL "):
-            detail = ln
-    return proc.returncode, line, detail
+    return proc.returncode, line
 
 
 def init_ranks(backend: str, dev):
@@ -1183,7 +1181,7 @@ def parse_args(argv=None):
                          "matrices, log-normal LayerNorm gains, massive-activation channels — reports fallback_batches / pinned_layers on such a checkpoint")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
-                    help="file that receives the FULL result object (also printed on an earlier `BENCH_DETAIL ` stdout line); the LAST stdout line is the compact object")
+                    help="file that receives the FULL result object (also printed on a `BENCH_DETAIL ` line on stderr); stdout carries the compact object alone")
     ap.add_argument("--full-line", action="store_true", help="print the full object as the one plain JSON line instead (the repo's tools/*.sh; not what the driver runs)")
     ap.add_argument("--stress-range", action="store_true",
                     help="semantic_m with one split site overflowing the fp16 range on every batch: times the product's per-batch fallback (bf16x3 repeat)")
@@ -1204,10 +1202,8 @@ def main(argv=None):
             if n_dev < args.gpus:
                 print(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} device(s)", file=sys.stderr)
                 return 2
-        rc, line, detail = launch_children(args.gpus, sys.argv[1:] if argv is None else list(argv))
-        if detail is not None:
-            print(detail, flush=True)
-        if line is not None:   # rank 0's compact object stays the LAST stdout line
+        rc, line = launch_children(args.gpus, sys.argv[1:] if argv is None else list(argv))
+        if line is not None:   # rank 0's compact object is the parent's ONE stdout line
             print(line, flush=True)
         return rc if rc != 0 or line is not None else 1
 

@@ -31,7 +31,7 @@ def test_self_launch_world2_gloo():
 def test_launch_children_function_and_external_torchrun():
     sys.path.insert(0, ROOT)
     import bench
-    rc, line, _detail = bench.launch_children(2, ["--gpus", "2", "--workload", "selftest", "--backend", "gloo", "--steps", "2"], extra_env=_env(), timeout=300)
+    rc, line = bench.launch_children(2, ["--gpus", "2", "--workload", "selftest", "--backend", "gloo", "--steps", "2"], extra_env=_env(), timeout=300)
     assert rc == 0 and line is not None
     assert json.loads(line)["rccl_ranks"] == [0, 1]
 

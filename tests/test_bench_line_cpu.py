@@ -1,5 +1,5 @@
 """The bench line the driver records (a 22 KB line gave `BENCH_r05.parsed: null`). The LAST stdout line must be a compact strict-JSON
-object (< 6 KB) that still carries the contract's keys, `roofline` and `cpu_baseline`; the full object goes to an earlier prefixed line and a file."""
+object (< 6 KB) that still carries the contract's keys, `roofline` and `cpu_baseline` — and the ONLY thing on stdout; the full object goes to stderr (prefixed) and a file."""
 import json
 import os
 import subprocess
@@ -59,20 +59,21 @@ def test_non_finite_numbers_become_null():
     assert out == {"a": None, "b": [1.0, None], "c": {"d": None, "e": 2}}
 
 
-def test_last_stdout_line_is_the_compact_object(tmp_path):
+def test_stdout_is_the_compact_object_alone(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     detail = str(tmp_path / "detail.json")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "selftest", "--backend", "gloo", "--steps", "3",
                         "--detail-out", detail], env=dict(env, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    last = _strict(lines[-1])
-    assert len(lines[-1]) < 6144 and last["n_gpus"] == 2 and last["rccl_ranks"] == [0, 1] and "roofline" in last and "cpu_baseline" in last
-    details = [ln for ln in lines if ln.startswith("BENCH_DETAIL ")]
-    assert len(details) == 1 and lines.index(details[0]) < len(lines) - 1
+    assert len(lines) == 1, p.stdout                                   # nothing but the line: whatever the driver keeps of stdout, it keeps this
+    last = _strict(lines[0])
+    assert len(lines[0]) < 6144 and last["n_gpus"] == 2 and last["rccl_ranks"] == [0, 1] and "roofline" in last and "cpu_baseline" in last
+    details = [ln for ln in p.stderr.splitlines() if ln.startswith("BENCH_DETAIL ")]
+    assert len(details) == 1                                           # rank 0's full object, on stderr
     full = _strict(details[0][len("BENCH_DETAIL "):])
     assert full["value"] == last["value"]
-    assert _strict(open(detail).read())["value"] == last["value"]     # rank 0 of the children wrote the file
+    assert _strict(open(detail).read())["value"] == last["value"]     # ... and in the file
 
 
 def test_full_line_flag_keeps_the_tools_format():

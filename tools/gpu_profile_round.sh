@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp
-# exactly what the driver runs but for the step counts: stdout = BENCH_DETAIL line + the compact line (kept as bench_line.json), full object -> bench.json
+# exactly what the driver runs: stdout = the compact line alone (kept as bench_line.json), full object -> bench.json (and stderr)
 python3 $R/bench.py --steps 20 --warmup 5 --detail-out $O/bench.json > $O/bench_stdout.txt 2> $O/bench.err
 tail -n 1 $O/bench_stdout.txt > $O/bench_line.json; rm -f $O/bench_stdout.txt
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --full-line --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $O/stats_bench.json 2> $O/stats.err
