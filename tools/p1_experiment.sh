@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 6 experiment (VERDICT round 5, next #5b): P.V with the probabilities as ONE fp16 piece (tools/_lib_p1.so = the library with attention_f16x2_w8.hip built
-# with -DW8_P_PIECES=1). Oracle in the loop: the attention operator against its oracle, the bench batches of semantic_m on both families, the fitted code book; then
+# with -DW8_P_PIECES=1: `hipcc <Makefile CXXFLAGS> -DW8_P_PIECES=1 -c attention_f16x2_w8.hip -o /tmp/a.o && hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_lib_p1.so
+# $(ls audiotoken_amd/csrc/build/*.o | grep -v attention_f16x2_w8) /tmp/a.o`, built here before gpurun; the .so is git-ignored). Oracle in the loop: the attention operator against its oracle, the bench batches of semantic_m on both families, the fitted code book; then
 # the time, interleaved with the product build.   gpurun --timeout 2400 -- bash tools/p1_experiment.sh
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 O=$R/gpurun_out/p1; mkdir -p $O
